@@ -1,0 +1,208 @@
+/*
+ * relp_engine.h -- C ABI of the MI355X-native revised-simplex pivot engine.
+ *
+ * This is the drop-in boundary for RELP's hot path (vandenheuvel/rust-lp, `relp` 0.0.5).  The
+ * reference has no FFI; the unit replaced is `Tableau<Carry<F, BI>, K>` + `PivotRule` driven by
+ * `phase_one::primal` / `phase_two::primal`.  Each entry point names the reference interface it
+ * replaces (file:line under /root/reference/src/algorithm/two_phase/).  A Rust maintainer binds
+ * these with `extern "C"` and implements `InverseMaintener` / `PivotRule` on top.
+ *
+ * Conventions
+ *   - plain C types only; every function returns a relp_status_t (0 = ok, < 0 = error); no panics
+ *     or aborts cross the boundary (the reference panics on a zero pivot, carry/mod.rs:291).
+ *   - a handle is not thread-safe: one host thread per handle; each handle owns one HIP stream
+ *     (relp_set_stream lets the caller supply its own, e.g. the stream RCCL collectives run on).
+ *   - the problem is copied at create time (the reference borrows the provider, `&'a MP`); all
+ *     getters copy into caller-provided host buffers.
+ *   - field = f64 (the reference has no float field, README.md:27: this is the build's extension);
+ *     comparisons use the tolerances of relp_config_t, all-zero tolerances = the reference's exact
+ *     `<`, `>`, `==`.
+ *   - column indices are tableau indices: in phase 1 the `nr_artificial` artificial columns come
+ *     first (kind/artificial/partially.rs:72-80), in phase 2 they are provider indices.
+ */
+#ifndef RELP_ENGINE_H
+#define RELP_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct relp_engine relp_engine_t;
+
+typedef enum {
+    RELP_OK = 0,
+    RELP_E_ARG = -1,          /* bad argument */
+    RELP_E_HIP = -2,          /* HIP runtime error (relp_last_error gives the text) */
+    RELP_E_ZERO_PIVOT = -3,   /* "Pivot value can't be zero." carry/mod.rs:291, basis_inverse_rows.rs:47 */
+    RELP_E_SINGULAR = -4,     /* basis could not be inverted (from_basis) */
+    RELP_E_STATE = -5,        /* call not valid in the current phase / state */
+    RELP_E_UNSUPPORTED = -6,
+    RELP_E_ALLOC = -7
+} relp_status_t;
+
+/* Outcome of a loop (algorithm/mod.rs:46-50 `OptimizationResult`, phase_one.rs:177-194). */
+typedef enum {
+    RELP_RUNNING = 0,          /* iteration limit hit, more pivots possible */
+    RELP_OPTIMAL = 1,          /* phase 2: no candidate column (FiniteOptimum) */
+    RELP_UNBOUNDED = 2,        /* phase 2: no pivot row (Unbounded) */
+    RELP_INFEASIBLE = 3,       /* phase 1 ended with objective != 0 */
+    RELP_PHASE_ONE_DONE = 4,   /* phase 1 ended feasible; the tableau is now NonArtificial */
+    RELP_NO_ROW_PHASE_ONE = 5  /* "Artificial cost can not be unbounded." phase_one.rs:143 */
+} relp_outcome_t;
+
+/* strategy/pivot_rule.rs:38,62,97 */
+typedef enum {
+    RELP_RULE_FIRST_PROFITABLE = 0,
+    RELP_RULE_FIRST_PROFITABLE_WITH_MEMORY = 1,   /* phase-1 default, phase_one.rs:55,97 */
+    RELP_RULE_STEEPEST_DESCENT = 2                /* = most negative d_j; phase-2 default, two_phase/mod.rs:44 */
+} relp_pivot_rule_t;
+
+typedef enum { RELP_FORMAT_CSC = 0, RELP_FORMAT_DENSE = 1 } relp_format_t;
+typedef enum { RELP_MEM_HOST = 0, RELP_MEM_DEVICE = 1 } relp_memory_t;
+
+/* matrix_provider/matrix_data.rs:54-90.  Constraint rows are ordered [== | range | <= | >=]; the
+ * slack, bound-slack columns and bound rows are virtual (matrix_data.rs:37-52, 308-348). */
+typedef struct {
+    int32_t nr_normal;                        /* structural columns */
+    int32_t nr_eq, nr_range, nr_le, nr_ge;    /* constraint rows */
+    int32_t format;                           /* relp_format_t */
+    int32_t matrix_memory;                    /* relp_memory_t: where col_ptr/row_idx/values/dense live */
+    const int64_t *col_ptr;                   /* CSC: nr_normal + 1 */
+    const int32_t *row_idx;                   /* CSC: sorted inside a column */
+    const double  *values;                    /* CSC */
+    const double  *dense;                     /* DENSE: column-major nr_constraints x nr_normal */
+    int64_t        dense_ld;                  /* DENSE: leading dimension (>= nr_constraints) */
+    const double  *b;                         /* host, nr_constraints (all >= 0, general_form/mod.rs:574) */
+    const double  *ranges;                    /* host, nr_range */
+    const double  *cost;                      /* host, nr_normal */
+    const double  *upper_bound;               /* host, nr_normal; +inf = none (lower bounds are 0) */
+} relp_matrix_data_t;
+
+typedef struct {
+    int32_t device;               /* HIP device ordinal, -1 = current */
+    int32_t phase_one_rule;       /* relp_pivot_rule_t */
+    int32_t phase_two_rule;
+    double  tol_cost;             /* candidate iff d_j < -tol_cost          (pivot_rule.rs:56,81,117) */
+    double  tol_pivot;            /* ratio test iff alpha_i > tol_pivot      (tableau/mod.rs:227) */
+    double  tol_zero;             /* |b_i| <= tol_zero reads as 0 in the ratio */
+    double  tol_tie;              /* ratio ties: <= min + tol_tie*max(1,|min|), smallest leaving column wins
+                                     (tableau/mod.rs:229-239) */
+    double  tol_feas;             /* phase 1 feasible iff |obj| <= tol_feas*max(1, initial obj) (phase_one.rs:146) */
+    int32_t poll_interval;        /* relp_run: iterations enqueued between host polls of the outcome */
+    int32_t trace_capacity;       /* pivots recorded on the device (0 = no trace) */
+    /* column / row sharding for multi-GPU pricing; 0,1 = everything local */
+    int32_t shard_rank, shard_count;
+} relp_config_t;
+
+void relp_default_config(relp_config_t *cfg);
+const char *relp_last_error(const relp_engine_t *h);
+const char *relp_version(void);
+
+/* ---- construction ----------------------------------------------------------------------------
+ * Tableau::<_, Partially<_>>::new (kind/artificial/partially.rs:125-206) +
+ * InverseMaintener::create_for_partially_artificial (carry/mod.rs:381-426): B^-1 = I, b = rhs,
+ * -pi_i = -1 on artificial rows, -obj = -sum of b over artificial rows. */
+relp_status_t relp_engine_create(const relp_matrix_data_t *md, const relp_config_t *cfg, relp_engine_t **out);
+void          relp_engine_destroy(relp_engine_t *h);
+relp_status_t relp_set_stream(relp_engine_t *h, void *hip_stream);
+
+/* ---- one pivot, step by step (the body of phase_one.rs:135-146 / phase_two.rs:32-50) ---------- */
+/* PivotRule::select_primal_pivot_column (strategy/pivot_rule.rs:25-33): full PRICE on the device. */
+relp_status_t relp_select_primal_pivot_column(relp_engine_t *h, int32_t rule, int32_t *found,
+                                              int32_t *column, double *relative_cost);
+/* Tableau::relative_cost (tableau/mod.rs:102-108) for every column (basic columns included). */
+relp_status_t relp_relative_costs(relp_engine_t *h, double *out_n);
+/* Tableau::generate_column (tableau/mod.rs:122-126) = BasisInverse::generate_column
+ * (basis_inverse_rows.rs:144-155): FTRAN; result stays on the device until the next call;
+ * `out_m` (may be NULL) receives the dense column. */
+relp_status_t relp_generate_column(relp_engine_t *h, int32_t column, double *out_m);
+/* Tableau::generate_element (tableau/mod.rs:129-134). */
+relp_status_t relp_generate_element(relp_engine_t *h, int32_t row, int32_t column, double *out);
+/* Tableau::select_primal_pivot_row (tableau/mod.rs:221-247) on the last generated column. */
+relp_status_t relp_select_primal_pivot_row(relp_engine_t *h, int32_t *found, int32_t *row);
+/* Tableau::bring_into_basis (tableau/mod.rs:47-60) -> Carry::change_basis (carry/mod.rs:549-570):
+ * consumes the last generated column; returns the leaving column. */
+relp_status_t relp_bring_into_basis(relp_engine_t *h, int32_t column, int32_t row, double relative_cost,
+                                    int32_t *leaving_column);
+
+/* ---- whole loops on the device ------------------------------------------------------------------
+ * relp_run: up to max_iters basis changes of the current phase with no per-pivot host sync.
+ * phase_one::primal (phase_one.rs:125-170) / phase_two::primal (phase_two.rs:22-51). */
+relp_status_t relp_run(relp_engine_t *h, int64_t max_iters, int64_t *iterations_done, int32_t *outcome);
+/* SolveRelaxation::solve_relaxation (two_phase/mod.rs:30-76): phase 1, artificial removal
+ * (phase_one.rs:223-260), phase switch (kind/non_artificial.rs:151-220), phase 2. */
+relp_status_t relp_solve_relaxation(relp_engine_t *h, int64_t max_iters, int32_t *outcome);
+/* InverseMaintener::from_basis (carry/mod.rs:428-463): warm start from provider column indices,
+ * one per row; switches to phase 2. */
+relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
+
+/* ---- state getters (InverseMaintener accessors, inverse_maintenance/mod.rs:200-266) ----------- */
+int32_t relp_nr_rows(const relp_engine_t *h);
+int32_t relp_nr_columns(const relp_engine_t *h);
+int32_t relp_phase(const relp_engine_t *h);                 /* 1 or 2 */
+int32_t relp_nr_artificial(const relp_engine_t *h);
+relp_status_t relp_get_objective(relp_engine_t *h, double *out);        /* get_objective_function_value */
+relp_status_t relp_get_b(relp_engine_t *h, double *out_m);              /* b() */
+relp_status_t relp_get_minus_pi(relp_engine_t *h, double *out_m);
+relp_status_t relp_get_basis_indices(relp_engine_t *h, int32_t *out_m); /* basis_column_index_for_row */
+relp_status_t relp_get_basis_inverse(relp_engine_t *h, double *out_mm); /* dense row-major B^-1 */
+/* current_bfs (carry/mod.rs:616-625): (column, value) pairs sorted by column, zeros dropped. */
+relp_status_t relp_current_bfs(relp_engine_t *h, int32_t *cols, double *vals, int32_t cap, int32_t *count);
+relp_status_t relp_get_iterations(relp_engine_t *h, int64_t *out);
+/* recorded pivots: phase, entering, row, leaving (each `cap` long); count = pivots so far */
+relp_status_t relp_get_trace(relp_engine_t *h, int32_t *phase, int32_t *entering, int32_t *row,
+                             int32_t *leaving, int64_t cap, int64_t *count);
+/* Debug invariant checker (tableau/mod.rs:253-289): max |B^-1 B - I|, max |d_basic|, min b. */
+relp_status_t relp_check_basis(relp_engine_t *h, double *max_identity_error, double *max_basic_cost,
+                               double *min_b);
+
+/* ---- per-kernel timing (bench.py roofline) ------------------------------------------------------ */
+typedef enum {
+    RELP_K_PRICE = 0, RELP_K_SELECT_COLUMN = 1, RELP_K_BUILD_COLUMN = 2, RELP_K_FTRAN = 3,
+    RELP_K_RATIO = 4, RELP_K_UPDATE_VECTORS = 5, RELP_K_UPDATE_INVERSE = 6, RELP_K_COUNT = 7
+} relp_kernel_id_t;
+/* When enabled, every launch of the listed kernel classes inside relp_run is bracketed by HIP
+ * events on the engine's stream; relp_profile_read sums them (this synchronises). */
+relp_status_t relp_profile_enable(relp_engine_t *h, int32_t enable, int64_t max_launches);
+relp_status_t relp_profile_read(relp_engine_t *h, int32_t kernel_id, int64_t *launches, double *total_ms);
+
+/* ---- synthetic workloads (bench / tests; rust-lp_amd/synthetic.py defines the numbers) ----------
+ * Fills a column-major m x n matrix on the device with A[i,j] = (1 + x(0, j*m+i) % 999) / 1000. */
+relp_status_t relp_synth_fill_dense(double *device_a, int64_t ld, int32_t m, int32_t n, uint64_t seed,
+                                    int64_t first_column, void *hip_stream);
+relp_status_t relp_device_alloc(void **out, int64_t bytes);
+relp_status_t relp_device_free(void *p);
+
+/* ---- multi-GPU shards: structural columns [col_lo, col_hi) and rows
+ * [row_lo, row_hi) of B^-1 live on this rank; b, -pi, basis are replicated.  Buffers are device
+ * pointers the caller exchanges with RCCL on the engine's stream; no host sync inside. ----------- */
+relp_status_t relp_shard_ranges(const relp_engine_t *h, int32_t *col_lo, int32_t *col_hi,
+                                int32_t *row_lo, int32_t *row_hi, int32_t *row_slice_stride);
+/* columns [lo, hi) of the structural block owned by `rank` of `count` (what relp_engine_create
+ * expects in `dense` when cfg.shard_count > 1) */
+void          relp_shard_column_range(int32_t nr_normal, int32_t rank, int32_t count, int32_t *lo, int32_t *hi);
+/* message length in doubles of one PRICE candidate: [key, j, d_j, a_j (m entries, tableau row space)] */
+int64_t       relp_shard_candidate_len(const relp_engine_t *h);
+/* length in doubles of the rho buffer (m rounded up to the B^-1 row pitch) */
+int64_t       relp_shard_rho_len(const relp_engine_t *h);
+/* local PRICE over the owned columns (+ every virtual column) -> candidate message */
+relp_status_t relp_shard_price(relp_engine_t *h, double *dev_candidate);
+/* choose the global entering column from `count` gathered candidates (min d, then min j) */
+relp_status_t relp_shard_select_column(relp_engine_t *h, const double *dev_candidates, int32_t count);
+/* FTRAN slice: alpha[row_lo:row_hi) into dev_alpha_slice (row_slice_stride entries, zero padded) */
+relp_status_t relp_shard_ftran(relp_engine_t *h, double *dev_alpha_slice);
+/* ratio test on the gathered alpha (count slices of row_slice_stride); the owner of the pivot row
+ * writes rho = row_r(B^-1)/alpha_r into dev_rho (m entries), every other rank writes zeros, so a
+ * SUM all-reduce of dev_rho is the broadcast */
+relp_status_t relp_shard_ratio(relp_engine_t *h, const double *dev_alpha_slices, int32_t count, double *dev_rho);
+/* rank-1 update of the owned rows + replicated b, -pi, obj, basis */
+relp_status_t relp_shard_update(relp_engine_t *h, const double *dev_rho);
+/* outcome poll (one small device->host copy) */
+relp_status_t relp_poll(relp_engine_t *h, int32_t *outcome, int64_t *iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELP_ENGINE_H */

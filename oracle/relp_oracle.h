@@ -1,0 +1,83 @@
+/*
+ * relp_oracle.h -- C (f64) CPU restatement of RELP's revised-simplex pivot path.
+ *
+ * TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library, and only as the checker / the reported CPU baseline.  The product
+ * (rust-lp_amd/) never links or loads it.
+ *
+ * It restates, single-threaded and with the reference's own data structures (sorted sparse
+ * (index, value) vectors with exact zeros removed, dense b and -pi, per-column clone in PRICE):
+ *   two_phase/phase_one.rs, phase_two.rs, strategy/pivot_rule.rs, tableau/mod.rs,
+ *   tableau/kind/{artificial/partially.rs, non_artificial.rs},
+ *   inverse_maintenance/carry/{mod.rs, basis_inverse_rows.rs}, matrix_provider/matrix_data.rs.
+ * Field = double.  The reference has NO float field (README.md:27; ops.rs:43-46 needs Ord+Eq), so
+ * this is the build's f64 extension of the same algorithm; its results are pinned by comparing
+ * its pivot traces with the exact oracle (oracle/relp_exact.py) in tests/.
+ *
+ * Tolerances (all 0 => literally the reference's exact comparisons):
+ *   tol_cost  : column j is a candidate iff d_j < -tol_cost          (pivot_rule.rs:56,81,117)
+ *   tol_pivot : row i takes part in the ratio test iff alpha_i > tol_pivot   (tableau/mod.rs:227)
+ *   tol_zero  : |b_i| <= tol_zero is read as b_i = 0 in the ratio            (f64 only)
+ *   tol_tie   : rows with ratio <= min + tol_tie*max(1,|min|) tie; smallest leaving column wins
+ *               (tableau/mod.rs:229-239, Bland)
+ *   tol_feas  : phase 1 is feasible iff |objective| <= tol_feas*max(1, initial objective)
+ */
+#ifndef RELP_ORACLE_H
+#define RELP_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t nr_normal;                       /* structural columns */
+    int32_t nr_eq, nr_range, nr_le, nr_ge;   /* constraint rows, stored in this order */
+    const int64_t *col_ptr;                  /* CSC over constraint rows: nr_normal + 1 */
+    const int32_t *row_idx;                  /* sorted inside each column */
+    const double  *values;
+    const double  *b;                        /* nr_constraints */
+    const double  *ranges;                   /* nr_range */
+    const double  *cost;                     /* nr_normal */
+    const double  *upper_bound;              /* nr_normal; +inf = no upper bound */
+} oracle_matrix_data_t;
+
+typedef struct {
+    double tol_cost, tol_pivot, tol_zero, tol_tie, tol_feas;
+    int32_t phase_one_rule;                  /* 0 FirstProfitable, 1 FirstProfitableWithMemory, 2 SteepestDescent */
+    int32_t phase_two_rule;
+} oracle_config_t;
+
+enum { ORACLE_RULE_FIRST_PROFITABLE = 0, ORACLE_RULE_FIRST_PROFITABLE_WITH_MEMORY = 1, ORACLE_RULE_STEEPEST_DESCENT = 2 };
+enum { ORACLE_RUNNING = 0, ORACLE_OPTIMAL = 1, ORACLE_UNBOUNDED = 2, ORACLE_INFEASIBLE = 3,
+       ORACLE_ITERATION_LIMIT = 4, ORACLE_PHASE_ONE_DONE = 5, ORACLE_ERROR = -1 };
+
+typedef struct oracle_engine oracle_engine_t;
+
+/* Copies the problem.  Builds the partially-artificial phase-1 tableau (partially.rs:125-206). */
+oracle_engine_t *oracle_create(const oracle_matrix_data_t *md, const oracle_config_t *cfg);
+void oracle_destroy(oracle_engine_t *e);
+
+/* Run up to max_iters basis changes of the current phase (phase-1 -> phase-2 switch included when
+ * `through_phases` != 0).  Appends to the trace arrays (each of capacity trace_cap, may be NULL).
+ * Returns the status enum. */
+int oracle_run(oracle_engine_t *e, int64_t max_iters, int through_phases,
+               int32_t *tr_phase, int32_t *tr_entering, int32_t *tr_row, int32_t *tr_leaving,
+               int64_t trace_cap, int64_t *n_done);
+
+int32_t oracle_m(const oracle_engine_t *e);           /* rows of the current tableau */
+int32_t oracle_n(const oracle_engine_t *e);           /* columns of the current tableau (incl. artificials) */
+int32_t oracle_phase(const oracle_engine_t *e);       /* 1 or 2 */
+int32_t oracle_nr_artificial(const oracle_engine_t *e);
+double  oracle_objective(const oracle_engine_t *e);
+void    oracle_get_b(const oracle_engine_t *e, double *out);
+void    oracle_get_minus_pi(const oracle_engine_t *e, double *out);
+void    oracle_get_basis(const oracle_engine_t *e, int32_t *out);
+/* dense row-major copy of B^-1 (m*m) */
+void    oracle_get_basis_inverse(const oracle_engine_t *e, double *out);
+int64_t oracle_basis_inverse_nnz(const oracle_engine_t *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

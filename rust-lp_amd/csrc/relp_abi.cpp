@@ -1,0 +1,130 @@
+// relp_abi.cpp -- the extern "C" boundary declared in include/relp_engine.h.  Thin forwarding only.
+#include <cstring>
+#include <new>
+
+#include "relp_engine.hpp"
+
+using relp::Engine;
+
+struct relp_engine { Engine impl; };
+
+#define H(h) ((h)->impl)
+
+extern "C" {
+
+void relp_default_config(relp_config_t* cfg) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->device = -1;
+    cfg->phase_one_rule = RELP_RULE_FIRST_PROFITABLE_WITH_MEMORY;   // phase_one.rs:55,97
+    cfg->phase_two_rule = RELP_RULE_STEEPEST_DESCENT;               // two_phase/mod.rs:44,101
+    cfg->tol_cost = 1e-9; cfg->tol_pivot = 1e-9; cfg->tol_zero = 1e-11; cfg->tol_tie = 1e-9; cfg->tol_feas = 1e-9;
+    cfg->poll_interval = 64;
+    cfg->trace_capacity = 0;
+    cfg->shard_rank = 0; cfg->shard_count = 1;
+}
+
+const char* relp_last_error(const relp_engine_t* h) { return h ? H(h).last_error() : "null handle"; }
+const char* relp_version(void) { return "relp-mi355x 0.1 (gfx950, explicit-inverse engine)"; }
+
+relp_status_t relp_engine_create(const relp_matrix_data_t* md, const relp_config_t* cfg, relp_engine_t** out) {
+    if (!md || !cfg || !out) return RELP_E_ARG;
+    relp_engine_t* h = new (std::nothrow) relp_engine_t();
+    if (!h) return RELP_E_ALLOC;
+    relp_status_t st = H(h).create(*md, *cfg);
+    *out = h;   // returned even on failure so that relp_last_error can be read; caller destroys it
+    return st;
+}
+
+void relp_engine_destroy(relp_engine_t* h) { delete h; }
+relp_status_t relp_set_stream(relp_engine_t* h, void* s) { return h ? H(h).set_stream((hipStream_t)s) : RELP_E_ARG; }
+
+relp_status_t relp_select_primal_pivot_column(relp_engine_t* h, int32_t rule, int32_t* found, int32_t* column, double* cost) {
+    return h ? H(h).select_primal_pivot_column(rule, found, column, cost) : RELP_E_ARG;
+}
+relp_status_t relp_relative_costs(relp_engine_t* h, double* out) { return (h && out) ? H(h).relative_costs(out) : RELP_E_ARG; }
+relp_status_t relp_generate_column(relp_engine_t* h, int32_t column, double* out) { return h ? H(h).generate_column(column, out) : RELP_E_ARG; }
+relp_status_t relp_generate_element(relp_engine_t* h, int32_t row, int32_t column, double* out) {
+    return h ? H(h).generate_element(row, column, out) : RELP_E_ARG;
+}
+relp_status_t relp_select_primal_pivot_row(relp_engine_t* h, int32_t* found, int32_t* row) {
+    return h ? H(h).select_primal_pivot_row(found, row) : RELP_E_ARG;
+}
+relp_status_t relp_bring_into_basis(relp_engine_t* h, int32_t column, int32_t row, double cost, int32_t* leaving) {
+    return h ? H(h).bring_into_basis(column, row, cost, leaving) : RELP_E_ARG;
+}
+
+relp_status_t relp_run(relp_engine_t* h, int64_t max_iters, int64_t* done, int32_t* outcome) {
+    return h ? H(h).run(max_iters, done, outcome) : RELP_E_ARG;
+}
+relp_status_t relp_solve_relaxation(relp_engine_t* h, int64_t max_iters, int32_t* outcome) {
+    return h ? H(h).solve_relaxation(max_iters, outcome) : RELP_E_ARG;
+}
+relp_status_t relp_from_basis(relp_engine_t* h, const int32_t* basis) { return (h && basis) ? H(h).from_basis(basis) : RELP_E_ARG; }
+
+int32_t relp_nr_rows(const relp_engine_t* h) { return h ? H(h).nr_rows() : -1; }
+int32_t relp_nr_columns(const relp_engine_t* h) { return h ? H(h).nr_columns() : -1; }
+int32_t relp_phase(const relp_engine_t* h) { return h ? H(h).phase() : -1; }
+int32_t relp_nr_artificial(const relp_engine_t* h) { return h ? H(h).nr_artificial() : -1; }
+relp_status_t relp_get_objective(relp_engine_t* h, double* out) { return (h && out) ? H(h).get_objective(out) : RELP_E_ARG; }
+relp_status_t relp_get_b(relp_engine_t* h, double* out) { return (h && out) ? H(h).get_vector(0, out) : RELP_E_ARG; }
+relp_status_t relp_get_minus_pi(relp_engine_t* h, double* out) { return (h && out) ? H(h).get_vector(1, out) : RELP_E_ARG; }
+relp_status_t relp_get_basis_indices(relp_engine_t* h, int32_t* out) { return (h && out) ? H(h).get_basis_indices(out) : RELP_E_ARG; }
+relp_status_t relp_get_basis_inverse(relp_engine_t* h, double* out) { return (h && out) ? H(h).get_basis_inverse(out) : RELP_E_ARG; }
+relp_status_t relp_current_bfs(relp_engine_t* h, int32_t* cols, double* vals, int32_t cap, int32_t* count) {
+    return h ? H(h).current_bfs(cols, vals, cap, count) : RELP_E_ARG;
+}
+relp_status_t relp_get_iterations(relp_engine_t* h, int64_t* out) { return (h && out) ? H(h).get_iterations(out) : RELP_E_ARG; }
+relp_status_t relp_get_trace(relp_engine_t* h, int32_t* phase, int32_t* entering, int32_t* row, int32_t* leaving,
+                             int64_t cap, int64_t* count) {
+    return h ? H(h).get_trace(phase, entering, row, leaving, cap, count) : RELP_E_ARG;
+}
+relp_status_t relp_check_basis(relp_engine_t* h, double* e1, double* e2, double* mb) { return h ? H(h).check_basis(e1, e2, mb) : RELP_E_ARG; }
+
+relp_status_t relp_profile_enable(relp_engine_t* h, int32_t enable, int64_t max_launches) {
+    return h ? H(h).profile_enable(enable != 0, max_launches) : RELP_E_ARG;
+}
+relp_status_t relp_profile_read(relp_engine_t* h, int32_t kid, int64_t* launches, double* total_ms) {
+    return h ? H(h).profile_read(kid, launches, total_ms) : RELP_E_ARG;
+}
+
+relp_status_t relp_synth_fill_dense(double* device_a, int64_t ld, int32_t m, int32_t n, uint64_t seed,
+                                    int64_t first_column, void* hip_stream) {
+    if (!device_a || ld < m || m < 0 || n < 0) return RELP_E_ARG;
+    relp::launch_fill_dense(device_a, ld, m, n, seed, first_column, (hipStream_t)hip_stream);
+    if (hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) return RELP_E_HIP;
+    return hipGetLastError() == hipSuccess ? RELP_OK : RELP_E_HIP;
+}
+relp_status_t relp_device_alloc(void** out, int64_t bytes) {
+    if (!out || bytes < 0) return RELP_E_ARG;
+    return hipMalloc(out, (size_t)(bytes ? bytes : 1)) == hipSuccess ? RELP_OK : RELP_E_ALLOC;
+}
+relp_status_t relp_device_free(void* p) { return hipFree(p) == hipSuccess ? RELP_OK : RELP_E_HIP; }
+
+relp_status_t relp_shard_ranges(const relp_engine_t* h, int32_t* col_lo, int32_t* col_hi, int32_t* row_lo,
+                                int32_t* row_hi, int32_t* stride) {
+    if (!h) return RELP_E_ARG;
+    H(h).shard_ranges(col_lo, col_hi, row_lo, row_hi, stride);
+    return RELP_OK;
+}
+void relp_shard_column_range(int32_t nr_normal, int32_t rank, int32_t count, int32_t* lo, int32_t* hi) {
+    if (count < 1) count = 1;
+    const int32_t per = (nr_normal + count - 1) / count;
+    int32_t a = rank * per; if (a > nr_normal) a = nr_normal;
+    int32_t b = a + per; if (b > nr_normal) b = nr_normal;
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+}
+int64_t relp_shard_candidate_len(const relp_engine_t* h) { return h ? H(h).candidate_len() : -1; }
+int64_t relp_shard_rho_len(const relp_engine_t* h) { return h ? H(h).rho_len() : -1; }
+relp_status_t relp_shard_price(relp_engine_t* h, double* c) { return (h && c) ? H(h).shard_price(c) : RELP_E_ARG; }
+relp_status_t relp_shard_select_column(relp_engine_t* h, const double* c, int32_t count) {
+    return (h && c) ? H(h).shard_select_column(c, count) : RELP_E_ARG;
+}
+relp_status_t relp_shard_ftran(relp_engine_t* h, double* a) { return (h && a) ? H(h).shard_ftran(a) : RELP_E_ARG; }
+relp_status_t relp_shard_ratio(relp_engine_t* h, const double* a, int32_t count, double* rho) {
+    return (h && a && rho) ? H(h).shard_ratio(a, count, rho) : RELP_E_ARG;
+}
+relp_status_t relp_shard_update(relp_engine_t* h, const double* rho) { return (h && rho) ? H(h).shard_update(rho) : RELP_E_ARG; }
+relp_status_t relp_poll(relp_engine_t* h, int32_t* outcome, int64_t* iterations) { return h ? H(h).poll(outcome, iterations) : RELP_E_ARG; }
+
+}  // extern "C"

@@ -1,0 +1,828 @@
+// relp_engine.cpp -- host driver: problem upload, phase logic, launch sequencing.  See relp_engine.hpp.
+#include "relp_engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace relp {
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        if (!hip_ok((expr), #expr)) return RELP_E_HIP;                       \
+    } while (0)
+
+static inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+bool Engine::hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err_ = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+template <class T>
+static hipError_t dev_alloc(T** p, int64_t count) {
+    if (count < 1) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, (size_t)count * sizeof(T));
+}
+
+void Engine::free_all() {
+    auto fr = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    if (owns_A_) fr(dA_);
+    dA_ = nullptr;
+    fr(dBinv_); fr(d_minus_pi_); fr(d_b_); fr(d_alpha_); fr(d_aq_); fr(d_rho_); fr(d_d_); fr(d_w_); fr(d_cost_);
+    fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
+    fr(d_in_basis_); fr(d_rec_);
+    if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
+    for (auto e : prof_ev_) (void)hipEventDestroy(e);
+    prof_ev_.clear();
+    if (owns_stream_ && stream_) { (void)hipStreamDestroy(stream_); }
+    stream_ = nullptr;
+}
+
+Engine::~Engine() { free_all(); }
+
+ColumnTable Engine::table() const {
+    ColumnTable ct;
+    ct.nr_artificial = nr_artificial_;
+    ct.nr_normal = nr_normal_;
+    ct.nr_virtual = nr_virtual_;
+    ct.nr_constraints = mc_;
+    ct.column_to_row = d_column_to_row_;
+    ct.bound_row = d_bound_row_;
+    ct.vrow0 = d_vrow0_;
+    ct.vrow1 = d_vrow1_;
+    ct.vsign = d_vsign_;
+    ct.cost = d_cost_;
+    return ct;
+}
+
+Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie}; }
+
+relp_status_t Engine::download_rec() {
+    HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+relp_status_t Engine::upload_rec() {
+    HIP_TRY(hipMemcpyAsync(d_rec_, h_rec_, sizeof(PivotRecord), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+relp_status_t Engine::set_stream(hipStream_t s) {
+    if (stream_) HIP_TRY(hipStreamSynchronize(stream_));
+    if (owns_stream_ && stream_) HIP_TRY(hipStreamDestroy(stream_));
+    stream_ = s;
+    owns_stream_ = false;
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Construction: MatrixData layout (matrix_data.rs:198-268, 308-371, 432-452) and the partially
+// artificial start (partially.rs:125-206, carry/mod.rs:381-426)
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& cfg) {
+    cfg_ = cfg;
+    if (md.nr_normal < 0 || md.nr_eq < 0 || md.nr_range < 0 || md.nr_le < 0 || md.nr_ge < 0)
+        return fail(RELP_E_ARG, "negative size");
+    if (cfg_.shard_count < 1) cfg_.shard_count = 1;
+    if (cfg_.shard_rank < 0 || cfg_.shard_rank >= cfg_.shard_count) return fail(RELP_E_ARG, "bad shard rank");
+    if (cfg_.poll_interval < 1) cfg_.poll_interval = 64;
+    if (cfg_.device >= 0) HIP_TRY(hipSetDevice(cfg_.device));
+
+    nr_normal_ = md.nr_normal; nr_eq_ = md.nr_eq; nr_range_ = md.nr_range; nr_le_ = md.nr_le; nr_ge_ = md.nr_ge;
+    mc_ = nr_eq_ + nr_range_ + nr_le_ + nr_ge_;
+    if ((mc_ > 0 && !md.b) || (nr_normal_ > 0 && (!md.cost || !md.upper_bound)) || (nr_range_ > 0 && !md.ranges))
+        return fail(RELP_E_ARG, "missing b / cost / upper_bound / ranges");
+
+    cost_h_.assign(md.cost, md.cost + nr_normal_);
+    upper_h_.assign(md.upper_bound, md.upper_bound + nr_normal_);
+    bound_row_h_.assign(nr_normal_, -1);
+    std::vector<int32_t> bound_to_var;
+    for (int32_t j = 0; j < nr_normal_; ++j)
+        if (std::isfinite(upper_h_[j])) { bound_row_h_[j] = mc_ + (int32_t)bound_to_var.size(); bound_to_var.push_back(j); }
+    nr_bounds_ = (int32_t)bound_to_var.size();
+    m_ = mc_ + nr_bounds_ + nr_range_;
+    if (m_ < 1) return fail(RELP_E_ARG, "empty problem");
+    const int32_t row_start[7] = {0, nr_eq_, nr_eq_ + nr_range_, nr_eq_ + nr_range_ + nr_le_, mc_, mc_ + nr_bounds_, m_};
+    // virtual columns in provider order: range slack | <= slack | >= slack | bound slack | range-bound slack
+    nr_virtual_ = nr_range_ + nr_le_ + nr_ge_ + nr_bounds_ + nr_range_;
+    n_provider_ = nr_normal_ + nr_virtual_;
+    vrow0_h_.clear(); vrow1_h_.clear(); vsign_h_.clear();
+    for (int32_t k = 0; k < nr_range_; ++k) { vrow0_h_.push_back(row_start[1] + k); vrow1_h_.push_back(row_start[5] + k); vsign_h_.push_back(1); }
+    for (int32_t k = 0; k < nr_le_; ++k) { vrow0_h_.push_back(row_start[2] + k); vrow1_h_.push_back(-1); vsign_h_.push_back(1); }
+    for (int32_t k = 0; k < nr_ge_; ++k) { vrow0_h_.push_back(row_start[3] + k); vrow1_h_.push_back(-1); vsign_h_.push_back(-1); }
+    for (int32_t k = 0; k < nr_bounds_; ++k) { vrow0_h_.push_back(row_start[4] + k); vrow1_h_.push_back(-1); vsign_h_.push_back(1); }
+    for (int32_t k = 0; k < nr_range_; ++k) { vrow0_h_.push_back(row_start[5] + k); vrow1_h_.push_back(-1); vsign_h_.push_back(1); }
+    // right_hand_side = (b, upper bounds, ranges), matrix_data.rs:359-371
+    rhs_h_.assign(m_, 0.0);
+    for (int32_t i = 0; i < mc_; ++i) rhs_h_[i] = md.b[i];
+    for (int32_t k = 0; k < nr_bounds_; ++k) rhs_h_[mc_ + k] = upper_h_[bound_to_var[k]];
+    for (int32_t k = 0; k < nr_range_; ++k) rhs_h_[mc_ + nr_bounds_ + k] = md.ranges[k];
+
+    // shards: structural columns and rows of B^-1
+    {
+        const int32_t G = cfg_.shard_count, g = cfg_.shard_rank;
+        const int32_t cper = (nr_normal_ + G - 1) / G;
+        col_lo_ = std::min(nr_normal_, g * cper);
+        col_hi_ = std::min(nr_normal_, col_lo_ + cper);
+        row_stride_ = (int32_t)round_up((m_ + G - 1) / G, 2);
+        row_lo_ = std::min(m_, g * row_stride_);
+        row_hi_ = std::min(m_, row_lo_ + row_stride_);
+        cand_len_ = round_up(3 + (int64_t)m_, 2);
+    }
+
+    // initial basis: <=-slacks, bound slacks, range-bound slacks are real pivots (matrix_data.rs:432-452);
+    // every other row gets an artificial, numbered before all provider columns (partially.rs:72-80)
+    std::vector<int32_t> real_row, real_col;
+    const int32_t col_start2 = nr_normal_ + nr_range_;                    // <= slacks
+    const int32_t col_start4 = nr_normal_ + nr_range_ + nr_le_ + nr_ge_;  // bound slacks
+    const int32_t col_start5 = col_start4 + nr_bounds_;                   // range-bound slacks
+    for (int32_t k = 0; k < nr_le_; ++k) { real_row.push_back(row_start[2] + k); real_col.push_back(col_start2 + k); }
+    for (int32_t k = 0; k < nr_bounds_; ++k) { real_row.push_back(row_start[4] + k); real_col.push_back(col_start4 + k); }
+    for (int32_t k = 0; k < nr_range_; ++k) { real_row.push_back(row_start[5] + k); real_col.push_back(col_start5 + k); }
+    const int32_t nr_real = (int32_t)real_row.size();
+    nr_artificial_ = m_ - nr_real;
+    if (cfg_.shard_count > 1 && nr_artificial_ > 0)
+        return fail(RELP_E_UNSUPPORTED, "sharded engine needs a full slack basis (no artificial variables)");
+    column_to_row_.assign(nr_artificial_, 0);
+    {
+        int32_t i = 0;
+        for (int32_t ith = 0; ith < nr_artificial_; ++ith) {
+            while (i < nr_real && ith + i == real_row[i]) ++i;
+            column_to_row_[ith] = ith + i;
+        }
+    }
+    std::vector<int32_t> basis(m_);
+    {
+        int32_t ac = 0;
+        for (int32_t row = 0; row < m_; ++row) {
+            const bool can_a = ac < nr_artificial_, can_r = (row - ac) < nr_real;
+            if (can_a && can_r) {
+                if (column_to_row_[ac] < real_row[row - ac]) basis[row] = ac++;
+                else basis[row] = nr_artificial_ + real_col[row - ac];
+            } else if (can_a) basis[row] = ac++;
+            else basis[row] = nr_artificial_ + real_col[row - ac];
+        }
+    }
+    phase_ = 1;
+    n_alloc_ = nr_artificial_ + n_provider_;
+
+    // ---- device allocations ----
+    HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    owns_stream_ = true;
+    const int32_t n_local = col_hi_ - col_lo_;
+    if (md.format == RELP_FORMAT_DENSE) {
+        if (nr_normal_ > 0 && mc_ > 0 && !md.dense) return fail(RELP_E_ARG, "dense matrix missing");
+        const int64_t src_ld = md.dense_ld > 0 ? md.dense_ld : mc_;
+        if (src_ld < mc_) return fail(RELP_E_ARG, "dense_ld < nr_constraints");
+        // In sharded mode `dense` holds only the owned columns [col_lo, col_hi).
+        if (md.matrix_memory == RELP_MEM_DEVICE && (src_ld % 2) == 0) {
+            dA_ = const_cast<double*>(md.dense); ld_a_ = src_ld; owns_A_ = false;          // zero-copy adoption
+        } else {
+            ld_a_ = round_up(std::max<int64_t>(mc_, 1), 2);
+            HIP_TRY(dev_alloc(&dA_, ld_a_ * std::max(n_local, 1)));
+            owns_A_ = true;
+            if (n_local > 0 && mc_ > 0)
+                HIP_TRY(hipMemcpy2D(dA_, ld_a_ * sizeof(double), md.dense, src_ld * sizeof(double), mc_ * sizeof(double),
+                                    n_local, md.matrix_memory == RELP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        }
+    } else if (md.format == RELP_FORMAT_CSC) {
+        if (md.matrix_memory != RELP_MEM_HOST) return fail(RELP_E_UNSUPPORTED, "CSC input must be in host memory");
+        if (!md.col_ptr) return fail(RELP_E_ARG, "col_ptr missing");
+        ld_a_ = round_up(std::max<int64_t>(mc_, 1), 2);
+        std::vector<double> dense((size_t)ld_a_ * std::max(n_local, 1), 0.0);
+        for (int32_t j = col_lo_; j < col_hi_; ++j)
+            for (int64_t p = md.col_ptr[j]; p < md.col_ptr[j + 1]; ++p) {
+                const int32_t i = md.row_idx[p];
+                if (i < 0 || i >= mc_) return fail(RELP_E_ARG, "row index out of range");
+                dense[(size_t)(j - col_lo_) * ld_a_ + i] = md.values[p];
+            }
+        HIP_TRY(dev_alloc(&dA_, (int64_t)dense.size()));
+        owns_A_ = true;
+        HIP_TRY(hipMemcpy(dA_, dense.data(), dense.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        return fail(RELP_E_ARG, "unknown matrix format");
+    }
+
+    ld_b_ = round_up(m_, 16);
+    const int64_t rows_local = std::max(row_hi_ - row_lo_, 1);
+    HIP_TRY(dev_alloc(&dBinv_, rows_local * ld_b_));
+    HIP_TRY(dev_alloc(&d_minus_pi_, ld_b_));
+    HIP_TRY(dev_alloc(&d_b_, ld_b_));
+    HIP_TRY(dev_alloc(&d_alpha_, ld_b_));
+    HIP_TRY(dev_alloc(&d_aq_, ld_b_));
+    HIP_TRY(dev_alloc(&d_rho_, ld_b_));
+    HIP_TRY(dev_alloc(&d_w_, ld_b_));
+    HIP_TRY(dev_alloc(&d_d_, n_alloc_));
+    HIP_TRY(dev_alloc(&d_cost_, nr_normal_));
+    HIP_TRY(dev_alloc(&d_basis_, m_));
+    HIP_TRY(dev_alloc(&d_column_to_row_, nr_artificial_));
+    HIP_TRY(dev_alloc(&d_bound_row_, nr_normal_));
+    HIP_TRY(dev_alloc(&d_vrow0_, nr_virtual_));
+    HIP_TRY(dev_alloc(&d_vrow1_, nr_virtual_));
+    HIP_TRY(dev_alloc(&d_vsign_, nr_virtual_));
+    HIP_TRY(dev_alloc(&d_in_basis_, n_alloc_));
+    HIP_TRY(dev_alloc(&d_rec_, 1));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_rec_), sizeof(PivotRecord), hipHostMallocDefault));
+    trace_cap_ = std::max(cfg_.trace_capacity, 0);
+    if (trace_cap_ > 0) HIP_TRY(dev_alloc(&d_trace_, 4 * trace_cap_));
+
+    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    HIP_TRY(up(d_cost_, cost_h_.data(), sizeof(double) * nr_normal_));
+    HIP_TRY(up(d_bound_row_, bound_row_h_.data(), sizeof(int32_t) * nr_normal_));
+    HIP_TRY(up(d_vrow0_, vrow0_h_.data(), sizeof(int32_t) * nr_virtual_));
+    HIP_TRY(up(d_vrow1_, vrow1_h_.data(), sizeof(int32_t) * nr_virtual_));
+    HIP_TRY(up(d_vsign_, vsign_h_.data(), sizeof(int32_t) * nr_virtual_));
+    HIP_TRY(up(d_column_to_row_, column_to_row_.data(), sizeof(int32_t) * nr_artificial_));
+    HIP_TRY(up(d_basis_, basis.data(), sizeof(int32_t) * m_));
+    HIP_TRY(up(d_b_, rhs_h_.data(), sizeof(double) * m_));
+    // Carry::create_for_partially_artificial, carry/mod.rs:381-426
+    std::vector<double> minus_pi(m_, 0.0);
+    double objective = 0.0;
+    for (int32_t k = 0; k < nr_artificial_; ++k) { objective += rhs_h_[column_to_row_[k]]; minus_pi[column_to_row_[k]] = -1.0; }
+    initial_phase1_objective_ = objective;
+    HIP_TRY(up(d_minus_pi_, minus_pi.data(), sizeof(double) * m_));
+    std::vector<uint8_t> flags(n_alloc_, 0);
+    for (int32_t r = 0; r < m_; ++r) flags[basis[r]] = 1;
+    HIP_TRY(up(d_in_basis_, flags.data(), flags.size()));
+    if (row_hi_ > row_lo_) {
+        // identity rows [row_lo, row_hi): local row i has its 1 in column row_lo + i
+        std::vector<double> ones(1, 1.0);
+        HIP_TRY(hipMemset(dBinv_, 0, sizeof(double) * rows_local * ld_b_));
+        for (int32_t i = row_lo_; i < row_hi_; ++i)
+            HIP_TRY(hipMemcpy(dBinv_ + (int64_t)(i - row_lo_) * ld_b_ + i, ones.data(), sizeof(double), hipMemcpyHostToDevice));
+    }
+    std::memset(h_rec_, 0, sizeof(PivotRecord));
+    h_rec_->outcome = DEV_RUNNING;
+    h_rec_->minus_objective = -objective;
+    h_rec_->last_selected = -1;
+    h_rec_->phase = 1;
+    relp_status_t st = upload_rec();
+    if (st) return st;
+    HIP_TRY(hipDeviceSynchronize());   // hipMemset on the null stream vs. our non-blocking stream
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Profiling
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::profile_enable(bool enable, int64_t max_launches) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (auto e : prof_ev_) (void)hipEventDestroy(e);
+    prof_ev_.clear(); prof_kid_.clear(); prof_open_ = false;
+    prof_on_ = enable;
+    if (enable) {
+        prof_ev_.resize((size_t)max_launches * 2);
+        for (auto& e : prof_ev_) HIP_TRY(hipEventCreate(&e));
+        prof_kid_.reserve((size_t)max_launches);
+    }
+    return RELP_OK;
+}
+
+void Engine::prof_begin(int kid) {
+    prof_open_ = false;
+    if (!prof_on_ || (prof_kid_.size() + 1) * 2 > prof_ev_.size()) return;
+    (void)hipEventRecord(prof_ev_[2 * prof_kid_.size()], stream_);
+    prof_kid_.push_back(kid);
+    prof_open_ = true;
+}
+
+void Engine::prof_end() {
+    if (!prof_open_) return;
+    (void)hipEventRecord(prof_ev_[2 * (prof_kid_.size() - 1) + 1], stream_);
+    prof_open_ = false;
+}
+
+relp_status_t Engine::profile_read(int kernel_id, int64_t* launches, double* total_ms) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    int64_t n = 0; double ms = 0.0;
+    for (size_t k = 0; k < prof_kid_.size(); ++k) {
+        if (prof_kid_[k] != kernel_id) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, prof_ev_[2 * k], prof_ev_[2 * k + 1]) == hipSuccess) { ms += t; ++n; }
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One pivot on the device
+// ------------------------------------------------------------------------------------------------
+// PRICE over the owned structural columns and every virtual column with vector `vec` (= -pi).
+void Engine::enqueue_price(int cost_mode, const double* vec, const PivotRecord* rec, int32_t p_lo, int32_t p_hi) {
+    const ColumnTable ct = table();
+    // dA_ holds the owned columns only: shift the base so that global column p indexes correctly
+    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+    launch_price_structural(A, ld_a_, ct, vec, d_d_, p_lo, p_hi, cost_mode, rec, stream_);
+    if (p_lo > 0 || p_hi < nr_normal_) launch_price_mask_unowned(ct, d_d_, p_lo, p_hi, rec, stream_);
+    launch_price_virtual(ct, vec, d_d_, cost_mode, rec, stream_);
+}
+
+void Engine::enqueue_iteration(int rule) {
+    const ColumnTable ct = table();
+    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    const int n = nr_columns();
+    prof_begin(RELP_K_PRICE);
+    enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
+    prof_end();
+    prof_begin(RELP_K_SELECT_COLUMN);
+    launch_select_column(d_d_, d_in_basis_, n, rule, cfg_.tol_cost, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_BUILD_COLUMN);
+    launch_build_column(A, ld_a_, ct, m_, d_aq_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_FTRAN);
+    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_RATIO);
+    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_VECTORS);
+    launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
+    launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
+                          stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_INVERSE);
+    launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, d_rho_, d_rec_, stream_);
+    prof_end();
+}
+
+// ---- step-wise API ------------------------------------------------------------------------------
+relp_status_t Engine::select_primal_pivot_column(int rule, int32_t* found, int32_t* column, double* cost) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    h_rec_->outcome = DEV_RUNNING;
+    if ((st = upload_rec())) return st;
+    enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
+    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, d_rec_, stream_);
+    if ((st = download_rec())) return st;
+    const bool ok = h_rec_->outcome == DEV_RUNNING;
+    if (found) *found = ok ? 1 : 0;
+    if (ok) { if (column) *column = h_rec_->q; if (cost) *cost = h_rec_->d_q; }
+    h_rec_->outcome = DEV_RUNNING;
+    return upload_rec();
+}
+
+relp_status_t Engine::relative_costs(double* out_n) {
+    enqueue_price(phase_, d_minus_pi_, nullptr, col_lo_, col_hi_);
+    HIP_TRY(hipMemcpyAsync(out_n, d_d_, sizeof(double) * nr_columns(), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+relp_status_t Engine::generate_column(int32_t column, double* out_m) {
+    if (column < 0 || column >= nr_columns()) return fail(RELP_E_ARG, "column out of range");
+    relp_status_t st = download_rec();
+    if (st) return st;
+    h_rec_->outcome = DEV_RUNNING;
+    h_rec_->q = column;
+    if ((st = upload_rec())) return st;
+    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
+    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+    if (out_m) HIP_TRY(hipMemcpyAsync(out_m, d_alpha_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+relp_status_t Engine::generate_element(int32_t row, int32_t column, double* out) {
+    if (row < 0 || row >= m_) return fail(RELP_E_ARG, "row out of range");
+    std::vector<double> col(m_);
+    relp_status_t st = generate_column(column, col.data());
+    if (st) return st;
+    if (out) *out = col[row];
+    return RELP_OK;
+}
+
+relp_status_t Engine::select_primal_pivot_row(int32_t* found, int32_t* row) {
+    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    relp_status_t st = download_rec();
+    if (st) return st;
+    const bool ok = h_rec_->outcome == DEV_RUNNING;
+    if (found) *found = ok ? 1 : 0;
+    if (ok && row) *row = h_rec_->r;
+    h_rec_->outcome = DEV_RUNNING;
+    return upload_rec();
+}
+
+relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost, int32_t* leaving) {
+    if (column < 0 || column >= nr_columns() || row < 0 || row >= m_) return fail(RELP_E_ARG, "index out of range");
+    relp_status_t st = download_rec();
+    if (st) return st;
+    double alpha_r = 0.0, b_r = 0.0; int32_t lv = 0;
+    HIP_TRY(hipMemcpy(&alpha_r, d_alpha_ + row, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&b_r, d_b_ + row, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&lv, d_basis_ + row, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
+    h_rec_->outcome = DEV_RUNNING;
+    h_rec_->q = column; h_rec_->d_q = cost; h_rec_->r = row; h_rec_->leaving = lv; h_rec_->alpha_r = alpha_r; h_rec_->b_r = b_r;
+    if ((st = upload_rec())) return st;
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
+    launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
+                          stream_);
+    launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, d_rho_, d_rec_, stream_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (leaving) *leaving = lv;
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loops (phase_one.rs:125-170, phase_two.rs:22-51)
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    const long long start = h_rec_->iterations;
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
+        enqueue_iteration(rule);
+        if ((it + 1) % cfg_.poll_interval == 0) {
+            if ((st = download_rec())) return st;
+            if (h_rec_->outcome != DEV_RUNNING) break;
+        }
+    }
+    if ((st = download_rec())) return st;
+    if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
+    if (done) *done = h_rec_->iterations - start;
+    int32_t oc = RELP_RUNNING;
+    if (h_rec_->outcome == DEV_NO_CANDIDATE) {
+        if (phase_ == 2) oc = RELP_OPTIMAL;
+        else if ((st = finish_phase_one(&oc))) return st;
+    } else if (h_rec_->outcome == DEV_NO_ROW) {
+        oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
+    }
+    if (outcome) *outcome = oc;
+    return RELP_OK;
+}
+
+relp_status_t Engine::solve_relaxation(int64_t max_iters, int32_t* outcome) {
+    int32_t oc = RELP_RUNNING; int64_t done = 0, total = 0;
+    relp_status_t st;
+    if (phase_ == 1) {
+        if ((st = run(max_iters, &done, &oc))) return st;
+        total += done;
+        if (oc != RELP_PHASE_ONE_DONE) { if (outcome) *outcome = oc; return RELP_OK; }
+    }
+    if ((st = run(std::max<int64_t>(max_iters - total, 0), &done, &oc))) return st;
+    if (outcome) *outcome = oc;
+    return RELP_OK;
+}
+
+// phase_one.rs:146-166: objective == 0 -> feasible (remove artificials, switch) else infeasible
+relp_status_t Engine::finish_phase_one(int32_t* outcome) {
+    const double obj = -h_rec_->minus_objective;
+    if (std::fabs(obj) > cfg_.tol_feas * std::max(1.0, initial_phase1_objective_)) { *outcome = RELP_INFEASIBLE; return RELP_OK; }
+    std::vector<int32_t> rows_to_remove;
+    relp_status_t st = remove_artificial_basis_variables(rows_to_remove);
+    if (st) return st;
+    if ((st = switch_to_phase_two(rows_to_remove))) return st;
+    *outcome = RELP_PHASE_ONE_DONE;
+    return RELP_OK;
+}
+
+// phase_one.rs:223-260 (pivots "at zero level"; pushes the artificial index like the reference)
+relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& rows_to_remove) {
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    std::vector<int32_t> arts;
+    for (int32_t v : basis) if (v < nr_artificial_) arts.push_back(v);
+    if (arts.empty()) return RELP_OK;
+    std::sort(arts.begin(), arts.end());
+    const int n = nr_columns();
+    std::vector<double> d(n), tau(n);
+    std::vector<uint8_t> inb(n);
+    relp_status_t st;
+    for (int32_t a : arts) {
+        const int32_t pivot_row = column_to_row_[a];
+        if ((st = relative_costs(d.data()))) return st;
+        // tableau row pivot_row over every column: (row of B^-1) . a_j, no cost term
+        double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+        enqueue_price(0, Binv + (int64_t)pivot_row * ld_b_, nullptr, col_lo_, col_hi_);
+        HIP_TRY(hipMemcpyAsync(tau.data(), d_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(inb.data(), d_in_basis_, n, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        int32_t q = -1;
+        for (int32_t j = nr_artificial_; j < n; ++j) {
+            if (inb[j]) continue;
+            if (std::fabs(d[j]) > cfg_.tol_cost) continue;
+            if (std::fabs(tau[j]) > cfg_.tol_pivot) { q = j; break; }
+        }
+        if (q < 0) { rows_to_remove.push_back(a); continue; }
+        if ((st = generate_column(q, nullptr))) return st;
+        if ((st = bring_into_basis(q, pivot_row, d[q], nullptr))) return st;
+    }
+    return RELP_OK;
+}
+
+// kind/non_artificial.rs:151-220, carry/mod.rs:484-510 (+ :650-689 when rows are removed)
+relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_remove) {
+    relp_status_t st;
+    if (!rows_to_remove.empty() && (st = remove_rows(rows_to_remove))) return st;
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    const int32_t na = nr_artificial_;
+    for (auto& v : basis) v -= na;
+    nr_artificial_ = 0;
+    phase_ = 2;
+    HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
+    std::vector<uint8_t> flags(n_alloc_, 0);
+    for (int32_t v : basis) { if (v < 0 || v >= n_provider_) return fail(RELP_E_STATE, "artificial variable left in the basis"); flags[v] = 1; }
+    HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));
+    // -pi = -(c_B' B^-1) (create_minus_pi_from_artificial, carry/mod.rs:214-248), accumulated over rows in order
+    std::vector<double> w(m_, 0.0), b(m_);
+    for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = cost_h_[basis[i]];
+    HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    launch_weighted_column_sums(Binv, ld_b_, m_, d_w_, d_minus_pi_, stream_);
+    // -obj = -sum_i b_i c_B(i) (create_minus_obj_from_artificial, carry/mod.rs:258-271)
+    HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+    if ((st = download_rec())) return st;
+    double objective = 0.0;
+    for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) objective += b[i] * cost_h_[basis[i]];
+    h_rec_->minus_objective = -objective;
+    h_rec_->outcome = DEV_RUNNING;
+    h_rec_->last_selected = -1;
+    h_rec_->phase = 2;
+    return upload_rec();
+}
+
+// Rank-deficient problems (filter/generic_wrapper.rs:51, carry/mod.rs:650-689, basis_inverse_rows.rs:190-204):
+// delete the given rows (and the same columns of B^-1) everywhere.  Rare, host round trip.
+relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
+    if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "row removal in sharded mode");
+    std::vector<int32_t> map(m_, 0);   // old row -> new row, -1 = removed
+    {
+        size_t f = 0; int32_t out = 0;
+        for (int32_t i = 0; i < m_; ++i) {
+            if (f < rows.size() && rows[f] == i) { map[i] = -1; ++f; } else map[i] = out++;
+        }
+    }
+    const int32_t m_new = m_ - (int32_t)rows.size();
+    for (int32_t r : rows) if (r >= mc_) return fail(RELP_E_STATE, "only constraint rows can be redundant");
+    const int32_t mc_new = mc_ - (int32_t)rows.size();
+    // B^-1, b, basis
+    std::vector<double> Bh((size_t)m_ * ld_b_), b(m_);
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpy(Bh.data(), dBinv_, Bh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    const int64_t ld_new = ld_b_;
+    std::vector<double> Bn((size_t)m_ * ld_new, 0.0), bn(m_, 0.0);
+    std::vector<int32_t> basisn(m_, 0);
+    for (int32_t i = 0; i < m_; ++i) {
+        if (map[i] < 0) continue;
+        for (int32_t j = 0; j < m_; ++j) if (map[j] >= 0) Bn[(size_t)map[i] * ld_new + map[j]] = Bh[(size_t)i * ld_b_ + j];
+        bn[map[i]] = b[i];
+        basisn[map[i]] = basis[i];
+    }
+    HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_b_, 0, sizeof(double) * ld_b_));
+    HIP_TRY(hipMemcpy(d_b_, bn.data(), sizeof(double) * m_new, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_basis_, basisn.data(), sizeof(int32_t) * m_new, hipMemcpyHostToDevice));
+    // A: drop the rows inside every structural column
+    if (nr_normal_ > 0) {
+        std::vector<double> Ah((size_t)ld_a_ * nr_normal_);
+        HIP_TRY(hipMemcpy(Ah.data(), dA_, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> An((size_t)ld_a_ * nr_normal_, 0.0);
+        for (int32_t j = 0; j < nr_normal_; ++j)
+            for (int32_t i = 0; i < mc_; ++i) if (map[i] >= 0) An[(size_t)j * ld_a_ + map[i]] = Ah[(size_t)j * ld_a_ + i];
+        if (!owns_A_) { HIP_TRY(dev_alloc(&dA_, (int64_t)An.size())); owns_A_ = true; }
+        HIP_TRY(hipMemcpy(dA_, An.data(), An.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // descriptors: every remaining row index shifts down (column/into_filtered, matrix_data.rs:592-614)
+    auto remap = [&](std::vector<int32_t>& v) { for (auto& x : v) if (x >= 0) x = map[x]; };
+    remap(bound_row_h_); remap(vrow0_h_); remap(vrow1_h_);
+    for (auto x : vrow0_h_) if (x < 0) return fail(RELP_E_STATE, "a slack row cannot be redundant");
+    for (auto& x : column_to_row_) x = map[x] >= 0 ? map[x] : 0;
+    HIP_TRY(hipMemcpy(d_bound_row_, bound_row_h_.data(), sizeof(int32_t) * nr_normal_, hipMemcpyHostToDevice));
+    if (nr_virtual_) {
+        HIP_TRY(hipMemcpy(d_vrow0_, vrow0_h_.data(), sizeof(int32_t) * nr_virtual_, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_vrow1_, vrow1_h_.data(), sizeof(int32_t) * nr_virtual_, hipMemcpyHostToDevice));
+    }
+    std::vector<double> rhs_new;
+    for (int32_t i = 0; i < m_; ++i) if (map[i] >= 0) rhs_new.push_back(rhs_h_[i]);
+    rhs_h_ = rhs_new;
+    m_ = m_new; mc_ = mc_new;
+    row_lo_ = 0; row_hi_ = m_;
+    row_stride_ = (int32_t)round_up(m_, 2);
+    cand_len_ = round_up(3 + (int64_t)m_, 2);
+    // stale tails of the m-vectors must be zero for the 16-byte loads
+    HIP_TRY(hipMemset(d_alpha_, 0, sizeof(double) * ld_b_));
+    HIP_TRY(hipMemset(d_aq_, 0, sizeof(double) * ld_b_));
+    HIP_TRY(hipMemset(d_rho_, 0, sizeof(double) * ld_b_));
+    HIP_TRY(hipMemset(d_minus_pi_, 0, sizeof(double) * ld_b_));
+    HIP_TRY(hipDeviceSynchronize());
+    return RELP_OK;
+}
+
+relp_status_t Engine::from_basis(const int32_t* basis_columns) {
+    // InverseMaintener::from_basis (carry/mod.rs:428-463).  Supported today: a basis made of unit
+    // columns only (slack bases, two_phase/mod.rs:103-111 `FullInitialBasis`), whose inverse is a
+    // signed permutation.  General warm starts need the dense inversion kernel (next round).
+    if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
+    std::vector<int32_t> basis(basis_columns, basis_columns + m_);
+    std::vector<double> Bn((size_t)m_ * ld_b_, 0.0), b(m_, 0.0);
+    std::vector<uint8_t> seen(m_, 0);
+    for (int32_t i = 0; i < m_; ++i) {
+        const int32_t p = basis[i];
+        if (p < nr_normal_ || p >= n_provider_) return fail(RELP_E_UNSUPPORTED, "from_basis: only slack bases are supported yet");
+        const int32_t v = p - nr_normal_;
+        if (vrow1_h_[v] >= 0) return fail(RELP_E_UNSUPPORTED, "from_basis: range slack in basis");
+        const int32_t row = vrow0_h_[v];
+        if (seen[row]) return fail(RELP_E_SINGULAR, "from_basis: duplicate pivot row");
+        seen[row] = 1;
+        // column i of B is sign * e_row  =>  row i of B^-1 is sign * e_row'
+        Bn[(size_t)i * ld_b_ + row] = (double)vsign_h_[v];
+        b[i] = (double)vsign_h_[v] * rhs_h_[row];
+    }
+    HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b_, b.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
+    std::vector<double> zeros(ld_b_, 0.0);
+    HIP_TRY(hipMemcpy(d_minus_pi_, zeros.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice));
+    std::vector<uint8_t> flags(n_alloc_, 0);
+    for (int32_t v : basis) flags[v] = 1;
+    HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));
+    nr_artificial_ = 0; phase_ = 2;
+    relp_status_t st = download_rec();
+    if (st) return st;
+    h_rec_->minus_objective = 0.0; h_rec_->outcome = DEV_RUNNING; h_rec_->last_selected = -1; h_rec_->phase = 2;
+    return upload_rec();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Getters
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::get_objective(double* out) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    *out = -h_rec_->minus_objective;
+    return RELP_OK;
+}
+
+relp_status_t Engine::get_vector(int which, double* out) {
+    const double* src = which == 0 ? d_b_ : which == 1 ? d_minus_pi_ : d_alpha_;
+    HIP_TRY(hipMemcpyAsync(out, src, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+relp_status_t Engine::get_basis_indices(int32_t* out) {
+    HIP_TRY(hipMemcpyAsync(out, d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+relp_status_t Engine::get_basis_inverse(double* out) {
+    if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "B^-1 is row-sharded");
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemcpy2D(out, sizeof(double) * m_, dBinv_, sizeof(double) * ld_b_, sizeof(double) * m_, m_, hipMemcpyDeviceToHost));
+    return RELP_OK;
+}
+
+relp_status_t Engine::current_bfs(int32_t* cols, double* vals, int32_t cap, int32_t* count) {
+    std::vector<double> b(m_); std::vector<int32_t> basis(m_);
+    relp_status_t st = get_vector(0, b.data());
+    if (st) return st;
+    if ((st = get_basis_indices(basis.data()))) return st;
+    std::vector<std::pair<int32_t, double>> t;
+    for (int32_t i = 0; i < m_; ++i) if (b[i] != 0.0) t.emplace_back(basis[i], b[i]);
+    std::sort(t.begin(), t.end(), [](auto& a, auto& c) { return a.first < c.first; });
+    int32_t k = 0;
+    for (auto& e : t) { if (k < cap) { cols[k] = e.first; vals[k] = e.second; } ++k; }
+    if (count) *count = k;
+    return RELP_OK;
+}
+
+relp_status_t Engine::get_iterations(int64_t* out) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    *out = h_rec_->iterations;
+    return RELP_OK;
+}
+
+relp_status_t Engine::get_trace(int32_t* phase, int32_t* entering, int32_t* row, int32_t* leaving, int64_t cap,
+                                int64_t* count) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    const int64_t n = std::min<int64_t>(h_rec_->iterations, trace_cap_);
+    const int64_t k = std::min(n, cap);
+    int32_t* outs[4] = {phase, entering, row, leaving};
+    for (int f = 0; f < 4; ++f)
+        if (outs[f] && k > 0) HIP_TRY(hipMemcpy(outs[f], d_trace_ + f * trace_cap_, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+    if (count) *count = n;
+    return RELP_OK;
+}
+
+// tableau/mod.rs:253-289: regenerate every basis column (must be e_i), basic reduced costs (0), b >= 0
+relp_status_t Engine::check_basis(double* max_identity_error, double* max_basic_cost, double* min_b) {
+    std::vector<int32_t> basis(m_);
+    relp_status_t st = get_basis_indices(basis.data());
+    if (st) return st;
+    std::vector<double> col(m_), d(nr_columns()), b(m_);
+    double e1 = 0.0, e2 = 0.0, mb = std::numeric_limits<double>::infinity();
+    for (int32_t i = 0; i < m_; ++i) {
+        if ((st = generate_column(basis[i], col.data()))) return st;
+        for (int32_t k = 0; k < m_; ++k) e1 = std::max(e1, std::fabs(col[k] - (k == i ? 1.0 : 0.0)));
+    }
+    if ((st = relative_costs(d.data()))) return st;
+    for (int32_t i = 0; i < m_; ++i) e2 = std::max(e2, std::fabs(d[basis[i]]));
+    if ((st = get_vector(0, b.data()))) return st;
+    for (double v : b) mb = std::min(mb, v);
+    if (max_identity_error) *max_identity_error = e1;
+    if (max_basic_cost) *max_basic_cost = e2;
+    if (min_b) *min_b = mb;
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shards.  Everything is enqueued on stream_; the caller interleaves the
+// RCCL collectives on the same stream, so there is no host sync inside a pivot.
+// ------------------------------------------------------------------------------------------------
+void Engine::shard_ranges(int32_t* col_lo, int32_t* col_hi, int32_t* row_lo, int32_t* row_hi, int32_t* stride) const {
+    if (col_lo) *col_lo = col_lo_;
+    if (col_hi) *col_hi = col_hi_;
+    if (row_lo) *row_lo = row_lo_;
+    if (row_hi) *row_hi = row_hi_;
+    if (stride) *stride = row_stride_;
+}
+
+relp_status_t Engine::shard_price(double* dev_candidate) {
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+    prof_begin(RELP_K_PRICE);
+    enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
+    prof_end();
+    prof_begin(RELP_K_SELECT_COLUMN);
+    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_BUILD_COLUMN);
+    launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
+    launch_pack_candidate(d_aq_, m_, dev_candidate, d_rec_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t count) {
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    launch_select_candidate(dev_candidates, count, cand_len_, m_, d_aq_, rule, d_rec_, stream_);
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_ftran(double* dev_alpha_slice) {
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FTRAN);
+    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, dev_alpha_slice, row_lo_, d_rec_, stream_);
+    launch_pad_slice(dev_alpha_slice, row_hi_ - row_lo_, row_stride_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho) {
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_RATIO);
+    launch_gather_alpha(dev_alpha_slices, count, row_stride_, m_, d_alpha_, d_rec_, stream_);
+    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, dev_rho, d_rec_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_update(const double* dev_rho) {
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_UPDATE_VECTORS);
+    launch_update_vectors(m_, d_alpha_, dev_rho, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
+                          stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_INVERSE);
+    launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, dev_rho, d_rec_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::poll(int32_t* outcome, int64_t* iterations) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    if (iterations) *iterations = h_rec_->iterations;
+    int32_t oc = RELP_RUNNING;
+    if (h_rec_->outcome == DEV_NO_CANDIDATE) {
+        if (phase_ == 2) oc = RELP_OPTIMAL;
+        else if ((st = finish_phase_one(&oc))) return st;
+    } else if (h_rec_->outcome == DEV_NO_ROW) oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
+    if (outcome) *outcome = oc;
+    return RELP_OK;
+}
+
+}  // namespace relp

@@ -1,0 +1,138 @@
+// relp_engine.hpp -- host driver of the explicit-inverse pivot engine.
+//
+// `Engine` plays the role of the reference's `Tableau<Carry<f64, BasisInverseRows<f64>>, K>` plus
+// the `PivotRule` state and the `MatrixData` provider (file:line under
+// /root/reference/src/algorithm/two_phase/):
+//   MatrixData columns/rows          matrix_provider/matrix_data.rs:198-268, 308-371, 432-452
+//   Partially / NonArtificial kinds  tableau/kind/artificial/partially.rs:125-206, kind/non_artificial.rs:151-220
+//   Carry constructors / updates     tableau/inverse_maintenance/carry/mod.rs:214-271, 283-333, 381-426, 484-570
+//   phase loops                      phase_one.rs:125-170, 223-260; phase_two.rs:22-51; two_phase/mod.rs:30-76
+// All numeric state lives in HBM; the host only sequences launches and handles the rare
+// phase-boundary work.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/relp_engine.h"
+#include "relp_kernels.h"
+
+namespace relp {
+
+class Engine {
+  public:
+    Engine() = default;
+    ~Engine();
+
+    relp_status_t create(const relp_matrix_data_t& md, const relp_config_t& cfg);
+    relp_status_t set_stream(hipStream_t s);
+
+    // step-wise pivot
+    relp_status_t select_primal_pivot_column(int rule, int32_t* found, int32_t* column, double* cost);
+    relp_status_t relative_costs(double* out_n);
+    relp_status_t generate_column(int32_t column, double* out_m);
+    relp_status_t generate_element(int32_t row, int32_t column, double* out);
+    relp_status_t select_primal_pivot_row(int32_t* found, int32_t* row);
+    relp_status_t bring_into_basis(int32_t column, int32_t row, double cost, int32_t* leaving);
+
+    // loops
+    relp_status_t run(int64_t max_iters, int64_t* done, int32_t* outcome);
+    relp_status_t solve_relaxation(int64_t max_iters, int32_t* outcome);
+    relp_status_t from_basis(const int32_t* basis_columns);
+
+    // getters
+    int32_t nr_rows() const { return m_; }
+    int32_t nr_columns() const { return nr_artificial_ + n_provider_; }
+    int32_t phase() const { return phase_; }
+    int32_t nr_artificial() const { return nr_artificial_; }
+    relp_status_t get_objective(double* out);
+    relp_status_t get_vector(int which, double* out);  // 0 b, 1 minus_pi, 2 alpha
+    relp_status_t get_basis_indices(int32_t* out);
+    relp_status_t get_basis_inverse(double* out);
+    relp_status_t current_bfs(int32_t* cols, double* vals, int32_t cap, int32_t* count);
+    relp_status_t get_iterations(int64_t* out);
+    relp_status_t get_trace(int32_t* phase, int32_t* entering, int32_t* row, int32_t* leaving, int64_t cap,
+                            int64_t* count);
+    relp_status_t check_basis(double* max_identity_error, double* max_basic_cost, double* min_b);
+
+    relp_status_t profile_enable(bool enable, int64_t max_launches);
+    relp_status_t profile_read(int kernel_id, int64_t* launches, double* total_ms);
+
+    // shards
+    void shard_ranges(int32_t* col_lo, int32_t* col_hi, int32_t* row_lo, int32_t* row_hi, int32_t* stride) const;
+    int64_t candidate_len() const { return cand_len_; }
+    int64_t rho_len() const { return ld_b_; }
+    relp_status_t shard_price(double* dev_candidate);
+    relp_status_t shard_select_column(const double* dev_candidates, int32_t count);
+    relp_status_t shard_ftran(double* dev_alpha_slice);
+    relp_status_t shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho);
+    relp_status_t shard_update(const double* dev_rho);
+    relp_status_t poll(int32_t* outcome, int64_t* iterations);
+
+    const char* last_error() const { return err_.c_str(); }
+
+  private:
+    // ---- MatrixData (host mirror) ----
+    int32_t nr_normal_ = 0, nr_eq_ = 0, nr_range_ = 0, nr_le_ = 0, nr_ge_ = 0;
+    int32_t mc_ = 0;          // constraint rows of A
+    int32_t nr_bounds_ = 0;   // variables with an upper bound
+    int32_t m_ = 0;           // tableau rows
+    int32_t n_provider_ = 0;  // provider columns (structural + virtual)
+    int32_t nr_virtual_ = 0;
+    std::vector<double> cost_h_, upper_h_, rhs_h_;
+    std::vector<int32_t> bound_row_h_, vrow0_h_, vrow1_h_, vsign_h_;
+    relp_config_t cfg_{};
+
+    // ---- Kind ----
+    int32_t phase_ = 1;
+    int32_t nr_artificial_ = 0;
+    std::vector<int32_t> column_to_row_;
+    double initial_phase1_objective_ = 0.0;
+
+    // ---- device state ----
+    double* dA_ = nullptr; int64_t ld_a_ = 0; bool owns_A_ = false;
+    double* dBinv_ = nullptr; int64_t ld_b_ = 0;
+    double *d_minus_pi_ = nullptr, *d_b_ = nullptr, *d_alpha_ = nullptr, *d_aq_ = nullptr, *d_rho_ = nullptr,
+           *d_d_ = nullptr, *d_w_ = nullptr, *d_cost_ = nullptr;
+    int32_t *d_basis_ = nullptr, *d_column_to_row_ = nullptr, *d_bound_row_ = nullptr, *d_vrow0_ = nullptr,
+            *d_vrow1_ = nullptr, *d_vsign_ = nullptr, *d_trace_ = nullptr;
+    uint8_t* d_in_basis_ = nullptr;
+    PivotRecord* d_rec_ = nullptr;
+    PivotRecord* h_rec_ = nullptr;  // pinned
+    hipStream_t stream_ = nullptr; bool owns_stream_ = false;
+    int64_t trace_cap_ = 0;
+    int32_t n_alloc_ = 0;     // allocated tableau columns (artificial + provider)
+
+    // ---- shards ----
+    int32_t col_lo_ = 0, col_hi_ = 0, row_lo_ = 0, row_hi_ = 0, row_stride_ = 0;
+    int64_t cand_len_ = 0;
+
+    // ---- profiling ----
+    bool prof_on_ = false;
+    std::vector<hipEvent_t> prof_ev_;
+    std::vector<int> prof_kid_;
+    bool prof_open_ = false;
+
+    std::string err_;
+
+    // helpers
+    ColumnTable table() const;
+    Tolerances tolerances() const;
+    bool hip_ok(hipError_t e, const char* what);
+    relp_status_t fail(relp_status_t code, const std::string& msg) { err_ = msg; return code; }
+    relp_status_t download_rec();
+    relp_status_t upload_rec();
+    void prof_begin(int kid);
+    void prof_end();
+    void enqueue_price(int cost_mode, const double* vec, const PivotRecord* rec, int32_t p_lo, int32_t p_hi);
+    void enqueue_iteration(int rule);
+    relp_status_t finish_phase_one(int32_t* outcome);
+    relp_status_t remove_artificial_basis_variables(std::vector<int32_t>& rows_to_remove);
+    relp_status_t switch_to_phase_two(const std::vector<int32_t>& rows_to_remove);
+    relp_status_t remove_rows(const std::vector<int32_t>& rows);
+    void free_all();
+};
+
+}  // namespace relp

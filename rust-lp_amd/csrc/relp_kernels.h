@@ -1,0 +1,103 @@
+// relp_kernels.h -- device-side state and kernel launchers of the explicit-inverse pivot engine.
+//
+// Layout in HBM (all f64 unless noted):
+//   A        dense column-major  nr_constraints x nr_normal (ld_a even, column j contiguous)
+//   Binv     dense row-major     m x m (ld_b multiple of 16, row i contiguous) = `BasisInverseRows`
+//   minus_pi, b, alpha, aq, rho  dense m-vectors (`Carry`, carry/mod.rs:45-65)
+//   d        reduced costs, one per tableau column
+//   basis_indices (i32, m), in_basis (u8, n_tableau), virtual-column descriptors (i32)
+//   PivotRecord: the per-pivot scalars every kernel reads instead of the host (no sync in the loop)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace relp {
+
+enum DeviceOutcome : int32_t { DEV_RUNNING = 0, DEV_NO_CANDIDATE = 1, DEV_NO_ROW = 2 };
+
+struct PivotRecord {
+    int32_t outcome;        // DeviceOutcome; once != RUNNING every loop kernel is a no-op
+    int32_t q;              // entering column (tableau index)
+    double  d_q;            // its reduced cost
+    int32_t r;              // pivot row
+    int32_t leaving;        // basis_indices[r] before the update
+    double  alpha_r;        // pivot element
+    double  b_r;            // b[r] before the update
+    double  minus_objective;
+    long long iterations;   // basis changes so far (all phases)
+    int32_t last_selected;  // FirstProfitableWithMemory state, -1 = None (pivot_rule.rs:62-64)
+    int32_t phase;          // 1 or 2
+    int32_t owner_has_row;  // sharded: 1 iff this rank owns row r
+    int32_t pad_;
+    double  key1;           // selection key of q (d_q, or its position in the search order)
+};
+
+// Read-only description of the tableau's columns (Kind + MatrixData, partially.rs:72-80,
+// matrix_data.rs:308-348).  Tableau column j: j < nr_artificial -> artificial unit column,
+// else provider column p = j - nr_artificial; p < nr_normal structural, else virtual.
+struct ColumnTable {
+    int32_t nr_artificial;
+    int32_t nr_normal;
+    int32_t nr_virtual;           // provider columns that are slack / bound slack
+    int32_t nr_constraints;       // rows of A
+    const int32_t* column_to_row; // artificial k -> row                      (nr_artificial)
+    const int32_t* bound_row;     // structural p -> bound row or -1          (nr_normal)
+    const int32_t* vrow0;         // virtual v -> first row                   (nr_virtual)
+    const int32_t* vrow1;         // virtual v -> second row or -1 (range slack)
+    const int32_t* vsign;         // virtual v -> +1 / -1 on vrow0
+    const double*  cost;          // structural p -> phase-2 cost             (nr_normal)
+};
+
+struct Tolerances { double cost, pivot, zero, tie; };
+
+// ---- launchers (all asynchronous on `s`) -------------------------------------------------------
+// cost_mode: 0 = no cost term (tableau row), 1 = phase-1 costs (artificial: 1), 2 = phase-2 costs
+// PRICE, structural part: d[na + p] = c_p + (-pi[0:mc]) . A[:,p] (+ -pi[bound_row]) for p in [p_lo, p_hi)
+void launch_price_structural(const double* A, int64_t ld_a, const ColumnTable& ct, const double* minus_pi,
+                             double* d, int32_t p_lo, int32_t p_hi, int32_t cost_mode, const PivotRecord* rec,
+                             hipStream_t s);
+// structural columns outside [p_lo, p_hi) get +inf (sharded pricing)
+void launch_price_mask_unowned(const ColumnTable& ct, double* d, int32_t p_lo, int32_t p_hi,
+                               const PivotRecord* rec, hipStream_t s);
+// PRICE, artificial + virtual columns
+void launch_price_virtual(const ColumnTable& ct, const double* minus_pi, double* d, int32_t cost_mode,
+                          const PivotRecord* rec, hipStream_t s);
+// entering-column choice over d (masked by in_basis), rule = relp_pivot_rule_t
+void launch_select_column(const double* d, const uint8_t* in_basis, int32_t n, int32_t rule, double tol_cost,
+                          PivotRecord* rec, hipStream_t s);
+// aq := dense column rec->q in tableau row space (m entries)
+void launch_build_column(const double* A, int64_t ld_a, const ColumnTable& ct, int32_t m, double* aq,
+                         const PivotRecord* rec, hipStream_t s);
+// FTRAN: alpha[i] = Binv[i,:] . aq for i in [row_lo, row_hi); out[i - out_offset]
+void launch_ftran(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
+                  const double* aq, double* out, int32_t out_offset, const PivotRecord* rec, hipStream_t s);
+// RATIO TEST over alpha/b/basis_indices (two-pass tie rule)
+void launch_ratio(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m,
+                  Tolerances tol, PivotRecord* rec, hipStream_t s);
+// rho = Binv[r,:] / alpha_r if row r in [row_lo,row_hi) else 0   (ld_b entries, padding zero)
+void launch_compute_rho(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
+                        double* rho, PivotRecord* rec, hipStream_t s);
+// b, -pi, -obj, basis_indices, in_basis, trace, iteration counter
+void launch_update_vectors(int32_t m, const double* alpha, const double* rho, double* b, double* minus_pi,
+                           int32_t* basis_indices, uint8_t* in_basis, int32_t* trace, int64_t trace_cap,
+                           PivotRecord* rec, hipStream_t s);
+// rank-1 update of rows [row_lo,row_hi) of Binv: row_r = rho; row_i -= alpha_i * rho
+void launch_update_inverse(double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
+                           const double* alpha, const double* rho, const PivotRecord* rec, hipStream_t s);
+
+// phase switch: minus_pi[j] = -sum_i w[i] * Binv[i,j]  (w = cost of basis column of row i)
+void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, const double* w,
+                                 double* minus_pi, hipStream_t s);
+void launch_set_identity(double* Binv, int64_t ld_b, int32_t m, hipStream_t s);
+void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
+                       hipStream_t s);
+
+// sharded helpers
+void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);
+void launch_select_candidate(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* aq,
+                             int32_t rule, PivotRecord* rec, hipStream_t s);
+void launch_gather_alpha(const double* slices, int32_t count, int32_t stride, int32_t m, double* alpha,
+                         const PivotRecord* rec, hipStream_t s);
+void launch_pad_slice(double* slice, int32_t valid, int32_t stride, hipStream_t s);
+
+}  // namespace relp

@@ -1,0 +1,594 @@
+// relp_kernels.hip -- hand-written gfx950 kernels of the explicit-inverse revised-simplex engine.
+//
+// Every hot kernel is an HBM stream (<= 0.25 flop/byte), so the design rules are: 16-byte
+// coalesced loads per lane along the contiguous dimension (columns of A, rows of B^-1), several
+// independent vectors in flight per thread, 64-wide wavefront shuffle reductions, no host sync:
+// per-pivot scalars travel through the device-resident PivotRecord.
+//
+// Reference rows implemented (SURVEY.md section 8a / 8a'):
+//   k_price_structural + k_price_virtual  a2+a3  tableau/mod.rs:102-108, carry/mod.rs:572-577
+//   k_select_column                        a2     strategy/pivot_rule.rs:38-126
+//   k_build_column + k_ftran               a4     carry/basis_inverse_rows.rs:144-173
+//   k_ratio                                a5     tableau/mod.rs:221-247
+//   k_compute_rho + k_update_vectors       a6     carry/mod.rs:283-333, 549-570
+//   k_update_inverse                       a7     carry/basis_inverse_rows.rs:42-83,131-142
+//   k_weighted_column_sums                 a10    carry/mod.rs:214-248
+#include "relp_kernels.h"
+
+#include <math.h>
+
+namespace relp {
+
+static constexpr int kThreads = 256;     // 4 wavefronts
+static constexpr int kVecPerBlock = 8;   // vectors (columns of A / rows of B^-1) per workgroup
+static constexpr int kSingleBlock = 1024;
+
+// ------------------------------------------------------------------------------------------------
+// Wavefront (64 lanes) and workgroup reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Dot products of kVecPerBlock contiguous vectors (stride ld) with one shared vector x.
+// Thread t streams 16-byte pairs k = 2t, 2t + 512, ...; all 8 loads of one step are independent.
+// Vectors beyond `v_hi` are clamped (duplicate loads, results discarded) so there is no branch in
+// the stream.  result[v] is valid for threads < kVecPerBlock after the call.
+__device__ __forceinline__ void block_multi_dot(const double* __restrict__ M, int64_t ld, int len,
+                                                int v0, int v_hi, const double* __restrict__ x,
+                                                double* s_partial /* [4][kVecPerBlock] */,
+                                                double& result) {
+    const int t = threadIdx.x;
+    double acc[kVecPerBlock];
+    const double* base[kVecPerBlock];
+#pragma unroll
+    for (int v = 0; v < kVecPerBlock; ++v) {
+        acc[v] = 0.0;
+        int vi = v0 + v;
+        if (vi >= v_hi) vi = v_hi - 1;
+        base[v] = M + (int64_t)vi * ld;
+    }
+    const int len2 = len & ~1;
+    for (int k = 2 * t; k < len2; k += 2 * kThreads) {
+        const double2 xv = *reinterpret_cast<const double2*>(x + k);
+#pragma unroll
+        for (int v = 0; v < kVecPerBlock; ++v) {
+            const double2 a = *reinterpret_cast<const double2*>(base[v] + k);
+            acc[v] = fma(a.x, xv.x, acc[v]);
+            acc[v] = fma(a.y, xv.y, acc[v]);
+        }
+    }
+    if ((len & 1) && t == 0) {
+        const double xl = x[len - 1];
+#pragma unroll
+        for (int v = 0; v < kVecPerBlock; ++v) acc[v] = fma(base[v][len - 1], xl, acc[v]);
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int v = 0; v < kVecPerBlock; ++v) {
+        const double w = wave_sum(acc[v]);
+        if (lane == 0) s_partial[wave * kVecPerBlock + v] = w;
+    }
+    __syncthreads();
+    if (t < kVecPerBlock) {
+        result = (s_partial[0 * kVecPerBlock + t] + s_partial[1 * kVecPerBlock + t]) +
+                 (s_partial[2 * kVecPerBlock + t] + s_partial[3 * kVecPerBlock + t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PRICE
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_price_structural(
+    const double* __restrict__ A, int64_t ld_a, ColumnTable ct, const double* __restrict__ minus_pi,
+    double* __restrict__ d, int p_lo, int p_hi, int cost_mode, const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_partial[4 * kVecPerBlock];
+    const int v0 = p_lo + blockIdx.x * kVecPerBlock;
+    double dot = 0.0;
+    block_multi_dot(A, ld_a, ct.nr_constraints, v0, p_hi, minus_pi, s_partial, dot);
+    const int p = v0 + threadIdx.x;
+    if (threadIdx.x < kVecPerBlock && p < p_hi) {
+        double v = dot;
+        const int br = ct.bound_row[p];
+        if (br >= 0) v += minus_pi[br];                           // +1 entry in the bound row
+        if (cost_mode == 2) v += ct.cost[p];                      // phase 1: Cost::Zero
+        d[ct.nr_artificial + p] = v;
+    }
+}
+
+__global__ void k_price_mask_unowned(ColumnTable ct, double* __restrict__ d, int p_lo, int p_hi,
+                                     const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < ct.nr_normal && (p < p_lo || p >= p_hi)) d[ct.nr_artificial + p] = INFINITY;
+}
+
+__global__ void k_price_virtual(ColumnTable ct, const double* __restrict__ minus_pi, double* __restrict__ d,
+                                int cost_mode, const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ct.nr_artificial) {
+        d[t] = (cost_mode == 1 ? 1.0 : 0.0) + minus_pi[ct.column_to_row[t]];   // Cost::One + (-pi)_row
+    } else {
+        const int v = t - ct.nr_artificial;
+        if (v < ct.nr_virtual) {
+            double s = (double)ct.vsign[v] * minus_pi[ct.vrow0[v]];
+            const int r1 = ct.vrow1[v];
+            if (r1 >= 0) s += minus_pi[r1];
+            d[ct.nr_artificial + ct.nr_normal + v] = s;           // slack cost is None (zero)
+        }
+    }
+}
+
+// Single-workgroup selection over the reduced costs.  key = (k1, j) lexicographic minimum:
+//   SteepestDescent: k1 = d_j (strict `<` => lowest j wins ties, pivot_rule.rs:118)
+//   FirstProfitable[WithMemory]: k1 = position of j in the search order (pivot_rule.rs:88)
+__global__ __launch_bounds__(kSingleBlock) void k_select_column(
+    const double* __restrict__ d, const uint8_t* __restrict__ in_basis, int n, int rule, double tol_cost,
+    PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_k1[kSingleBlock / 64];
+    __shared__ int s_j[kSingleBlock / 64];
+    const int last = (rule == 1) ? rec->last_selected : -1;
+    double k1 = INFINITY;
+    int bj = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += kSingleBlock) {
+        if (in_basis[j]) continue;
+        const double v = d[j];
+        if (v < -tol_cost) {
+            double key;
+            if (rule == 2) key = v;
+            else if (last >= 0) key = (double)(j >= last ? j - last : j - last + n);
+            else key = (double)j;
+            if (key < k1 || (key == k1 && j < bj)) { k1 = key; bj = j; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(k1, off, 64);
+        const int oj = __shfl_down(bj, off, 64);
+        if (ok < k1 || (ok == k1 && oj < bj)) { k1 = ok; bj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k1[wave] = k1; s_j[wave] = bj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kSingleBlock / 64; ++w) {
+            if (s_k1[w] < k1 || (s_k1[w] == k1 && s_j[w] < bj)) { k1 = s_k1[w]; bj = s_j[w]; }
+        }
+        if (bj == 0x7fffffff) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (rule == 1) rec->last_selected = -1;
+        } else {
+            rec->q = bj;
+            rec->d_q = d[bj];
+            rec->key1 = k1;
+            if (rule == 1) rec->last_selected = bj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FTRAN
+// ------------------------------------------------------------------------------------------------
+// aq := column q of the tableau's original matrix, dense over the m rows (padding stays zero).
+__global__ void k_build_column(const double* __restrict__ A, int64_t ld_a, ColumnTable ct, int m,
+                               double* __restrict__ aq, const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int q = rec->q;
+    double v = 0.0;
+    if (q < ct.nr_artificial) {
+        v = (i == ct.column_to_row[q]) ? 1.0 : 0.0;
+    } else {
+        const int p = q - ct.nr_artificial;
+        if (p < ct.nr_normal) {
+            if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
+            else v = (i == ct.bound_row[p]) ? 1.0 : 0.0;
+        } else {
+            const int vv = p - ct.nr_normal;
+            if (i == ct.vrow0[vv]) v = (double)ct.vsign[vv];
+            else if (i == ct.vrow1[vv]) v = 1.0;
+        }
+    }
+    aq[i] = v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_ftran(const double* __restrict__ Binv, int64_t ld_b, int m,
+                                                    int row_lo, int row_hi, const double* __restrict__ aq,
+                                                    double* __restrict__ out, int out_offset,
+                                                    const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_partial[4 * kVecPerBlock];
+    const int v0 = row_lo + blockIdx.x * kVecPerBlock;
+    double dot = 0.0;
+    block_multi_dot(Binv, ld_b, m, v0, row_hi, aq, s_partial, dot);
+    const int i = v0 + threadIdx.x;
+    if (threadIdx.x < kVecPerBlock && i < row_hi) out[i - out_offset] = dot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RATIO TEST (single workgroup; two passes: strict minimum, then Bland tie-break on the leaving
+// column among rows within the tie band -- identical to tableau/mod.rs:221-247 for zero tolerances)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict__ alpha,
+                                                        const double* __restrict__ b,
+                                                        const int32_t* __restrict__ basis_indices, int m,
+                                                        Tolerances tol, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_min[kSingleBlock / 64];
+    __shared__ int s_leave[kSingleBlock / 64];
+    __shared__ int s_row[kSingleBlock / 64];
+    __shared__ double s_bcast;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    double mn = INFINITY;
+    for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+        const double a = alpha[i];
+        if (a > tol.pivot) {
+            double bi = b[i];
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            const double ratio = bi / a;
+            if (ratio < mn) mn = ratio;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if (lane == 0) s_min[wave] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = s_min[0];
+        for (int w = 1; w < kSingleBlock / 64; ++w) g = fmin(g, s_min[w]);
+        s_bcast = g;
+    }
+    __syncthreads();
+    const double gmin = s_bcast;
+    if (gmin == INFINITY) {
+        if (threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
+        return;
+    }
+    const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
+    int best_leave = 0x7fffffff, best_row = -1;
+    for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+        const double a = alpha[i];
+        if (a > tol.pivot) {
+            double bi = b[i];
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            if (bi / a <= bound) {
+                const int lv = basis_indices[i];
+                if (lv < best_leave) { best_leave = lv; best_row = i; }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ol = __shfl_down(best_leave, off, 64);
+        const int orow = __shfl_down(best_row, off, 64);
+        if (ol < best_leave) { best_leave = ol; best_row = orow; }
+    }
+    if (lane == 0) { s_leave[wave] = best_leave; s_row[wave] = best_row; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kSingleBlock / 64; ++w)
+            if (s_leave[w] < best_leave) { best_leave = s_leave[w]; best_row = s_row[w]; }
+        rec->r = best_row;
+        rec->leaving = best_leave;
+        rec->alpha_r = alpha[best_row];
+        rec->b_r = b[best_row];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// UPDATE
+// ------------------------------------------------------------------------------------------------
+// rho = normalised pivot row (row r of the NEW inverse), staged outside B^-1 so that the rank-1
+// kernel can overwrite row r without racing its readers.
+__global__ void k_compute_rho(const double* __restrict__ Binv, int64_t ld_b, int m, int row_lo, int row_hi,
+                              double* __restrict__ rho, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = rec->r;
+    const bool own = (r >= row_lo && r < row_hi);
+    if (j == 0) rec->owner_has_row = own ? 1 : 0;
+    if (j >= (int)ld_b) return;
+    double v = 0.0;
+    if (own && j < m) {
+        v = Binv[(int64_t)r * ld_b + j] / rec->alpha_r;            // element_wise_divide, sparse.rs:291
+    }
+    rho[j] = v;
+}
+
+// b_r /= alpha_r; b_i -= alpha_i b_r; -pi -= d_q rho; -obj -= d_q b_r; basis_indices[r] = q
+// (carry/mod.rs:283-333, 549-570; tableau/mod.rs:72-84)
+__global__ void k_update_vectors(int m, const double* __restrict__ alpha, const double* __restrict__ rho,
+                                 double* __restrict__ b, double* __restrict__ minus_pi,
+                                 int32_t* __restrict__ basis_indices, uint8_t* __restrict__ in_basis,
+                                 int32_t* __restrict__ trace, int64_t trace_cap, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = rec->r;
+    const double d_q = rec->d_q;
+    const double br = rec->b_r / rec->alpha_r;
+    if (i < m) {
+        minus_pi[i] = fma(-d_q, rho[i], minus_pi[i]);
+        if (i == r) b[i] = br;
+        else {
+            const double a = alpha[i];
+            if (a != 0.0) b[i] = fma(-a, br, b[i]);
+        }
+    }
+    if (i == 0) {
+        const int q = rec->q, leaving = rec->leaving;
+        rec->minus_objective = fma(-d_q, br, rec->minus_objective);
+        basis_indices[r] = q;
+        in_basis[leaving] = 0;
+        in_basis[q] = 1;
+        const long long it = rec->iterations;
+        if (trace && it < trace_cap) {
+            trace[0 * trace_cap + it] = rec->phase;
+            trace[1 * trace_cap + it] = q;
+            trace[2 * trace_cap + it] = r;
+            trace[3 * trace_cap + it] = leaving;
+        }
+        rec->iterations = it + 1;
+    }
+}
+
+// Rank-1 update of the explicit inverse: row_r := rho, row_i := row_i - alpha_i * rho  (i != r).
+// Grid = (column strips of 512) x (row chunks); each thread owns one 16-byte column pair of the
+// strip, keeps its rho pair in registers and streams the chunk's rows read-modify-write.  Rows
+// with alpha_i == 0 are skipped (wave-uniform), like the reference skips absent entries.
+static constexpr int kUpdRowsPerBlock = 32;
+__global__ __launch_bounds__(kThreads) void k_update_inverse(double* __restrict__ Binv, int64_t ld_b, int m,
+                                                             int row_lo, int row_hi,
+                                                             const double* __restrict__ alpha,
+                                                             const double* __restrict__ rho,
+                                                             const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int c = (blockIdx.x * kThreads + threadIdx.x) * 2;
+    if (c >= (int)ld_b) return;
+    const int r = rec->r;
+    const double2 rh = *reinterpret_cast<const double2*>(rho + c);
+    const int i0 = row_lo + blockIdx.y * kUpdRowsPerBlock;
+    const int i1 = min(i0 + kUpdRowsPerBlock, row_hi);
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+        double2* p = reinterpret_cast<double2*>(Binv + (int64_t)i * ld_b + c);
+        if (i == r) {
+            *p = rh;
+        } else {
+            const double a = alpha[i];
+            if (a != 0.0) {
+                double2 v = *p;
+                v.x = fma(-a, rh.x, v.x);
+                v.y = fma(-a, rh.y, v.y);
+                *p = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase switch, identity, synthetic fill
+// ------------------------------------------------------------------------------------------------
+__global__ void k_weighted_column_sums(const double* __restrict__ Binv, int64_t ld_b, int m,
+                                       const double* __restrict__ w, double* __restrict__ minus_pi) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double s = 0.0;
+    for (int i = 0; i < m; ++i) {
+        const double wi = w[i];
+        if (wi != 0.0) s = fma(Binv[(int64_t)i * ld_b + j], wi, s);
+    }
+    minus_pi[j] = -s;
+}
+
+__global__ void k_set_identity(double* __restrict__ Binv, int64_t ld_b, int m) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)m * ld_b;
+    if (idx >= total) return;
+    const int64_t i = idx / ld_b, j = idx % ld_b;
+    Binv[idx] = (i == j) ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t stream, uint64_t idx) {
+    uint64_t z = seed + stream * 0xD1B54A32D192ED03ull + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// A[i, j] = (1 + x(0, (first_column + j) * m + i) % 999) / 1000   (rust-lp_amd/synthetic.py)
+__global__ void k_fill_dense(double* __restrict__ A, int64_t ld, int m, int n, uint64_t seed,
+                             int64_t first_column) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)m * n;
+    if (idx >= total) return;
+    const int64_t j = idx / m, i = idx % m;
+    const uint64_t x = splitmix64(seed, 0, (uint64_t)((first_column + j) * m + i));
+    A[j * ld + i] = (double)(1 + x % 999) / 1000.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sharded pricing / FTRAN helpers
+// ------------------------------------------------------------------------------------------------
+// msg = [key1, j, d_j, a_j[0..m)]; key1 = +inf when this rank has no candidate.  Resets the local
+// "no candidate" so that only the GLOBAL decision freezes the loop.
+__global__ void k_pack_candidate(const double* __restrict__ aq, int m, double* __restrict__ msg,
+                                 PivotRecord* rec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int outcome = rec->outcome;
+    if (outcome == DEV_NO_ROW) return;
+    if (i < m) msg[3 + i] = (outcome == DEV_RUNNING) ? aq[i] : 0.0;
+    if (i == 0) {
+        if (outcome == DEV_RUNNING) {
+            msg[0] = rec->key1; msg[1] = (double)rec->q; msg[2] = rec->d_q;
+        } else {
+            msg[0] = INFINITY; msg[1] = 0.0; msg[2] = 0.0;
+        }
+    }
+}
+
+// The local "no candidate" must not freeze this rank: only the global decision does.  Runs after
+// k_pack_candidate (separate launch, so every thread of the pack saw the old outcome).
+__global__ void k_clear_no_candidate(PivotRecord* rec) {
+    if (rec->outcome == DEV_NO_CANDIDATE) rec->outcome = DEV_RUNNING;
+}
+
+__global__ __launch_bounds__(kSingleBlock) void k_select_candidate(const double* __restrict__ msgs, int count,
+                                                                   int64_t msg_len, int m,
+                                                                   double* __restrict__ aq, int rule,
+                                                                   PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ int s_win;
+    if (threadIdx.x == 0) {
+        int win = -1; double k1 = INFINITY; double kj = 0.0;
+        for (int g = 0; g < count; ++g) {
+            const double a = msgs[g * msg_len + 0], j = msgs[g * msg_len + 1];
+            if (a < k1 || (a == k1 && win >= 0 && j < kj)) { k1 = a; kj = j; win = g; }
+        }
+        s_win = win;
+        if (win < 0) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (rule == 1) rec->last_selected = -1;
+        } else {
+            rec->q = (int)msgs[win * msg_len + 1];
+            rec->d_q = msgs[win * msg_len + 2];
+            if (rule == 1) rec->last_selected = rec->q;
+        }
+    }
+    __syncthreads();
+    const int win = s_win;
+    if (win < 0) return;
+    for (int i = threadIdx.x; i < m; i += kSingleBlock) aq[i] = msgs[win * msg_len + 3 + i];
+}
+
+__global__ void k_gather_alpha(const double* __restrict__ slices, int count, int stride, int m,
+                               double* __restrict__ alpha, const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int g = i / stride;
+    alpha[i] = (g < count) ? slices[(int64_t)g * stride + (i - g * stride)] : 0.0;
+}
+
+__global__ void k_pad_slice(double* __restrict__ slice, int valid, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= valid && i < stride) slice[i] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+void launch_price_structural(const double* A, int64_t ld_a, const ColumnTable& ct, const double* minus_pi,
+                             double* d, int32_t p_lo, int32_t p_hi, int32_t cost_mode, const PivotRecord* rec,
+                             hipStream_t s) {
+    if (p_hi <= p_lo) return;
+    const int blocks = cdiv(p_hi - p_lo, kVecPerBlock);
+    hipLaunchKernelGGL(k_price_structural, dim3(blocks), dim3(kThreads), 0, s, A, ld_a, ct, minus_pi, d, p_lo,
+                       p_hi, cost_mode, rec);
+}
+
+void launch_price_mask_unowned(const ColumnTable& ct, double* d, int32_t p_lo, int32_t p_hi,
+                               const PivotRecord* rec, hipStream_t s) {
+    if (ct.nr_normal <= 0) return;
+    hipLaunchKernelGGL(k_price_mask_unowned, dim3(cdiv(ct.nr_normal, 256)), dim3(256), 0, s, ct, d, p_lo, p_hi,
+                       rec);
+}
+
+void launch_price_virtual(const ColumnTable& ct, const double* minus_pi, double* d, int32_t cost_mode,
+                          const PivotRecord* rec, hipStream_t s) {
+    const int n = ct.nr_artificial + ct.nr_virtual;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_price_virtual, dim3(cdiv(n, 256)), dim3(256), 0, s, ct, minus_pi, d, cost_mode, rec);
+}
+
+void launch_select_column(const double* d, const uint8_t* in_basis, int32_t n, int32_t rule, double tol_cost,
+                          PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_column, dim3(1), dim3(kSingleBlock), 0, s, d, in_basis, n, rule, tol_cost, rec);
+}
+
+void launch_build_column(const double* A, int64_t ld_a, const ColumnTable& ct, int32_t m, double* aq,
+                         const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_column, dim3(cdiv(m, 256)), dim3(256), 0, s, A, ld_a, ct, m, aq, rec);
+}
+
+void launch_ftran(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
+                  const double* aq, double* out, int32_t out_offset, const PivotRecord* rec, hipStream_t s) {
+    if (row_hi <= row_lo) return;
+    const int blocks = cdiv(row_hi - row_lo, kVecPerBlock);
+    hipLaunchKernelGGL(k_ftran, dim3(blocks), dim3(kThreads), 0, s, Binv, ld_b, m, row_lo, row_hi, aq, out,
+                       out_offset, rec);
+}
+
+void launch_ratio(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m,
+                  Tolerances tol, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_ratio, dim3(1), dim3(kSingleBlock), 0, s, alpha, b, basis_indices, m, tol, rec);
+}
+
+void launch_compute_rho(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
+                        double* rho, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_compute_rho, dim3(cdiv(ld_b, 256)), dim3(256), 0, s, Binv, ld_b, m, row_lo, row_hi, rho,
+                       rec);
+}
+
+void launch_update_vectors(int32_t m, const double* alpha, const double* rho, double* b, double* minus_pi,
+                           int32_t* basis_indices, uint8_t* in_basis, int32_t* trace, int64_t trace_cap,
+                           PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_update_vectors, dim3(cdiv(m, 256)), dim3(256), 0, s, m, alpha, rho, b, minus_pi,
+                       basis_indices, in_basis, trace, trace_cap, rec);
+}
+
+void launch_update_inverse(double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
+                           const double* alpha, const double* rho, const PivotRecord* rec, hipStream_t s) {
+    if (row_hi <= row_lo) return;
+    dim3 grid(cdiv(ld_b, 2 * kThreads), cdiv(row_hi - row_lo, kUpdRowsPerBlock));
+    hipLaunchKernelGGL(k_update_inverse, grid, dim3(kThreads), 0, s, Binv, ld_b, m, row_lo, row_hi, alpha, rho,
+                       rec);
+}
+
+void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, const double* w,
+                                 double* minus_pi, hipStream_t s) {
+    hipLaunchKernelGGL(k_weighted_column_sums, dim3(cdiv(m, 128)), dim3(128), 0, s, Binv, ld_b, m, w, minus_pi);
+}
+
+void launch_set_identity(double* Binv, int64_t ld_b, int32_t m, hipStream_t s) {
+    const int64_t total = (int64_t)m * ld_b;
+    hipLaunchKernelGGL(k_set_identity, dim3(cdiv(total, 256)), dim3(256), 0, s, Binv, ld_b, m);
+}
+
+void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
+                       hipStream_t s) {
+    const int64_t total = (int64_t)m * n;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_fill_dense, dim3(cdiv(total, 256)), dim3(256), 0, s, A, ld, m, n, seed, first_column);
+}
+
+void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_candidate, dim3(cdiv(m, 256)), dim3(256), 0, s, aq, m, msg, rec);
+    hipLaunchKernelGGL(k_clear_no_candidate, dim3(1), dim3(1), 0, s, rec);
+}
+
+void launch_select_candidate(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* aq,
+                             int32_t rule, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_candidate, dim3(1), dim3(kSingleBlock), 0, s, msgs, count, msg_len, m, aq, rule,
+                       rec);
+}
+
+void launch_gather_alpha(const double* slices, int32_t count, int32_t stride, int32_t m, double* alpha,
+                         const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_alpha, dim3(cdiv(m, 256)), dim3(256), 0, s, slices, count, stride, m, alpha, rec);
+}
+
+void launch_pad_slice(double* slice, int32_t valid, int32_t stride, hipStream_t s) {
+    if (stride <= valid) return;
+    hipLaunchKernelGGL(k_pad_slice, dim3(cdiv(stride, 256)), dim3(256), 0, s, slice, valid, stride);
+}
+
+}  // namespace relp

@@ -1,0 +1,370 @@
+"""ctypes binding of the C ABI (`include/relp_engine.h`, built into `librelp_engine.so`) and the
+host-side mirror of the reference interface for the pivot path.
+
+Names follow the reference (file:line under /root/reference/src/algorithm/two_phase/):
+  ``Tableau``            tableau/mod.rs:24 -- relative_cost(s), generate_column, generate_element,
+                         select_primal_pivot_row, bring_into_basis, current_bfs, objective_function_value
+  ``PivotRule`` values   strategy/pivot_rule.rs:38,62,97
+  ``phase_one_primal`` / ``phase_two_primal`` / ``solve_relaxation``
+                         phase_one.rs:125, phase_two.rs:22, two_phase/mod.rs:30
+
+The HIP library is mandatory.  If it is missing or fails to load this module raises: there is no
+CPU fallback (the CPU restatements live in ``oracle/`` and are test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .matrix_data import MatrixData
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librelp_engine.so")
+
+# relp_pivot_rule_t
+FIRST_PROFITABLE, FIRST_PROFITABLE_WITH_MEMORY, STEEPEST_DESCENT = 0, 1, 2
+# relp_outcome_t
+RUNNING, OPTIMAL, UNBOUNDED, INFEASIBLE, PHASE_ONE_DONE, NO_ROW_PHASE_ONE = range(6)
+OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded", INFEASIBLE: "infeasible",
+                 PHASE_ONE_DONE: "phase_one_done", NO_ROW_PHASE_ONE: "no_row_phase_one"}
+# relp_kernel_id_t
+K_PRICE, K_SELECT_COLUMN, K_BUILD_COLUMN, K_FTRAN, K_RATIO, K_UPDATE_VECTORS, K_UPDATE_INVERSE = range(7)
+KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse"]
+FORMAT_CSC, FORMAT_DENSE = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class RelpError(RuntimeError):
+    pass
+
+
+class _MatrixData(C.Structure):
+    _fields_ = [("nr_normal", C.c_int32), ("nr_eq", C.c_int32), ("nr_range", C.c_int32), ("nr_le", C.c_int32),
+                ("nr_ge", C.c_int32), ("format", C.c_int32), ("matrix_memory", C.c_int32),
+                ("col_ptr", C.c_void_p), ("row_idx", C.c_void_p), ("values", C.c_void_p),
+                ("dense", C.c_void_p), ("dense_ld", C.c_int64),
+                ("b", C.c_void_p), ("ranges", C.c_void_p), ("cost", C.c_void_p), ("upper_bound", C.c_void_p)]
+
+
+class Config(C.Structure):
+    """relp_config_t"""
+    _fields_ = [("device", C.c_int32), ("phase_one_rule", C.c_int32), ("phase_two_rule", C.c_int32),
+                ("tol_cost", C.c_double), ("tol_pivot", C.c_double), ("tol_zero", C.c_double),
+                ("tol_tie", C.c_double), ("tol_feas", C.c_double),
+                ("poll_interval", C.c_int32), ("trace_capacity", C.c_int32),
+                ("shard_rank", C.c_int32), ("shard_count", C.c_int32)]
+
+
+# every symbol include/relp_engine.h declares (tests/test_abi.py checks the export list against the header)
+_SIGNATURES = {
+    "relp_default_config": (None, [C.POINTER(Config)]),
+    "relp_last_error": (C.c_char_p, [C.c_void_p]),
+    "relp_version": (C.c_char_p, []),
+    "relp_engine_create": (C.c_int, [C.POINTER(_MatrixData), C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "relp_engine_destroy": (None, [C.c_void_p]),
+    "relp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_select_primal_pivot_column": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                  C.POINTER(C.c_double)]),
+    "relp_relative_costs": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_generate_column": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "relp_generate_element": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "relp_select_primal_pivot_row": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "relp_bring_into_basis": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_int32)]),
+    "relp_run": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "relp_solve_relaxation": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "relp_from_basis": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_nr_rows": (C.c_int32, [C.c_void_p]),
+    "relp_nr_columns": (C.c_int32, [C.c_void_p]),
+    "relp_phase": (C.c_int32, [C.c_void_p]),
+    "relp_nr_artificial": (C.c_int32, [C.c_void_p]),
+    "relp_get_objective": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "relp_get_b": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_get_minus_pi": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_get_basis_indices": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_get_basis_inverse": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_current_bfs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "relp_get_iterations": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_get_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_int64)]),
+    "relp_check_basis": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "relp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "relp_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "relp_synth_fill_dense": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_int64, C.c_void_p]),
+    "relp_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
+    "relp_device_free": (C.c_int, [C.c_void_p]),
+    "relp_shard_ranges": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 5),
+    "relp_shard_column_range": (None, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "relp_shard_candidate_len": (C.c_int64, [C.c_void_p]),
+    "relp_shard_rho_len": (C.c_int64, [C.c_void_p]),
+    "relp_shard_price": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_shard_select_column": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "relp_shard_ftran": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_shard_ratio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "relp_shard_update": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load ``librelp_engine.so``; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RelpError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def default_config(**overrides) -> Config:
+    cfg = Config()
+    load_library().relp_default_config(C.byref(cfg))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def shard_column_range(nr_normal: int, rank: int, count: int) -> Tuple[int, int]:
+    lo, hi = C.c_int32(), C.c_int32()
+    load_library().relp_shard_column_range(nr_normal, rank, count, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class Tableau:
+    """Device-resident ``Tableau<Carry<f64, BasisInverseRows<f64>>, K>`` (tableau/mod.rs:24-38)."""
+
+    def __init__(self, provider: MatrixData, config: Optional[Config] = None, *, device_dense_ptr: Optional[int] = None,
+                 device_dense_ld: Optional[int] = None, **config_overrides):
+        """``Tableau::<_, Partially<_>>::new(provider)`` (kind/artificial/partially.rs:125).
+
+        ``device_dense_ptr``: address of a column-major dense matrix already in HBM (e.g. a torch
+        tensor's ``data_ptr()``), holding this shard's structural columns.
+        """
+        self._lib = load_library()
+        cfg = config if config is not None else default_config()
+        for k, v in config_overrides.items():
+            setattr(cfg, k, v)
+        self.config = cfg
+        keep = []
+
+        def ptr(a, dtype):
+            arr = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(arr)
+            return arr.ctypes.data
+
+        md = _MatrixData()
+        md.nr_normal, md.nr_eq, md.nr_range = provider.nr_normal, provider.nr_eq, provider.nr_range
+        md.nr_le, md.nr_ge = provider.nr_le, provider.nr_ge
+        if device_dense_ptr is not None:
+            md.format, md.matrix_memory = FORMAT_DENSE, MEM_DEVICE
+            md.dense = device_dense_ptr
+            md.dense_ld = device_dense_ld or provider.nr_constraints
+        elif provider.dense is not None:
+            md.format, md.matrix_memory = FORMAT_DENSE, MEM_HOST
+            dense = np.asfortranarray(provider.dense, dtype=np.float64)
+            keep.append(dense)
+            md.dense = dense.ctypes.data
+            md.dense_ld = dense.shape[0]
+        else:
+            md.format, md.matrix_memory = FORMAT_CSC, MEM_HOST
+            md.col_ptr = ptr(provider.col_ptr, np.int64)
+            md.row_idx = ptr(provider.row_idx, np.int32)
+            md.values = ptr(provider.values, np.float64)
+        md.b = ptr(provider.b, np.float64)
+        md.ranges = ptr(provider.ranges, np.float64)
+        md.cost = ptr(provider.cost, np.float64)
+        md.upper_bound = ptr(provider.upper_bound, np.float64)
+        h = C.c_void_p()
+        st = self._lib.relp_engine_create(C.byref(md), C.byref(cfg), C.byref(h))
+        self._h = h
+        if st != 0:
+            msg = self._lib.relp_last_error(h).decode() if h else "allocation failed"
+            if h:
+                self._lib.relp_engine_destroy(h)
+            self._h = None
+            raise RelpError(f"relp_engine_create failed ({st}): {msg}")
+        self.provider = provider
+        del keep
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.relp_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        if st != 0:
+            raise RelpError(f"relp call failed ({st}): {self._lib.relp_last_error(self._h).decode()}")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream: int):
+        self._ck(self._lib.relp_set_stream(self._h, hip_stream))
+
+    # -- sizes / kind -----------------------------------------------------------------------
+    def nr_rows(self) -> int:
+        return self._lib.relp_nr_rows(self._h)
+
+    def nr_columns(self) -> int:
+        return self._lib.relp_nr_columns(self._h)
+
+    def nr_artificial_variables(self) -> int:
+        return self._lib.relp_nr_artificial(self._h)
+
+    @property
+    def phase(self) -> int:
+        return self._lib.relp_phase(self._h)
+
+    # -- one pivot (tableau/mod.rs:47-247, pivot_rule.rs:25) ---------------------------------
+    def select_primal_pivot_column(self, rule: int) -> Optional[Tuple[int, float]]:
+        found, col, cost = C.c_int32(), C.c_int32(), C.c_double()
+        self._ck(self._lib.relp_select_primal_pivot_column(self._h, rule, C.byref(found), C.byref(col), C.byref(cost)))
+        return (col.value, cost.value) if found.value else None
+
+    def relative_costs(self) -> np.ndarray:
+        out = np.zeros(self.nr_columns())
+        self._ck(self._lib.relp_relative_costs(self._h, out.ctypes.data))
+        return out
+
+    def relative_cost(self, j: int) -> float:
+        return float(self.relative_costs()[j])
+
+    def generate_column(self, j: int) -> np.ndarray:
+        out = np.zeros(self.nr_rows())
+        self._ck(self._lib.relp_generate_column(self._h, j, out.ctypes.data))
+        return out
+
+    def generate_element(self, i: int, j: int) -> float:
+        v = C.c_double()
+        self._ck(self._lib.relp_generate_element(self._h, i, j, C.byref(v)))
+        return v.value
+
+    def select_primal_pivot_row(self) -> Optional[int]:
+        found, row = C.c_int32(), C.c_int32()
+        self._ck(self._lib.relp_select_primal_pivot_row(self._h, C.byref(found), C.byref(row)))
+        return row.value if found.value else None
+
+    def bring_into_basis(self, column: int, row: int, cost: float) -> int:
+        leaving = C.c_int32()
+        self._ck(self._lib.relp_bring_into_basis(self._h, column, row, cost, C.byref(leaving)))
+        return leaving.value
+
+    # -- loops ------------------------------------------------------------------------------
+    def run(self, max_iters: int) -> Tuple[int, int]:
+        """Up to ``max_iters`` basis changes of the current phase; returns (iterations, outcome)."""
+        done, oc = C.c_int64(), C.c_int32()
+        self._ck(self._lib.relp_run(self._h, max_iters, C.byref(done), C.byref(oc)))
+        return done.value, oc.value
+
+    def solve_relaxation(self, max_iters: int = 1 << 40) -> int:
+        oc = C.c_int32()
+        self._ck(self._lib.relp_solve_relaxation(self._h, max_iters, C.byref(oc)))
+        return oc.value
+
+    def from_basis(self, basis_columns) -> None:
+        arr = np.ascontiguousarray(basis_columns, dtype=np.int32)
+        self._ck(self._lib.relp_from_basis(self._h, arr.ctypes.data))
+
+    # -- state ------------------------------------------------------------------------------
+    def objective_function_value(self) -> float:
+        v = C.c_double()
+        self._ck(self._lib.relp_get_objective(self._h, C.byref(v)))
+        return v.value
+
+    def b(self) -> np.ndarray:
+        out = np.zeros(self.nr_rows())
+        self._ck(self._lib.relp_get_b(self._h, out.ctypes.data))
+        return out
+
+    def minus_pi(self) -> np.ndarray:
+        out = np.zeros(self.nr_rows())
+        self._ck(self._lib.relp_get_minus_pi(self._h, out.ctypes.data))
+        return out
+
+    def basis_indices(self) -> np.ndarray:
+        out = np.zeros(self.nr_rows(), dtype=np.int32)
+        self._ck(self._lib.relp_get_basis_indices(self._h, out.ctypes.data))
+        return out
+
+    def basis_inverse(self) -> np.ndarray:
+        m = self.nr_rows()
+        out = np.zeros((m, m))
+        self._ck(self._lib.relp_get_basis_inverse(self._h, out.ctypes.data))
+        return out
+
+    def current_bfs(self) -> List[Tuple[int, float]]:
+        m = self.nr_rows()
+        cols, vals, cnt = np.zeros(m, dtype=np.int32), np.zeros(m), C.c_int32()
+        self._ck(self._lib.relp_current_bfs(self._h, cols.ctypes.data, vals.ctypes.data, m, C.byref(cnt)))
+        return list(zip(cols[:cnt.value].tolist(), vals[:cnt.value].tolist()))
+
+    def iterations(self) -> int:
+        v = C.c_int64()
+        self._ck(self._lib.relp_get_iterations(self._h, C.byref(v)))
+        return v.value
+
+    def trace(self) -> List[Tuple[int, int, int, int]]:
+        cap = int(self.config.trace_capacity)
+        arrs = [np.zeros(max(cap, 1), dtype=np.int32) for _ in range(4)]
+        cnt = C.c_int64()
+        self._ck(self._lib.relp_get_trace(self._h, *[a.ctypes.data for a in arrs], cap, C.byref(cnt)))
+        k = min(cnt.value, cap)
+        return list(zip(*(a[:k].tolist() for a in arrs)))
+
+    def check_basis(self) -> Tuple[float, float, float]:
+        """``is_in_basic_feasible_solution_state`` (tableau/mod.rs:253-289) as three residuals."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._ck(self._lib.relp_check_basis(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # -- profiling --------------------------------------------------------------------------
+    def profile_enable(self, enable: bool, max_launches: int = 0):
+        self._ck(self._lib.relp_profile_enable(self._h, int(enable), max_launches))
+
+    def profile_read(self):
+        out = {}
+        for kid, name in enumerate(KERNEL_NAMES):
+            n, ms = C.c_int64(), C.c_double()
+            self._ck(self._lib.relp_profile_read(self._h, kid, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
+
+def phase_one_primal(tableau: Tableau, max_iters: int = 1 << 40) -> int:
+    """phase_one::primal (phase_one.rs:125-170)."""
+    if tableau.phase != 1:
+        raise RelpError("tableau is not artificial")
+    return tableau.run(max_iters)[1]
+
+
+def phase_two_primal(tableau: Tableau, max_iters: int = 1 << 40) -> int:
+    """phase_two::primal (phase_two.rs:22-51)."""
+    if tableau.phase != 2:
+        raise RelpError("tableau still has artificial variables")
+    return tableau.run(max_iters)[1]
+
+
+def solve_relaxation(provider: MatrixData, **config_overrides):
+    """SolveRelaxation::solve_relaxation (two_phase/mod.rs:30-76).  Returns (outcome, tableau)."""
+    t = Tableau(provider, **config_overrides)
+    return t.solve_relaxation(), t
