@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- simplex iterations/s of the MI355X pivot engine on the synthetic dense LP.
+
+A "step" is one pass of the hot path (PRICE -> FTRAN -> RATIO -> UPDATE = one basis change) of
+the revised simplex on the synthetic dense LP of BASELINE.json (rust-lp_amd/synthetic.py), inputs
+resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workloads (config.workload):
+  dense10k  (default) m = 10,000 rows, n = 10,000 structural columns (+10,000 slacks), f64,
+            SteepestDescent (Dantzig), explicit dense B^-1: the LP BASELINE.json's target is quoted on.
+  c2        2,000 x 2,000 (BASELINE.json configs[1]); c4: 10,000 x 50,000 (configs[3]).
+N > 1: the same LP, structural columns and rows of B^-1 sharded over the ranks (strong scaling);
+per pivot one all-gather of PRICE candidates, one all-gather of FTRAN slices and one SUM
+all-reduce that broadcasts the pivot row, all on RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {"dense10k": (10000, 10000, 20250002), "c2": (2000, 2000, 20250001), "c4": (10000, 50000, 20250003)}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(m, n, seed, warmup, steps, budget_s=20.0):
+    """The C (f64) restatement of the reference path (oracle/relp_f64.c, kind "port"), one core,
+    timed on the same LP over the same iteration window [warmup, warmup + k) until ~budget_s."""
+    import numpy as np
+    from rust_lp_amd import MatrixData, synthetic
+    from oracle import relp_f64
+    lp = synthetic.dense_lp(m, n, seed)
+    md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]).ensure_csc()
+    md.dense = None
+    del lp
+    ref = relp_f64.OracleF64(md)
+    ref.run(max_iters=1 << 40, through_phases=False, record=False)      # empty phase 1 -> phase 2
+    ref.run(max_iters=warmup, record=False)
+    done, t0 = 0, time.perf_counter()
+    chunk = max(1, min(5, steps))
+    while done < steps and time.perf_counter() - t0 < budget_s:
+        ref.run(max_iters=min(chunk, steps - done), record=False)
+        done += ref.last_n_done
+        if ref.last_n_done == 0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt if dt > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} pivots (iterations {warmup}..{warmup + done}) of the same {m}x{n} LP, "
+                      f"oracle/relp_f64.c (f64 restatement of Carry<_, BasisInverseRows>), {dt:.1f} s",
+            "nproc": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dense10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rust_lp_amd  # noqa: F401
+    from rust_lp_amd import MatrixData, engine, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    m, n, seed = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+    lib = engine.load_library()
+
+    # ---- synthetic inputs, generated directly in HBM ------------------------------------------
+    col_lo, col_hi = engine.shard_column_range(n, rank, world)
+    n_local = col_hi - col_lo
+    A = torch.empty((max(n_local, 1), m), dtype=torch.float64, device=dev)    # column-major m x n_local
+    stream = torch.cuda.current_stream().cuda_stream
+    st = lib.relp_synth_fill_dense(A.data_ptr(), m, m, n_local, seed, col_lo, stream)
+    assert st == 0, "synthetic fill failed"
+    nums_b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
+    nums_c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
+    md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=nums_b / 4000.0, cost=nums_c / 1000.0,
+                    upper_bound=np.full(n, np.inf))
+    events = not args.no_kernel_events
+    t = engine.Tableau(md, device_dense_ptr=A.data_ptr(), device_dense_ld=m, device=local_rank,
+                       poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world)
+    torch.cuda.synchronize()
+
+    if world == 1:
+        done, oc = t.run(1 << 30)                     # phase 1 is empty (slack basis) -> phase 2
+        assert oc == engine.PHASE_ONE_DONE, engine.OUTCOME_NAMES.get(oc)
+        done, oc = t.run(W)
+        assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
+        if events:
+            t.profile_enable(True, 8 * K + 16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done, oc = t.run(K)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert done == K, f"only {done} of {K} pivots were possible"
+        prof = t.profile_read() if events else {}
+    else:
+        import torch.distributed as dist
+        from rust_lp_amd.sharded import ShardedPivotLoop
+        loop = ShardedPivotLoop(t, dist, dev)
+        oc = loop.finish_phase_one()
+        assert oc == engine.PHASE_ONE_DONE
+        done, oc = loop.run(W)
+        assert done == W and oc == engine.RUNNING
+        if events:
+            t.profile_enable(True, 8 * K + 16)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done, oc = loop.run(K)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        assert done == K, f"only {done} of {K} pivots were possible"
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        prof = t.profile_read() if events else {}
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per launch / measured duration) ----
+    rows_local = (m + world - 1) // world
+    alg_bytes = {"price": 8.0 * m * n_local, "ftran": 8.0 * rows_local * m + 16.0 * m,
+                 "update_inverse": 16.0 * rows_local * m}
+    kernels = {}
+    for name, (cnt, ms) in prof.items():
+        if cnt > 0:
+            avg_us = ms * 1e3 / cnt
+            entry = {"launches": cnt, "avg_us": round(avg_us, 3)}
+            if name in alg_bytes:
+                entry["GBps"] = round(alg_bytes[name] / (avg_us * 1e-6) / 1e9, 1)
+            kernels[name] = entry
+    roofline = None
+    if kernels:
+        dom = max((k for k in kernels if k in alg_bytes), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes[dom]}
+
+    if rank == 0:
+        out = {
+            "metric": "simplex iterations/sec", "value": K / dt, "unit": "iterations/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), "
+                                   "SteepestDescent, explicit dense basis inverse",
+                       "m": m, "n": n, "seed": seed,
+                       "parallelism": "single GPU" if world == 1 else f"columns of A and rows of B^-1 sharded x{world}"},
+            "roofline": roofline, "kernels": kernels,
+            "iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
+            "iteration_GBps": (8.0 * m * n + 24.0 * m * m) / (dt / K) / 1e9,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(m, n, seed, W, K)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -543,6 +543,8 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     // -pi = -(c_B' B^-1) (create_minus_pi_from_artificial, carry/mod.rs:214-248), accumulated over rows in order
     std::vector<double> w(m_, 0.0), b(m_);
     for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = cost_h_[basis[i]];
+    if (cfg_.shard_count > 1)
+        for (double v : w) if (v != 0.0) return fail(RELP_E_UNSUPPORTED, "sharded phase switch needs an all-slack basis");
     HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     launch_weighted_column_sums(Binv, ld_b_, m_, d_w_, d_minus_pi_, stream_);

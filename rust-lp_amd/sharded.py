@@ -1,0 +1,129 @@
+"""Multi-GPU pivot loop: structural columns of A and rows of B^-1 sharded over the ranks
+(SURVEY.md section 8e), one process per GPU, collectives through ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Per pivot, with G ranks and m rows (all messages are device buffers, no host sync):
+  1. local PRICE over the owned columns            -> candidate [key, j, d_j, a_j (m)]
+     all-gather of the G candidates                   (8 * (m + 3) B per rank)
+     every rank picks the same winner: min key, then min j   (pivot_rule.rs:118 first-wins)
+  2. local FTRAN slice alpha[rows of this rank]     -> all-gather of the G slices (8 * m / G B per rank)
+     every rank runs the same ratio test on the full alpha (b, basis are replicated)
+  3. the owner of pivot row r writes rho = row_r(B^-1) / alpha_r, everyone else zeros;
+     a SUM all-reduce is the broadcast               (8 * m B)
+  4. every rank updates its rows of B^-1 and its replicas of b, -pi, -obj, basis.
+RCCL has no MINLOC, so step 1 gathers (key, j) pairs instead of emulating it with two
+all-reduces.  The messages are <= 80 KB at m = 10,000: latency-bound on xGMI, not bandwidth-bound.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+from . import engine as _engine
+
+
+class HipShardOps:
+    """The shard entry points of the C ABI (include/relp_engine.h, `relp_shard_*`)."""
+
+    def __init__(self, tableau: "_engine.Tableau"):
+        self.t = tableau
+        self.lib = _engine.load_library()
+        self.h = tableau.handle
+        lo, hi, rlo, rhi, stride = (C.c_int32() for _ in range(5))
+        self.lib.relp_shard_ranges(self.h, C.byref(lo), C.byref(hi), C.byref(rlo), C.byref(rhi), C.byref(stride))
+        self.row_stride = stride.value
+        self.candidate_len = self.lib.relp_shard_candidate_len(self.h)
+        self.rho_len = self.lib.relp_shard_rho_len(self.h)
+
+    def _ck(self, st):
+        if st != 0:
+            raise _engine.RelpError(f"shard call failed ({st}): {self.lib.relp_last_error(self.h).decode()}")
+
+    def set_stream(self, stream_ptr: int):
+        self.t.set_stream(stream_ptr)
+
+    def price(self, cand):
+        self._ck(self.lib.relp_shard_price(self.h, cand.data_ptr()))
+
+    def select_column(self, cands, count: int):
+        self._ck(self.lib.relp_shard_select_column(self.h, cands.data_ptr(), count))
+
+    def ftran(self, alpha_slice):
+        self._ck(self.lib.relp_shard_ftran(self.h, alpha_slice.data_ptr()))
+
+    def ratio(self, slices, count: int, rho):
+        self._ck(self.lib.relp_shard_ratio(self.h, slices.data_ptr(), count, rho.data_ptr()))
+
+    def update(self, rho):
+        self._ck(self.lib.relp_shard_update(self.h, rho.data_ptr()))
+
+    def poll(self) -> Tuple[int, int]:
+        oc, it = C.c_int32(), C.c_int64()
+        self._ck(self.lib.relp_poll(self.h, C.byref(oc), C.byref(it)))
+        return oc.value, it.value
+
+
+class ShardedPivotLoop:
+    """phase_one::primal / phase_two::primal (phase_one.rs:125, phase_two.rs:22) across ranks."""
+
+    def __init__(self, tableau_or_ops, dist, device, poll_interval: int = 64):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.ops = tableau_or_ops if hasattr(tableau_or_ops, "price") else HipShardOps(tableau_or_ops)
+        self.world = dist.get_world_size()
+        self.device = device
+        self.poll_interval = max(1, poll_interval)
+        o = self.ops
+        f64 = torch.float64
+        self.cand = torch.zeros(o.candidate_len, dtype=f64, device=device)
+        self.cands = torch.zeros(o.candidate_len * self.world, dtype=f64, device=device)
+        self.slice = torch.zeros(o.row_stride, dtype=f64, device=device)
+        self.slices = torch.zeros(o.row_stride * self.world, dtype=f64, device=device)
+        self.rho = torch.zeros(o.rho_len, dtype=f64, device=device)
+        self.stream = None
+        if device.type == "cuda":
+            # collectives are ordered against the current stream: put the kernels on it too
+            self.stream = torch.cuda.Stream(device=device)
+            o.set_stream(self.stream.cuda_stream)
+
+    def _iteration(self):
+        o, d = self.ops, self.dist
+        o.price(self.cand)
+        d.all_gather_into_tensor(self.cands, self.cand)
+        o.select_column(self.cands, self.world)
+        o.ftran(self.slice)
+        d.all_gather_into_tensor(self.slices, self.slice)
+        o.ratio(self.slices, self.world, self.rho)
+        d.all_reduce(self.rho, op=d.ReduceOp.SUM)
+        o.update(self.rho)
+
+    def _enqueue(self, count: int):
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                for _ in range(count):
+                    self._iteration()
+        else:
+            for _ in range(count):
+                self._iteration()
+
+    def run(self, max_iters: int) -> Tuple[int, int]:
+        """Up to ``max_iters`` basis changes; returns (iterations done, outcome).  Every rank takes
+        the same decisions from the same gathered data, so the outcome is identical on all ranks."""
+        oc, start = self.ops.poll()
+        if oc != _engine.RUNNING:
+            return 0, oc
+        left = max_iters
+        while left > 0:
+            chunk = min(left, self.poll_interval)
+            self._enqueue(chunk)
+            left -= chunk
+            oc, it = self.ops.poll()
+            if oc != _engine.RUNNING:
+                return it - start, oc
+        oc, it = self.ops.poll()
+        return it - start, oc
+
+    def finish_phase_one(self) -> int:
+        """With a full slack basis phase 1 has no candidate: one PRICE proves it and switches."""
+        return self.run(1)[1]

@@ -1,0 +1,134 @@
+"""numpy stand-in for the `relp_shard_*` entry points (test infrastructure): the same shard
+protocol as rust-lp_amd/csrc (message layouts, padding, tie rules) computed on the CPU so that the
+multi-rank orchestration in rust_lp_amd.sharded can be exercised with the gloo backend."""
+import numpy as np
+
+RUNNING, OPTIMAL, UNBOUNDED, PHASE_ONE_DONE = 0, 1, 2, 4
+
+
+class NumpyShardOps:
+    def __init__(self, rank, world, m, n, A_local, col_lo, b, c, tol_cost=1e-9, tol_pivot=1e-9, tol_zero=1e-11,
+                 tol_tie=1e-9):
+        self.rank, self.world, self.m, self.n = rank, world, m, n
+        self.A, self.col_lo, self.col_hi = A_local, col_lo, col_lo + A_local.shape[1]
+        self.c = c
+        self.tol = (tol_cost, tol_pivot, tol_zero, tol_tie)
+        stride = -(-m // world)
+        stride += stride % 2
+        self.row_stride = stride
+        self.row_lo = min(m, rank * stride)
+        self.row_hi = min(m, self.row_lo + stride)
+        self.candidate_len = 3 + m + ((3 + m) % 2)
+        self.rho_len = -(-m // 16) * 16
+        self.Binv = np.eye(m)[self.row_lo:self.row_hi].copy()
+        self.b = b.astype(np.float64).copy()
+        self.minus_pi = np.zeros(m)
+        self.basis = np.arange(n, n + m)
+        self.in_basis = np.zeros(n + m, dtype=bool)
+        self.in_basis[self.basis] = True
+        self.minus_obj = 0.0
+        self.phase, self.outcome, self.iterations = 1, RUNNING, 0
+        self.trace = []
+        self.alpha = np.zeros(m)
+
+    def set_stream(self, _):
+        pass
+
+    # ---- PRICE -------------------------------------------------------------------------------
+    def price(self, cand):
+        out = cand.numpy()
+        out[:] = 0.0
+        out[0] = np.inf
+        if self.outcome != RUNNING:
+            return
+        d = np.full(self.n + self.m, np.inf)
+        cost = self.c if self.phase == 2 else np.zeros(self.n)
+        d[self.col_lo:self.col_hi] = cost[self.col_lo:self.col_hi] + self.minus_pi @ self.A
+        d[self.n:] = self.minus_pi                      # +1 slack columns, zero cost
+        ok = (~self.in_basis) & (d < -self.tol[0])
+        if ok.any():
+            j = int(np.lexsort((np.arange(len(d))[ok], d[ok]))[0])
+            j = int(np.arange(len(d))[ok][j])
+            aq = np.zeros(self.m)
+            if j < self.n:
+                aq[:] = self.A[:, j - self.col_lo]
+            else:
+                aq[j - self.n] = 1.0
+            out[0], out[1], out[2] = d[j], j, d[j]
+            out[3:3 + self.m] = aq
+
+    def select_column(self, cands, count):
+        if self.outcome != RUNNING:
+            return
+        msgs = cands.numpy().reshape(count, self.candidate_len)
+        best = None
+        for g in range(count):
+            if np.isfinite(msgs[g, 0]) and (best is None or (msgs[g, 0], msgs[g, 1]) < (msgs[best, 0], msgs[best, 1])):
+                best = g
+        if best is None:
+            self.outcome = 1          # no candidate
+            return
+        self.q, self.d_q = int(msgs[best, 1]), float(msgs[best, 2])
+        self.aq = msgs[best, 3:3 + self.m].copy()
+
+    # ---- FTRAN / RATIO -----------------------------------------------------------------------
+    def ftran(self, alpha_slice):
+        out = alpha_slice.numpy()
+        out[:] = 0.0
+        if self.outcome != RUNNING:
+            return
+        out[:self.row_hi - self.row_lo] = self.Binv @ self.aq
+
+    def ratio(self, slices, count, rho):
+        rh = rho.numpy()
+        rh[:] = 0.0
+        if self.outcome != RUNNING:
+            return
+        self.alpha = slices.numpy()[:count * self.row_stride][:self.m].copy()
+        tc, tp, tz, tt = self.tol
+        pos = self.alpha > tp
+        if not pos.any():
+            self.outcome = 2
+            return
+        bb = np.where(np.abs(self.b) <= tz, 0.0, self.b)
+        ratios = np.where(pos, bb / np.where(pos, self.alpha, 1.0), np.inf)
+        mn = ratios.min()
+        tie = pos & (ratios <= mn + tt * max(1.0, abs(mn)))
+        rows = np.nonzero(tie)[0]
+        r = int(rows[np.argmin(self.basis[rows])])
+        self.r, self.alpha_r, self.b_r = r, float(self.alpha[r]), float(self.b[r])
+        if self.row_lo <= r < self.row_hi:
+            rh[:self.m] = self.Binv[r - self.row_lo] / self.alpha_r
+
+    # ---- UPDATE ------------------------------------------------------------------------------
+    def update(self, rho):
+        if self.outcome != RUNNING:
+            return
+        rh = rho.numpy()[:self.m]
+        r, br = self.r, self.b_r / self.alpha_r
+        self.minus_pi -= self.d_q * rh
+        nb = self.b - self.alpha * br
+        nb[r] = br
+        self.b = nb
+        self.minus_obj -= self.d_q * br
+        leaving = int(self.basis[r])
+        self.basis[r] = self.q
+        self.in_basis[leaving] = False
+        self.in_basis[self.q] = True
+        a_loc = self.alpha[self.row_lo:self.row_hi]
+        new = self.Binv - np.outer(a_loc, rh)
+        if self.row_lo <= r < self.row_hi:
+            new[r - self.row_lo] = rh
+        self.Binv = new
+        self.trace.append((self.phase, self.q, r, leaving))
+        self.iterations += 1
+
+    def poll(self):
+        if self.outcome == 1:
+            if self.phase == 1:
+                self.phase, self.outcome = 2, RUNNING
+                return PHASE_ONE_DONE, self.iterations
+            return OPTIMAL, self.iterations
+        if self.outcome == 2:
+            return UNBOUNDED, self.iterations
+        return RUNNING, self.iterations
