@@ -108,7 +108,7 @@ def main():
     torch.cuda.synchronize()
 
     if world == 1:
-        done, oc = t.run(1 << 30)                     # phase 1 is empty (slack basis) -> phase 2
+        done, oc = t.run(1)                           # phase 1 is empty (slack basis): one PRICE proves it
         assert oc == engine.PHASE_ONE_DONE, engine.OUTCOME_NAMES.get(oc)
         done, oc = t.run(W)
         assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turns a gpurun_out/prof_<tag>/ directory (written by profiles/collect.sh) into the committed
+evidence: profiles/<tag>_kernel_stats.csv (rocprofv3 --stats output, verbatim),
+profiles/<tag>_summary.md and profiles/traffic.json (HBM bytes per launch from the PMC passes,
+FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).
+
+Launches that ran as no-ops (the loop kernels return at once when the PivotRecord says the loop
+ended) are excluded from the per-kernel averages: a launch counts when its duration is at least
+half of that kernel's longest launch.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, value_col=None):
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"].split("(")[0].replace("relp::", "")
+        dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        val = float(row[value_col]) if value_col else 0.0
+        agg[name].append((dur, val))
+    out = {}
+    for name, rows in agg.items():
+        mx = max(d for d, _ in rows)
+        eff = [(d, v) for d, v in rows if d >= 0.5 * mx]
+        out[name] = {"launches": len(rows), "effective": len(eff),
+                     "avg_us": statistics.mean(d for d, _ in eff) / 1e3,
+                     "value": statistics.mean(v for _, v in eff)}
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    workload = sys.argv[2] if len(sys.argv) > 2 else "dense10k"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    trace = per_kernel(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])
+    fetch = per_kernel(glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+    write = per_kernel(glob.glob(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+    lines = [f"# rocprofv3 summary `{tag}` ({workload})", "",
+             "Command: `bash profiles/collect.sh` (rocprofv3 --kernel-trace --stats; separate --pmc FETCH_SIZE and",
+             "--pmc WRITE_SIZE passes).  Durations from the kernel trace, effective launches only (see",
+             "profiles/summarize.py).  HBM traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per launch.", "",
+             "| kernel | launches (effective) | avg us | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM MB / launch |",
+             "|---|---|---|---|---|---|"]
+    traffic = {}
+    for name in sorted(trace, key=lambda k: -trace[k]["avg_us"] * trace[k]["effective"]):
+        if not name.startswith("k_"):
+            continue
+        t = trace[name]
+        f = fetch.get(name, {}).get("value", 0.0)
+        w = write.get(name, {}).get("value", 0.0)
+        hbm = (2.0 * f + w) * 1024.0
+        traffic[name[2:]] = hbm
+        lines.append(f"| {name} | {t['launches']} ({t['effective']}) | {t['avg_us']:.1f} | {f:.1f} | {w:.1f} | {hbm / 1e6:.1f} |")
+    open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    allt[workload] = traffic
+    allt["_source"] = f"profiles/{tag}_summary.md"
+    json.dump(allt, open(tpath, "w"), indent=1, sort_keys=True)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

@@ -253,13 +253,8 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     std::vector<uint8_t> flags(n_alloc_, 0);
     for (int32_t r = 0; r < m_; ++r) flags[basis[r]] = 1;
     HIP_TRY(up(d_in_basis_, flags.data(), flags.size()));
-    if (row_hi_ > row_lo_) {
-        // identity rows [row_lo, row_hi): local row i has its 1 in column row_lo + i
-        std::vector<double> ones(1, 1.0);
-        HIP_TRY(hipMemset(dBinv_, 0, sizeof(double) * rows_local * ld_b_));
-        for (int32_t i = row_lo_; i < row_hi_; ++i)
-            HIP_TRY(hipMemcpy(dBinv_ + (int64_t)(i - row_lo_) * ld_b_ + i, ones.data(), sizeof(double), hipMemcpyHostToDevice));
-    }
+    // identity rows [row_lo, row_hi): local row i has its 1 in column row_lo + i (BasisInverse::identity)
+    if (row_hi_ > row_lo_) launch_set_identity(dBinv_, ld_b_, row_lo_, row_hi_, stream_);
     std::memset(h_rec_, 0, sizeof(PivotRecord));
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->minus_objective = -objective;
@@ -446,9 +441,13 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     if (st) return st;
     const long long start = h_rec_->iterations;
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    // Phase 1 often ends after very few pivots (none at all with a full slack basis): poll at 1, 2, 4, ...
+    // there so that an early end does not leave a long tail of no-op launches queued.
+    int64_t next_poll = phase_ == 1 ? 1 : cfg_.poll_interval;
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
         enqueue_iteration(rule);
-        if ((it + 1) % cfg_.poll_interval == 0) {
+        if (it + 1 == next_poll) {
+            next_poll += phase_ == 1 ? std::min<int64_t>(next_poll, cfg_.poll_interval) : cfg_.poll_interval;
             if ((st = download_rec())) return st;
             if (h_rec_->outcome != DEV_RUNNING) break;
         }

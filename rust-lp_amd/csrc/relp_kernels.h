@@ -88,7 +88,7 @@ void launch_update_inverse(double* Binv, int64_t ld_b, int32_t m, int32_t row_lo
 // phase switch: minus_pi[j] = -sum_i w[i] * Binv[i,j]  (w = cost of basis column of row i)
 void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, const double* w,
                                  double* minus_pi, hipStream_t s);
-void launch_set_identity(double* Binv, int64_t ld_b, int32_t m, hipStream_t s);
+void launch_set_identity(double* Binv_local, int64_t ld_b, int32_t row_lo, int32_t row_hi, hipStream_t s);
 void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
                        hipStream_t s);
 

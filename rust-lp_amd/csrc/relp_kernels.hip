@@ -387,12 +387,13 @@ __global__ void k_weighted_column_sums(const double* __restrict__ Binv, int64_t 
     minus_pi[j] = -s;
 }
 
-__global__ void k_set_identity(double* __restrict__ Binv, int64_t ld_b, int m) {
+// rows [row_lo, row_hi) of the identity, stored locally starting at row 0
+__global__ void k_set_identity(double* __restrict__ Binv, int64_t ld_b, int row_lo, int row_hi) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)m * ld_b;
+    const int64_t total = (int64_t)(row_hi - row_lo) * ld_b;
     if (idx >= total) return;
     const int64_t i = idx / ld_b, j = idx % ld_b;
-    Binv[idx] = (i == j) ? 1.0 : 0.0;
+    Binv[idx] = (row_lo + i == j) ? 1.0 : 0.0;
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t stream, uint64_t idx) {
@@ -558,9 +559,10 @@ void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, co
     hipLaunchKernelGGL(k_weighted_column_sums, dim3(cdiv(m, 128)), dim3(128), 0, s, Binv, ld_b, m, w, minus_pi);
 }
 
-void launch_set_identity(double* Binv, int64_t ld_b, int32_t m, hipStream_t s) {
-    const int64_t total = (int64_t)m * ld_b;
-    hipLaunchKernelGGL(k_set_identity, dim3(cdiv(total, 256)), dim3(256), 0, s, Binv, ld_b, m);
+void launch_set_identity(double* Binv, int64_t ld_b, int32_t row_lo, int32_t row_hi, hipStream_t s) {
+    const int64_t total = (int64_t)(row_hi - row_lo) * ld_b;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_set_identity, dim3(cdiv(total, 256)), dim3(256), 0, s, Binv, ld_b, row_lo, row_hi);
 }
 
 void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
