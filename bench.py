@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--workload", default="dense10k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,10 +84,12 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     m, n, seed = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
@@ -107,7 +111,7 @@ def main():
                        poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world)
     torch.cuda.synchronize()
 
-    if world == 1:
+    if not sharded:
         done, oc = t.run(1)                           # phase 1 is empty (slack basis): one PRICE proves it
         assert oc == engine.PHASE_ONE_DONE, engine.OUTCOME_NAMES.get(oc)
         done, oc = t.run(W)
@@ -188,7 +192,7 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

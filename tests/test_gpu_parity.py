@@ -214,3 +214,56 @@ def test_dense_2000_properties():
         e = binv @ a[:, basis[i]]
         e[i] -= 1.0
         assert np.max(np.abs(e)) <= 1e-8
+
+
+@pytest.mark.parametrize("world,m,n,seed", [(2, 48, 64, 17), (3, 61, 45, 23)])
+def test_shard_entry_points_on_one_gpu(world, m, n, seed):
+    """`relp_shard_*` with G engines in one process on one GPU: the exchange steps (all-gather of
+    candidates, all-gather of alpha slices, SUM all-reduce of rho) are done with torch ops on a
+    shared stream.  Every shard must walk the single-engine pivot sequence."""
+    import torch
+    from rust_lp_amd.sharded import HipShardOps
+    lp = synthetic.dense_lp(m, n, seed)
+    full = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"])
+    single = engine.Tableau(full, trace_capacity=4096)
+    assert single.solve_relaxation() == engine.OPTIMAL
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    tabs, ops = [], []
+    for r in range(world):
+        lo, hi = engine.shard_column_range(n, r, world)
+        md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=lp["b"], cost=lp["c"],
+                        upper_bound=np.full(n, np.inf), dense=np.asfortranarray(lp["A"][:, lo:hi]))
+        t = engine.Tableau(md, trace_capacity=4096, shard_rank=r, shard_count=world)
+        t.set_stream(stream)
+        tabs.append(t)
+        ops.append(HipShardOps(t))
+    L, S, RL = ops[0].candidate_len, ops[0].row_stride, ops[0].rho_len
+    cands = torch.zeros(world * L, dtype=torch.float64, device=dev)
+    slices = torch.zeros(world * S, dtype=torch.float64, device=dev)
+    rhos = torch.zeros((world, RL), dtype=torch.float64, device=dev)
+
+    def iteration():
+        for r, o in enumerate(ops):
+            o.price(cands[r * L:(r + 1) * L])
+        for o in ops:
+            o.select_column(cands, world)
+        for r, o in enumerate(ops):
+            o.ftran(slices[r * S:(r + 1) * S])
+        for r, o in enumerate(ops):
+            o.ratio(slices, world, rhos[r])
+        rho = rhos.sum(dim=0)
+        for o in ops:
+            o.update(rho)
+
+    iteration()                                   # phase 1: no candidate anywhere
+    assert [o.poll()[0] for o in ops] == [engine.PHASE_ONE_DONE] * world
+    for _ in range(len(single.trace()) + 3):
+        iteration()
+    torch.cuda.synchronize()
+    for o, t in zip(ops, tabs):
+        oc, it = o.poll()
+        assert oc == engine.OPTIMAL and it == len(single.trace())
+        assert t.trace() == single.trace()
+        assert abs(t.objective_function_value() - single.objective_function_value()) <= 1e-9 * abs(single.objective_function_value())
+        np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
