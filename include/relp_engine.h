@@ -94,6 +94,12 @@ typedef struct {
     int32_t trace_capacity;       /* pivots recorded on the device (0 = no trace) */
     /* column / row sharding for multi-GPU pricing; 0,1 = everything local */
     int32_t shard_rank, shard_count;
+    /* basis-inverse maintenance: 0 = rank-1 update of the explicit inverse at every pivot
+     * (basis_inverse_rows.rs:131-142 literally); K > 0 = deferred: the explicit inverse is kept as
+     * (I + W S') B0inv and the K most recent pivots are folded in by one m x K x m GEMM ("flush");
+     * -1 = automatic (64 when m >= 1024, else 0).  Results are the same up to f64 rounding. */
+    int32_t update_block;
+    int32_t reserved_;
 } relp_config_t;
 
 void relp_default_config(relp_config_t *cfg);
@@ -137,6 +143,10 @@ relp_status_t relp_solve_relaxation(relp_engine_t *h, int64_t max_iters, int32_t
 /* InverseMaintener::from_basis (carry/mod.rs:428-463): warm start from provider column indices,
  * one per row; switches to phase 2. */
 relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
+/* Fold every pending deferred update into the explicit inverse (no-op when update_block = 0). */
+relp_status_t relp_flush(relp_engine_t *h);
+/* The block size K in effect (0 = explicit rank-1 updates). */
+int32_t       relp_update_block(const relp_engine_t *h);
 
 /* ---- state getters (InverseMaintener accessors, inverse_maintenance/mod.rs:200-266) ----------- */
 int32_t relp_nr_rows(const relp_engine_t *h);
@@ -161,7 +171,11 @@ relp_status_t relp_check_basis(relp_engine_t *h, double *max_identity_error, dou
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------------------ */
 typedef enum {
     RELP_K_PRICE = 0, RELP_K_SELECT_COLUMN = 1, RELP_K_BUILD_COLUMN = 2, RELP_K_FTRAN = 3,
-    RELP_K_RATIO = 4, RELP_K_UPDATE_VECTORS = 5, RELP_K_UPDATE_INVERSE = 6, RELP_K_COUNT = 7
+    RELP_K_RATIO = 4, RELP_K_UPDATE_VECTORS = 5, RELP_K_UPDATE_INVERSE = 6,
+    RELP_K_APPLY_W = 7,          /* deferred update: alpha = v + W (S'v) */
+    RELP_K_UPDATE_W = 8,         /* deferred update: W <- E W, pivot row rho */
+    RELP_K_FLUSH = 9,            /* deferred update: B0inv += W (S' B0inv) */
+    RELP_K_COUNT = 10
 } relp_kernel_id_t;
 /* When enabled, every launch of the listed kernel classes inside relp_run is bracketed by HIP
  * events on the engine's stream; relp_profile_read sums them (this synchronises). */
@@ -199,6 +213,11 @@ relp_status_t relp_shard_ftran(relp_engine_t *h, double *dev_alpha_slice);
 relp_status_t relp_shard_ratio(relp_engine_t *h, const double *dev_alpha_slices, int32_t count, double *dev_rho);
 /* rank-1 update of the owned rows + replicated b, -pi, obj, basis */
 relp_status_t relp_shard_update(relp_engine_t *h, const double *dev_rho);
+/* deferred update in sharded mode, every relp_update_block() pivots: `begin` snapshots the rows
+ * S' B0inv this rank owns (zeros elsewhere) and returns the buffer to SUM all-reduce in place
+ * (*len_doubles = 0: nothing pending); `end` applies W (S' B0inv) to the owned rows. */
+relp_status_t relp_shard_flush_begin(relp_engine_t *h, double **dev_snapshot, int64_t *len_doubles);
+relp_status_t relp_shard_flush_end(relp_engine_t *h);
 /* outcome poll (one small device->host copy) */
 relp_status_t relp_poll(relp_engine_t *h, int32_t *outcome, int64_t *iterations);
 

@@ -21,6 +21,7 @@ void relp_default_config(relp_config_t* cfg) {
     cfg->poll_interval = 64;
     cfg->trace_capacity = 0;
     cfg->shard_rank = 0; cfg->shard_count = 1;
+    cfg->update_block = -1;
 }
 
 const char* relp_last_error(const relp_engine_t* h) { return h ? H(h).last_error() : "null handle"; }
@@ -60,6 +61,13 @@ relp_status_t relp_solve_relaxation(relp_engine_t* h, int64_t max_iters, int32_t
     return h ? H(h).solve_relaxation(max_iters, outcome) : RELP_E_ARG;
 }
 relp_status_t relp_from_basis(relp_engine_t* h, const int32_t* basis) { return (h && basis) ? H(h).from_basis(basis) : RELP_E_ARG; }
+
+relp_status_t relp_flush(relp_engine_t* h) { return h ? H(h).flush() : RELP_E_ARG; }
+int32_t relp_update_block(const relp_engine_t* h) { return h ? H(h).update_block() : -1; }
+relp_status_t relp_shard_flush_begin(relp_engine_t* h, double** snap, int64_t* len) {
+    return h ? H(h).shard_flush_begin(snap, len) : RELP_E_ARG;
+}
+relp_status_t relp_shard_flush_end(relp_engine_t* h) { return h ? H(h).shard_flush_end() : RELP_E_ARG; }
 
 int32_t relp_nr_rows(const relp_engine_t* h) { return h ? H(h).nr_rows() : -1; }
 int32_t relp_nr_columns(const relp_engine_t* h) { return h ? H(h).nr_columns() : -1; }

@@ -36,6 +36,7 @@ void Engine::free_all() {
     fr(dBinv_); fr(d_minus_pi_); fr(d_b_); fr(d_alpha_); fr(d_aq_); fr(d_rho_); fr(d_d_); fr(d_w_); fr(d_cost_);
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
+    fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
     prof_ev_.clear();
@@ -61,6 +62,12 @@ ColumnTable Engine::table() const {
 }
 
 Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie}; }
+
+DeferredUpdate Engine::deferred() const {
+    DeferredUpdate du;
+    du.W = d_W_; du.ld = ld_b_; du.kmax = block_; du.S = d_S_; du.pos_of_row = d_pos_of_row_; du.wr = d_wr_; du.R = d_R_;
+    return du;
+}
 
 relp_status_t Engine::download_rec() {
     HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
@@ -229,6 +236,16 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     HIP_TRY(dev_alloc(&d_vsign_, nr_virtual_));
     HIP_TRY(dev_alloc(&d_in_basis_, n_alloc_));
     HIP_TRY(dev_alloc(&d_rec_, 1));
+    block_ = cfg_.update_block < 0 ? (m_ >= 1024 ? 64 : 0) : std::min(cfg_.update_block, 128);
+    if (block_ > 0) {
+        HIP_TRY(dev_alloc(&d_v_, ld_b_));
+        HIP_TRY(dev_alloc(&d_W_, ld_b_ * block_));
+        HIP_TRY(dev_alloc(&d_R_, ld_b_ * block_));
+        HIP_TRY(dev_alloc(&d_wr_, block_));
+        HIP_TRY(dev_alloc(&d_S_, block_));
+        HIP_TRY(dev_alloc(&d_pos_of_row_, m_));
+        HIP_TRY(hipMemset(d_pos_of_row_, 0xFF, sizeof(int32_t) * m_));      // -1 everywhere
+    }
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_rec_), sizeof(PivotRecord), hipHostMallocDefault));
     trace_cap_ = std::max(cfg_.trace_capacity, 0);
     if (trace_cap_ > 0) HIP_TRY(dev_alloc(&d_trace_, 4 * trace_cap_));
@@ -336,20 +353,65 @@ void Engine::enqueue_iteration(int rule) {
     prof_begin(RELP_K_BUILD_COLUMN);
     launch_build_column(A, ld_a_, ct, m_, d_aq_, d_rec_, stream_);
     prof_end();
+    if (block_ == 0) {
+        // explicit inverse, rank-1 update at every pivot (basis_inverse_rows.rs:131-142)
+        prof_begin(RELP_K_FTRAN);
+        launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+        prof_end();
+        prof_begin(RELP_K_RATIO);
+        launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+        prof_end();
+        prof_begin(RELP_K_UPDATE_VECTORS);
+        launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
+        launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_,
+                              d_rec_, stream_);
+        prof_end();
+        prof_begin(RELP_K_UPDATE_INVERSE);
+        launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, d_rho_, d_rec_, stream_);
+        prof_end();
+        return;
+    }
+    // deferred update: B^-1 = (I + W S') B0inv
+    const DeferredUpdate du = deferred();
     prof_begin(RELP_K_FTRAN);
-    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_v_, 0, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_APPLY_W);
+    launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_RATIO);
     launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
     prof_end();
+    prof_begin(RELP_K_UPDATE_W);
+    launch_eta_prepare(du, d_rec_, stream_);
+    launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+    launch_rho_deferred(du, Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
+    prof_end();
     prof_begin(RELP_K_UPDATE_VECTORS);
-    launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
     launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
                           stream_);
     prof_end();
-    prof_begin(RELP_K_UPDATE_INVERSE);
-    launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, d_rho_, d_rec_, stream_);
+    if (++since_flush_ >= block_) enqueue_flush();
+}
+
+// Fold the pending pivots into the explicit inverse: B0inv += W (S' B0inv).  Valid in any state
+// (also after the loop froze): (B0inv, W, S) is consistent after every completed pivot.
+void Engine::enqueue_flush() {
+    if (block_ == 0) return;
+    const DeferredUpdate du = deferred();
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FLUSH);
+    launch_flush_snapshot(du, Binv, ld_b_, row_lo_, row_hi_, d_rec_, stream_);
+    launch_flush_apply(du, Binv, ld_b_, m_, row_lo_, row_hi_, d_rec_, stream_);
+    launch_flush_reset(du, d_rec_, stream_);
     prof_end();
+    since_flush_ = 0;
+}
+
+relp_status_t Engine::flush() {
+    if (cfg_.shard_count > 1 && block_ > 0) return fail(RELP_E_STATE, "sharded flush needs relp_shard_flush_begin/end");
+    enqueue_flush();
+    return RELP_OK;
 }
 
 // ---- step-wise API ------------------------------------------------------------------------------
@@ -382,6 +444,7 @@ relp_status_t Engine::generate_column(int32_t column, double* out_m) {
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->q = column;
     if ((st = upload_rec())) return st;
+    enqueue_flush();                                   // the step-wise calls work on the explicit inverse
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
@@ -420,6 +483,7 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
     HIP_TRY(hipMemcpy(&b_r, d_b_ + row, sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&lv, d_basis_ + row, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
+    enqueue_flush();
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->q = column; h_rec_->d_q = cost; h_rec_->r = row; h_rec_->leaving = lv; h_rec_->alpha_r = alpha_r; h_rec_->b_r = b_r;
     if ((st = upload_rec())) return st;
@@ -484,6 +548,7 @@ relp_status_t Engine::finish_phase_one(int32_t* outcome) {
     const double obj = -h_rec_->minus_objective;
     if (std::fabs(obj) > cfg_.tol_feas * std::max(1.0, initial_phase1_objective_)) { *outcome = RELP_INFEASIBLE; return RELP_OK; }
     std::vector<int32_t> rows_to_remove;
+    if (cfg_.shard_count == 1) enqueue_flush();        // the phase boundary works on the explicit inverse
     relp_status_t st = remove_artificial_basis_variables(rows_to_remove);
     if (st) return st;
     if ((st = switch_to_phase_two(rows_to_remove))) return st;
@@ -633,6 +698,8 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     // columns only (slack bases, two_phase/mod.rs:103-111 `FullInitialBasis`), whose inverse is a
     // signed permutation.  General warm starts need the dense inversion kernel (next round).
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
+    enqueue_flush();                                   // leaves the deferred state empty
+    HIP_TRY(hipStreamSynchronize(stream_));
     std::vector<int32_t> basis(basis_columns, basis_columns + m_);
     std::vector<double> Bn((size_t)m_ * ld_b_, 0.0), b(m_, 0.0);
     std::vector<uint8_t> seen(m_, 0);
@@ -688,6 +755,7 @@ relp_status_t Engine::get_basis_indices(int32_t* out) {
 
 relp_status_t Engine::get_basis_inverse(double* out) {
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "B^-1 is row-sharded");
+    enqueue_flush();
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * m_, dBinv_, sizeof(double) * ld_b_, sizeof(double) * m_, m_, hipMemcpyDeviceToHost));
     return RELP_OK;
@@ -793,11 +861,53 @@ relp_status_t Engine::shard_ftran(double* dev_alpha_slice) {
 
 relp_status_t Engine::shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho) {
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
-    prof_begin(RELP_K_RATIO);
-    launch_gather_alpha(dev_alpha_slices, count, row_stride_, m_, d_alpha_, d_rec_, stream_);
-    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
-    launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, dev_rho, d_rec_, stream_);
+    if (block_ == 0) {
+        prof_begin(RELP_K_RATIO);
+        launch_gather_alpha(dev_alpha_slices, count, row_stride_, m_, d_alpha_, d_rec_, stream_);
+        launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+        launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, dev_rho, d_rec_, stream_);
+        prof_end();
+        return RELP_OK;
+    }
+    // deferred: the slices hold v = B0inv a_q; W is replicated, so every rank forms the full alpha,
+    // updates its copy of W and contributes the rows of B0inv it owns to rho (SUM over ranks).
+    const DeferredUpdate du = deferred();
+    prof_begin(RELP_K_APPLY_W);
+    launch_gather_alpha(dev_alpha_slices, count, row_stride_, m_, d_v_, d_rec_, stream_);
+    launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
     prof_end();
+    prof_begin(RELP_K_RATIO);
+    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_W);
+    launch_eta_prepare(du, d_rec_, stream_);
+    launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+    launch_rho_deferred(du, Binv, ld_b_, m_, row_lo_, row_hi_, dev_rho, d_rec_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_flush_begin(double** dev_snapshot, int64_t* len) {
+    if (len) *len = 0;
+    if (block_ == 0) return RELP_OK;
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FLUSH);
+    launch_flush_snapshot(deferred(), Binv, ld_b_, row_lo_, row_hi_, d_rec_, stream_);
+    prof_end();
+    if (dev_snapshot) *dev_snapshot = d_R_;
+    if (len) *len = ld_b_ * block_;
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_flush_end() {
+    if (block_ == 0) return RELP_OK;
+    const DeferredUpdate du = deferred();
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FLUSH);
+    launch_flush_apply(du, Binv, ld_b_, m_, row_lo_, row_hi_, d_rec_, stream_);
+    launch_flush_reset(du, d_rec_, stream_);
+    prof_end();
+    since_flush_ = 0;
     return RELP_OK;
 }
 
@@ -807,9 +917,13 @@ relp_status_t Engine::shard_update(const double* dev_rho) {
     launch_update_vectors(m_, d_alpha_, dev_rho, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
                           stream_);
     prof_end();
-    prof_begin(RELP_K_UPDATE_INVERSE);
-    launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, dev_rho, d_rec_, stream_);
-    prof_end();
+    if (block_ == 0) {
+        prof_begin(RELP_K_UPDATE_INVERSE);
+        launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, dev_rho, d_rec_, stream_);
+        prof_end();
+    } else {
+        ++since_flush_;
+    }
     return RELP_OK;
 }
 

@@ -41,6 +41,10 @@ class Engine {
     relp_status_t run(int64_t max_iters, int64_t* done, int32_t* outcome);
     relp_status_t solve_relaxation(int64_t max_iters, int32_t* outcome);
     relp_status_t from_basis(const int32_t* basis_columns);
+    relp_status_t flush();
+    int32_t update_block() const { return block_; }
+    relp_status_t shard_flush_begin(double** dev_snapshot, int64_t* len);
+    relp_status_t shard_flush_end();
 
     // getters
     int32_t nr_rows() const { return m_; }
@@ -103,6 +107,14 @@ class Engine {
     PivotRecord* h_rec_ = nullptr;  // pinned
     hipStream_t stream_ = nullptr; bool owns_stream_ = false;
     int64_t trace_cap_ = 0;
+    // deferred update (B^-1 = (I + W S') B0inv), see relp_kernels.h
+    int32_t block_ = 0;            // K, 0 = explicit rank-1 updates
+    int64_t since_flush_ = 0;      // pivots enqueued since the last flush
+    double* d_v_ = nullptr;        // B0inv a_q before the W correction
+    double *d_W_ = nullptr, *d_wr_ = nullptr, *d_R_ = nullptr;
+    int32_t *d_S_ = nullptr, *d_pos_of_row_ = nullptr;
+    DeferredUpdate deferred() const;
+    void enqueue_flush();
     int32_t n_alloc_ = 0;     // allocated tableau columns (artificial + provider)
 
     // ---- shards ----

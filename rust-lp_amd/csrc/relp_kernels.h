@@ -30,6 +30,25 @@ struct PivotRecord {
     int32_t owner_has_row;  // sharded: 1 iff this rank owns row r
     int32_t pad_;
     double  key1;           // selection key of q (d_q, or its position in the search order)
+    int32_t n_eta;          // deferred update: columns of W in use (distinct pivot rows since the last flush)
+    int32_t eta_target;     // deferred update: column of W that receives this pivot's u
+    int32_t n_eta_old;      // deferred update: n_eta before this pivot
+    int32_t pad2_;
+};
+
+// Deferred (blocked) update of the explicit inverse:  B^-1 = (I + W S') B0inv, where B0inv is the
+// dense inverse at the last flush, S = [e_s1 .. e_sp] selects the distinct pivot rows since then and
+// W (m x p, column-major) accumulates the elementary matrices E_k = I + u_k e_rk'.  A flush folds the
+// p pivots into B0inv with one m x p x m GEMM (B0inv += W (S' B0inv)), so the 16 m^2 bytes of
+// basis_inverse_rows.rs:63-83 are paid once per K pivots instead of once per pivot.
+struct DeferredUpdate {
+    double*  W;             // m x kmax, column j contiguous with pitch ld
+    int64_t  ld;
+    int32_t  kmax;
+    int32_t* S;             // column j of W belongs to pivot row S[j]            (kmax)
+    int32_t* pos_of_row;    // row -> column of W, or -1                          (m)
+    double*  wr;            // row r of W before this pivot's update              (kmax)
+    double*  R;             // flush snapshot S' B0inv, kmax x ld (row j contiguous)
 };
 
 // Read-only description of the tableau's columns (Kind + MatrixData, partially.rs:72-80,
@@ -91,6 +110,24 @@ void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, co
 void launch_set_identity(double* Binv_local, int64_t ld_b, int32_t row_lo, int32_t row_hi, hipStream_t s);
 void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
                        hipStream_t s);
+
+// deferred update (see DeferredUpdate)
+// alpha[i] = v[i] + sum_j W[i,j] v[S[j]] for every row
+void launch_apply_w(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const PivotRecord* rec,
+                    hipStream_t s);
+// wr = W[r,:], pick the target column (existing column of row r or a new one), book-keeping
+void launch_eta_prepare(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
+// W <- W + u W[r,:], then column target += / = u, with u = eta - e_r built from alpha
+void launch_update_w(const DeferredUpdate& du, int32_t m, const double* alpha, const PivotRecord* rec, hipStream_t s);
+// rho = sum over owned rows in {r} U S of coefficient * B0inv[row,:]  (coefficient 1 for r, W[r,j] for S[j])
+void launch_rho_deferred(const DeferredUpdate& du, const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo,
+                         int32_t row_hi, double* rho, PivotRecord* rec, hipStream_t s);
+// B0inv[rows] += W[rows,:] (S' B0inv); the snapshot R must hold S' B0inv of ALL ranks' rows
+void launch_flush_snapshot(const DeferredUpdate& du, const double* Binv, int64_t ld_b, int32_t row_lo, int32_t row_hi,
+                           const PivotRecord* rec, hipStream_t s);
+void launch_flush_apply(const DeferredUpdate& du, double* Binv, int64_t ld_b, int32_t m, int32_t row_lo,
+                        int32_t row_hi, const PivotRecord* rec, hipStream_t s);
+void launch_flush_reset(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
 
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);

@@ -373,6 +373,169 @@ __global__ __launch_bounds__(kThreads) void k_update_inverse(double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Deferred (blocked) update:  B^-1 = (I + W S') B0inv   -- see DeferredUpdate in relp_kernels.h
+// ------------------------------------------------------------------------------------------------
+static constexpr int kMaxEta = 128;
+
+// alpha = M v = v + W (S' v).  One thread per row; the p gathered entries v[S[j]] sit in LDS.
+__global__ __launch_bounds__(kThreads) void k_apply_w(DeferredUpdate du, int m, const double* __restrict__ v,
+                                                      double* __restrict__ alpha, const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_vs[kMaxEta];
+    const int p = rec->n_eta;
+    if ((int)threadIdx.x < p) s_vs[threadIdx.x] = v[du.S[threadIdx.x]];
+    __syncthreads();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= m) return;
+    double a = v[i];
+    for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
+    alpha[i] = a;
+}
+
+// One wavefront-sized workgroup: save row r of W, choose the column that will receive u.
+__global__ void k_eta_prepare(DeferredUpdate du, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int p = rec->n_eta, r = rec->r;
+    __syncthreads();                         // every wavefront has read n_eta before lane 0 bumps it
+    for (int j = threadIdx.x; j < p; j += blockDim.x) du.wr[j] = du.W[(int64_t)j * du.ld + r];
+    if (threadIdx.x == 0) {
+        int jt = du.pos_of_row[r];
+        rec->n_eta_old = p;
+        if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
+        rec->eta_target = jt;
+    }
+}
+
+// E_k = I + u e_r' with u_r = 1/alpha_r - 1, u_i = -alpha_i/alpha_r:
+//   (I + u e_r')(I + W S') = I + (W + u W[r,:]) S' + u e_r'
+__global__ __launch_bounds__(kThreads) void k_update_w(DeferredUpdate du, int m, const double* __restrict__ alpha,
+                                                       const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_wr[kMaxEta];
+    const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r;
+    if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= m) return;
+    const double ar = rec->alpha_r;
+    const double u = (i == r) ? (1.0 / ar - 1.0) : (-alpha[i] / ar);
+    if (u != 0.0) {
+        for (int j = 0; j < p_old; ++j) {
+            const double w = s_wr[j];
+            if (w != 0.0) du.W[(int64_t)j * du.ld + i] = fma(u, w, du.W[(int64_t)j * du.ld + i]);
+        }
+    }
+    double* tgt = du.W + (int64_t)jt * du.ld + i;
+    if (jt < p_old) *tgt += u; else *tgt = u;
+}
+
+// rho = e_r' (I + W S') B0inv restricted to the rows this rank owns (a SUM over ranks completes it).
+__global__ __launch_bounds__(kThreads) void k_rho_deferred(DeferredUpdate du, const double* __restrict__ Binv,
+                                                           int64_t ld_b, int m, int row_lo, int row_hi,
+                                                           double* __restrict__ rho, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_coef[kMaxEta];
+    __shared__ int s_row[kMaxEta];
+    const int p = rec->n_eta, r = rec->r;
+    if ((int)threadIdx.x < p) {
+        const int row = du.S[threadIdx.x];
+        s_row[threadIdx.x] = row;
+        s_coef[threadIdx.x] = (row >= row_lo && row < row_hi) ? du.W[(int64_t)threadIdx.x * du.ld + r] : 0.0;
+    }
+    __syncthreads();
+    const int c = (blockIdx.x * kThreads + threadIdx.x) * 2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) rec->owner_has_row = (r >= row_lo && r < row_hi) ? 1 : 0;
+    if (c >= (int)ld_b) return;
+    double2 acc = make_double2(0.0, 0.0);
+    if (r >= row_lo && r < row_hi) acc = *reinterpret_cast<const double2*>(Binv + (int64_t)r * ld_b + c);
+    for (int j = 0; j < p; ++j) {
+        const double w = s_coef[j];
+        if (w != 0.0) {
+            const double2 b = *reinterpret_cast<const double2*>(Binv + (int64_t)s_row[j] * ld_b + c);
+            acc.x = fma(w, b.x, acc.x);
+            acc.y = fma(w, b.y, acc.y);
+        }
+    }
+    *reinterpret_cast<double2*>(rho + c) = acc;
+}
+
+// R[j,:] = B0inv[S[j],:] for the rows this rank owns, zero otherwise (a SUM over ranks completes it).
+__global__ void k_flush_snapshot(DeferredUpdate du, const double* __restrict__ Binv, int64_t ld_b, int row_lo,
+                                 int row_hi, const PivotRecord* rec) {
+    const int p = rec->n_eta;
+    const int j = blockIdx.y;
+    if (j >= p) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int)ld_b) return;
+    const int row = du.S[j];
+    du.R[(int64_t)j * du.ld + c] = (row >= row_lo && row < row_hi) ? Binv[(int64_t)row * ld_b + c] : 0.0;
+}
+
+// B0inv[i, c] += sum_j W[i, j] R[j, c]   (m x p x m GEMM, p <= kmax).  64 x 64 output tile per
+// workgroup, W and R tiles staged through LDS, 4 x 4 outputs per thread.
+static constexpr int kFT = 64;   // tile edge
+static constexpr int kFK = 16;   // k-chunk
+__global__ __launch_bounds__(kThreads) void k_flush_apply(DeferredUpdate du, double* __restrict__ Binv, int64_t ld_b,
+                                                          int m, int row_lo, int row_hi, const PivotRecord* rec) {
+    const int p = rec->n_eta;
+    if (p == 0) return;
+    __shared__ double s_w[kFK][kFT + 1];   // W tile, [k][row]
+    __shared__ double s_r[kFK][kFT];       // R tile, [k][col]
+    const int i0 = row_lo + blockIdx.y * kFT, c0 = blockIdx.x * kFT;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4 x 4 outputs each
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = 0; k0 < p; k0 += kFK) {
+        // 16 x 64 = 1024 entries per tile, 4 per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = threadIdx.x + e * kThreads;
+            const int kk = idx >> 6, x = idx & 63;
+            const int k = k0 + kk;
+            const int i = i0 + x, c = c0 + x;
+            s_w[kk][x] = (k < p && i < row_hi) ? du.W[(int64_t)k * du.ld + i] : 0.0;
+            s_r[kk][x] = (k < p && c < (int)ld_b) ? du.R[(int64_t)k * du.ld + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kFK; ++kk) {
+            double wv[4], rv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wv[a] = s_w[kk][ty * 4 + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rv[b] = s_r[kk][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(wv[a], rv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = i0 + ty * 4 + a;
+        if (i >= row_hi) continue;
+        const int c = c0 + tx * 4;
+        if (c + 3 < (int)ld_b) {
+            double2* p0 = reinterpret_cast<double2*>(Binv + (int64_t)i * ld_b + c);
+            double2 v0 = p0[0], v1 = p0[1];
+            v0.x += acc[a][0]; v0.y += acc[a][1]; v1.x += acc[a][2]; v1.y += acc[a][3];
+            p0[0] = v0; p0[1] = v1;
+        }
+    }
+}
+
+__global__ void k_flush_reset(DeferredUpdate du, PivotRecord* rec) {
+    const int p = rec->n_eta;
+    for (int j = threadIdx.x; j < p; j += blockDim.x) du.pos_of_row[du.S[j]] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) { rec->n_eta = 0; rec->n_eta_old = 0; rec->eta_target = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Phase switch, identity, synthetic fill
 // ------------------------------------------------------------------------------------------------
 __global__ void k_weighted_column_sums(const double* __restrict__ Binv, int64_t ld_b, int m,
@@ -570,6 +733,42 @@ void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t see
     const int64_t total = (int64_t)m * n;
     if (total <= 0) return;
     hipLaunchKernelGGL(k_fill_dense, dim3(cdiv(total, 256)), dim3(256), 0, s, A, ld, m, n, seed, first_column);
+}
+
+void launch_apply_w(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const PivotRecord* rec,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_apply_w, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, v, alpha, rec);
+}
+
+void launch_eta_prepare(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_eta_prepare, dim3(1), dim3(128), 0, s, du, rec);
+}
+
+void launch_update_w(const DeferredUpdate& du, int32_t m, const double* alpha, const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_update_w, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, alpha, rec);
+}
+
+void launch_rho_deferred(const DeferredUpdate& du, const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo,
+                         int32_t row_hi, double* rho, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_rho_deferred, dim3(cdiv(ld_b, 2 * kThreads)), dim3(kThreads), 0, s, du, Binv, ld_b, m, row_lo,
+                       row_hi, rho, rec);
+}
+
+void launch_flush_snapshot(const DeferredUpdate& du, const double* Binv, int64_t ld_b, int32_t row_lo, int32_t row_hi,
+                           const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_flush_snapshot, dim3(cdiv(ld_b, 256), du.kmax), dim3(256), 0, s, du, Binv, ld_b, row_lo, row_hi,
+                       rec);
+}
+
+void launch_flush_apply(const DeferredUpdate& du, double* Binv, int64_t ld_b, int32_t m, int32_t row_lo,
+                        int32_t row_hi, const PivotRecord* rec, hipStream_t s) {
+    if (row_hi <= row_lo) return;
+    dim3 grid(cdiv(ld_b, kFT), cdiv(row_hi - row_lo, kFT));
+    hipLaunchKernelGGL(k_flush_apply, grid, dim3(kThreads), 0, s, du, Binv, ld_b, m, row_lo, row_hi, rec);
+}
+
+void launch_flush_reset(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_flush_reset, dim3(1), dim3(128), 0, s, du, rec);
 }
 
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {

@@ -31,8 +31,10 @@ RUNNING, OPTIMAL, UNBOUNDED, INFEASIBLE, PHASE_ONE_DONE, NO_ROW_PHASE_ONE = rang
 OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded", INFEASIBLE: "infeasible",
                  PHASE_ONE_DONE: "phase_one_done", NO_ROW_PHASE_ONE: "no_row_phase_one"}
 # relp_kernel_id_t
-K_PRICE, K_SELECT_COLUMN, K_BUILD_COLUMN, K_FTRAN, K_RATIO, K_UPDATE_VECTORS, K_UPDATE_INVERSE = range(7)
-KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse"]
+(K_PRICE, K_SELECT_COLUMN, K_BUILD_COLUMN, K_FTRAN, K_RATIO, K_UPDATE_VECTORS, K_UPDATE_INVERSE, K_APPLY_W,
+ K_UPDATE_W, K_FLUSH) = range(10)
+KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
+                "apply_w", "update_w", "flush"]
 FORMAT_CSC, FORMAT_DENSE = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -55,7 +57,8 @@ class Config(C.Structure):
                 ("tol_cost", C.c_double), ("tol_pivot", C.c_double), ("tol_zero", C.c_double),
                 ("tol_tie", C.c_double), ("tol_feas", C.c_double),
                 ("poll_interval", C.c_int32), ("trace_capacity", C.c_int32),
-                ("shard_rank", C.c_int32), ("shard_count", C.c_int32)]
+                ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
+                ("update_block", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/relp_engine.h declares (tests/test_abi.py checks the export list against the header)
@@ -76,6 +79,10 @@ _SIGNATURES = {
     "relp_run": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "relp_solve_relaxation": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
     "relp_from_basis": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "relp_flush": (C.c_int, [C.c_void_p]),
+    "relp_update_block": (C.c_int32, [C.c_void_p]),
+    "relp_shard_flush_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "relp_shard_flush_end": (C.c_int, [C.c_void_p]),
     "relp_nr_rows": (C.c_int32, [C.c_void_p]),
     "relp_nr_columns": (C.c_int32, [C.c_void_p]),
     "relp_phase": (C.c_int32, [C.c_void_p]),
@@ -280,6 +287,13 @@ class Tableau:
         oc = C.c_int32()
         self._ck(self._lib.relp_solve_relaxation(self._h, max_iters, C.byref(oc)))
         return oc.value
+
+    def flush(self) -> None:
+        """Fold pending deferred updates into the explicit inverse."""
+        self._ck(self._lib.relp_flush(self._h))
+
+    def update_block(self) -> int:
+        return self._lib.relp_update_block(self._h)
 
     def from_basis(self, basis_columns) -> None:
         arr = np.ascontiguousarray(basis_columns, dtype=np.int32)

@@ -34,6 +34,7 @@ class HipShardOps:
         self.row_stride = stride.value
         self.candidate_len = self.lib.relp_shard_candidate_len(self.h)
         self.rho_len = self.lib.relp_shard_rho_len(self.h)
+        self.update_block = self.lib.relp_update_block(self.h)
 
     def _ck(self, st):
         if st != 0:
@@ -62,6 +63,23 @@ class HipShardOps:
         self._ck(self.lib.relp_poll(self.h, C.byref(oc), C.byref(it)))
         return oc.value, it.value
 
+    def flush_begin(self, torch, device):
+        """Snapshot of S' B0inv (own rows, zeros elsewhere) as a tensor view to all-reduce, or None."""
+        ptr, ln = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.relp_shard_flush_begin(self.h, C.byref(ptr), C.byref(ln)))
+        if ln.value == 0:
+            return None
+        if getattr(self, "_snap", None) is None or self._snap_ptr != ptr.value:
+            # wrap the engine-owned buffer without copying (device memory plumbing only)
+            iface = {"shape": (ln.value,), "typestr": "<f8", "data": (ptr.value, False), "version": 3}
+            holder = type("_DevBuf", (), {"__cuda_array_interface__": iface})()
+            self._snap = torch.as_tensor(holder, device=device)
+            self._snap_ptr = ptr.value
+        return self._snap
+
+    def flush_end(self):
+        self._ck(self.lib.relp_shard_flush_end(self.h))
+
 
 class ShardedPivotLoop:
     """phase_one::primal / phase_two::primal (phase_one.rs:125, phase_two.rs:22) across ranks."""
@@ -81,6 +99,8 @@ class ShardedPivotLoop:
         self.slice = torch.zeros(o.row_stride, dtype=f64, device=device)
         self.slices = torch.zeros(o.row_stride * self.world, dtype=f64, device=device)
         self.rho = torch.zeros(o.rho_len, dtype=f64, device=device)
+        self._block = int(getattr(o, "update_block", 0))
+        self._since_flush = 0
         self.stream = None
         if device.type == "cuda":
             # collectives are ordered against the current stream: put the kernels on it too
@@ -97,6 +117,19 @@ class ShardedPivotLoop:
         o.ratio(self.slices, self.world, self.rho)
         d.all_reduce(self.rho, op=d.ReduceOp.SUM)
         o.update(self.rho)
+        self._since_flush += 1
+        if self._block > 0 and self._since_flush >= self._block:
+            self._flush()
+
+    def _flush(self):
+        """Deferred update: fold the last K pivots into the owned rows of B0inv.  The rows S' B0inv
+        live on different ranks, so their snapshot is completed by one SUM all-reduce (8 K m bytes,
+        once per K pivots)."""
+        snap = self.ops.flush_begin(self.torch, self.device)
+        if snap is not None:
+            self.dist.all_reduce(snap, op=self.dist.ReduceOp.SUM)
+            self.ops.flush_end()
+        self._since_flush = 0
 
     def _enqueue(self, count: int):
         if self.stream is not None:

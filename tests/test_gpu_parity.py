@@ -30,10 +30,17 @@ def dense_problem(m, n, seed):
     return MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"])
 
 
+# update_block: 0 = rank-1 update of the explicit inverse per pivot (reference-literal), K > 0 =
+# deferred update folded in every K pivots (K = 3 forces frequent flushes and repeated pivot rows)
+BLOCKS = [0, 3, 64]
+
+
+@pytest.mark.parametrize("block", BLOCKS)
 @pytest.mark.parametrize("m,n,seed", [(8, 8, 1), (32, 48, 7), (128, 128, 20250001), (257, 131, 3), (300, 700, 11)])
-def test_dense_trace_matches_f64_oracle(m, n, seed):
+def test_dense_trace_matches_f64_oracle(m, n, seed, block):
     md = dense_problem(m, n, seed)
-    t = engine.Tableau(md, trace_capacity=1 << 16)
+    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block)
+    assert t.update_block() == block
     assert t.solve_relaxation() == engine.OPTIMAL
     ref = relp_f64.OracleF64(md.ensure_csc())
     assert ref.run() == "optimal"
@@ -43,11 +50,12 @@ def test_dense_trace_matches_f64_oracle(m, n, seed):
     assert ident <= 1e-8 and basic <= 1e-8 and min_b >= -1e-9
 
 
+@pytest.mark.parametrize("block", [0, 16])
 @pytest.mark.parametrize("m,n,seed", [(8, 8, 1), (32, 48, 7), (128, 128, 20250001)])
-def test_dense_trace_matches_exact_oracle(m, n, seed):
+def test_dense_trace_matches_exact_oracle(m, n, seed, block):
     """Parity shadows of config C2: the f64 GPU pivot sequence equals the exact-rational trace."""
     md = dense_problem(m, n, seed)
-    t = engine.Tableau(md, trace_capacity=1 << 16)
+    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block)
     assert t.solve_relaxation() == engine.OPTIMAL
     cols, b, c = synthetic.dense_lp_exact(m, n, seed)
     emd = ox.MatrixData(cols, b, [], 0, 0, m, 0, c, [None] * n)
@@ -62,12 +70,13 @@ def test_dense_trace_matches_exact_oracle(m, n, seed):
         assert abs(bfs[j] - float(v)) <= VEC_TOL * max(1.0, abs(float(v)))
 
 
+@pytest.mark.parametrize("block", [0, 5, 64])
 @pytest.mark.parametrize("m,n,seed", [(20, 30, 5), (60, 90, 2), (150, 220, 9)])
-def test_sparse_two_phase_matches_f64_oracle(m, n, seed):
+def test_sparse_two_phase_matches_f64_oracle(m, n, seed, block):
     """==, <=, >= rows and upper bounds: phase 1 (FirstProfitableWithMemory), the phase switch and
     phase 2 (SteepestDescent), CSC input."""
     md = MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, seed))
-    t = engine.Tableau(md, trace_capacity=1 << 16)
+    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block)
     outcome = t.solve_relaxation()
     ref = relp_f64.OracleF64(md)
     status = ref.run()
@@ -104,7 +113,7 @@ def test_stepwise_api_matches_loop():
 
 def test_relative_costs_and_generate_element():
     md = dense_problem(24, 36, 21)
-    t = engine.Tableau(md)
+    t = engine.Tableau(md, update_block=4)
     t.run(1 << 20)          # finishes the (empty) phase 1
     t.run(5)
     ref = relp_f64.OracleF64(md.ensure_csc())
@@ -190,6 +199,7 @@ def test_dense_2000_properties():
     m = n = 2000
     md = dense_problem(m, n, 20250001)
     t = engine.Tableau(md, trace_capacity=1 << 16)
+    assert t.update_block() == 64                  # automatic choice at this size
     assert t.run(1 << 20)[1] == engine.PHASE_ONE_DONE
     done, outcome = t.run(60)
     assert done == 60 and outcome == engine.RUNNING
@@ -216,8 +226,9 @@ def test_dense_2000_properties():
         assert np.max(np.abs(e)) <= 1e-8
 
 
+@pytest.mark.parametrize("block", [0, 4])
 @pytest.mark.parametrize("world,m,n,seed", [(2, 48, 64, 17), (3, 61, 45, 23)])
-def test_shard_entry_points_on_one_gpu(world, m, n, seed):
+def test_shard_entry_points_on_one_gpu(world, m, n, seed, block):
     """`relp_shard_*` with G engines in one process on one GPU: the exchange steps (all-gather of
     candidates, all-gather of alpha slices, SUM all-reduce of rho) are done with torch ops on a
     shared stream.  Every shard must walk the single-engine pivot sequence."""
@@ -234,7 +245,7 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed):
         lo, hi = engine.shard_column_range(n, r, world)
         md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=lp["b"], cost=lp["c"],
                         upper_bound=np.full(n, np.inf), dense=np.asfortranarray(lp["A"][:, lo:hi]))
-        t = engine.Tableau(md, trace_capacity=4096, shard_rank=r, shard_count=world)
+        t = engine.Tableau(md, trace_capacity=4096, shard_rank=r, shard_count=world, update_block=block)
         t.set_stream(stream)
         tabs.append(t)
         ops.append(HipShardOps(t))
@@ -256,10 +267,21 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed):
         for o in ops:
             o.update(rho)
 
+    def flush():
+        snaps = [o.flush_begin(torch, dev) for o in ops]
+        if snaps[0] is None:
+            return
+        total = torch.stack(snaps).sum(dim=0)
+        for sn, o in zip(snaps, ops):
+            sn.copy_(total)
+            o.flush_end()
+
     iteration()                                   # phase 1: no candidate anywhere
     assert [o.poll()[0] for o in ops] == [engine.PHASE_ONE_DONE] * world
-    for _ in range(len(single.trace()) + 3):
+    for k in range(len(single.trace()) + 3):
         iteration()
+        if block and (k + 1) % block == 0:
+            flush()
     torch.cuda.synchronize()
     for o, t in zip(ops, tabs):
         oc, it = o.poll()
