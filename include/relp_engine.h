@@ -97,7 +97,7 @@ typedef struct {
     /* basis-inverse maintenance: 0 = rank-1 update of the explicit inverse at every pivot
      * (basis_inverse_rows.rs:131-142 literally); K > 0 = deferred: the explicit inverse is kept as
      * (I + W S') B0inv and the K most recent pivots are folded in by one m x K x m GEMM ("flush");
-     * -1 = automatic (64 when m >= 1024, else 0).  Results are the same up to f64 rounding. */
+     * -1 = automatic (64 when m >= 4096, else 0).  Results are the same up to f64 rounding. */
     int32_t update_block;
     int32_t reserved_;
 } relp_config_t;

@@ -36,6 +36,7 @@ void Engine::free_all() {
     fr(dBinv_); fr(d_minus_pi_); fr(d_b_); fr(d_alpha_); fr(d_aq_); fr(d_rho_); fr(d_d_); fr(d_w_); fr(d_cost_);
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
+    fr(d_part_k1_); fr(d_part_j_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
@@ -236,7 +237,12 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     HIP_TRY(dev_alloc(&d_vsign_, nr_virtual_));
     HIP_TRY(dev_alloc(&d_in_basis_, n_alloc_));
     HIP_TRY(dev_alloc(&d_rec_, 1));
-    block_ = cfg_.update_block < 0 ? (m_ >= 1024 ? 64 : 0) : std::min(cfg_.update_block, 128);
+    {
+        const int64_t slots = price_structural_blocks(col_lo_, col_hi_) + (nr_artificial_ + nr_virtual_ + 255) / 256 + 8;
+        HIP_TRY(dev_alloc(&d_part_k1_, slots));
+        HIP_TRY(dev_alloc(&d_part_j_, slots));
+    }
+    block_ = cfg_.update_block < 0 ? (m_ >= 4096 ? 64 : 0) : std::min(cfg_.update_block, 128);
     if (block_ > 0) {
         HIP_TRY(dev_alloc(&d_v_, ld_b_));
         HIP_TRY(dev_alloc(&d_W_, ld_b_ * block_));
@@ -344,14 +350,22 @@ void Engine::enqueue_iteration(int rule) {
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     const int n = nr_columns();
+    // PRICE with the partial argmin fused in, then one single-workgroup launch that picks the
+    // entering column and builds it in row space
+    SelectPartials sp;
+    sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+    sp.n = n; sp.offset = 0; sp.pad_ = 0;
+    const int nb_struct = price_structural_blocks(col_lo_, col_hi_);
+    const int nb_virt = price_virtual_blocks(ct);
     prof_begin(RELP_K_PRICE);
-    enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
+    launch_price_structural_sel(A, ld_a_, ct, d_minus_pi_, d_d_, col_lo_, col_hi_, phase_, sp, d_rec_, stream_);
+    if (col_lo_ > 0 || col_hi_ < nr_normal_) launch_price_mask_unowned(ct, d_d_, col_lo_, col_hi_, d_rec_, stream_);
+    SelectPartials spv = sp;
+    spv.offset = nb_struct;
+    launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_SELECT_COLUMN);
-    launch_select_column(d_d_, d_in_basis_, n, rule, cfg_.tol_cost, d_rec_, stream_);
-    prof_end();
-    prof_begin(RELP_K_BUILD_COLUMN);
-    launch_build_column(A, ld_a_, ct, m_, d_aq_, d_rec_, stream_);
+    launch_select_partials(sp, nb_struct + nb_virt, d_d_, A, ld_a_, ct, m_, d_aq_, d_rec_, stream_);
     prof_end();
     if (block_ == 0) {
         // explicit inverse, rank-1 update at every pivot (basis_inverse_rows.rs:131-142)
@@ -380,10 +394,9 @@ void Engine::enqueue_iteration(int rule) {
     launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_RATIO);
-    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_UPDATE_W);
-    launch_eta_prepare(du, d_rec_, stream_);
     launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
     launch_rho_deferred(du, Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
     prof_end();

@@ -113,6 +113,8 @@ class Engine {
     double* d_v_ = nullptr;        // B0inv a_q before the W correction
     double *d_W_ = nullptr, *d_wr_ = nullptr, *d_R_ = nullptr;
     int32_t *d_S_ = nullptr, *d_pos_of_row_ = nullptr;
+    double* d_part_k1_ = nullptr;  // PRICE workgroups' partial argmin (SelectPartials)
+    int32_t* d_part_j_ = nullptr;
     DeferredUpdate deferred() const;
     void enqueue_flush();
     int32_t n_alloc_ = 0;     // allocated tableau columns (artificial + provider)

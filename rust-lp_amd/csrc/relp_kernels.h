@@ -69,6 +69,19 @@ struct ColumnTable {
 
 struct Tolerances { double cost, pivot, zero, tie; };
 
+// PRICE -> entering-column choice without a second pass over d: every PRICE workgroup leaves the
+// best (key, j) of its own columns here (key as in k_select_column), k_select_partials reduces them.
+struct SelectPartials {
+    double*        k1;        // per workgroup: best key (+inf = none)
+    int32_t*       j;         // per workgroup: its column
+    const uint8_t* in_basis;
+    double         tol_cost;
+    int32_t        rule;      // relp_pivot_rule_t
+    int32_t        n;         // tableau columns (search-order wrap for FirstProfitableWithMemory)
+    int32_t        offset;    // first slot this launch may use
+    int32_t        pad_;
+};
+
 // ---- launchers (all asynchronous on `s`) -------------------------------------------------------
 // cost_mode: 0 = no cost term (tableau row), 1 = phase-1 costs (artificial: 1), 2 = phase-2 costs
 // PRICE, structural part: d[na + p] = c_p + (-pi[0:mc]) . A[:,p] (+ -pi[bound_row]) for p in [p_lo, p_hi)
@@ -78,6 +91,20 @@ void launch_price_structural(const double* A, int64_t ld_a, const ColumnTable& c
 // structural columns outside [p_lo, p_hi) get +inf (sharded pricing)
 void launch_price_mask_unowned(const ColumnTable& ct, double* d, int32_t p_lo, int32_t p_hi,
                                const PivotRecord* rec, hipStream_t s);
+// fused PRICE + partial selection (hot loop): same results as the two-kernel form
+void launch_price_structural_sel(const double* A, int64_t ld_a, const ColumnTable& ct, const double* minus_pi,
+                                 double* d, int32_t p_lo, int32_t p_hi, int32_t cost_mode, SelectPartials sp,
+                                 const PivotRecord* rec, hipStream_t s);
+void launch_price_virtual_sel(const ColumnTable& ct, const double* minus_pi, double* d, int32_t cost_mode,
+                              SelectPartials sp, const PivotRecord* rec, hipStream_t s);
+int32_t price_structural_blocks(int32_t p_lo, int32_t p_hi);
+int32_t price_virtual_blocks(const ColumnTable& ct);
+// reduce `count` partials, record q / d_q, and build aq (= k_select_column + k_build_column)
+void launch_select_partials(SelectPartials sp, int32_t count, const double* d, const double* A, int64_t ld_a,
+                            const ColumnTable& ct, int32_t m, double* aq, PivotRecord* rec, hipStream_t s);
+// ratio test followed by the deferred-update bookkeeping of k_eta_prepare (du.kmax = 0: ratio only)
+void launch_ratio_eta(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
+                      const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
 // PRICE, artificial + virtual columns
 void launch_price_virtual(const ColumnTable& ct, const double* minus_pi, double* d, int32_t cost_mode,
                           const PivotRecord* rec, hipStream_t s);

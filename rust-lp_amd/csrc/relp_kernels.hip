@@ -78,24 +78,46 @@ __device__ __forceinline__ void block_multi_dot(const double* __restrict__ M, in
     }
 }
 
+// Selection key of a candidate column (smaller wins, ties by smaller j):
+//   SteepestDescent: d_j (pivot_rule.rs:118); FirstProfitable[WithMemory]: position in the search order (:88)
+__device__ __forceinline__ double select_key(int rule, int n, const PivotRecord* rec, int j, double d_j) {
+    if (rule == 2) return d_j;
+    const int last = (rule == 1 && rec) ? rec->last_selected : -1;
+    if (last >= 0) return (double)(j >= last ? j - last : j - last + n);
+    return (double)j;
+}
+
 // ------------------------------------------------------------------------------------------------
 // PRICE
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_price_structural(
     const double* __restrict__ A, int64_t ld_a, ColumnTable ct, const double* __restrict__ minus_pi,
-    double* __restrict__ d, int p_lo, int p_hi, int cost_mode, const PivotRecord* rec) {
+    double* __restrict__ d, int p_lo, int p_hi, int cost_mode, SelectPartials sp, const PivotRecord* rec) {
     if (rec && rec->outcome != DEV_RUNNING) return;
     __shared__ double s_partial[4 * kVecPerBlock];
     const int v0 = p_lo + blockIdx.x * kVecPerBlock;
     double dot = 0.0;
     block_multi_dot(A, ld_a, ct.nr_constraints, v0, p_hi, minus_pi, s_partial, dot);
     const int p = v0 + threadIdx.x;
+    double key = INFINITY;
+    int kj = 0x7fffffff;
     if (threadIdx.x < kVecPerBlock && p < p_hi) {
         double v = dot;
         const int br = ct.bound_row[p];
         if (br >= 0) v += minus_pi[br];                           // +1 entry in the bound row
         if (cost_mode == 2) v += ct.cost[p];                      // phase 1: Cost::Zero
-        d[ct.nr_artificial + p] = v;
+        const int j = ct.nr_artificial + p;
+        d[j] = v;
+        if (sp.k1 && !sp.in_basis[j] && v < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, v); kj = j; }
+    }
+    if (sp.k1 && threadIdx.x < 64) {                              // lanes 0..7 of wavefront 0 hold the candidates
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            const double ok = __shfl_down(key, off, 64);
+            const int oj = __shfl_down(kj, off, 64);
+            if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+        }
+        if (threadIdx.x == 0) { sp.k1[sp.offset + blockIdx.x] = key; sp.j[sp.offset + blockIdx.x] = kj; }
     }
 }
 
@@ -106,20 +128,114 @@ __global__ void k_price_mask_unowned(ColumnTable ct, double* __restrict__ d, int
     if (p < ct.nr_normal && (p < p_lo || p >= p_hi)) d[ct.nr_artificial + p] = INFINITY;
 }
 
-__global__ void k_price_virtual(ColumnTable ct, const double* __restrict__ minus_pi, double* __restrict__ d,
-                                int cost_mode, const PivotRecord* rec) {
+__global__ __launch_bounds__(kThreads) void k_price_virtual(ColumnTable ct, const double* __restrict__ minus_pi,
+                                                            double* __restrict__ d, int cost_mode, SelectPartials sp,
+                                                            const PivotRecord* rec) {
     if (rec && rec->outcome != DEV_RUNNING) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = -1;
+    double val = 0.0;
     if (t < ct.nr_artificial) {
-        d[t] = (cost_mode == 1 ? 1.0 : 0.0) + minus_pi[ct.column_to_row[t]];   // Cost::One + (-pi)_row
+        j = t;
+        val = (cost_mode == 1 ? 1.0 : 0.0) + minus_pi[ct.column_to_row[t]];   // Cost::One + (-pi)_row
     } else {
         const int v = t - ct.nr_artificial;
         if (v < ct.nr_virtual) {
             double s = (double)ct.vsign[v] * minus_pi[ct.vrow0[v]];
             const int r1 = ct.vrow1[v];
             if (r1 >= 0) s += minus_pi[r1];
-            d[ct.nr_artificial + ct.nr_normal + v] = s;           // slack cost is None (zero)
+            j = ct.nr_artificial + ct.nr_normal + v;              // slack cost is None (zero)
+            val = s;
         }
+    }
+    if (j >= 0) d[j] = val;
+    if (!sp.k1) return;
+    __shared__ double s_k[kThreads / 64];
+    __shared__ int s_j[kThreads / 64];
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (j >= 0 && !sp.in_basis[j] && val < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, val); kj = j; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(key, off, 64);
+        const int oj = __shfl_down(kj, off, 64);
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k[wave] = key; s_j[wave] = kj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w)
+            if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
+        sp.k1[sp.offset + blockIdx.x] = key;
+        sp.j[sp.offset + blockIdx.x] = kj;
+    }
+}
+
+// Entering column from the PRICE workgroups' partial results, then aq := that column in row space
+// (k_select_column + k_build_column in one single-workgroup launch).
+__global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials sp, int count,
+                                                                  const double* __restrict__ d,
+                                                                  const double* __restrict__ A, int64_t ld_a,
+                                                                  ColumnTable ct, int m, double* __restrict__ aq,
+                                                                  PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_k1[kSingleBlock / 64];
+    __shared__ int s_j[kSingleBlock / 64];
+    __shared__ int s_q;
+    double k1 = INFINITY;
+    int bj = 0x7fffffff;
+    for (int t = threadIdx.x; t < count; t += kSingleBlock) {
+        const double key = sp.k1[t];
+        const int j = sp.j[t];
+        if (key < k1 || (key == k1 && j < bj)) { k1 = key; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(k1, off, 64);
+        const int oj = __shfl_down(bj, off, 64);
+        if (ok < k1 || (ok == k1 && oj < bj)) { k1 = ok; bj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k1[wave] = k1; s_j[wave] = bj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kSingleBlock / 64; ++w)
+            if (s_k1[w] < k1 || (s_k1[w] == k1 && s_j[w] < bj)) { k1 = s_k1[w]; bj = s_j[w]; }
+        if (bj == 0x7fffffff) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (sp.rule == 1) rec->last_selected = -1;
+            s_q = -1;
+        } else {
+            rec->q = bj;
+            rec->d_q = d[bj];
+            rec->key1 = k1;
+            if (sp.rule == 1) rec->last_selected = bj;
+            s_q = bj;
+        }
+    }
+    __syncthreads();
+    const int q = s_q;
+    if (q < 0) return;
+    // build the entering column (k_build_column)
+    int kind = 0, p = 0, r0 = -1, r1 = -1;
+    double sgn = 1.0;
+    if (q < ct.nr_artificial) { kind = 1; r0 = ct.column_to_row[q]; }
+    else {
+        p = q - ct.nr_artificial;
+        if (p < ct.nr_normal) { kind = 0; r0 = ct.bound_row[p]; }
+        else { kind = 1; const int vv = p - ct.nr_normal; r0 = ct.vrow0[vv]; r1 = ct.vrow1[vv]; sgn = (double)ct.vsign[vv]; }
+    }
+    for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+        double v = 0.0;
+        if (kind == 0) {
+            if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
+            else if (i == r0) v = 1.0;
+        } else {
+            if (i == r0) v = sgn;
+            else if (i == r1) v = 1.0;
+        }
+        aq[i] = v;
     }
 }
 
@@ -218,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_ftran(const double* __restrict__ B
 __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict__ alpha,
                                                         const double* __restrict__ b,
                                                         const int32_t* __restrict__ basis_indices, int m,
-                                                        Tolerances tol, PivotRecord* rec) {
+                                                        Tolerances tol, DeferredUpdate du, PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
     __shared__ double s_min[kSingleBlock / 64];
     __shared__ int s_leave[kSingleBlock / 64];
@@ -279,6 +395,19 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
         rec->leaving = best_leave;
         rec->alpha_r = alpha[best_row];
         rec->b_r = b[best_row];
+        s_row[0] = best_row;
+    }
+    if (du.kmax <= 0) return;
+    // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
+    const int p = rec->n_eta;
+    __syncthreads();
+    const int r = s_row[0];
+    for (int j = threadIdx.x; j < p; j += kSingleBlock) du.wr[j] = du.W[(int64_t)j * du.ld + r];
+    if (threadIdx.x == 0) {
+        int jt = du.pos_of_row[r];
+        rec->n_eta_old = p;
+        if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
+        rec->eta_target = jt;
     }
 }
 
@@ -448,12 +577,29 @@ __global__ __launch_bounds__(kThreads) void k_rho_deferred(DeferredUpdate du, co
     if (c >= (int)ld_b) return;
     double2 acc = make_double2(0.0, 0.0);
     if (r >= row_lo && r < row_hi) acc = *reinterpret_cast<const double2*>(Binv + (int64_t)r * ld_b + c);
-    for (int j = 0; j < p; ++j) {
+    // rows with a zero coefficient are skipped through a clamped row index (no divergent branch, loads
+    // stay independent so eight of them are in flight per lane); the sum order is j ascending.
+    const int safe = (r >= row_lo && r < row_hi) ? r : row_lo;
+    int j = 0;
+    for (; j + 8 <= p; j += 8) {
+        double2 bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = (s_coef[j + u] != 0.0) ? s_row[j + u] : safe;
+            bv[u] = *reinterpret_cast<const double2*>(Binv + (int64_t)row * ld_b + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x = fma(s_coef[j + u], bv[u].x, acc.x);
+            acc.y = fma(s_coef[j + u], bv[u].y, acc.y);
+        }
+    }
+    for (; j < p; ++j) {
         const double w = s_coef[j];
         if (w != 0.0) {
-            const double2 b = *reinterpret_cast<const double2*>(Binv + (int64_t)s_row[j] * ld_b + c);
-            acc.x = fma(w, b.x, acc.x);
-            acc.y = fma(w, b.y, acc.y);
+            const double2 bv = *reinterpret_cast<const double2*>(Binv + (int64_t)s_row[j] * ld_b + c);
+            acc.x = fma(w, bv.x, acc.x);
+            acc.y = fma(w, bv.y, acc.y);
         }
     }
     *reinterpret_cast<double2*>(rho + c) = acc;
@@ -656,7 +802,7 @@ void launch_price_structural(const double* A, int64_t ld_a, const ColumnTable& c
     if (p_hi <= p_lo) return;
     const int blocks = cdiv(p_hi - p_lo, kVecPerBlock);
     hipLaunchKernelGGL(k_price_structural, dim3(blocks), dim3(kThreads), 0, s, A, ld_a, ct, minus_pi, d, p_lo,
-                       p_hi, cost_mode, rec);
+                       p_hi, cost_mode, SelectPartials{}, rec);
 }
 
 void launch_price_mask_unowned(const ColumnTable& ct, double* d, int32_t p_lo, int32_t p_hi,
@@ -670,7 +816,40 @@ void launch_price_virtual(const ColumnTable& ct, const double* minus_pi, double*
                           const PivotRecord* rec, hipStream_t s) {
     const int n = ct.nr_artificial + ct.nr_virtual;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_price_virtual, dim3(cdiv(n, 256)), dim3(256), 0, s, ct, minus_pi, d, cost_mode, rec);
+    hipLaunchKernelGGL(k_price_virtual, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, s, ct, minus_pi, d, cost_mode,
+                       SelectPartials{}, rec);
+}
+
+int32_t price_structural_blocks(int32_t p_lo, int32_t p_hi) { return p_hi > p_lo ? cdiv(p_hi - p_lo, kVecPerBlock) : 0; }
+int32_t price_virtual_blocks(const ColumnTable& ct) {
+    const int n = ct.nr_artificial + ct.nr_virtual;
+    return n > 0 ? cdiv(n, kThreads) : 0;
+}
+
+void launch_price_structural_sel(const double* A, int64_t ld_a, const ColumnTable& ct, const double* minus_pi,
+                                 double* d, int32_t p_lo, int32_t p_hi, int32_t cost_mode, SelectPartials sp,
+                                 const PivotRecord* rec, hipStream_t s) {
+    const int blocks = price_structural_blocks(p_lo, p_hi);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_price_structural, dim3(blocks), dim3(kThreads), 0, s, A, ld_a, ct, minus_pi, d, p_lo,
+                       p_hi, cost_mode, sp, rec);
+}
+
+void launch_price_virtual_sel(const ColumnTable& ct, const double* minus_pi, double* d, int32_t cost_mode,
+                              SelectPartials sp, const PivotRecord* rec, hipStream_t s) {
+    const int blocks = price_virtual_blocks(ct);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_price_virtual, dim3(blocks), dim3(kThreads), 0, s, ct, minus_pi, d, cost_mode, sp, rec);
+}
+
+void launch_select_partials(SelectPartials sp, int32_t count, const double* d, const double* A, int64_t ld_a,
+                            const ColumnTable& ct, int32_t m, double* aq, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_partials, dim3(1), dim3(kSingleBlock), 0, s, sp, count, d, A, ld_a, ct, m, aq, rec);
+}
+
+void launch_ratio_eta(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
+                      const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_ratio, dim3(1), dim3(kSingleBlock), 0, s, alpha, b, basis_indices, m, tol, du, rec);
 }
 
 void launch_select_column(const double* d, const uint8_t* in_basis, int32_t n, int32_t rule, double tol_cost,
@@ -693,7 +872,8 @@ void launch_ftran(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, i
 
 void launch_ratio(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m,
                   Tolerances tol, PivotRecord* rec, hipStream_t s) {
-    hipLaunchKernelGGL(k_ratio, dim3(1), dim3(kSingleBlock), 0, s, alpha, b, basis_indices, m, tol, rec);
+    DeferredUpdate none{};
+    hipLaunchKernelGGL(k_ratio, dim3(1), dim3(kSingleBlock), 0, s, alpha, b, basis_indices, m, tol, none, rec);
 }
 
 void launch_compute_rho(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,

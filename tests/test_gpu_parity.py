@@ -199,7 +199,7 @@ def test_dense_2000_properties():
     m = n = 2000
     md = dense_problem(m, n, 20250001)
     t = engine.Tableau(md, trace_capacity=1 << 16)
-    assert t.update_block() == 64                  # automatic choice at this size
+    assert t.update_block() == 0                   # automatic choice at this size (64 from m = 4096)
     assert t.run(1 << 20)[1] == engine.PHASE_ONE_DONE
     done, outcome = t.run(60)
     assert done == 60 and outcome == engine.RUNNING
