@@ -342,15 +342,15 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     __shared__ double s_bcast;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
+    // both operands are loaded unconditionally so that the loads of several rows overlap
     double mn = INFINITY;
+#pragma unroll 4
     for (int i = threadIdx.x; i < m; i += kSingleBlock) {
         const double a = alpha[i];
-        if (a > tol.pivot) {
-            double bi = b[i];
-            if (fabs(bi) <= tol.zero) bi = 0.0;
-            const double ratio = bi / a;
-            if (ratio < mn) mn = ratio;
-        }
+        double bi = b[i];
+        if (fabs(bi) <= tol.zero) bi = 0.0;
+        const double ratio = (a > tol.pivot) ? bi / a : INFINITY;
+        mn = fmin(mn, ratio);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
@@ -369,16 +369,13 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     }
     const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
     int best_leave = 0x7fffffff, best_row = -1;
+#pragma unroll 4
     for (int i = threadIdx.x; i < m; i += kSingleBlock) {
         const double a = alpha[i];
-        if (a > tol.pivot) {
-            double bi = b[i];
-            if (fabs(bi) <= tol.zero) bi = 0.0;
-            if (bi / a <= bound) {
-                const int lv = basis_indices[i];
-                if (lv < best_leave) { best_leave = lv; best_row = i; }
-            }
-        }
+        double bi = b[i];
+        const int lv = basis_indices[i];
+        if (fabs(bi) <= tol.zero) bi = 0.0;
+        if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
