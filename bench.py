@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--workload", default="dense10k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
     args = ap.parse_args()
@@ -117,7 +119,7 @@ def main():
         done, oc = t.run(W)
         assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
         if events:
-            t.profile_enable(True, 8 * K + 16)
+            t.profile_enable(True, 12 * K + 16, args.event_stride)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         done, oc = t.run(K)
@@ -134,7 +136,7 @@ def main():
         done, oc = loop.run(W)
         assert done == W and oc == engine.RUNNING
         if events:
-            t.profile_enable(True, 8 * K + 16)
+            t.profile_enable(True, 12 * K + 16, args.event_stride)
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -183,7 +185,7 @@ def main():
                                    "SteepestDescent, explicit dense basis inverse",
                        "m": m, "n": n, "seed": seed,
                        "parallelism": "single GPU" if world == 1 else f"columns of A and rows of B^-1 sharded x{world}"},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "kernels": kernels, "kernel_event_stride": args.event_stride if events else None,
             "iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
             "iteration_GBps": (8.0 * m * n + 24.0 * m * m) / (dt / K) / 1e9,
         }

@@ -177,9 +177,10 @@ typedef enum {
     RELP_K_FLUSH = 9,            /* deferred update: B0inv += W (S' B0inv) */
     RELP_K_COUNT = 10
 } relp_kernel_id_t;
-/* When enabled, every launch of the listed kernel classes inside relp_run is bracketed by HIP
- * events on the engine's stream; relp_profile_read sums them (this synchronises). */
-relp_status_t relp_profile_enable(relp_engine_t *h, int32_t enable, int64_t max_launches);
+/* When enabled, the kernel classes of every `sample_every`-th pivot inside relp_run are bracketed by
+ * HIP events on the engine's stream (an event pair costs ~4 us of stream time, so bracketing every
+ * launch would slow a 330 us pivot by 15 %); relp_profile_read sums them (this synchronises). */
+relp_status_t relp_profile_enable(relp_engine_t *h, int32_t enable, int64_t max_launches, int32_t sample_every);
 relp_status_t relp_profile_read(relp_engine_t *h, int32_t kernel_id, int64_t *launches, double *total_ms);
 
 /* ---- synthetic workloads (bench / tests; rust-lp_amd/synthetic.py defines the numbers) ----------

@@ -296,15 +296,25 @@ static int select_primal_pivot_column(oracle_engine_t *e, int rule, int32_t *j_o
         e->last_selected = found ? *j_out : -1;
         return found;
     }
-    /* SteepestDescent = most negative reduced cost, first index wins ties (:97-126) */
-    int any = 0;
+    /* SteepestDescent = most negative reduced cost, first index wins ties (:97-126).  Stated in two
+     * passes like the ratio test: strict minimum, then the lowest index among the columns within
+     * tol_tie of it (identical to the reference's one-pass loop for tol_tie = 0). */
+    int any = 0; double dmin = 0.0;
+    double *d = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     for (int32_t j = 0; j < n; j++) {
+        d[j] = 0.0;
         if (e->in_basis[j]) continue;
-        double d = relative_cost(e, j);
-        if (d < -e->cfg.tol_cost) {
-            if (!any || d < *d_out) { *j_out = j; *d_out = d; any = 1; }
+        d[j] = relative_cost(e, j);
+        if (d[j] < -e->cfg.tol_cost) { if (!any || d[j] < dmin) { dmin = d[j]; any = 1; } }
+    }
+    if (any) {
+        double bound = dmin + e->cfg.tol_tie * fmax(1.0, fabs(dmin));
+        for (int32_t j = 0; j < n; j++) {
+            if (e->in_basis[j]) continue;
+            if (d[j] < -e->cfg.tol_cost && d[j] <= bound) { *j_out = j; *d_out = d[j]; break; }
         }
     }
+    free(d);
     return any;
 }
 

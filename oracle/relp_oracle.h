@@ -19,7 +19,8 @@
  *   tol_pivot : row i takes part in the ratio test iff alpha_i > tol_pivot   (tableau/mod.rs:227)
  *   tol_zero  : |b_i| <= tol_zero is read as b_i = 0 in the ratio            (f64 only)
  *   tol_tie   : rows with ratio <= min + tol_tie*max(1,|min|) tie; smallest leaving column wins
- *               (tableau/mod.rs:229-239, Bland)
+ *               (tableau/mod.rs:229-239, Bland).  SteepestDescent uses the same band on d_j: columns
+ *               with d_j <= min + tol_tie*max(1,|min|) tie and the lowest index wins (pivot_rule.rs:118)
  *   tol_feas  : phase 1 is feasible iff |objective| <= tol_feas*max(1, initial objective)
  */
 #ifndef RELP_ORACLE_H

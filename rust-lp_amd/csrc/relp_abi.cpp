@@ -88,8 +88,8 @@ relp_status_t relp_get_trace(relp_engine_t* h, int32_t* phase, int32_t* entering
 }
 relp_status_t relp_check_basis(relp_engine_t* h, double* e1, double* e2, double* mb) { return h ? H(h).check_basis(e1, e2, mb) : RELP_E_ARG; }
 
-relp_status_t relp_profile_enable(relp_engine_t* h, int32_t enable, int64_t max_launches) {
-    return h ? H(h).profile_enable(enable != 0, max_launches) : RELP_E_ARG;
+relp_status_t relp_profile_enable(relp_engine_t* h, int32_t enable, int64_t max_launches, int32_t sample_every) {
+    return h ? H(h).profile_enable(enable != 0, max_launches, sample_every) : RELP_E_ARG;
 }
 relp_status_t relp_profile_read(relp_engine_t* h, int32_t kid, int64_t* launches, double* total_ms) {
     return h ? H(h).profile_read(kid, launches, total_ms) : RELP_E_ARG;

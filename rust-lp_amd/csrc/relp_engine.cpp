@@ -292,7 +292,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
 // ------------------------------------------------------------------------------------------------
 // Profiling
 // ------------------------------------------------------------------------------------------------
-relp_status_t Engine::profile_enable(bool enable, int64_t max_launches) {
+relp_status_t Engine::profile_enable(bool enable, int64_t max_launches, int32_t sample_every) {
+    prof_stride_ = sample_every > 0 ? sample_every : 1;
+    prof_tick_ = 0;
     HIP_TRY(hipStreamSynchronize(stream_));
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
     prof_ev_.clear(); prof_kid_.clear(); prof_open_ = false;
@@ -308,6 +310,7 @@ relp_status_t Engine::profile_enable(bool enable, int64_t max_launches) {
 void Engine::prof_begin(int kid) {
     prof_open_ = false;
     if (!prof_on_ || (prof_kid_.size() + 1) * 2 > prof_ev_.size()) return;
+    if (kid != RELP_K_FLUSH && (prof_tick_ % prof_stride_) != 0) return;   // sampled pivots only
     (void)hipEventRecord(prof_ev_[2 * prof_kid_.size()], stream_);
     prof_kid_.push_back(kid);
     prof_open_ = true;
@@ -346,6 +349,7 @@ void Engine::enqueue_price(int cost_mode, const double* vec, const PivotRecord* 
 }
 
 void Engine::enqueue_iteration(int rule) {
+    struct Tick { int64_t& t; ~Tick() { ++t; } } tick{prof_tick_};
     const ColumnTable ct = table();
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -354,8 +358,8 @@ void Engine::enqueue_iteration(int rule) {
     // entering column and builds it in row space
     SelectPartials sp;
     sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
-    sp.n = n; sp.offset = 0; sp.pad_ = 0;
     const int nb_struct = price_structural_blocks(col_lo_, col_hi_);
+    sp.n = n; sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = col_lo_; sp.pad_ = 0;
     const int nb_virt = price_virtual_blocks(ct);
     prof_begin(RELP_K_PRICE);
     launch_price_structural_sel(A, ld_a_, ct, d_minus_pi_, d_d_, col_lo_, col_hi_, phase_, sp, d_rec_, stream_);
@@ -434,7 +438,7 @@ relp_status_t Engine::select_primal_pivot_column(int rule, int32_t* found, int32
     h_rec_->outcome = DEV_RUNNING;
     if ((st = upload_rec())) return st;
     enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
-    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, d_rec_, stream_);
+    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, cfg_.tol_tie, d_rec_, stream_);
     if ((st = download_rec())) return st;
     const bool ok = h_rec_->outcome == DEV_RUNNING;
     if (found) *found = ok ? 1 : 0;
@@ -848,7 +852,7 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
     enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
     prof_end();
     prof_begin(RELP_K_SELECT_COLUMN);
-    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, d_rec_, stream_);
+    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, cfg_.tol_tie, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_BUILD_COLUMN);
     launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
@@ -859,7 +863,7 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
 
 relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t count) {
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
-    launch_select_candidate(dev_candidates, count, cand_len_, m_, d_aq_, rule, d_rec_, stream_);
+    launch_select_candidate(dev_candidates, count, cand_len_, m_, d_aq_, rule, cfg_.tol_tie, d_rec_, stream_);
     return RELP_OK;
 }
 

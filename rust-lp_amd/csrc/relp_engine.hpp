@@ -61,7 +61,7 @@ class Engine {
                             int64_t* count);
     relp_status_t check_basis(double* max_identity_error, double* max_basic_cost, double* min_b);
 
-    relp_status_t profile_enable(bool enable, int64_t max_launches);
+    relp_status_t profile_enable(bool enable, int64_t max_launches, int32_t sample_every);
     relp_status_t profile_read(int kernel_id, int64_t* launches, double* total_ms);
 
     // shards
@@ -128,6 +128,8 @@ class Engine {
     std::vector<hipEvent_t> prof_ev_;
     std::vector<int> prof_kid_;
     bool prof_open_ = false;
+    int32_t prof_stride_ = 1;      // bracket the kernels of every prof_stride_-th pivot only
+    int64_t prof_tick_ = 0;
 
     std::string err_;
 

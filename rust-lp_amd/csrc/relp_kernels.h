@@ -79,6 +79,9 @@ struct SelectPartials {
     int32_t        rule;      // relp_pivot_rule_t
     int32_t        n;         // tableau columns (search-order wrap for FirstProfitableWithMemory)
     int32_t        offset;    // first slot this launch may use
+    int32_t        nb_struct; // slots [0, nb_struct) belong to structural workgroups of 8 columns from p_lo
+    double         tol_tie;   // SteepestDescent: columns within tol_tie*max(1,|min|) of the minimum tie
+    int32_t        p_lo;      // first structural column priced by this rank
     int32_t        pad_;
 };
 
@@ -110,7 +113,7 @@ void launch_price_virtual(const ColumnTable& ct, const double* minus_pi, double*
                           const PivotRecord* rec, hipStream_t s);
 // entering-column choice over d (masked by in_basis), rule = relp_pivot_rule_t
 void launch_select_column(const double* d, const uint8_t* in_basis, int32_t n, int32_t rule, double tol_cost,
-                          PivotRecord* rec, hipStream_t s);
+                          double tol_tie, PivotRecord* rec, hipStream_t s);
 // aq := dense column rec->q in tableau row space (m entries)
 void launch_build_column(const double* A, int64_t ld_a, const ColumnTable& ct, int32_t m, double* aq,
                          const PivotRecord* rec, hipStream_t s);
@@ -159,7 +162,7 @@ void launch_flush_reset(const DeferredUpdate& du, PivotRecord* rec, hipStream_t 
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);
 void launch_select_candidate(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* aq,
-                             int32_t rule, PivotRecord* rec, hipStream_t s);
+                             int32_t rule, double tol_tie, PivotRecord* rec, hipStream_t s);
 void launch_gather_alpha(const double* slices, int32_t count, int32_t stride, int32_t m, double* alpha,
                          const PivotRecord* rec, hipStream_t s);
 void launch_pad_slice(double* slice, int32_t valid, int32_t stride, hipStream_t s);

@@ -202,6 +202,52 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
     if (threadIdx.x == 0) {
         for (int w = 1; w < kSingleBlock / 64; ++w)
             if (s_k1[w] < k1 || (s_k1[w] == k1 && s_j[w] < bj)) { k1 = s_k1[w]; bj = s_j[w]; }
+        s_k1[0] = k1;
+        s_j[0] = bj;
+    }
+    __syncthreads();
+    k1 = s_k1[0];
+    bj = s_j[0];
+    __syncthreads();
+    if (bj != 0x7fffffff && sp.rule == 2 && sp.tol_tie > 0.0) {
+        // Dantzig ties: lowest index among the columns within the tie band of the minimum.  A column
+        // inside the band lives in a workgroup whose own minimum is inside the band, so only those
+        // workgroups' columns are re-read (8 structural columns, or 256 virtual ones).
+        const double bound = k1 + sp.tol_tie * fmax(1.0, fabs(k1));
+        int lowest = 0x7fffffff;
+        for (int t = threadIdx.x; t < count; t += kSingleBlock) {
+            if (!(sp.k1[t] <= bound)) continue;
+            if (t < sp.nb_struct) {
+                const int p0 = sp.p_lo + t * kVecPerBlock;
+                for (int u = 0; u < kVecPerBlock; ++u) {
+                    const int p = p0 + u;
+                    if (p >= ct.nr_normal) break;
+                    const int j = ct.nr_artificial + p;
+                    const double v = d[j];
+                    if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
+                }
+            } else {
+                const int v0 = (t - sp.nb_struct) * kThreads;
+                for (int u = 0; u < kThreads; ++u) {
+                    const int vt = v0 + u;
+                    if (vt >= ct.nr_artificial + ct.nr_virtual) break;
+                    const int j = vt < ct.nr_artificial ? vt : ct.nr_artificial + ct.nr_normal + (vt - ct.nr_artificial);
+                    const double v = d[j];
+                    if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
+        if (lane == 0) s_j[wave] = lowest;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int low = 0x7fffffff;
+            for (int w = 0; w < kSingleBlock / 64; ++w) low = min(low, s_j[w]);
+            bj = low;
+        }
+    }
+    if (threadIdx.x == 0) {
         if (bj == 0x7fffffff) {
             rec->outcome = DEV_NO_CANDIDATE;
             if (sp.rule == 1) rec->last_selected = -1;
@@ -244,7 +290,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
 //   FirstProfitable[WithMemory]: k1 = position of j in the search order (pivot_rule.rs:88)
 __global__ __launch_bounds__(kSingleBlock) void k_select_column(
     const double* __restrict__ d, const uint8_t* __restrict__ in_basis, int n, int rule, double tol_cost,
-    PivotRecord* rec) {
+    double tol_tie, PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
     __shared__ double s_k1[kSingleBlock / 64];
     __shared__ int s_j[kSingleBlock / 64];
@@ -275,6 +321,32 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_column(
         for (int w = 1; w < kSingleBlock / 64; ++w) {
             if (s_k1[w] < k1 || (s_k1[w] == k1 && s_j[w] < bj)) { k1 = s_k1[w]; bj = s_j[w]; }
         }
+        s_j[0] = bj;
+        s_k1[0] = k1;
+    }
+    __syncthreads();
+    bj = s_j[0];
+    k1 = s_k1[0];
+    if (bj != 0x7fffffff && rule == 2 && tol_tie > 0.0) {
+        // Dantzig ties: lowest index among the columns within the tie band of the minimum
+        const double bound = k1 + tol_tie * fmax(1.0, fabs(k1));
+        int lowest = 0x7fffffff;
+        for (int j = threadIdx.x; j < n; j += kSingleBlock) {
+            const double v = d[j];
+            if (!in_basis[j] && v < -tol_cost && v <= bound && j < lowest) lowest = j;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
+        if (lane == 0) s_j[wave] = lowest;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int low = 0x7fffffff;
+            for (int w = 0; w < kSingleBlock / 64; ++w) low = min(low, s_j[w]);
+            bj = low;                                  // the minimum itself is inside the band
+        }
+    }
+    if (threadIdx.x == 0) {
         if (bj == 0x7fffffff) {
             rec->outcome = DEV_NO_CANDIDATE;
             if (rule == 1) rec->last_selected = -1;
@@ -749,7 +821,7 @@ __global__ void k_clear_no_candidate(PivotRecord* rec) {
 __global__ __launch_bounds__(kSingleBlock) void k_select_candidate(const double* __restrict__ msgs, int count,
                                                                    int64_t msg_len, int m,
                                                                    double* __restrict__ aq, int rule,
-                                                                   PivotRecord* rec) {
+                                                                   double tol_tie, PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
     __shared__ int s_win;
     if (threadIdx.x == 0) {
@@ -757,6 +829,15 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_candidate(const double*
         for (int g = 0; g < count; ++g) {
             const double a = msgs[g * msg_len + 0], j = msgs[g * msg_len + 1];
             if (a < k1 || (a == k1 && win >= 0 && j < kj)) { k1 = a; kj = j; win = g; }
+        }
+        if (win >= 0 && rule == 2 && tol_tie > 0.0) {
+            // Dantzig ties across ranks: every rank sent (its minimum, its lowest index within the band
+            // of that minimum); the lowest index among the ranks inside the global band wins
+            const double bound = k1 + tol_tie * fmax(1.0, fabs(k1));
+            for (int g = 0; g < count; ++g) {
+                const double a = msgs[g * msg_len + 0], j = msgs[g * msg_len + 1];
+                if (a <= bound && j < kj) { kj = j; win = g; }
+            }
         }
         s_win = win;
         if (win < 0) {
@@ -850,8 +931,9 @@ void launch_ratio_eta(const double* alpha, const double* b, const int32_t* basis
 }
 
 void launch_select_column(const double* d, const uint8_t* in_basis, int32_t n, int32_t rule, double tol_cost,
-                          PivotRecord* rec, hipStream_t s) {
-    hipLaunchKernelGGL(k_select_column, dim3(1), dim3(kSingleBlock), 0, s, d, in_basis, n, rule, tol_cost, rec);
+                          double tol_tie, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_column, dim3(1), dim3(kSingleBlock), 0, s, d, in_basis, n, rule, tol_cost, tol_tie,
+                       rec);
 }
 
 void launch_build_column(const double* A, int64_t ld_a, const ColumnTable& ct, int32_t m, double* aq,
@@ -954,9 +1036,9 @@ void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord
 }
 
 void launch_select_candidate(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* aq,
-                             int32_t rule, PivotRecord* rec, hipStream_t s) {
+                             int32_t rule, double tol_tie, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_select_candidate, dim3(1), dim3(kSingleBlock), 0, s, msgs, count, msg_len, m, aq, rule,
-                       rec);
+                       tol_tie, rec);
 }
 
 void launch_gather_alpha(const double* slices, int32_t count, int32_t stride, int32_t m, double* alpha,

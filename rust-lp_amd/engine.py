@@ -97,7 +97,7 @@ _SIGNATURES = {
     "relp_get_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64)]),
     "relp_check_basis": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "relp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "relp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32]),
     "relp_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "relp_synth_fill_dense": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_int64, C.c_void_p]),
     "relp_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
@@ -352,8 +352,8 @@ class Tableau:
         return a.value, b.value, c.value
 
     # -- profiling --------------------------------------------------------------------------
-    def profile_enable(self, enable: bool, max_launches: int = 0):
-        self._ck(self._lib.relp_profile_enable(self._h, int(enable), max_launches))
+    def profile_enable(self, enable: bool, max_launches: int = 0, sample_every: int = 1):
+        self._ck(self._lib.relp_profile_enable(self._h, int(enable), max_launches, sample_every))
 
     def profile_read(self):
         out = {}

@@ -47,14 +47,15 @@ class NumpyShardOps:
         d[self.n:] = self.minus_pi                      # +1 slack columns, zero cost
         ok = (~self.in_basis) & (d < -self.tol[0])
         if ok.any():
-            j = int(np.lexsort((np.arange(len(d))[ok], d[ok]))[0])
-            j = int(np.arange(len(d))[ok][j])
+            dmin = d[ok].min()
+            band = ok & (d <= dmin + self.tol[3] * max(1.0, abs(dmin)))      # Dantzig tie band, lowest index
+            j = int(np.nonzero(band)[0][0])
             aq = np.zeros(self.m)
             if j < self.n:
                 aq[:] = self.A[:, j - self.col_lo]
             else:
                 aq[j - self.n] = 1.0
-            out[0], out[1], out[2] = d[j], j, d[j]
+            out[0], out[1], out[2] = dmin, j, d[j]
             out[3:3 + self.m] = aq
 
     def select_column(self, cands, count):
@@ -65,6 +66,11 @@ class NumpyShardOps:
         for g in range(count):
             if np.isfinite(msgs[g, 0]) and (best is None or (msgs[g, 0], msgs[g, 1]) < (msgs[best, 0], msgs[best, 1])):
                 best = g
+        if best is not None:
+            bound = msgs[best, 0] + self.tol[3] * max(1.0, abs(msgs[best, 0]))
+            for g in range(count):
+                if msgs[g, 0] <= bound and msgs[g, 1] < msgs[best, 1]:
+                    best = g
         if best is None:
             self.outcome = 1          # no candidate
             return

@@ -289,3 +289,63 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, block):
         assert t.trace() == single.trace()
         assert abs(t.objective_function_value() - single.objective_function_value()) <= 1e-9 * abs(single.objective_function_value())
         np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# File-driven configs (MPS reader + standardisation feed the engine)
+# ------------------------------------------------------------------------------------------------
+def test_adlittle_gpu_pivot_sequence_equals_exact_trace():
+    """Config C1: burkardt adlittle.mps.  The f64 GPU engine walks the exact-rational pivot sequence
+    (127 pivots, 2 phases) and lands on the reference's pinned optimum
+    24975305659811992079614961229/120651674036153428931840 (tests/burkardt/test.rs:34-54)."""
+    from fractions import Fraction as Fr
+    from lp_files import exact_solve, load
+    gf, ex, md, emd = load("burkardt/adlittle.mps")
+    tr = []
+    status, obj, sol = exact_solve(gf, emd, trace=tr.append)
+    assert status == "optimal" and obj == Fr(24975305659811992079614961229, 120651674036153428931840)
+    for block in (0, 8):
+        t = engine.Tableau(md, trace_capacity=4096, update_block=block)
+        assert t.solve_relaxation() == engine.OPTIMAL
+        assert t.trace() == [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
+        got = t.objective_function_value() + float(gf.fixed_cost)
+        assert abs(got - float(obj)) <= 1e-9 * float(obj)
+        reduced = {j: v for j, v in t.current_bfs() if j < md.nr_normal}
+        _, x = gf.compute_full_solution(reduced)
+        for name, v in sol.items():
+            assert abs(x[name] - float(v)) <= 1e-7 * max(1.0, abs(float(v)))
+
+
+FILES = [("burkardt/afiro.mps", False, -406659 / 875, 1e-9), ("burkardt/testprob.mps", False, 54.0, 1e-9),
+         ("burkardt/maros.mps", False, 385 / 3, 1e-9), ("cook/small_example.mps", False, -243 / 4, 1e-9),
+         ("netlib/AFIRO.SIF", True, -464.75314, 1e-3), ("netlib/SC50A.SIF", True, -6.457507706e+01, 1e-5),
+         ("netlib/SC50B.SIF", True, -70.0, 1e-9), ("netlib/KB2.SIF", True, -1.749900130e+03, 1e-3),
+         ("netlib/SC105.SIF", True, -5.220206121e+01, 1e-3), ("netlib/ADLITTLE.SIF", True, 2.254949632e+05, 1e-3),
+         ("netlib/STOCFOR1.SIF", True, -4.113197622e+04, 1e-3), ("netlib/BLEND.SIF", True, -30.81215, 1e-3),
+         ("netlib/SCAGR7.SIF", True, -2.331389824e+06, 1e-1), ("netlib/SC205.SIF", True, -5.220206121e+01, 1e-5),
+         ("netlib/SHARE2B.SIF", True, -4.157322407e+02, 1e-5), ("netlib/RECIPELP.SIF", True, -0.266616e3, 1e-2),
+         ("netlib/LOTFI.SIF", True, -0.2526470606188e2, 1e-6), ("netlib/VTP-BASE.SIF", True, 0.1298314624613613e6, 1e-2),
+         ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3), ("miplib/50v-10.mps", False, 2879.065687, 1e-3)]
+
+
+@pytest.mark.parametrize("path,fixed,objective,tol", FILES)
+def test_reference_problem_files_on_gpu(path, fixed, objective, tol):
+    """The reference's own problem files (tests/{burkardt,cook,netlib,miplib}) through the GPU engine:
+    the pivot sequence equals the f64 CPU oracle's and the objective meets the reference's pin with the
+    reference's tolerance."""
+    from lp_files import load
+    gf, ex, md, emd = load(path, fixed=fixed)
+    t = engine.Tableau(md, trace_capacity=1 << 15)
+    assert t.solve_relaxation() == engine.OPTIMAL
+    ref = relp_f64.OracleF64(md)
+    assert ref.run() == "optimal"
+    assert t.trace() == ref.trace
+    got = t.objective_function_value() + float(gf.fixed_cost)
+    assert abs(got - objective) < max(tol, 1e-9 * abs(objective))
+    assert abs(got - (ref.objective + float(gf.fixed_cost))) <= 1e-9 * max(1.0, abs(objective))
+
+
+def test_nazareth_is_unbounded_on_gpu():
+    from lp_files import load
+    gf, ex, md, emd = load("burkardt/nazareth.mps")
+    assert engine.Tableau(md).solve_relaxation() == engine.UNBOUNDED           # tests/burkardt/test.rs:149-157

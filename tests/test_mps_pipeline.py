@@ -1,0 +1,143 @@
+"""MPS reader + standardisation + solution reconstruction against the
+reference's own file-driven known answers, solved with the exact oracle (small files) or the f64 C
+oracle (larger ones).  NB: presolve is not restated, so these pin optimal values, not the
+reference's post-presolve MatrixData."""
+from fractions import Fraction as Fr
+
+import numpy as np
+import pytest
+
+import rust_lp_amd  # noqa: F401
+from rust_lp_amd import mps
+from oracle import relp_exact as ox
+from oracle import relp_f64
+
+from lp_files import exact_solve, load
+
+
+def test_number_parsing_is_exact():
+    """io/mps/number/parse.rs:53-121."""
+    assert mps.parse_number("1") == 1 and mps.parse_number("-.022") == Fr(-22, 1000)
+    assert mps.parse_number("12.5") == Fr(25, 2) and mps.parse_number("3.") == 3 and mps.parse_number(".5") == Fr(1, 2)
+    with pytest.raises(mps.MPSError):
+        mps.parse_number("1e3")
+
+
+def test_rows_are_sorted_by_name_and_two_pairs_per_line():
+    """parse/mod.rs:296 (rows sorted by name) and free.rs `five_and_six` (third pair dropped:
+    tests/cook small_example loses `r2 2`, which is why its optimum is -243/4)."""
+    gf, ex, md, emd = load("cook/small_example.mps")
+    status, obj, _ = exact_solve(gf, emd, ox.LUDecomposition)
+    assert status == "optimal" and obj == Fr(-243, 4)                       # tests/cook/test.rs:32
+
+
+def test_burkardt_testprob():
+    gf, ex, md, emd = load("burkardt/testprob.mps")
+    status, obj, sol = exact_solve(gf, emd, ox.LUDecomposition)
+    assert (status, obj) == ("optimal", 54)                                # tests/burkardt/test.rs:170-183
+    assert (sol["X1"], sol["X2"], sol["X3"]) == (4, -1, 6)
+
+
+def test_burkardt_maros():
+    gf, ex, md, emd = load("burkardt/maros.mps")
+    status, obj, sol = exact_solve(gf, emd, ox.LUDecomposition)
+    assert (status, obj) == ("optimal", Fr(385, 3))                        # tests/burkardt/test.rs:128-146
+    assert (sol["VOL1"], sol["VOL2"], sol["VOL3"], sol["VOL4"]) == (Fr(10, 3), Fr(40, 3), 20, 0)
+
+
+def test_burkardt_nazareth_is_unbounded():
+    gf, ex, md, emd = load("burkardt/nazareth.mps")
+    assert exact_solve(gf, emd, ox.LUDecomposition)[0] == "unbounded"       # tests/burkardt/test.rs:149-157
+
+
+def test_burkardt_afiro_exact():
+    gf, ex, md, emd = load("burkardt/afiro.mps")
+    status, obj, sol = exact_solve(gf, emd, ox.LUDecomposition)
+    assert (status, obj) == ("optimal", Fr(-406659, 875))                  # tests/burkardt/test.rs:56-110
+    # `Solution::is_probably_equal_to(.., 0.1)` (solution.rs:47-79): equal objective and more than 10 % of
+    # the values equal (the LP has alternative optima)
+    pins = {"X01": 80, "X02": Fr(51, 2), "X03": Fr(109, 2), "X04": Fr(424, 5), "X06": Fr(255, 14), "X14": Fr(255, 14),
+            "X16": 999, "X22": 500, "X23": Fr(11898, 25), "X24": Fr(602, 25), "X26": 215, "X36": Fr(11898, 35),
+            "X37": Fr(11898, 35), "X07": 0, "X08": 0, "X09": 0, "X10": 0, "X11": 0, "X12": 0, "X13": 0, "X15": 0,
+            "X25": 0, "X28": 0, "X29": 0, "X30": 0, "X31": 0, "X32": 0, "X33": 0, "X34": 0, "X35": 0, "X38": 0, "X39": 0}
+    assert set(pins) == set(sol)
+    assert sum(1 for k, v in pins.items() if sol[k] == v) / len(pins) > 0.1
+
+
+def test_burkardt_adlittle_exact_optimum_and_f64_trace():
+    """Config C1: the exact optimum of tests/burkardt/test.rs:34-54, and the f64 C oracle walks the
+    exact pivot sequence (needs the tie band on reduced costs: d_37 == d_38 exactly at pivot 72)."""
+    gf, ex, md, emd = load("burkardt/adlittle.mps")
+    tr = []
+    status, obj, _ = exact_solve(gf, emd, ox.BasisInverseRows, trace=tr.append)
+    assert status == "optimal"
+    assert obj == Fr(24975305659811992079614961229, 120651674036153428931840)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run() == "optimal"
+    assert ref.trace == [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
+    assert abs(ref.objective + float(gf.fixed_cost) - float(obj)) <= 1e-9 * float(obj)
+
+
+UNICAMP = [("model_data_1", Fr(123, 38)), ("model_data_3_1", 70), ("model_data_3_2", 180), ("model_data_3_3", 245),
+           ("model_data_3_4", 2250), ("model_data_4", 7), ("model_data_6", 28)]
+
+
+@pytest.mark.parametrize("name,objective", UNICAMP)
+def test_unicamp(name, objective):
+    """tests/unicamp/test.rs (the non-ignored cases), `Carry<_, LUDecomposition<_>>`."""
+    gf, ex, md, emd = load(f"unicamp/{name}.mps")
+    status, obj, _ = exact_solve(gf, emd, ox.LUDecomposition)
+    assert (status, obj) == ("optimal", objective)
+
+
+NETLIB = [("AFIRO", -464.75314, 1e-3), ("SC50A", -6.457507706e+01, 1e-5), ("SC50B", -70, 1e-10),
+          ("KB2", -1.749900130e+03, 1e-3), ("SC105", -5.220206121e+01, 1e-3), ("ADLITTLE", 2.254949632e+05, 1e-3),
+          ("STOCFOR1", -4.113197622e+04, 1e-3), ("BLEND", -30.81215, 1e-3), ("SCAGR7", -2.331389824e+06, 1e-1),
+          ("SC205", -5.220206121e+01, 1e-5), ("SHARE2B", -4.157322407e+02, 1e-5), ("RECIPELP", -0.266616e3, 1e-2),
+          ("LOTFI", -0.2526470606188e2, 1e-6), ("VTP-BASE", 0.1298314624613613657395984384889e6, 1e-2),
+          ("SHARE1B", -0.7658931857918568112797274346007e5, 1e-3)]
+# These two need the reference's presolve: on the un-presolved problem the reference's own zero-level
+# rule (phase_one.rs:239-244 only accepts columns whose relative cost is exactly zero) declares a
+# non-redundant equality row redundant, and the LP that is left is unbounded / different.  The exact
+# oracle reproduces that literally (it is the reference's behaviour; its tests `test_SCORPION` and
+# `test_30n` are ignored for "Incorrect optimal value").  Known gap: presolve.
+NETLIB_NEEDS_PRESOLVE = [("BOEING2", -0.31501872801520287870462195913263e3, 1e-3),
+                         ("BORE3D", 0.13730803942084927215581987251301e4, 1e-2)]
+
+
+@pytest.mark.parametrize("name,objective,tol", NETLIB)
+def test_netlib_objectives_f64_oracle(name, objective, tol):
+    """tests/netlib/test.rs:10-125 (fixed-format parser, tests/netlib/mod.rs:54) through the f64 C
+    oracle; tolerances are the reference's."""
+    gf, ex, md, emd = load(f"netlib/{name}.SIF", fixed=True)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run() == "optimal"
+    assert abs(ref.objective + float(gf.fixed_cost) - objective) < max(tol, 1e-9 * abs(objective))
+
+
+@pytest.mark.parametrize("name,objective,tol", NETLIB_NEEDS_PRESOLVE)
+@pytest.mark.xfail(strict=True, reason="presolve (general_form/presolve/**) is not restated yet")
+def test_netlib_objectives_that_need_presolve(name, objective, tol):
+    gf, ex, md, emd = load(f"netlib/{name}.SIF", fixed=True)
+    ref = relp_f64.OracleF64(md)
+    status = ref.run(max_iters=20000)
+    assert status == "optimal" and abs(ref.objective + float(gf.fixed_cost) - objective) < tol
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "SC50B"])
+def test_netlib_small_exact_equals_f64_trace(name):
+    gf, ex, md, emd = load(f"netlib/{name}.SIF", fixed=True)
+    tr = []
+    status, obj, _ = exact_solve(gf, emd, trace=tr.append)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run() == status == "optimal"
+    assert ref.trace == [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
+
+
+def test_free_and_fixed_parsers_agree_on_adlittle():
+    from rust_lp_amd import general_form
+    import os
+    from lp_files import GOLDEN
+    text = open(os.path.join(GOLDEN, "netlib", "ADLITTLE.SIF")).read()
+    a, b = mps.parse(text), mps.parse_fixed(text)
+    assert a.rows == b.rows and a.columns == b.columns and a.rhss == b.rhss and a.cost_values == b.cost_values
