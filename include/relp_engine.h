@@ -99,8 +99,20 @@ typedef struct {
      * (I + W S') B0inv and the K most recent pivots are folded in by one m x K x m GEMM ("flush");
      * -1 = automatic (64 when m >= 4096, else 0).  Results are the same up to f64 rounding. */
     int32_t update_block;
-    int32_t reserved_;
+    /* relp_engine_kind_t: which device representation maintains the basis inverse */
+    int32_t engine;
 } relp_config_t;
+
+typedef enum {
+    /* revised simplex with the explicit dense inverse (`Carry<_, BasisInverseRows<_>>`): PRICE and FTRAN
+     * are HBM streams over A and B^-1 at every pivot */
+    RELP_ENGINE_REVISED = 0,
+    /* dense tableau T = B^-1 [A | slacks] kept as (I + W S') T0: PRICE is one tableau row, FTRAN one
+     * tableau column per pivot, and T0 is updated by an m x K x n GEMM on the f64 matrix cores every
+     * update_block pivots (needs 8 m n bytes; same pivots as the revised engine up to f64 rounding).
+     * Restrictions: no row removal (rank-deficient problems), no relp_from_basis, no sharding yet. */
+    RELP_ENGINE_TABLEAU = 1
+} relp_engine_kind_t;
 
 void relp_default_config(relp_config_t *cfg);
 const char *relp_last_error(const relp_engine_t *h);

@@ -22,6 +22,7 @@ void relp_default_config(relp_config_t* cfg) {
     cfg->trace_capacity = 0;
     cfg->shard_rank = 0; cfg->shard_count = 1;
     cfg->update_block = -1;
+    cfg->engine = RELP_ENGINE_REVISED;
 }
 
 const char* relp_last_error(const relp_engine_t* h) { return h ? H(h).last_error() : "null handle"; }

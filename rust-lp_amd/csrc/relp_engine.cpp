@@ -37,6 +37,7 @@ void Engine::free_all() {
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
     fr(d_part_k1_); fr(d_part_j_);
+    fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
@@ -63,6 +64,14 @@ ColumnTable Engine::table() const {
 }
 
 Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie}; }
+
+TableauView Engine::tview() const {
+    TableauView tv;
+    tv.T0 = dT0_; tv.ld_t = ld_t_; tv.R0 = dR0_; tv.ld_r = ld_r_; tv.d = d_d_; tv.m = m_; tv.n_store = n_store_;
+    tv.col_off = phase_ == 1 ? 0 : tab_na_;
+    tv.n = nr_columns();
+    return tv;
+}
 
 DeferredUpdate Engine::deferred() const {
     DeferredUpdate du;
@@ -220,7 +229,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
 
     ld_b_ = round_up(m_, 16);
     const int64_t rows_local = std::max(row_hi_ - row_lo_, 1);
-    HIP_TRY(dev_alloc(&dBinv_, rows_local * ld_b_));
+    const bool want_tableau = cfg_.engine == RELP_ENGINE_TABLEAU;
+    // the tableau engine reads B^-1 off the identity columns of T; the explicit inverse is not stored
+    HIP_TRY(dev_alloc(&dBinv_, want_tableau ? 16 : rows_local * ld_b_));
     HIP_TRY(dev_alloc(&d_minus_pi_, ld_b_));
     HIP_TRY(dev_alloc(&d_b_, ld_b_));
     HIP_TRY(dev_alloc(&d_alpha_, ld_b_));
@@ -238,15 +249,29 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     HIP_TRY(dev_alloc(&d_in_basis_, n_alloc_));
     HIP_TRY(dev_alloc(&d_rec_, 1));
     {
-        const int64_t slots = price_structural_blocks(col_lo_, col_hi_) + (nr_artificial_ + nr_virtual_ + 255) / 256 + 8;
+        const int64_t slots = price_structural_blocks(col_lo_, col_hi_) + (nr_artificial_ + nr_virtual_ + 255) / 256 + 8 +
+                              tab_scan_blocks(n_alloc_);
         HIP_TRY(dev_alloc(&d_part_k1_, slots));
         HIP_TRY(dev_alloc(&d_part_j_, slots));
     }
     block_ = cfg_.update_block < 0 ? (m_ >= 4096 ? 64 : 0) : std::min(cfg_.update_block, 128);
+    tableau_ = cfg_.engine == RELP_ENGINE_TABLEAU;
+    if (tableau_) {
+        if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "the tableau engine is not sharded yet");
+        if (block_ == 0) block_ = 64;                  // the tableau is always maintained in blocks
+        n_store_ = n_alloc_;
+        tab_na_ = nr_artificial_;
+        ld_t_ = round_up(m_, 2);
+        ld_r_ = round_up(n_store_, 2);
+        HIP_TRY(dev_alloc(&dT0_, ld_t_ * n_store_));
+        HIP_TRY(dev_alloc(&dR0_, ld_r_ * (block_ + 1)));        // + one scratch row (d_aq_big)
+        HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
+        HIP_TRY(dev_alloc(&d_idcol_, m_));
+    }
     if (block_ > 0) {
         HIP_TRY(dev_alloc(&d_v_, ld_b_));
         HIP_TRY(dev_alloc(&d_W_, ld_b_ * block_));
-        HIP_TRY(dev_alloc(&d_R_, ld_b_ * block_));
+        if (!tableau_) HIP_TRY(dev_alloc(&d_R_, ld_b_ * block_));
         HIP_TRY(dev_alloc(&d_wr_, block_));
         HIP_TRY(dev_alloc(&d_S_, block_));
         HIP_TRY(dev_alloc(&d_pos_of_row_, m_));
@@ -277,7 +302,21 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     for (int32_t r = 0; r < m_; ++r) flags[basis[r]] = 1;
     HIP_TRY(up(d_in_basis_, flags.data(), flags.size()));
     // identity rows [row_lo, row_hi): local row i has its 1 in column row_lo + i (BasisInverse::identity)
-    if (row_hi_ > row_lo_) launch_set_identity(dBinv_, ld_b_, row_lo_, row_hi_, stream_);
+    if (row_hi_ > row_lo_ && !tableau_) launch_set_identity(dBinv_, ld_b_, row_lo_, row_hi_, stream_);
+    if (tableau_) {
+        // T0 = the original matrix in row space (B = I), d = c - c_B' T0 with the phase-1 costs
+        idcol_h_ = basis;                                    // the initial basis column of row k is e_k
+        HIP_TRY(up(d_idcol_, idcol_h_.data(), sizeof(int32_t) * m_));
+        const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+        launch_tab_build(tview(), A, ld_a_, table(), stream_);
+        cost_store_h_.assign(n_store_, 0.0);
+        for (int32_t k = 0; k < nr_artificial_; ++k) cost_store_h_[k] = 1.0;
+        std::vector<double> w(ld_b_, 0.0);
+        for (int32_t k = 0; k < nr_artificial_; ++k) w[column_to_row_[k]] = 1.0;
+        HIP_TRY(up(d_cost_store_, cost_store_h_.data(), sizeof(double) * n_store_));
+        HIP_TRY(up(d_w_, w.data(), sizeof(double) * ld_b_));
+        launch_tab_price_init(tview(), d_w_, d_cost_store_, stream_);
+    }
     std::memset(h_rec_, 0, sizeof(PivotRecord));
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->minus_objective = -objective;
@@ -348,8 +387,37 @@ void Engine::enqueue_price(int cost_mode, const double* vec, const PivotRecord* 
     launch_price_virtual(ct, vec, d_d_, cost_mode, rec, stream_);
 }
 
+// One pivot of the dense-tableau engine: 5 launches, O(K (m + n)) bytes.
+void Engine::enqueue_iteration_tableau(int rule) {
+    const TableauView tv = tview();
+    const DeferredUpdate du = deferred();
+    SelectPartials sp;
+    sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+    sp.n = tv.n; sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+    prof_begin(RELP_K_SELECT_COLUMN);
+    launch_tab_select(tv, sp, tab_scan_blocks(n_store_), d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_FTRAN);
+    launch_tab_column(tv, du, d_alpha_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_RATIO);
+    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_PRICE);
+    launch_tab_row_update(tv, du, sp, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_W);
+    launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_VECTORS);
+    launch_tab_update_vectors(m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+    prof_end();
+    if (++since_flush_ >= block_) enqueue_flush();
+}
+
 void Engine::enqueue_iteration(int rule) {
     struct Tick { int64_t& t; ~Tick() { ++t; } } tick{prof_tick_};
+    if (tableau_) { enqueue_iteration_tableau(rule); return; }
     const ColumnTable ct = table();
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -415,6 +483,16 @@ void Engine::enqueue_iteration(int rule) {
 // (also after the loop froze): (B0inv, W, S) is consistent after every completed pivot.
 void Engine::enqueue_flush() {
     if (block_ == 0) return;
+    if (tableau_) {
+        // T0 += W R0 on the f64 matrix cores
+        const DeferredUpdate dut = deferred();
+        prof_begin(RELP_K_FLUSH);
+        launch_tab_flush(tview(), dut, d_rec_, stream_);
+        launch_flush_reset(dut, d_rec_, stream_);
+        prof_end();
+        since_flush_ = 0;
+        return;
+    }
     const DeferredUpdate du = deferred();
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     prof_begin(RELP_K_FLUSH);
@@ -437,8 +515,16 @@ relp_status_t Engine::select_primal_pivot_column(int rule, int32_t* found, int32
     if (st) return st;
     h_rec_->outcome = DEV_RUNNING;
     if ((st = upload_rec())) return st;
-    enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
-    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, cfg_.tol_tie, d_rec_, stream_);
+    if (tableau_) {
+        SelectPartials sp;
+        sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+        sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+        launch_tab_scan(tview(), sp, d_rec_, stream_);
+        launch_tab_select(tview(), sp, tab_scan_blocks(n_store_), d_rec_, stream_);
+    } else {
+        enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
+        launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, cfg_.tol_tie, d_rec_, stream_);
+    }
     if ((st = download_rec())) return st;
     const bool ok = h_rec_->outcome == DEV_RUNNING;
     if (found) *found = ok ? 1 : 0;
@@ -448,8 +534,9 @@ relp_status_t Engine::select_primal_pivot_column(int rule, int32_t* found, int32
 }
 
 relp_status_t Engine::relative_costs(double* out_n) {
-    enqueue_price(phase_, d_minus_pi_, nullptr, col_lo_, col_hi_);
-    HIP_TRY(hipMemcpyAsync(out_n, d_d_, sizeof(double) * nr_columns(), hipMemcpyDeviceToHost, stream_));
+    if (!tableau_) enqueue_price(phase_, d_minus_pi_, nullptr, col_lo_, col_hi_);
+    const double* src = tableau_ ? d_d_ + (phase_ == 1 ? 0 : tab_na_) : d_d_;     // the tableau keeps d up to date
+    HIP_TRY(hipMemcpyAsync(out_n, src, sizeof(double) * nr_columns(), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     return RELP_OK;
 }
@@ -461,11 +548,15 @@ relp_status_t Engine::generate_column(int32_t column, double* out_m) {
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->q = column;
     if ((st = upload_rec())) return st;
-    enqueue_flush();                                   // the step-wise calls work on the explicit inverse
-    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
-    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
-    launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
-    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+    if (tableau_) {
+        launch_tab_column(tview(), deferred(), d_alpha_, d_rec_, stream_);
+    } else {
+        enqueue_flush();                               // the step-wise calls work on the explicit inverse
+        const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+        double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+        launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
+        launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+    }
     if (out_m) HIP_TRY(hipMemcpyAsync(out_m, d_alpha_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     return RELP_OK;
@@ -500,10 +591,27 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
     HIP_TRY(hipMemcpy(&b_r, d_b_ + row, sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&lv, d_basis_ + row, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
-    enqueue_flush();
+    if (!tableau_) enqueue_flush();
+    if ((st = download_rec())) return st;               // the flush may have reset the block counters
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->q = column; h_rec_->d_q = cost; h_rec_->r = row; h_rec_->leaving = lv; h_rec_->alpha_r = alpha_r; h_rec_->b_r = b_r;
     if ((st = upload_rec())) return st;
+    if (tableau_) {
+        const TableauView tv = tview();
+        const DeferredUpdate du = deferred();
+        SelectPartials sp;
+        sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost;
+        sp.rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+        sp.n = tv.n; sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+        launch_eta_prepare(du, d_rec_, stream_);
+        launch_tab_row_update(tv, du, sp, d_rec_, stream_);
+        launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+        launch_tab_update_vectors(m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+        if (++since_flush_ >= block_) enqueue_flush();
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (leaving) *leaving = lv;
+        return RELP_OK;
+    }
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
     launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
@@ -524,6 +632,13 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     // Phase 1 often ends after very few pivots (none at all with a full slack basis): poll at 1, 2, 4, ...
     // there so that an early end does not leave a long tail of no-op launches queued.
+    if (tableau_) {
+        // (re)entering the loop: rebuild the PRICE partials from d (afterwards every pivot leaves them behind)
+        SelectPartials sp;
+        sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+        sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+        launch_tab_scan(tview(), sp, d_rec_, stream_);
+    }
     int64_t next_poll = phase_ == 1 ? 1 : cfg_.poll_interval;
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
         enqueue_iteration(rule);
@@ -589,9 +704,14 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
         const int32_t pivot_row = column_to_row_[a];
         if ((st = relative_costs(d.data()))) return st;
         // tableau row pivot_row over every column: (row of B^-1) . a_j, no cost term
-        double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
-        enqueue_price(0, Binv + (int64_t)pivot_row * ld_b_, nullptr, col_lo_, col_hi_);
-        HIP_TRY(hipMemcpyAsync(tau.data(), d_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+        if (tableau_) {
+            launch_tab_row(tview(), deferred(), pivot_row, d_aq_big(), d_rec_, stream_);
+            HIP_TRY(hipMemcpyAsync(tau.data(), d_aq_big(), sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+        } else {
+            double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+            enqueue_price(0, Binv + (int64_t)pivot_row * ld_b_, nullptr, col_lo_, col_hi_);
+            HIP_TRY(hipMemcpyAsync(tau.data(), d_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+        }
         HIP_TRY(hipMemcpyAsync(inb.data(), d_in_basis_, n, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         int32_t q = -1;
@@ -610,6 +730,7 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
 // kind/non_artificial.rs:151-220, carry/mod.rs:484-510 (+ :650-689 when rows are removed)
 relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_remove) {
     relp_status_t st;
+    if (cfg_.shard_count == 1) enqueue_flush();     // zero-level pivots may have left updates pending
     if (!rows_to_remove.empty() && (st = remove_rows(rows_to_remove))) return st;
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
@@ -627,8 +748,16 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     if (cfg_.shard_count > 1)
         for (double v : w) if (v != 0.0) return fail(RELP_E_UNSUPPORTED, "sharded phase switch needs an all-slack basis");
     HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
-    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
-    launch_weighted_column_sums(Binv, ld_b_, m_, d_w_, d_minus_pi_, stream_);
+    if (tableau_) {
+        // phase-2 reduced costs of every stored column: d = c - c_B' T (the artificial block keeps cost 0)
+        cost_store_h_.assign(n_store_, 0.0);
+        for (int32_t p = 0; p < nr_normal_; ++p) cost_store_h_[tab_na_ + p] = cost_h_[p];
+        HIP_TRY(hipMemcpy(d_cost_store_, cost_store_h_.data(), sizeof(double) * n_store_, hipMemcpyHostToDevice));
+        launch_tab_price_init(tview(), d_w_, d_cost_store_, stream_);
+    } else {
+        double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+        launch_weighted_column_sums(Binv, ld_b_, m_, d_w_, d_minus_pi_, stream_);
+    }
     // -obj = -sum_i b_i c_B(i) (create_minus_obj_from_artificial, carry/mod.rs:258-271)
     HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
     if ((st = download_rec())) return st;
@@ -645,6 +774,7 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
 // delete the given rows (and the same columns of B^-1) everywhere.  Rare, host round trip.
 relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "row removal in sharded mode");
+    if (tableau_) return fail(RELP_E_UNSUPPORTED, "row removal (rank-deficient problem) in the tableau engine");
     std::vector<int32_t> map(m_, 0);   // old row -> new row, -1 = removed
     {
         size_t f = 0; int32_t out = 0;
@@ -715,6 +845,7 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     // columns only (slack bases, two_phase/mod.rs:103-111 `FullInitialBasis`), whose inverse is a
     // signed permutation.  General warm starts need the dense inversion kernel (next round).
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
+    if (tableau_) return fail(RELP_E_UNSUPPORTED, "from_basis in the tableau engine");
     enqueue_flush();                                   // leaves the deferred state empty
     HIP_TRY(hipStreamSynchronize(stream_));
     std::vector<int32_t> basis(basis_columns, basis_columns + m_);
@@ -758,6 +889,14 @@ relp_status_t Engine::get_objective(double* out) {
 }
 
 relp_status_t Engine::get_vector(int which, double* out) {
+    if (tableau_ && which == 1) {
+        // -pi_k = d_j - c_j for the stored column j that was e_k originally
+        std::vector<double> d(n_store_);
+        HIP_TRY(hipMemcpyAsync(d.data(), d_d_, sizeof(double) * n_store_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int32_t k = 0; k < m_; ++k) out[k] = d[idcol_h_[k]] - cost_store_h_[idcol_h_[k]];
+        return RELP_OK;
+    }
     const double* src = which == 0 ? d_b_ : which == 1 ? d_minus_pi_ : d_alpha_;
     HIP_TRY(hipMemcpyAsync(out, src, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -773,6 +912,16 @@ relp_status_t Engine::get_basis_indices(int32_t* out) {
 relp_status_t Engine::get_basis_inverse(double* out) {
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "B^-1 is row-sharded");
     enqueue_flush();
+    if (tableau_) {
+        // B^-1 = the tableau columns of the original identity columns
+        double* tmp = nullptr;
+        HIP_TRY(dev_alloc(&tmp, (int64_t)m_ * m_));
+        launch_tab_gather_columns(tview(), d_idcol_, tmp, stream_);
+        HIP_TRY(hipMemcpyAsync(out, tmp, sizeof(double) * m_ * m_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipFree(tmp));
+        return RELP_OK;
+    }
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * m_, dBinv_, sizeof(double) * ld_b_, sizeof(double) * m_, m_, hipMemcpyDeviceToHost));
     return RELP_OK;

@@ -115,6 +115,20 @@ class Engine {
     int32_t *d_S_ = nullptr, *d_pos_of_row_ = nullptr;
     double* d_part_k1_ = nullptr;  // PRICE workgroups' partial argmin (SelectPartials)
     int32_t* d_part_j_ = nullptr;
+    // dense-tableau engine (cfg.engine == RELP_ENGINE_TABLEAU)
+    bool tableau_ = false;
+    double* dT0_ = nullptr; int64_t ld_t_ = 0;
+    double* dR0_ = nullptr; int64_t ld_r_ = 0;
+    double* d_cost_store_ = nullptr;     // cost per stored column in the current phase
+    int32_t* d_idcol_ = nullptr;         // stored column that was e_k originally, per row k
+    int32_t n_store_ = 0;                // stored columns = original artificials + provider columns
+    int32_t tab_na_ = 0;                 // original number of artificial columns (their block is kept)
+    std::vector<int32_t> idcol_h_;
+    std::vector<double> cost_store_h_;
+    TableauView tview() const;
+    double* d_aq_big() { return dR0_ + (int64_t)block_ * ld_r_; }         // n_store scratch row behind R0
+    void enqueue_iteration_tableau(int rule);
+    relp_status_t tableau_reprice();
     DeferredUpdate deferred() const;
     void enqueue_flush();
     int32_t n_alloc_ = 0;     // allocated tableau columns (artificial + provider)

@@ -159,6 +159,45 @@ void launch_flush_apply(const DeferredUpdate& du, double* Binv, int64_t ld_b, in
                         int32_t row_hi, const PivotRecord* rec, hipStream_t s);
 void launch_flush_reset(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
 
+// ---- dense-tableau engine ------------------------------------------------------------------------
+// T = B^-1 [all columns] is kept as T = (I + W S') T0 with T0 dense column-major (m x n_store, column
+// pitch ld_t) and R0 = S' T0 (the rows of T0 at the distinct pivot rows of the block, row pitch ld_r).
+// Storage column = tableau column + col_off (phase 2 skips the artificial block).
+struct TableauView {
+    double*  T0;      int64_t ld_t;
+    double*  R0;      int64_t ld_r;
+    double*  d;       // reduced cost per storage column, maintained incrementally
+    int32_t  m;
+    int32_t  n_store; // stored columns (artificial block + provider columns)
+    int32_t  col_off; // first storage column of the current phase's tableau
+    int32_t  n;       // tableau columns of the current phase
+};
+// T0 := original matrix in row space (artificial unit columns | A + bound rows | virtual unit columns)
+void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s);
+// d[c] = cost[c] - w . T0[:,c] for every stored column (w = cost of the basic variable of each row)
+void launch_tab_price_init(const TableauView& tv, const double* w, const double* cost_store, hipStream_t s);
+// partial argmin over d (one slot per 256 columns) -- used when the loop is (re)entered
+void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s);
+int32_t tab_scan_blocks(int32_t n_store);
+// entering column from the partials (no column build: the tableau column is read directly)
+void launch_tab_select(const TableauView& tv, SelectPartials sp, int32_t count, PivotRecord* rec, hipStream_t s);
+// alpha = T[:,q] = T0[:,q] + W R0[:,q]
+void launch_tab_column(const TableauView& tv, const DeferredUpdate& du, double* alpha, const PivotRecord* rec,
+                       hipStream_t s);
+// row r of T (appending T0[r,:] to R0 when r is new in the block), d -= (d_q/alpha_r) row, partial argmin
+void launch_tab_row_update(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, PivotRecord* rec,
+                           hipStream_t s);
+// b, -obj, basis_indices, in_basis, trace, iteration counter (no -pi: it is read off d)
+void launch_tab_update_vectors(int32_t m, const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis,
+                               int32_t* trace, int64_t trace_cap, PivotRecord* rec, hipStream_t s);
+// flush: T0 += W R0 with v_mfma_f64_16x16x4_f64 tiles
+void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s);
+// out[i, k] = T0[i, cols[k]] (row-major m x m): B^-1 from the identity columns
+void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s);
+// tableau row `row` of the CURRENT T into out[0..n_store) (remove_artificial_basis_variables)
+void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row, double* out, const PivotRecord* rec,
+                    hipStream_t s);
+
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);
 void launch_select_candidate(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* aq,

@@ -750,6 +750,314 @@ __global__ void k_flush_reset(DeferredUpdate du, PivotRecord* rec) {
     if (threadIdx.x == 0) { rec->n_eta = 0; rec->n_eta_old = 0; rec->eta_target = 0; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Dense-tableau engine:  T = (I + W S') T0  (see TableauView / DeferredUpdate in relp_kernels.h)
+//   PRICE  = one row of T per pivot:   d <- d - (d_q / alpha_r) T[r,:]      (instead of 8 m n_s bytes)
+//   FTRAN  = one column of T per pivot: alpha = T0[:,q] + W R0[:,q]        (instead of 8 m^2 bytes)
+//   UPDATE = W <- E W per pivot; T0 += W R0 once per K pivots on the f64 matrix cores
+// ------------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ void k_tab_build(TableauView tv, const double* __restrict__ A, int64_t ld_a, ColumnTable ct) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)tv.m * tv.n_store;
+    if (idx >= total) return;
+    const int c = (int)(idx / tv.m), i = (int)(idx % tv.m);
+    double v = 0.0;
+    if (c < ct.nr_artificial) {
+        v = (i == ct.column_to_row[c]) ? 1.0 : 0.0;
+    } else {
+        const int p = c - ct.nr_artificial;
+        if (p < ct.nr_normal) {
+            if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
+            else v = (i == ct.bound_row[p]) ? 1.0 : 0.0;
+        } else {
+            const int vv = p - ct.nr_normal;
+            if (i == ct.vrow0[vv]) v = (double)ct.vsign[vv];
+            else if (i == ct.vrow1[vv]) v = 1.0;
+        }
+    }
+    tv.T0[(int64_t)c * tv.ld_t + i] = v;
+}
+
+// d[c] = cost[c] - w . T0[:,c]   (the PRICE multi-dot over the stored tableau, phase boundaries only)
+__global__ __launch_bounds__(kThreads) void k_tab_price_init(TableauView tv, const double* __restrict__ w,
+                                                             const double* __restrict__ cost_store) {
+    __shared__ double s_partial[4 * kVecPerBlock];
+    const int v0 = blockIdx.x * kVecPerBlock;
+    double dot = 0.0;
+    block_multi_dot(tv.T0, tv.ld_t, tv.m, v0, tv.n_store, w, s_partial, dot);
+    const int c = v0 + threadIdx.x;
+    if (threadIdx.x < kVecPerBlock && c < tv.n_store) tv.d[c] = cost_store[c] - dot;
+}
+
+// Workgroup-level (key, j) minimum of one candidate per thread -> partial slot `slot`.
+__device__ __forceinline__ void block_partial_min(double key, int kj, SelectPartials sp, int slot) {
+    __shared__ double s_k[kThreads / 64];
+    __shared__ int s_j[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(key, off, 64);
+        const int oj = __shfl_down(kj, off, 64);
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k[wave] = key; s_j[wave] = kj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w)
+            if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
+        sp.k1[slot] = key;
+        sp.j[slot] = kj;
+    }
+}
+
+// one slot per 256 storage columns
+__global__ __launch_bounds__(kThreads) void k_tab_scan(TableauView tv, SelectPartials sp, const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const int j = c - tv.col_off;
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (c < tv.n_store && j >= 0 && j < tv.n) {
+        const double v = tv.d[c];
+        if (!sp.in_basis[j] && v < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, v); kj = j; }
+    }
+    block_partial_min(key, kj, sp, blockIdx.x);
+}
+
+__global__ __launch_bounds__(kSingleBlock) void k_tab_select(TableauView tv, SelectPartials sp, int count,
+                                                             PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_k1[kSingleBlock / 64];
+    __shared__ int s_j[kSingleBlock / 64];
+    double k1 = INFINITY;
+    int bj = 0x7fffffff;
+    for (int t = threadIdx.x; t < count; t += kSingleBlock) {
+        const double key = sp.k1[t];
+        const int j = sp.j[t];
+        if (key < k1 || (key == k1 && j < bj)) { k1 = key; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(k1, off, 64);
+        const int oj = __shfl_down(bj, off, 64);
+        if (ok < k1 || (ok == k1 && oj < bj)) { k1 = ok; bj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k1[wave] = k1; s_j[wave] = bj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kSingleBlock / 64; ++w)
+            if (s_k1[w] < k1 || (s_k1[w] == k1 && s_j[w] < bj)) { k1 = s_k1[w]; bj = s_j[w]; }
+        s_k1[0] = k1;
+        s_j[0] = bj;
+    }
+    __syncthreads();
+    k1 = s_k1[0];
+    bj = s_j[0];
+    __syncthreads();
+    if (bj != 0x7fffffff && sp.rule == 2 && sp.tol_tie > 0.0) {
+        // Dantzig ties (pivot_rule.rs:118): lowest index inside the band; only slots whose minimum is
+        // inside the band can hold such a column
+        const double bound = k1 + sp.tol_tie * fmax(1.0, fabs(k1));
+        int lowest = 0x7fffffff;
+        for (int t = threadIdx.x; t < count; t += kSingleBlock) {
+            if (!(sp.k1[t] <= bound)) continue;
+            for (int u = 0; u < kThreads; ++u) {
+                const int c = t * kThreads + u;
+                const int j = c - tv.col_off;
+                if (c >= tv.n_store) break;
+                if (j < 0 || j >= tv.n) continue;
+                const double v = tv.d[c];
+                if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
+        if (lane == 0) s_j[wave] = lowest;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int low = 0x7fffffff;
+            for (int w = 0; w < kSingleBlock / 64; ++w) low = min(low, s_j[w]);
+            bj = low;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (bj == 0x7fffffff) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (sp.rule == 1) rec->last_selected = -1;
+        } else {
+            rec->q = bj;
+            rec->d_q = tv.d[bj + tv.col_off];
+            rec->key1 = k1;
+            if (sp.rule == 1) rec->last_selected = bj;
+        }
+    }
+}
+
+// alpha = T[:,q] = T0[:,q] + W (R0[:,q])
+__global__ __launch_bounds__(kThreads) void k_tab_column(TableauView tv, DeferredUpdate du, double* __restrict__ alpha,
+                                                         const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_vs[kMaxEta];
+    const int p = rec->n_eta;
+    const int cq = rec->q + tv.col_off;
+    if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
+    __syncthreads();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= tv.m) return;
+    double a = tv.T0[(int64_t)cq * tv.ld_t + i];
+    for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
+    alpha[i] = a;
+}
+
+// Row r of T before the pivot, the reduced-cost update and the next PRICE's partial argmin in one
+// pass over the stored columns.  When row r is new in the block its T0 row is appended to R0 here.
+__global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, DeferredUpdate du, SelectPartials sp,
+                                                             PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_wr[kMaxEta];
+    const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r, q = rec->q, leaving = rec->leaving;
+    if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
+    __syncthreads();
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (c < tv.n_store) {
+        double base;
+        if (jt < p_old) base = tv.R0[(int64_t)jt * tv.ld_r + c];
+        else { base = tv.T0[(int64_t)c * tv.ld_t + r]; tv.R0[(int64_t)jt * tv.ld_r + c] = base; }
+        double row = base;
+        for (int j = 0; j < p_old; ++j) row = fma(s_wr[j], tv.R0[(int64_t)j * tv.ld_r + c], row);
+        const double theta = rec->d_q / rec->alpha_r;
+        const int j = c - tv.col_off;
+        double dn = fma(-theta, row, tv.d[c]);
+        if (j == q) dn = 0.0;
+        tv.d[c] = dn;
+        if (j >= 0 && j < tv.n) {
+            const bool basic = (j == q) || (sp.in_basis[j] && j != leaving);   // flags are still the old ones
+            if (!basic && dn < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, dn); kj = j; }
+        }
+    }
+    block_partial_min(key, kj, sp, blockIdx.x);
+}
+
+__global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, double* __restrict__ b,
+                                     int32_t* __restrict__ basis_indices, uint8_t* __restrict__ in_basis,
+                                     int32_t* __restrict__ trace, int64_t trace_cap, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = rec->r;
+    const double br = rec->b_r / rec->alpha_r;
+    if (i < m) {
+        if (i == r) b[i] = br;
+        else {
+            const double a = alpha[i];
+            if (a != 0.0) b[i] = fma(-a, br, b[i]);
+        }
+    }
+    if (i == 0) {
+        const int q = rec->q, leaving = rec->leaving;
+        rec->minus_objective = fma(-rec->d_q, br, rec->minus_objective);
+        basis_indices[r] = q;
+        in_basis[leaving] = 0;
+        in_basis[q] = 1;
+        const long long it = rec->iterations;
+        if (trace && it < trace_cap) {
+            trace[0 * trace_cap + it] = rec->phase;
+            trace[1 * trace_cap + it] = q;
+            trace[2 * trace_cap + it] = r;
+            trace[3 * trace_cap + it] = leaving;
+        }
+        rec->iterations = it + 1;
+    }
+}
+
+// Flush: T0 += W R0 on the f64 matrix cores (v_mfma_f64_16x16x4_f64).  The MFMA computes the
+// transposed tile (R0' W')  so that the fast lane index of the accumulator runs along the rows of
+// T0, which are contiguous (column-major): stores are 128-byte segments.
+//   A operand (16 x 4): A[M][k] = R0[k][c0 + M]      lane l: M = l & 15, k = l >> 4
+//   B operand (4 x 16): B[k][N] = W[i0 + N][k]       lane l: N = l & 15, k = l >> 4
+//   D (16 x 16):        D[M][N] -> T0[i0 + N, c0 + M], lane l holds N = l & 15, M = (l >> 4) + 4 g, g = 0..3
+// Wavefront tile 64 columns x 64 rows (4 x 4 MFMA tiles, 8 operand loads per 16 MFMAs), workgroup
+// 128 x 128.
+template <int MT, int NT>
+__global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, DeferredUpdate du, const PivotRecord* rec) {
+    constexpr int kFlushMT = MT, kFlushNT = NT;
+    const int p = rec->n_eta;
+    if (p == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c_wave = blockIdx.x * (2 * 16 * MT) + (wave & 1) * (16 * MT);     // first T0 column of this wavefront
+    const int i_wave = blockIdx.y * (2 * 16 * NT) + (wave >> 1) * (16 * NT);    // first T0 row
+    if (c_wave >= tv.n_store || i_wave >= tv.m) return;
+    const int lm = lane & 15, lk = lane >> 4;
+    // the accumulators start as the T0 tile itself: all of its loads are in flight before the first MFMA
+    double4_t acc[kFlushMT][kFlushNT];
+#pragma unroll
+    for (int a = 0; a < kFlushMT; ++a)
+#pragma unroll
+        for (int b = 0; b < kFlushNT; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c_wave + a * 16 + lk + 4 * g;
+                const int i = i_wave + b * 16 + lm;
+                acc[a][b][g] = (c < tv.n_store && i < tv.m) ? tv.T0[(int64_t)c * tv.ld_t + i] : 0.0;
+            }
+    for (int k0 = 0; k0 < p; k0 += 4) {
+        const int k = k0 + lk;
+        const bool kv = k < p;
+        double af[kFlushMT], bf[kFlushNT];
+#pragma unroll
+        for (int a = 0; a < kFlushMT; ++a) {
+            const int c = c_wave + a * 16 + lm;
+            af[a] = (kv && c < tv.n_store) ? tv.R0[(int64_t)k * tv.ld_r + c] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < kFlushNT; ++b) {
+            const int i = i_wave + b * 16 + lm;
+            bf[b] = (kv && i < tv.m) ? du.W[(int64_t)k * du.ld + i] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < kFlushMT; ++a)
+#pragma unroll
+            for (int b = 0; b < kFlushNT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < kFlushMT; ++a)
+#pragma unroll
+        for (int b = 0; b < kFlushNT; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c_wave + a * 16 + lk + 4 * g;
+                const int i = i_wave + b * 16 + lm;
+                if (c < tv.n_store && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+            }
+}
+
+__global__ void k_tab_gather_columns(TableauView tv, const int32_t* __restrict__ cols, double* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)tv.m * tv.m;
+    if (idx >= total) return;
+    const int k = (int)(idx / tv.m), i = (int)(idx % tv.m);        // consecutive threads walk down a column of T0
+    out[(int64_t)i * tv.m + k] = tv.T0[(int64_t)cols[k] * tv.ld_t + i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_tab_row(TableauView tv, DeferredUpdate du, int row, double* __restrict__ out,
+                                                      const PivotRecord* rec) {
+    __shared__ double s_w[kMaxEta];
+    const int p = rec->n_eta;
+    if ((int)threadIdx.x < p) s_w[threadIdx.x] = du.W[(int64_t)threadIdx.x * du.ld + row];
+    __syncthreads();
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= tv.n_store) return;
+    double v = tv.T0[(int64_t)c * tv.ld_t + row];
+    for (int j = 0; j < p; ++j) v = fma(s_w[j], tv.R0[(int64_t)j * tv.ld_r + c], v);
+    out[c] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phase switch, identity, synthetic fill
 // ------------------------------------------------------------------------------------------------
@@ -1028,6 +1336,58 @@ void launch_flush_apply(const DeferredUpdate& du, double* Binv, int64_t ld_b, in
 
 void launch_flush_reset(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_flush_reset, dim3(1), dim3(128), 0, s, du, rec);
+}
+
+
+int32_t tab_scan_blocks(int32_t n_store) { return cdiv(n_store, kThreads); }
+
+void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s) {
+    const int64_t total = (int64_t)tv.m * tv.n_store;
+    hipLaunchKernelGGL(k_tab_build, dim3(cdiv(total, 256)), dim3(256), 0, s, tv, A, ld_a, ct);
+}
+
+void launch_tab_price_init(const TableauView& tv, const double* w, const double* cost_store, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_price_init, dim3(cdiv(tv.n_store, kVecPerBlock)), dim3(kThreads), 0, s, tv, w, cost_store);
+}
+
+void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_scan, dim3(tab_scan_blocks(tv.n_store)), dim3(kThreads), 0, s, tv, sp, rec);
+}
+
+void launch_tab_select(const TableauView& tv, SelectPartials sp, int32_t count, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_select, dim3(1), dim3(kSingleBlock), 0, s, tv, sp, count, rec);
+}
+
+void launch_tab_column(const TableauView& tv, const DeferredUpdate& du, double* alpha, const PivotRecord* rec,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, alpha, rec);
+}
+
+void launch_tab_row_update(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, PivotRecord* rec,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_row_update, dim3(tab_scan_blocks(tv.n_store)), dim3(kThreads), 0, s, tv, du, sp, rec);
+}
+
+void launch_tab_update_vectors(int32_t m, const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis,
+                               int32_t* trace, int64_t trace_cap, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_update_vectors, dim3(cdiv(m, 256)), dim3(256), 0, s, m, alpha, b, basis_indices, in_basis,
+                       trace, trace_cap, rec);
+}
+
+void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
+    constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
+    dim3 grid(cdiv(tv.n_store, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
+    hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, rec);
+}
+
+void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s) {
+    const int64_t total = (int64_t)tv.m * tv.m;
+    hipLaunchKernelGGL(k_tab_gather_columns, dim3(cdiv(total, 256)), dim3(256), 0, s, tv, cols, out);
+}
+
+void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row, double* out, const PivotRecord* rec,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_row, dim3(tab_scan_blocks(tv.n_store)), dim3(kThreads), 0, s, tv, du, row, out, rec);
 }
 
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {

@@ -35,6 +35,7 @@ OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded",
  K_UPDATE_W, K_FLUSH) = range(10)
 KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
                 "apply_w", "update_w", "flush"]
+ENGINE_REVISED, ENGINE_TABLEAU = 0, 1          # relp_engine_kind_t
 FORMAT_CSC, FORMAT_DENSE = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -58,7 +59,7 @@ class Config(C.Structure):
                 ("tol_tie", C.c_double), ("tol_feas", C.c_double),
                 ("poll_interval", C.c_int32), ("trace_capacity", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
-                ("update_block", C.c_int32), ("reserved_", C.c_int32)]
+                ("update_block", C.c_int32), ("engine", C.c_int32)]
 
 
 # every symbol include/relp_engine.h declares (tests/test_abi.py checks the export list against the header)

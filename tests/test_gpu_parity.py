@@ -33,13 +33,16 @@ def dense_problem(m, n, seed):
 # update_block: 0 = rank-1 update of the explicit inverse per pivot (reference-literal), K > 0 =
 # deferred update folded in every K pivots (K = 3 forces frequent flushes and repeated pivot rows)
 BLOCKS = [0, 3, 64]
+# engine kinds: revised (explicit / deferred inverse) and the dense tableau (always blocked)
+KINDS = [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 3), (engine.ENGINE_REVISED, 64),
+         (engine.ENGINE_TABLEAU, 3), (engine.ENGINE_TABLEAU, 64)]
 
 
-@pytest.mark.parametrize("block", BLOCKS)
+@pytest.mark.parametrize("kind,block", KINDS)
 @pytest.mark.parametrize("m,n,seed", [(8, 8, 1), (32, 48, 7), (128, 128, 20250001), (257, 131, 3), (300, 700, 11)])
-def test_dense_trace_matches_f64_oracle(m, n, seed, block):
+def test_dense_trace_matches_f64_oracle(m, n, seed, kind, block):
     md = dense_problem(m, n, seed)
-    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block)
+    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block, engine=kind)
     assert t.update_block() == block
     assert t.solve_relaxation() == engine.OPTIMAL
     ref = relp_f64.OracleF64(md.ensure_csc())
@@ -50,12 +53,12 @@ def test_dense_trace_matches_f64_oracle(m, n, seed, block):
     assert ident <= 1e-8 and basic <= 1e-8 and min_b >= -1e-9
 
 
-@pytest.mark.parametrize("block", [0, 16])
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 16), (engine.ENGINE_TABLEAU, 16)])
 @pytest.mark.parametrize("m,n,seed", [(8, 8, 1), (32, 48, 7), (128, 128, 20250001)])
-def test_dense_trace_matches_exact_oracle(m, n, seed, block):
+def test_dense_trace_matches_exact_oracle(m, n, seed, kind, block):
     """Parity shadows of config C2: the f64 GPU pivot sequence equals the exact-rational trace."""
     md = dense_problem(m, n, seed)
-    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block)
+    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block, engine=kind)
     assert t.solve_relaxation() == engine.OPTIMAL
     cols, b, c = synthetic.dense_lp_exact(m, n, seed)
     emd = ox.MatrixData(cols, b, [], 0, 0, m, 0, c, [None] * n)
@@ -70,13 +73,14 @@ def test_dense_trace_matches_exact_oracle(m, n, seed, block):
         assert abs(bfs[j] - float(v)) <= VEC_TOL * max(1.0, abs(float(v)))
 
 
-@pytest.mark.parametrize("block", [0, 5, 64])
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 5), (engine.ENGINE_REVISED, 64),
+                                        (engine.ENGINE_TABLEAU, 5), (engine.ENGINE_TABLEAU, 64)])
 @pytest.mark.parametrize("m,n,seed", [(20, 30, 5), (60, 90, 2), (150, 220, 9)])
-def test_sparse_two_phase_matches_f64_oracle(m, n, seed, block):
+def test_sparse_two_phase_matches_f64_oracle(m, n, seed, kind, block):
     """==, <=, >= rows and upper bounds: phase 1 (FirstProfitableWithMemory), the phase switch and
     phase 2 (SteepestDescent), CSC input."""
     md = MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, seed))
-    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block)
+    t = engine.Tableau(md, trace_capacity=1 << 16, update_block=block, engine=kind)
     outcome = t.solve_relaxation()
     ref = relp_f64.OracleF64(md)
     status = ref.run()
@@ -86,13 +90,14 @@ def test_sparse_two_phase_matches_f64_oracle(m, n, seed, block):
         assert_state_close(t, ref)
 
 
-def test_stepwise_api_matches_loop():
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 4), (engine.ENGINE_TABLEAU, 4)])
+def test_stepwise_api_matches_loop(kind, block):
     """The step-by-step entry points (select column / generate column / select row / bring into
     basis) walk the same path as relp_run."""
     md = dense_problem(40, 60, 13)
     loop = engine.Tableau(md, trace_capacity=4096)
     assert loop.solve_relaxation() == engine.OPTIMAL
-    t = engine.Tableau(md, trace_capacity=4096)
+    t = engine.Tableau(md, trace_capacity=4096, update_block=block, engine=kind)
     assert t.run(0)[1] in (engine.RUNNING, engine.PHASE_ONE_DONE)
     if t.phase == 1:
         assert t.run(1 << 20)[1] == engine.PHASE_ONE_DONE
@@ -111,9 +116,10 @@ def test_stepwise_api_matches_loop():
     assert abs(t.objective_function_value() - loop.objective_function_value()) <= 1e-12 * abs(loop.objective_function_value())
 
 
-def test_relative_costs_and_generate_element():
+@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU])
+def test_relative_costs_and_generate_element(kind):
     md = dense_problem(24, 36, 21)
-    t = engine.Tableau(md, update_block=4)
+    t = engine.Tableau(md, update_block=4, engine=kind)
     t.run(1 << 20)          # finishes the (empty) phase 1
     t.run(5)
     ref = relp_f64.OracleF64(md.ensure_csc())
@@ -304,8 +310,8 @@ def test_adlittle_gpu_pivot_sequence_equals_exact_trace():
     tr = []
     status, obj, sol = exact_solve(gf, emd, trace=tr.append)
     assert status == "optimal" and obj == Fr(24975305659811992079614961229, 120651674036153428931840)
-    for block in (0, 8):
-        t = engine.Tableau(md, trace_capacity=4096, update_block=block)
+    for kind, block in ((engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 8), (engine.ENGINE_TABLEAU, 8)):
+        t = engine.Tableau(md, trace_capacity=4096, update_block=block, engine=kind)
         assert t.solve_relaxation() == engine.OPTIMAL
         assert t.trace() == [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
         got = t.objective_function_value() + float(gf.fixed_cost)
@@ -328,15 +334,17 @@ FILES = [("burkardt/afiro.mps", False, -406659 / 875, 1e-9), ("burkardt/testprob
          ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3), ("miplib/50v-10.mps", False, 2879.065687, 1e-3)]
 
 
+@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU])
 @pytest.mark.parametrize("path,fixed,objective,tol", FILES)
-def test_reference_problem_files_on_gpu(path, fixed, objective, tol):
+def test_reference_problem_files_on_gpu(path, fixed, objective, tol, kind):
     """The reference's own problem files (tests/{burkardt,cook,netlib,miplib}) through the GPU engine:
     the pivot sequence equals the f64 CPU oracle's and the objective meets the reference's pin with the
     reference's tolerance."""
     from lp_files import load
     gf, ex, md, emd = load(path, fixed=fixed)
-    t = engine.Tableau(md, trace_capacity=1 << 15)
-    assert t.solve_relaxation() == engine.OPTIMAL
+    t = engine.Tableau(md, trace_capacity=1 << 15, engine=kind, update_block=32 if kind == engine.ENGINE_TABLEAU else -1)
+    outcome = t.solve_relaxation()
+    assert outcome == engine.OPTIMAL
     ref = relp_f64.OracleF64(md)
     assert ref.run() == "optimal"
     assert t.trace() == ref.trace
