@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--workload", default="dense10k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--engine", default="revised", choices=["revised", "tableau"],
+                    help="revised: explicit/deferred dense inverse (PRICE/FTRAN stream A and B^-1 every pivot); "
+                         "tableau: dense tableau with blocked MFMA updates")
+    ap.add_argument("--update-block", type=int, default=-1)
     ap.add_argument("--event-stride", type=int, default=4,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -110,7 +114,9 @@ def main():
                     upper_bound=np.full(n, np.inf))
     events = not args.no_kernel_events
     t = engine.Tableau(md, device_dense_ptr=A.data_ptr(), device_dense_ld=m, device=local_rank,
-                       poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world)
+                       poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world,
+                       engine=engine.ENGINE_TABLEAU if args.engine == "tableau" else engine.ENGINE_REVISED,
+                       update_block=args.update_block)
     torch.cuda.synchronize()
 
     if not sharded:

@@ -110,7 +110,7 @@ typedef enum {
     /* dense tableau T = B^-1 [A | slacks] kept as (I + W S') T0: PRICE is one tableau row, FTRAN one
      * tableau column per pivot, and T0 is updated by an m x K x n GEMM on the f64 matrix cores every
      * update_block pivots (needs 8 m n bytes; same pivots as the revised engine up to f64 rounding).
-     * Restrictions: no row removal (rank-deficient problems), no relp_from_basis, no sharding yet. */
+     * Restrictions: no relp_from_basis, no sharding yet. */
     RELP_ENGINE_TABLEAU = 1
 } relp_engine_kind_t;
 

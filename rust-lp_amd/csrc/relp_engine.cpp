@@ -774,7 +774,6 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
 // delete the given rows (and the same columns of B^-1) everywhere.  Rare, host round trip.
 relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "row removal in sharded mode");
-    if (tableau_) return fail(RELP_E_UNSUPPORTED, "row removal (rank-deficient problem) in the tableau engine");
     std::vector<int32_t> map(m_, 0);   // old row -> new row, -1 = removed
     {
         size_t f = 0; int32_t out = 0;
@@ -785,27 +784,46 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     const int32_t m_new = m_ - (int32_t)rows.size();
     for (int32_t r : rows) if (r >= mc_) return fail(RELP_E_STATE, "only constraint rows can be redundant");
     const int32_t mc_new = mc_ - (int32_t)rows.size();
-    // B^-1, b, basis
-    std::vector<double> Bh((size_t)m_ * ld_b_), b(m_);
+    // B^-1 (or the tableau), b, basis
+    std::vector<double> Bh(tableau_ ? 1 : (size_t)m_ * ld_b_), b(m_);
     std::vector<int32_t> basis(m_);
-    HIP_TRY(hipMemcpy(Bh.data(), dBinv_, Bh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (tableau_) {
+        // every stored column loses the rows; the columns that were the identity of those rows stay as
+        // (never priced) artificial columns.  Column by column to bound the host buffer.
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::vector<double> col(ld_t_), coln(ld_t_);
+        for (int32_t c = 0; c < n_store_; ++c) {
+            HIP_TRY(hipMemcpy(col.data(), dT0_ + (int64_t)c * ld_t_, sizeof(double) * m_, hipMemcpyDeviceToHost));
+            std::fill(coln.begin(), coln.end(), 0.0);
+            for (int32_t i = 0; i < m_; ++i) if (map[i] >= 0) coln[map[i]] = col[i];
+            HIP_TRY(hipMemcpy(dT0_ + (int64_t)c * ld_t_, coln.data(), sizeof(double) * ld_t_, hipMemcpyHostToDevice));
+        }
+        std::vector<int32_t> idn;
+        for (int32_t i = 0; i < m_; ++i) if (map[i] >= 0) idn.push_back(idcol_h_[i]);
+        idcol_h_ = idn;
+        HIP_TRY(hipMemcpy(d_idcol_, idcol_h_.data(), sizeof(int32_t) * idcol_h_.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(d_pos_of_row_, 0xFF, sizeof(int32_t) * m_));
+    } else {
+        HIP_TRY(hipMemcpy(Bh.data(), dBinv_, Bh.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     HIP_TRY(hipMemcpy(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     const int64_t ld_new = ld_b_;
-    std::vector<double> Bn((size_t)m_ * ld_new, 0.0), bn(m_, 0.0);
+    std::vector<double> Bn(tableau_ ? 1 : (size_t)m_ * ld_new, 0.0), bn(m_, 0.0);
     std::vector<int32_t> basisn(m_, 0);
     for (int32_t i = 0; i < m_; ++i) {
         if (map[i] < 0) continue;
-        for (int32_t j = 0; j < m_; ++j) if (map[j] >= 0) Bn[(size_t)map[i] * ld_new + map[j]] = Bh[(size_t)i * ld_b_ + j];
+        if (!tableau_)
+            for (int32_t j = 0; j < m_; ++j) if (map[j] >= 0) Bn[(size_t)map[i] * ld_new + map[j]] = Bh[(size_t)i * ld_b_ + j];
         bn[map[i]] = b[i];
         basisn[map[i]] = basis[i];
     }
-    HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!tableau_) HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_b_, 0, sizeof(double) * ld_b_));
     HIP_TRY(hipMemcpy(d_b_, bn.data(), sizeof(double) * m_new, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_basis_, basisn.data(), sizeof(int32_t) * m_new, hipMemcpyHostToDevice));
-    // A: drop the rows inside every structural column
-    if (nr_normal_ > 0) {
+    // A: drop the rows inside every structural column (the tableau engine no longer reads A)
+    if (nr_normal_ > 0 && !tableau_) {
         std::vector<double> Ah((size_t)ld_a_ * nr_normal_);
         HIP_TRY(hipMemcpy(Ah.data(), dA_, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<double> An((size_t)ld_a_ * nr_normal_, 0.0);
