@@ -160,6 +160,15 @@ def main():
     rows_local = (m + world - 1) // world
     alg_bytes = {"price": 8.0 * m * n_local, "ftran": 8.0 * rows_local * m + 16.0 * m,
                  "update_inverse": 16.0 * rows_local * m}
+    alg_flops = {}
+    tableau = args.engine == "tableau"
+    if tableau:
+        # dense tableau: the only kernel that touches the m x (n + m) matrix is the flush T0 += W R0
+        # (read + write of T0, K-deep GEMM on the f64 matrix cores); PRICE / FTRAN read one row / one column
+        kblk = t.update_block()
+        n_store = n + m
+        alg_bytes = {"flush": 16.0 * m * n_store, "price": 8.0 * n_store * (kblk / 2 + 2), "ftran": 8.0 * m * (kblk / 2 + 2)}
+        alg_flops = {"flush": 2.0 * m * n_store * kblk}
     kernels = {}
     for name, (cnt, ms) in prof.items():
         if cnt > 0:
@@ -167,6 +176,8 @@ def main():
             entry = {"launches": cnt, "avg_us": round(avg_us, 3)}
             if name in alg_bytes:
                 entry["GBps"] = round(alg_bytes[name] / (avg_us * 1e-6) / 1e9, 1)
+            if name in alg_flops:
+                entry["TFLOPs"] = round(alg_flops[name] / (avg_us * 1e-6) / 1e12, 2)
             kernels[name] = entry
     roofline = None
     if kernels:
@@ -181,6 +192,15 @@ def main():
         roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes[dom]}
+        if tableau and "flush" in kernels:
+            # the flush is the one kernel that streams the matrix; at K = 64 its HBM time (16 m n bytes) exceeds
+            # its MFMA time (2 m n K flops at 78.6 TFLOP/s), so it is priced against HBM, MFMA rate alongside
+            fl = kernels["flush"]
+            roofline = {"kernel": "k_tab_flush", "bound": "hbm", "achieved": fl["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(fl["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": alg_bytes["flush"],
+                        "mfma": {"achieved": fl.get("TFLOPs"), "peak": 78.6, "unit": "TFLOP/s (f64 matrix)",
+                                 "frac": round(fl.get("TFLOPs", 0.0) / 78.6, 4)}}
 
     if rank == 0:
         out = {
@@ -188,12 +208,13 @@ def main():
             "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), "
-                                   "SteepestDescent, explicit dense basis inverse",
+                                   "SteepestDescent, " + ("dense tableau with blocked MFMA updates" if args.engine == "tableau"
+                                                         else "explicit dense basis inverse"),
                        "m": m, "n": n, "seed": seed,
                        "parallelism": "single GPU" if world == 1 else f"columns of A and rows of B^-1 sharded x{world}"},
             "roofline": roofline, "kernels": kernels, "kernel_event_stride": args.event_stride if events else None,
-            "iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
-            "iteration_GBps": (8.0 * m * n + 24.0 * m * m) / (dt / K) / 1e9,
+            "engine": args.engine, "update_block": t.update_block(),
+            "reference_iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m, n, seed, W, K)

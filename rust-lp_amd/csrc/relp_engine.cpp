@@ -407,10 +407,7 @@ void Engine::enqueue_iteration_tableau(int rule) {
     launch_tab_row_update(tv, du, sp, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_UPDATE_W);
-    launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
-    prof_end();
-    prof_begin(RELP_K_UPDATE_VECTORS);
-    launch_tab_update_vectors(m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+    launch_tab_update_w_vectors(du, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
     if (++since_flush_ >= block_) enqueue_flush();
 }

@@ -863,13 +863,14 @@ __global__ __launch_bounds__(kSingleBlock) void k_tab_select(TableauView tv, Sel
         // inside the band can hold such a column
         const double bound = k1 + sp.tol_tie * fmax(1.0, fabs(k1));
         int lowest = 0x7fffffff;
-        for (int t = threadIdx.x; t < count; t += kSingleBlock) {
+        // four groups of 256 threads walk the slots; a slot inside the band is re-read by its group,
+        // one column per thread
+        const int grp = threadIdx.x >> 8, u = threadIdx.x & 255;
+        for (int t = grp; t < count; t += kSingleBlock / kThreads) {
             if (!(sp.k1[t] <= bound)) continue;
-            for (int u = 0; u < kThreads; ++u) {
-                const int c = t * kThreads + u;
-                const int j = c - tv.col_off;
-                if (c >= tv.n_store) break;
-                if (j < 0 || j >= tv.n) continue;
+            const int c = t * kThreads + u;
+            const int j = c - tv.col_off;
+            if (c < tv.n_store && j >= 0 && j < tv.n) {
                 const double v = tv.d[c];
                 if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
             }
@@ -942,6 +943,53 @@ __global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, Def
         }
     }
     block_partial_min(key, kj, sp, blockIdx.x);
+}
+
+// W <- E W  and  b, -obj, basis, flags, trace in one launch (both walk the m rows)
+__global__ __launch_bounds__(kThreads) void k_tab_update_w_vectors(DeferredUpdate du, int m,
+                                                                   const double* __restrict__ alpha,
+                                                                   double* __restrict__ b,
+                                                                   int32_t* __restrict__ basis_indices,
+                                                                   uint8_t* __restrict__ in_basis,
+                                                                   int32_t* __restrict__ trace, int64_t trace_cap,
+                                                                   PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_wr[kMaxEta];
+    const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r;
+    if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const double ar = rec->alpha_r;
+    const double br = rec->b_r / ar;
+    if (i < m) {
+        const double a = alpha[i];
+        const double u = (i == r) ? (1.0 / ar - 1.0) : (-a / ar);
+        if (u != 0.0) {
+            for (int j = 0; j < p_old; ++j) {
+                const double w = s_wr[j];
+                if (w != 0.0) du.W[(int64_t)j * du.ld + i] = fma(u, w, du.W[(int64_t)j * du.ld + i]);
+            }
+        }
+        double* tgt = du.W + (int64_t)jt * du.ld + i;
+        if (jt < p_old) *tgt += u; else *tgt = u;
+        if (i == r) b[i] = br;
+        else if (a != 0.0) b[i] = fma(-a, br, b[i]);
+    }
+    if (i == 0) {
+        const int q = rec->q, leaving = rec->leaving;
+        rec->minus_objective = fma(-rec->d_q, br, rec->minus_objective);
+        basis_indices[r] = q;
+        in_basis[leaving] = 0;
+        in_basis[q] = 1;
+        const long long it = rec->iterations;
+        if (trace && it < trace_cap) {
+            trace[0 * trace_cap + it] = rec->phase;
+            trace[1 * trace_cap + it] = q;
+            trace[2 * trace_cap + it] = r;
+            trace[3 * trace_cap + it] = leaving;
+        }
+        rec->iterations = it + 1;
+    }
 }
 
 __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, double* __restrict__ b,
@@ -1372,6 +1420,13 @@ void launch_tab_update_vectors(int32_t m, const double* alpha, double* b, int32_
                                int32_t* trace, int64_t trace_cap, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_update_vectors, dim3(cdiv(m, 256)), dim3(256), 0, s, m, alpha, b, basis_indices, in_basis,
                        trace, trace_cap, rec);
+}
+
+void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const double* alpha, double* b,
+                                 int32_t* basis_indices, uint8_t* in_basis, int32_t* trace, int64_t trace_cap,
+                                 PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_update_w_vectors, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, alpha, b,
+                       basis_indices, in_basis, trace, trace_cap, rec);
 }
 
 void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
