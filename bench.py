@@ -2,7 +2,7 @@
 """bench.py -- simplex iterations/s of the MI355X pivot engine on the synthetic dense LP.
 
 A "step" is one pass of the hot path (PRICE -> FTRAN -> RATIO -> UPDATE = one basis change) of
-the revised simplex on the synthetic dense LP of BASELINE.json (rust-lp_amd/synthetic.py), inputs
+the simplex on the synthetic dense LP of BASELINE.json (rust-lp_amd/synthetic.py), inputs
 resident in HBM before the timed region.  One JSON line on stdout (rank 0).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
@@ -11,11 +11,18 @@ resident in HBM before the timed region.  One JSON line on stdout (rank 0).
 
 Workloads (config.workload):
   dense10k  (default) m = 10,000 rows, n = 10,000 structural columns (+10,000 slacks), f64,
-            SteepestDescent (Dantzig), explicit dense B^-1: the LP BASELINE.json's target is quoted on.
+            SteepestDescent (Dantzig): the LP BASELINE.json's target is quoted on.
   c2        2,000 x 2,000 (BASELINE.json configs[1]); c4: 10,000 x 50,000 (configs[3]).
-N > 1: the same LP, structural columns and rows of B^-1 sharded over the ranks (strong scaling);
-per pivot one all-gather of PRICE candidates, one all-gather of FTRAN slices and one SUM
-all-reduce that broadcasts the pivot row, all on RCCL.
+Engines (--engine):
+  tableau   (default) dense tableau T = B^-1 [A | I] kept as (I + W S') T0: PRICE is one tableau row,
+            FTRAN one tableau column per pivot; T0 += W R0 (m x K x n GEMM on the f64 matrix cores)
+            every K pivots.  Same pivots as the revised engine (parity-tested).
+  revised   explicit dense inverse `Carry<_, BasisInverseRows<_>>`: PRICE streams A (8 m n bytes) and
+            FTRAN streams B^-1 (8 m^2 bytes) at every pivot -- the FTRAN/PRICE HBM-roofline numbers.
+  At N = 1 the default run measures the tableau engine as `value` and adds the revised engine's
+  numbers under "revised_engine" (its own K timed pivots).
+N > 1: the same LP (strong scaling); the stored tableau columns are split contiguously over the
+ranks, ONE all-gather of [key, j, d_j, alpha(m)] candidates per pivot over RCCL, everything else local.
 """
 import argparse
 import json
@@ -28,13 +35,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {"dense10k": (10000, 10000, 20250002), "c2": (2000, 2000, 20250001), "c4": (10000, 50000, 20250003)}
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_MFMA_PEAK_TF = 78.6    # FP64 matrix 78.6 TFLOP/s
 
 
 def cpu_baseline(m, n, seed, warmup, steps, budget_s=20.0):
     """The C (f64) restatement of the reference path (oracle/relp_f64.c, kind "port"), one core,
     timed on the same LP over the same iteration window [warmup, warmup + k) until ~budget_s."""
-    import numpy as np
     from rust_lp_amd import MatrixData, synthetic
     from oracle import relp_f64
     lp = synthetic.dense_lp(m, n, seed)
@@ -58,18 +65,41 @@ def cpu_baseline(m, n, seed, warmup, steps, budget_s=20.0):
             "nproc": os.cpu_count()}
 
 
+def kernel_table(prof, alg_bytes, alg_flops):
+    kernels = {}
+    for name, (cnt, ms) in prof.items():
+        if cnt > 0:
+            avg_us = ms * 1e3 / cnt
+            entry = {"launches": cnt, "avg_us": round(avg_us, 3)}
+            if name in alg_bytes:
+                entry["GBps"] = round(alg_bytes[name] / (avg_us * 1e-6) / 1e9, 1)
+            if name in alg_flops:
+                entry["TFLOPs"] = round(alg_flops[name] / (avg_us * 1e-6) / 1e12, 2)
+            kernels[name] = entry
+    return kernels
+
+
+def load_traffic(workload, kernel):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            return json.load(open(tpath)).get(workload, {}).get(kernel)
+        except Exception:
+            return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dense10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--engine", default="default", choices=["default", "revised", "tableau"],
+                    help="default = tableau as the measured engine (+ the revised engine's numbers at N = 1)")
+    ap.add_argument("--update-block", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--engine", default="revised", choices=["revised", "tableau"],
-                    help="revised: explicit/deferred dense inverse (PRICE/FTRAN stream A and B^-1 every pivot); "
-                         "tableau: dense tableau with blocked MFMA updates")
-    ap.add_argument("--update-block", type=int, default=-1)
     ap.add_argument("--event-stride", type=int, default=4,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -100,129 +130,138 @@ def main():
     m, n, seed = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
     lib = engine.load_library()
+    events = not args.no_kernel_events
+    primary = "tableau" if args.engine in ("default", "tableau") else "revised"
 
-    # ---- synthetic inputs, generated directly in HBM ------------------------------------------
-    col_lo, col_hi = engine.shard_column_range(n, rank, world)
-    n_local = col_hi - col_lo
-    A = torch.empty((max(n_local, 1), m), dtype=torch.float64, device=dev)    # column-major m x n_local
-    stream = torch.cuda.current_stream().cuda_stream
-    st = lib.relp_synth_fill_dense(A.data_ptr(), m, m, n_local, seed, col_lo, stream)
-    assert st == 0, "synthetic fill failed"
     nums_b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
     nums_c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
-    md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=nums_b / 4000.0, cost=nums_c / 1000.0,
-                    upper_bound=np.full(n, np.inf))
-    events = not args.no_kernel_events
-    t = engine.Tableau(md, device_dense_ptr=A.data_ptr(), device_dense_ld=m, device=local_rank,
-                       poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world,
-                       engine=engine.ENGINE_TABLEAU if args.engine == "tableau" else engine.ENGINE_REVISED,
-                       update_block=args.update_block)
-    torch.cuda.synchronize()
 
-    if not sharded:
-        done, oc = t.run(1)                           # phase 1 is empty (slack basis): one PRICE proves it
-        assert oc == engine.PHASE_ONE_DONE, engine.OUTCOME_NAMES.get(oc)
-        done, oc = t.run(W)
-        assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
-        if events:
-            t.profile_enable(True, 12 * K + 16, args.event_stride)
+    def measure(kind):
+        """Build the engine of `kind` on the synthetic LP (generated in HBM) and time K pivots."""
+        md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=nums_b / 4000.0, cost=nums_c / 1000.0,
+                        upper_bound=np.full(n, np.inf))
+        cfg = engine.default_config(device=local_rank, poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world,
+                                    engine=engine.ENGINE_TABLEAU if kind == "tableau" else engine.ENGINE_REVISED,
+                                    update_block=args.update_block)
+        col_lo, col_hi = engine.shard_plan(md, cfg)
+        n_local = col_hi - col_lo
+        A = torch.empty((max(n_local, 1), m), dtype=torch.float64, device=dev)      # column-major m x n_local
+        st = lib.relp_synth_fill_dense(A.data_ptr(), m, m, n_local, seed, col_lo, torch.cuda.current_stream().cuda_stream)
+        assert st == 0, "synthetic fill failed"
+        t = engine.Tableau(md, config=cfg, device_dense_ptr=A.data_ptr(), device_dense_ld=m)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        done, oc = t.run(K)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        if not sharded:
+            done, oc = t.run(1)                        # phase 1 is empty (slack basis): one PRICE proves it
+            assert oc == engine.PHASE_ONE_DONE, engine.OUTCOME_NAMES.get(oc)
+            done, oc = t.run(W)
+            assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
+            if events:
+                t.profile_enable(True, 12 * K + 16, args.event_stride)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done, oc = t.run(K)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        else:
+            from rust_lp_amd.sharded import ShardedPivotLoop
+            loop = ShardedPivotLoop(t, dist, dev)
+            oc = loop.finish_phase_one()
+            assert oc == engine.PHASE_ONE_DONE
+            done, oc = loop.run(W)
+            assert done == W and oc == engine.RUNNING
+            if events:
+                t.profile_enable(True, 12 * K + 16, args.event_stride)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done, oc = loop.run(K)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
         assert done == K, f"only {done} of {K} pivots were possible"
         prof = t.profile_read() if events else {}
-    else:
-        import torch.distributed as dist
-        from rust_lp_amd.sharded import ShardedPivotLoop
-        loop = ShardedPivotLoop(t, dist, dev)
-        oc = loop.finish_phase_one()
-        assert oc == engine.PHASE_ONE_DONE
-        done, oc = loop.run(W)
-        assert done == W and oc == engine.RUNNING
-        if events:
-            t.profile_enable(True, 12 * K + 16, args.event_stride)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        done, oc = loop.run(K)
-        torch.cuda.synchronize()
-        dist.barrier()
-        dt = time.perf_counter() - t0
-        assert done == K, f"only {done} of {K} pivots were possible"
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        prof = t.profile_read() if events else {}
+        block = t.update_block()
+        obj = t.objective_function_value()
+        t.close()
+        del A
+        torch.cuda.empty_cache()
+        # algorithmic bytes / flops per launch (DESIGN.md section 4), local shard
+        if kind == "tableau":
+            n_store = n + m
+            n_owned = (n_store + world - 1) // world
+            alg_bytes = {"flush": 16.0 * m * n_owned}
+            alg_flops = {"flush": 2.0 * m * n_owned * block}
+        else:
+            rows_local = (m + world - 1) // world
+            alg_bytes = {"price": 8.0 * m * n_local, "ftran": 8.0 * rows_local * m + 16.0 * m,
+                         "update_inverse": 16.0 * rows_local * m, "flush": 16.0 * rows_local * m}
+            alg_flops = {"flush": 2.0 * rows_local * m * max(block, 1)}
+        return {"dt": dt, "kernels": kernel_table(prof, alg_bytes, alg_flops), "alg_bytes": alg_bytes, "block": block,
+                "objective": obj}
 
-    # ---- roofline of the dominant kernel (algorithmic bytes per launch / measured duration) ----
-    rows_local = (m + world - 1) // world
-    alg_bytes = {"price": 8.0 * m * n_local, "ftran": 8.0 * rows_local * m + 16.0 * m,
-                 "update_inverse": 16.0 * rows_local * m}
-    alg_flops = {}
-    tableau = args.engine == "tableau"
-    if tableau:
-        # dense tableau: the only kernel that touches the m x (n + m) matrix is the flush T0 += W R0
-        # (read + write of T0, K-deep GEMM on the f64 matrix cores); PRICE / FTRAN read one row / one column
-        kblk = t.update_block()
-        n_store = n + m
-        alg_bytes = {"flush": 16.0 * m * n_store, "price": 8.0 * n_store * (kblk / 2 + 2), "ftran": 8.0 * m * (kblk / 2 + 2)}
-        alg_flops = {"flush": 2.0 * m * n_store * kblk}
-    kernels = {}
-    for name, (cnt, ms) in prof.items():
-        if cnt > 0:
-            avg_us = ms * 1e3 / cnt
-            entry = {"launches": cnt, "avg_us": round(avg_us, 3)}
-            if name in alg_bytes:
-                entry["GBps"] = round(alg_bytes[name] / (avg_us * 1e-6) / 1e9, 1)
-            if name in alg_flops:
-                entry["TFLOPs"] = round(alg_flops[name] / (avg_us * 1e-6) / 1e12, 2)
-            kernels[name] = entry
+    res = measure(primary)
+    dt, kernels = res["dt"], res["kernels"]
+
     roofline = None
     if kernels:
-        dom = max((k for k in kernels if k in alg_bytes), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
-            except Exception:
-                traffic = None
-        roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes[dom]}
-        if tableau and "flush" in kernels:
-            # the flush is the one kernel that streams the matrix; at K = 64 its HBM time (16 m n bytes) exceeds
-            # its MFMA time (2 m n K flops at 78.6 TFLOP/s), so it is priced against HBM, MFMA rate alongside
+        if primary == "tableau" and "flush" in kernels:
+            # the flush T0 += W R0 is the one kernel that streams the m x (n + m) tableau; at K = 64 its HBM time
+            # (16 m n bytes) exceeds its MFMA time (2 m n K flops at 78.6 TFLOP/s), so it is priced against HBM
             fl = kernels["flush"]
             roofline = {"kernel": "k_tab_flush", "bound": "hbm", "achieved": fl["GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(fl["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": alg_bytes["flush"],
-                        "mfma": {"achieved": fl.get("TFLOPs"), "peak": 78.6, "unit": "TFLOP/s (f64 matrix)",
-                                 "frac": round(fl.get("TFLOPs", 0.0) / 78.6, 4)}}
+                        "unit": "GB/s", "frac": round(fl["GBps"] / HBM_PEAK_GBS, 4),
+                        "traffic": load_traffic(args.workload, "tab_flush"),
+                        "algorithmic_bytes_per_launch": res["alg_bytes"]["flush"],
+                        "launches_per_pivot": 1.0 / max(res["block"], 1),
+                        "mfma": {"achieved": fl.get("TFLOPs"), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s (f64 matrix)",
+                                 "frac": round(fl.get("TFLOPs", 0.0) / F64_MFMA_PEAK_TF, 4)}}
+        else:
+            streaming = [k for k in kernels if k in ("price", "ftran", "update_inverse")]
+            dom = max(streaming, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+            traffic_key = {"price": "price_structural", "ftran": "ftran", "update_inverse": "update_inverse"}[dom]
+            roofline = {"kernel": "k_" + traffic_key, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4),
+                        "traffic": load_traffic(args.workload, traffic_key),
+                        "algorithmic_bytes_per_launch": res["alg_bytes"][dom]}
+
+    secondary = None
+    if args.engine == "default" and not sharded and rank == 0:
+        r2 = measure("revised")
+        k2 = r2["kernels"]
+        secondary = {"value": K / r2["dt"], "unit": "iterations/s", "ms_per_step": r2["dt"] * 1e3 / K,
+                     "update_block": r2["block"], "kernels": k2,
+                     "note": "explicit dense inverse (Carry<_, BasisInverseRows<_>>): PRICE streams A, FTRAN streams B^-1 "
+                             "every pivot; GB/s = algorithmic bytes / HIP-event duration",
+                     "ftran_hbm_frac": round(k2["ftran"]["GBps"] / HBM_PEAK_GBS, 4) if "ftran" in k2 else None,
+                     "price_hbm_frac": round(k2["price"]["GBps"] / HBM_PEAK_GBS, 4) if "price" in k2 else None,
+                     "ftran_traffic": load_traffic(args.workload, "ftran"),
+                     "objective_after_run": r2["objective"]}
 
     if rank == 0:
         out = {
             "metric": "simplex iterations/sec", "value": K / dt, "unit": "iterations/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), "
-                                   "SteepestDescent, " + ("dense tableau with blocked MFMA updates" if args.engine == "tableau"
-                                                         else "explicit dense basis inverse"),
-                       "m": m, "n": n, "seed": seed,
-                       "parallelism": "single GPU" if world == 1 else f"columns of A and rows of B^-1 sharded x{world}"},
+            "config": {"workload": f"{args.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), SteepestDescent, "
+                                   + ("dense tableau with blocked f64-MFMA updates" if primary == "tableau"
+                                      else "explicit dense basis inverse"),
+                       "m": m, "n": n, "seed": seed, "engine": primary, "update_block": res["block"],
+                       "parallelism": "single GPU" if world == 1 else
+                       (f"stored tableau columns sharded x{world}, one all-gather per pivot" if primary == "tableau"
+                        else f"columns of A and rows of B^-1 sharded x{world}")},
             "roofline": roofline, "kernels": kernels, "kernel_event_stride": args.event_stride if events else None,
-            "engine": args.engine, "update_block": t.update_block(),
+            "objective_after_run": res["objective"],
             "reference_iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(m, n, seed, W, K)
-        elif world == 1:
-            out["cpu_baseline"] = None
+        if secondary is not None:
+            out["revised_engine"] = secondary
+        if world == 1:
+            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(m, n, seed, W, K)
         print(json.dumps(out))
     if sharded:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -226,6 +226,13 @@ relp_status_t relp_shard_ftran(relp_engine_t *h, double *dev_alpha_slice);
 relp_status_t relp_shard_ratio(relp_engine_t *h, const double *dev_alpha_slices, int32_t count, double *dev_rho);
 /* rank-1 update of the owned rows + replicated b, -pi, obj, basis */
 relp_status_t relp_shard_update(relp_engine_t *h, const double *dev_rho);
+/* structural columns [lo, hi) that rank cfg->shard_rank must supply in `dense` for this problem and
+ * engine kind (only the counts and upper bounds of `md` are read).  The revised engine splits the
+ * structural columns; the tableau engine splits its stored columns [artificial | structural | virtual]. */
+relp_status_t relp_shard_plan(const relp_matrix_data_t *md, const relp_config_t *cfg, int32_t *col_lo, int32_t *col_hi);
+/* Tableau engine only: the whole pivot after relp_shard_select_column (ratio test, row update of the
+ * owned columns, W / b / basis update, local flush when due).  One all-gather per pivot in total. */
+relp_status_t relp_shard_pivot(relp_engine_t *h);
 /* deferred update in sharded mode, every relp_update_block() pivots: `begin` snapshots the rows
  * S' B0inv this rank owns (zeros elsewhere) and returns the buffer to SUM all-reduce in place
  * (*len_doubles = 0: nothing pending); `end` applies W (S' B0inv) to the owned rows. */

@@ -134,6 +134,29 @@ relp_status_t relp_shard_ratio(relp_engine_t* h, const double* a, int32_t count,
     return (h && a && rho) ? H(h).shard_ratio(a, count, rho) : RELP_E_ARG;
 }
 relp_status_t relp_shard_update(relp_engine_t* h, const double* rho) { return (h && rho) ? H(h).shard_update(rho) : RELP_E_ARG; }
+relp_status_t relp_shard_pivot(relp_engine_t* h) { return h ? H(h).shard_pivot() : RELP_E_ARG; }
+relp_status_t relp_shard_plan(const relp_matrix_data_t* md, const relp_config_t* cfg, int32_t* col_lo, int32_t* col_hi) {
+    if (!md || !cfg) return RELP_E_ARG;
+    const int32_t G = cfg->shard_count < 1 ? 1 : cfg->shard_count, g = cfg->shard_rank;
+    if (cfg->engine != RELP_ENGINE_TABLEAU) { relp_shard_column_range(md->nr_normal, g, G, col_lo, col_hi); return RELP_OK; }
+    // stored columns = artificial | structural | virtual (see relp_engine.cpp)
+    int32_t nr_bounds = 0;
+    for (int32_t j = 0; j < md->nr_normal; ++j) if (md->upper_bound && md->upper_bound[j] < 1e300 && md->upper_bound[j] > -1e300) ++nr_bounds;
+    const int32_t mc = md->nr_eq + md->nr_range + md->nr_le + md->nr_ge;
+    const int32_t m = mc + nr_bounds + md->nr_range;
+    const int32_t nr_real = md->nr_le + nr_bounds + md->nr_range;
+    const int32_t na = m - nr_real;
+    const int32_t n_store = na + md->nr_normal + md->nr_range + md->nr_le + md->nr_ge + nr_bounds + md->nr_range;
+    int32_t per = (n_store + G - 1) / G; per += per % 2;
+    int32_t lo = g * per; if (lo > n_store) lo = n_store;
+    int32_t hi = lo + per; if (hi > n_store) hi = n_store;
+    int32_t a = lo - na; if (a < 0) a = 0; if (a > md->nr_normal) a = md->nr_normal;
+    int32_t b = hi - na; if (b < 0) b = 0; if (b > md->nr_normal) b = md->nr_normal;
+    if (b < a) b = a;
+    if (col_lo) *col_lo = a;
+    if (col_hi) *col_hi = b;
+    return RELP_OK;
+}
 relp_status_t relp_poll(relp_engine_t* h, int32_t* outcome, int64_t* iterations) { return h ? H(h).poll(outcome, iterations) : RELP_E_ARG; }
 
 }  // extern "C"

@@ -67,10 +67,21 @@ Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.to
 
 TableauView Engine::tview() const {
     TableauView tv;
-    tv.T0 = dT0_; tv.ld_t = ld_t_; tv.R0 = dR0_; tv.ld_r = ld_r_; tv.d = d_d_; tv.m = m_; tv.n_store = n_store_;
+    // only the owned storage columns [sc_lo, sc_hi) are stored; shift so kernels index globally
+    tv.T0 = dT0_ - (int64_t)sc_lo_ * ld_t_; tv.ld_t = ld_t_;
+    tv.R0 = dR0_ - (int64_t)sc_lo_; tv.ld_r = ld_r_;
+    tv.d = d_d_; tv.m = m_; tv.n_store = n_store_;
     tv.col_off = phase_ == 1 ? 0 : tab_na_;
     tv.n = nr_columns();
+    tv.c_lo = sc_lo_; tv.c_hi = sc_hi_;
     return tv;
+}
+
+SelectPartials Engine::tab_partials(int rule) const {
+    SelectPartials sp;
+    sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+    sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+    return sp;
 }
 
 DeferredUpdate Engine::deferred() const {
@@ -153,6 +164,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         row_hi_ = std::min(m_, row_lo_ + row_stride_);
         cand_len_ = round_up(3 + (int64_t)m_, 2);
     }
+    const bool want_tableau_early = cfg_.engine == RELP_ENGINE_TABLEAU;
 
     // initial basis: <=-slacks, bound slacks, range-bound slacks are real pivots (matrix_data.rs:432-452);
     // every other row gets an artificial, numbered before all provider columns (partially.rs:72-80)
@@ -189,6 +201,17 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     }
     phase_ = 1;
     n_alloc_ = nr_artificial_ + n_provider_;
+    if (want_tableau_early) {
+        // the tableau shards its STORED columns [artificial | structural | virtual] contiguously; the
+        // structural part of the owned range is what the caller supplies in `dense`
+        const int32_t G = cfg_.shard_count, g = cfg_.shard_rank;
+        const int32_t per = (int32_t)round_up((n_alloc_ + G - 1) / G, 2);
+        sc_lo_ = std::min(n_alloc_, g * per);
+        sc_hi_ = std::min(n_alloc_, sc_lo_ + per);
+        col_lo_ = std::min(nr_normal_, std::max(0, sc_lo_ - nr_artificial_));
+        col_hi_ = std::min(nr_normal_, std::max(0, sc_hi_ - nr_artificial_));
+        if (col_hi_ < col_lo_) col_hi_ = col_lo_;
+    }
 
     // ---- device allocations ----
     HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -257,13 +280,13 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     block_ = cfg_.update_block < 0 ? (m_ >= 4096 ? 64 : 0) : std::min(cfg_.update_block, 128);
     tableau_ = cfg_.engine == RELP_ENGINE_TABLEAU;
     if (tableau_) {
-        if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "the tableau engine is not sharded yet");
         if (block_ == 0) block_ = 64;                  // the tableau is always maintained in blocks
         n_store_ = n_alloc_;
         tab_na_ = nr_artificial_;
+        const int64_t n_owned = std::max(sc_hi_ - sc_lo_, 1);
         ld_t_ = round_up(m_, 2);
-        ld_r_ = round_up(n_store_, 2);
-        HIP_TRY(dev_alloc(&dT0_, ld_t_ * n_store_));
+        ld_r_ = round_up(n_owned, 2);
+        HIP_TRY(dev_alloc(&dT0_, ld_t_ * n_owned));
         HIP_TRY(dev_alloc(&dR0_, ld_r_ * (block_ + 1)));        // + one scratch row (d_aq_big)
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
         HIP_TRY(dev_alloc(&d_idcol_, m_));
@@ -391,11 +414,9 @@ void Engine::enqueue_price(int cost_mode, const double* vec, const PivotRecord* 
 void Engine::enqueue_iteration_tableau(int rule) {
     const TableauView tv = tview();
     const DeferredUpdate du = deferred();
-    SelectPartials sp;
-    sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
-    sp.n = tv.n; sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+    const SelectPartials sp = tab_partials(rule);
     prof_begin(RELP_K_SELECT_COLUMN);
-    launch_tab_select(tv, sp, tab_scan_blocks(n_store_), d_rec_, stream_);
+    launch_tab_select(tv, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_FTRAN);
     launch_tab_column(tv, du, d_alpha_, d_rec_, stream_);
@@ -517,7 +538,7 @@ relp_status_t Engine::select_primal_pivot_column(int rule, int32_t* found, int32
         sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
         sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
         launch_tab_scan(tview(), sp, d_rec_, stream_);
-        launch_tab_select(tview(), sp, tab_scan_blocks(n_store_), d_rec_, stream_);
+        launch_tab_select(tview(), sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_rec_, stream_);
     } else {
         enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
         launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, cfg_.tol_tie, d_rec_, stream_);
@@ -631,10 +652,8 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     // there so that an early end does not leave a long tail of no-op launches queued.
     if (tableau_) {
         // (re)entering the loop: rebuild the PRICE partials from d (afterwards every pivot leaves them behind)
-        SelectPartials sp;
-        sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
-        sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
-        launch_tab_scan(tview(), sp, d_rec_, stream_);
+        launch_tab_scan(tview(), tab_partials(rule), d_rec_, stream_);
+        tab_partials_valid_ = true;
     }
     int64_t next_poll = phase_ == 1 ? 1 : cfg_.poll_interval;
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
@@ -702,7 +721,7 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
         if ((st = relative_costs(d.data()))) return st;
         // tableau row pivot_row over every column: (row of B^-1) . a_j, no cost term
         if (tableau_) {
-            launch_tab_row(tview(), deferred(), pivot_row, d_aq_big(), d_rec_, stream_);
+            launch_tab_row(tview(), deferred(), pivot_row, d_aq_big(), d_rec_, stream_);        // single GPU: all columns
             HIP_TRY(hipMemcpyAsync(tau.data(), d_aq_big(), sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
         } else {
             double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -751,6 +770,7 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
         for (int32_t p = 0; p < nr_normal_; ++p) cost_store_h_[tab_na_ + p] = cost_h_[p];
         HIP_TRY(hipMemcpy(d_cost_store_, cost_store_h_.data(), sizeof(double) * n_store_, hipMemcpyHostToDevice));
         launch_tab_price_init(tview(), d_w_, d_cost_store_, stream_);
+        tab_partials_valid_ = false;
     } else {
         double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
         launch_weighted_column_sums(Binv, ld_b_, m_, d_w_, d_minus_pi_, stream_);
@@ -905,6 +925,7 @@ relp_status_t Engine::get_objective(double* out) {
 
 relp_status_t Engine::get_vector(int which, double* out) {
     if (tableau_ && which == 1) {
+        if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "-pi of the sharded tableau: d is column-sharded");
         // -pi_k = d_j - c_j for the stored column j that was e_k originally
         std::vector<double> d(n_store_);
         HIP_TRY(hipMemcpyAsync(d.data(), d_d_, sizeof(double) * n_store_, hipMemcpyDeviceToHost, stream_));
@@ -1009,8 +1030,46 @@ void Engine::shard_ranges(int32_t* col_lo, int32_t* col_hi, int32_t* row_lo, int
     if (stride) *stride = row_stride_;
 }
 
+// Tableau engine, one pivot after the candidates were exchanged: ratio test (replicated), row update
+// of the owned columns, W / b / basis update (replicated); the flush is local to the owned columns.
+relp_status_t Engine::shard_pivot() {
+    if (!tableau_) return fail(RELP_E_STATE, "relp_shard_pivot is the tableau engine's step");
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    const TableauView tv = tview();
+    const DeferredUpdate du = deferred();
+    const SelectPartials sp = tab_partials(rule);
+    prof_begin(RELP_K_RATIO);
+    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_PRICE);
+    launch_tab_row_update(tv, du, sp, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_W);
+    launch_tab_update_w_vectors(du, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+    prof_end();
+    tab_partials_valid_ = true;
+    if (++since_flush_ >= block_) enqueue_flush();
+    ++prof_tick_;
+    return RELP_OK;
+}
+
 relp_status_t Engine::shard_price(double* dev_candidate) {
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    if (tableau_) {
+        // local PRICE result = the partial argmin the last row update left behind (or a scan of d);
+        // the candidate message carries the tableau column alpha itself
+        const TableauView tv = tview();
+        const SelectPartials sp = tab_partials(rule);
+        if (!tab_partials_valid_) { launch_tab_scan(tv, sp, d_rec_, stream_); tab_partials_valid_ = true; }
+        prof_begin(RELP_K_SELECT_COLUMN);
+        launch_tab_select(tv, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_rec_, stream_);
+        prof_end();
+        prof_begin(RELP_K_FTRAN);
+        launch_tab_column(tv, deferred(), d_aq_, d_rec_, stream_);
+        launch_pack_candidate(d_aq_, m_, dev_candidate, d_rec_, stream_);
+        prof_end();
+        return RELP_OK;
+    }
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     prof_begin(RELP_K_PRICE);
     enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
@@ -1027,7 +1086,9 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
 
 relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t count) {
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
-    launch_select_candidate(dev_candidates, count, cand_len_, m_, d_aq_, rule, cfg_.tol_tie, d_rec_, stream_);
+    // tableau engine: the winner's payload is the entering tableau column (alpha) itself
+    launch_select_candidate(dev_candidates, count, cand_len_, m_, tableau_ ? d_alpha_ : d_aq_, rule, cfg_.tol_tie, d_rec_,
+                            stream_);
     return RELP_OK;
 }
 

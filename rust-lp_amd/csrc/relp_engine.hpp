@@ -73,6 +73,7 @@ class Engine {
     relp_status_t shard_ftran(double* dev_alpha_slice);
     relp_status_t shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho);
     relp_status_t shard_update(const double* dev_rho);
+    relp_status_t shard_pivot();
     relp_status_t poll(int32_t* outcome, int64_t* iterations);
 
     const char* last_error() const { return err_.c_str(); }
@@ -123,10 +124,13 @@ class Engine {
     int32_t* d_idcol_ = nullptr;         // stored column that was e_k originally, per row k
     int32_t n_store_ = 0;                // stored columns = original artificials + provider columns
     int32_t tab_na_ = 0;                 // original number of artificial columns (their block is kept)
+    int32_t sc_lo_ = 0, sc_hi_ = 0;      // storage columns owned by this rank (sharded tableau)
+    bool tab_partials_valid_ = false;    // the PRICE partials describe the current d
     std::vector<int32_t> idcol_h_;
     std::vector<double> cost_store_h_;
     TableauView tview() const;
-    double* d_aq_big() { return dR0_ + (int64_t)block_ * ld_r_; }         // n_store scratch row behind R0
+    double* d_aq_big() { return dR0_ + (int64_t)block_ * ld_r_; }         // scratch row behind R0 (owned columns)
+    SelectPartials tab_partials(int rule) const;
     void enqueue_iteration_tableau(int rule);
     relp_status_t tableau_reprice();
     DeferredUpdate deferred() const;

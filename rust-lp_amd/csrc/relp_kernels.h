@@ -171,6 +171,8 @@ struct TableauView {
     int32_t  n_store; // stored columns (artificial block + provider columns)
     int32_t  col_off; // first storage column of the current phase's tableau
     int32_t  n;       // tableau columns of the current phase
+    int32_t  c_lo, c_hi;  // storage columns owned by this rank (T0, R0 hold only these; pointers are
+                          // pre-shifted so that kernels index by global storage column)
 };
 // T0 := original matrix in row space (artificial unit columns | A + bound rows | virtual unit columns)
 void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s);
@@ -178,7 +180,7 @@ void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, cons
 void launch_tab_price_init(const TableauView& tv, const double* w, const double* cost_store, hipStream_t s);
 // partial argmin over d (one slot per 256 columns) -- used when the loop is (re)entered
 void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s);
-int32_t tab_scan_blocks(int32_t n_store);
+int32_t tab_scan_blocks(int32_t n_owned_columns);
 // entering column from the partials (no column build: the tableau column is read directly)
 void launch_tab_select(const TableauView& tv, SelectPartials sp, int32_t count, PivotRecord* rec, hipStream_t s);
 // alpha = T[:,q] = T0[:,q] + W R0[:,q]

@@ -761,9 +761,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ void k_tab_build(TableauView tv, const double* __restrict__ A, int64_t ld_a, ColumnTable ct) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)tv.m * tv.n_store;
+    const int64_t total = (int64_t)tv.m * (tv.c_hi - tv.c_lo);
     if (idx >= total) return;
-    const int c = (int)(idx / tv.m), i = (int)(idx % tv.m);
+    const int c = tv.c_lo + (int)(idx / tv.m), i = (int)(idx % tv.m);
     double v = 0.0;
     if (c < ct.nr_artificial) {
         v = (i == ct.column_to_row[c]) ? 1.0 : 0.0;
@@ -785,11 +785,11 @@ __global__ void k_tab_build(TableauView tv, const double* __restrict__ A, int64_
 __global__ __launch_bounds__(kThreads) void k_tab_price_init(TableauView tv, const double* __restrict__ w,
                                                              const double* __restrict__ cost_store) {
     __shared__ double s_partial[4 * kVecPerBlock];
-    const int v0 = blockIdx.x * kVecPerBlock;
+    const int v0 = tv.c_lo + blockIdx.x * kVecPerBlock;
     double dot = 0.0;
-    block_multi_dot(tv.T0, tv.ld_t, tv.m, v0, tv.n_store, w, s_partial, dot);
+    block_multi_dot(tv.T0, tv.ld_t, tv.m, v0, tv.c_hi, w, s_partial, dot);
     const int c = v0 + threadIdx.x;
-    if (threadIdx.x < kVecPerBlock && c < tv.n_store) tv.d[c] = cost_store[c] - dot;
+    if (threadIdx.x < kVecPerBlock && c < tv.c_hi) tv.d[c] = cost_store[c] - dot;
 }
 
 // Workgroup-level (key, j) minimum of one candidate per thread -> partial slot `slot`.
@@ -816,11 +816,11 @@ __device__ __forceinline__ void block_partial_min(double key, int kj, SelectPart
 // one slot per 256 storage columns
 __global__ __launch_bounds__(kThreads) void k_tab_scan(TableauView tv, SelectPartials sp, const PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
-    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const int c = tv.c_lo + blockIdx.x * kThreads + threadIdx.x;
     const int j = c - tv.col_off;
     double key = INFINITY;
     int kj = 0x7fffffff;
-    if (c < tv.n_store && j >= 0 && j < tv.n) {
+    if (c < tv.c_hi && j >= 0 && j < tv.n) {
         const double v = tv.d[c];
         if (!sp.in_basis[j] && v < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, v); kj = j; }
     }
@@ -868,9 +868,9 @@ __global__ __launch_bounds__(kSingleBlock) void k_tab_select(TableauView tv, Sel
         const int grp = threadIdx.x >> 8, u = threadIdx.x & 255;
         for (int t = grp; t < count; t += kSingleBlock / kThreads) {
             if (!(sp.k1[t] <= bound)) continue;
-            const int c = t * kThreads + u;
+            const int c = tv.c_lo + t * kThreads + u;
             const int j = c - tv.col_off;
-            if (c < tv.n_store && j >= 0 && j < tv.n) {
+            if (c < tv.c_hi && j >= 0 && j < tv.n) {
                 const double v = tv.d[c];
                 if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
             }
@@ -923,10 +923,10 @@ __global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, Def
     const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r, q = rec->q, leaving = rec->leaving;
     if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
     __syncthreads();
-    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const int c = tv.c_lo + blockIdx.x * kThreads + threadIdx.x;
     double key = INFINITY;
     int kj = 0x7fffffff;
-    if (c < tv.n_store) {
+    if (c < tv.c_hi) {
         double base;
         if (jt < p_old) base = tv.R0[(int64_t)jt * tv.ld_r + c];
         else { base = tv.T0[(int64_t)c * tv.ld_t + r]; tv.R0[(int64_t)jt * tv.ld_r + c] = base; }
@@ -1037,9 +1037,9 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
     const int p = rec->n_eta;
     if (p == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c_wave = blockIdx.x * (2 * 16 * MT) + (wave & 1) * (16 * MT);     // first T0 column of this wavefront
-    const int i_wave = blockIdx.y * (2 * 16 * NT) + (wave >> 1) * (16 * NT);    // first T0 row
-    if (c_wave >= tv.n_store || i_wave >= tv.m) return;
+    const int c_wave = tv.c_lo + blockIdx.x * (2 * 16 * MT) + (wave & 1) * (16 * MT);   // first T0 column of this wavefront
+    const int i_wave = blockIdx.y * (2 * 16 * NT) + (wave >> 1) * (16 * NT);            // first T0 row
+    if (c_wave >= tv.c_hi || i_wave >= tv.m) return;
     const int lm = lane & 15, lk = lane >> 4;
     // the accumulators start as the T0 tile itself: all of its loads are in flight before the first MFMA
     double4_t acc[kFlushMT][kFlushNT];
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
             for (int g = 0; g < 4; ++g) {
                 const int c = c_wave + a * 16 + lk + 4 * g;
                 const int i = i_wave + b * 16 + lm;
-                acc[a][b][g] = (c < tv.n_store && i < tv.m) ? tv.T0[(int64_t)c * tv.ld_t + i] : 0.0;
+                acc[a][b][g] = (c < tv.c_hi && i < tv.m) ? tv.T0[(int64_t)c * tv.ld_t + i] : 0.0;
             }
     for (int k0 = 0; k0 < p; k0 += 4) {
         const int k = k0 + lk;
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
 #pragma unroll
         for (int a = 0; a < kFlushMT; ++a) {
             const int c = c_wave + a * 16 + lm;
-            af[a] = (kv && c < tv.n_store) ? tv.R0[(int64_t)k * tv.ld_r + c] : 0.0;
+            af[a] = (kv && c < tv.c_hi) ? tv.R0[(int64_t)k * tv.ld_r + c] : 0.0;
         }
 #pragma unroll
         for (int b = 0; b < kFlushNT; ++b) {
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
             for (int g = 0; g < 4; ++g) {
                 const int c = c_wave + a * 16 + lk + 4 * g;
                 const int i = i_wave + b * 16 + lm;
-                if (c < tv.n_store && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
             }
 }
 
@@ -1099,11 +1099,11 @@ __global__ __launch_bounds__(kThreads) void k_tab_row(TableauView tv, DeferredUp
     const int p = rec->n_eta;
     if ((int)threadIdx.x < p) s_w[threadIdx.x] = du.W[(int64_t)threadIdx.x * du.ld + row];
     __syncthreads();
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= tv.n_store) return;
+    const int c = tv.c_lo + blockIdx.x * kThreads + threadIdx.x;
+    if (c >= tv.c_hi) return;
     double v = tv.T0[(int64_t)c * tv.ld_t + row];
     for (int j = 0; j < p; ++j) v = fma(s_w[j], tv.R0[(int64_t)j * tv.ld_r + c], v);
-    out[c] = v;
+    out[c - tv.c_lo] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1387,19 +1387,23 @@ void launch_flush_reset(const DeferredUpdate& du, PivotRecord* rec, hipStream_t 
 }
 
 
-int32_t tab_scan_blocks(int32_t n_store) { return cdiv(n_store, kThreads); }
+int32_t tab_scan_blocks(int32_t n_owned_columns) { return cdiv(n_owned_columns, kThreads); }
 
 void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s) {
-    const int64_t total = (int64_t)tv.m * tv.n_store;
+    const int64_t total = (int64_t)tv.m * (tv.c_hi - tv.c_lo);
+    if (total <= 0) return;
     hipLaunchKernelGGL(k_tab_build, dim3(cdiv(total, 256)), dim3(256), 0, s, tv, A, ld_a, ct);
 }
 
 void launch_tab_price_init(const TableauView& tv, const double* w, const double* cost_store, hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_price_init, dim3(cdiv(tv.n_store, kVecPerBlock)), dim3(kThreads), 0, s, tv, w, cost_store);
+    if (tv.c_hi <= tv.c_lo) return;
+    hipLaunchKernelGGL(k_tab_price_init, dim3(cdiv(tv.c_hi - tv.c_lo, kVecPerBlock)), dim3(kThreads), 0, s, tv, w,
+                       cost_store);
 }
 
 void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_scan, dim3(tab_scan_blocks(tv.n_store)), dim3(kThreads), 0, s, tv, sp, rec);
+    if (tv.c_hi <= tv.c_lo) return;
+    hipLaunchKernelGGL(k_tab_scan, dim3(tab_scan_blocks(tv.c_hi - tv.c_lo)), dim3(kThreads), 0, s, tv, sp, rec);
 }
 
 void launch_tab_select(const TableauView& tv, SelectPartials sp, int32_t count, PivotRecord* rec, hipStream_t s) {
@@ -1413,7 +1417,9 @@ void launch_tab_column(const TableauView& tv, const DeferredUpdate& du, double* 
 
 void launch_tab_row_update(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, PivotRecord* rec,
                            hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_row_update, dim3(tab_scan_blocks(tv.n_store)), dim3(kThreads), 0, s, tv, du, sp, rec);
+    if (tv.c_hi <= tv.c_lo) return;
+    hipLaunchKernelGGL(k_tab_row_update, dim3(tab_scan_blocks(tv.c_hi - tv.c_lo)), dim3(kThreads), 0, s, tv, du, sp,
+                       rec);
 }
 
 void launch_tab_update_vectors(int32_t m, const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis,
@@ -1431,7 +1437,8 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 
 void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
     constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
-    dim3 grid(cdiv(tv.n_store, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
+    if (tv.c_hi <= tv.c_lo) return;
+    dim3 grid(cdiv(tv.c_hi - tv.c_lo, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
     hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, rec);
 }
 
@@ -1442,7 +1449,8 @@ void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, doubl
 
 void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row, double* out, const PivotRecord* rec,
                     hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_row, dim3(tab_scan_blocks(tv.n_store)), dim3(kThreads), 0, s, tv, du, row, out, rec);
+    if (tv.c_hi <= tv.c_lo) return;
+    hipLaunchKernelGGL(k_tab_row, dim3(tab_scan_blocks(tv.c_hi - tv.c_lo)), dim3(kThreads), 0, s, tv, du, row, out, rec);
 }
 
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {

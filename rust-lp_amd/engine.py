@@ -113,6 +113,8 @@ _SIGNATURES = {
     "relp_shard_ratio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "relp_shard_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "relp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "relp_shard_pivot": (C.c_int, [C.c_void_p]),
+    "relp_shard_plan": (C.c_int, [C.POINTER(_MatrixData), C.POINTER(Config), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -147,6 +149,20 @@ def default_config(**overrides) -> Config:
 def shard_column_range(nr_normal: int, rank: int, count: int) -> Tuple[int, int]:
     lo, hi = C.c_int32(), C.c_int32()
     load_library().relp_shard_column_range(nr_normal, rank, count, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def shard_plan(provider: MatrixData, config: Config) -> Tuple[int, int]:
+    """Structural columns [lo, hi) the rank ``config.shard_rank`` must supply (relp_shard_plan)."""
+    md = _MatrixData()
+    md.nr_normal, md.nr_eq, md.nr_range = provider.nr_normal, provider.nr_eq, provider.nr_range
+    md.nr_le, md.nr_ge = provider.nr_le, provider.nr_ge
+    ub = np.ascontiguousarray(provider.upper_bound, dtype=np.float64)
+    md.upper_bound = ub.ctypes.data
+    lo, hi = C.c_int32(), C.c_int32()
+    st = load_library().relp_shard_plan(C.byref(md), C.byref(config), C.byref(lo), C.byref(hi))
+    if st != 0:
+        raise RelpError(f"relp_shard_plan failed ({st})")
     return lo.value, hi.value
 
 

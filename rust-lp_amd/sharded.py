@@ -35,6 +35,7 @@ class HipShardOps:
         self.candidate_len = self.lib.relp_shard_candidate_len(self.h)
         self.rho_len = self.lib.relp_shard_rho_len(self.h)
         self.update_block = self.lib.relp_update_block(self.h)
+        self.tableau = int(tableau.config.engine) == _engine.ENGINE_TABLEAU
 
     def _ck(self, st):
         if st != 0:
@@ -57,6 +58,10 @@ class HipShardOps:
 
     def update(self, rho):
         self._ck(self.lib.relp_shard_update(self.h, rho.data_ptr()))
+
+    def pivot(self):
+        """Tableau engine: everything after the candidate exchange (no further collective)."""
+        self._ck(self.lib.relp_shard_pivot(self.h))
 
     def poll(self) -> Tuple[int, int]:
         oc, it = C.c_int32(), C.c_int64()
@@ -112,6 +117,11 @@ class ShardedPivotLoop:
         o.price(self.cand)
         d.all_gather_into_tensor(self.cands, self.cand)
         o.select_column(self.cands, self.world)
+        if getattr(o, "tableau", False):
+            # dense tableau: the candidate message already carried the entering tableau column; the
+            # rest of the pivot (and the flush) is local -- ONE collective per pivot
+            o.pivot()
+            return
         o.ftran(self.slice)
         d.all_gather_into_tensor(self.slices, self.slice)
         o.ratio(self.slices, self.world, self.rho)

@@ -232,12 +232,14 @@ def test_dense_2000_properties():
         assert np.max(np.abs(e)) <= 1e-8
 
 
-@pytest.mark.parametrize("block", [0, 4])
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 4), (engine.ENGINE_TABLEAU, 4),
+                                        (engine.ENGINE_TABLEAU, 64)])
 @pytest.mark.parametrize("world,m,n,seed", [(2, 48, 64, 17), (3, 61, 45, 23)])
-def test_shard_entry_points_on_one_gpu(world, m, n, seed, block):
+def test_shard_entry_points_on_one_gpu(world, m, n, seed, kind, block):
     """`relp_shard_*` with G engines in one process on one GPU: the exchange steps (all-gather of
-    candidates, all-gather of alpha slices, SUM all-reduce of rho) are done with torch ops on a
-    shared stream.  Every shard must walk the single-engine pivot sequence."""
+    candidates; for the revised engine also the all-gather of alpha slices and the SUM all-reduce of
+    rho) are done with torch ops on a shared stream.  Every shard must walk the single-engine pivot
+    sequence."""
     import torch
     from rust_lp_amd.sharded import HipShardOps
     lp = synthetic.dense_lp(m, n, seed)
@@ -247,14 +249,19 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, block):
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
     tabs, ops = [], []
+    covered = []
     for r in range(world):
-        lo, hi = engine.shard_column_range(n, r, world)
-        md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=lp["b"], cost=lp["c"],
-                        upper_bound=np.full(n, np.inf), dense=np.asfortranarray(lp["A"][:, lo:hi]))
-        t = engine.Tableau(md, trace_capacity=4096, shard_rank=r, shard_count=world, update_block=block)
+        counts = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=lp["b"], cost=lp["c"],
+                            upper_bound=np.full(n, np.inf))
+        cfg = engine.default_config(shard_rank=r, shard_count=world, engine=kind, update_block=block, trace_capacity=4096)
+        lo, hi = engine.shard_plan(counts, cfg)
+        covered.append((lo, hi))
+        counts.dense = np.asfortranarray(lp["A"][:, lo:hi]) if hi > lo else np.zeros((m, 1), order="F")
+        t = engine.Tableau(counts, config=cfg)
         t.set_stream(stream)
         tabs.append(t)
         ops.append(HipShardOps(t))
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
     L, S, RL = ops[0].candidate_len, ops[0].row_stride, ops[0].rho_len
     cands = torch.zeros(world * L, dtype=torch.float64, device=dev)
     slices = torch.zeros(world * S, dtype=torch.float64, device=dev)
@@ -265,6 +272,10 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, block):
             o.price(cands[r * L:(r + 1) * L])
         for o in ops:
             o.select_column(cands, world)
+        if kind == engine.ENGINE_TABLEAU:
+            for o in ops:
+                o.pivot()                          # one collective per pivot: nothing else to exchange
+            return
         for r, o in enumerate(ops):
             o.ftran(slices[r * S:(r + 1) * S])
         for r, o in enumerate(ops):
@@ -274,6 +285,8 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, block):
             o.update(rho)
 
     def flush():
+        if kind == engine.ENGINE_TABLEAU:
+            return                                 # the tableau flush is local and done inside relp_shard_pivot
         snaps = [o.flush_begin(torch, dev) for o in ops]
         if snaps[0] is None:
             return

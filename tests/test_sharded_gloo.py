@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, m, n, seed, q):
+def _worker(rank, world, port, m, n, seed, q, tableau=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -22,11 +22,14 @@ def _worker(rank, world, port, m, n, seed, q):
     import rust_lp_amd  # noqa: F401
     from rust_lp_amd import synthetic
     from rust_lp_amd.sharded import ShardedPivotLoop
-    from shard_standin import NumpyShardOps
+    from shard_standin import NumpyShardOps, NumpyTableauShardOps
     lp = synthetic.dense_lp(m, n, seed)
     per = -(-n // world)
     lo, hi = min(n, rank * per), min(n, rank * per + per)
-    ops = NumpyShardOps(rank, world, m, n, lp["A"][:, lo:hi], lo, lp["b"], lp["c"])
+    if tableau:
+        ops = NumpyTableauShardOps(rank, world, m, n, lp["A"], lp["b"], lp["c"])
+    else:
+        ops = NumpyShardOps(rank, world, m, n, lp["A"][:, lo:hi], lo, lp["b"], lp["c"])
     loop = ShardedPivotLoop(ops, dist, torch.device("cpu"), poll_interval=7)
     oc1 = loop.finish_phase_one()
     done, oc = loop.run(1 << 20)
@@ -35,8 +38,9 @@ def _worker(rank, world, port, m, n, seed, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("tableau", [False, True])
 @pytest.mark.parametrize("world,m,n,seed", [(2, 24, 36, 5), (2, 33, 20, 8), (3, 40, 50, 2)])
-def test_sharded_loop_matches_oracle(world, m, n, seed):
+def test_sharded_loop_matches_oracle(world, m, n, seed, tableau):
     sys.path.insert(0, ROOT)
     import rust_lp_amd  # noqa: F401
     from rust_lp_amd import MatrixData, synthetic
@@ -46,8 +50,8 @@ def test_sharded_loop_matches_oracle(world, m, n, seed):
     assert ref.run() == "optimal"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, seed, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + world + (10 if tableau else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, seed, q, tableau)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
