@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def per_kernel(path, value_col=None):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"].split("(")[0].replace("relp::", "")
+        name = row["Kernel_Name"].split("(")[0].replace("relp::", "").replace("void ", "").split("<")[0]
         dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         val = float(row[value_col]) if value_col else 0.0
         agg[name].append((dur, val))
@@ -60,8 +60,15 @@ def main():
         f = fetch.get(name, {}).get("value", 0.0)
         w = write.get(name, {}).get("value", 0.0)
         hbm = (2.0 * f + w) * 1024.0
+        note = ""
+        if name in ("k_tab_flush", "k_flush_apply"):
+            # 8-byte-per-lane loads: the x2 FETCH_SIZE correction is calibrated for 16-byte-per-lane streams only
+            # (MI355X_MICROARCH.md section HBM: other widths uncalibrated); the raw figure already matches the bytes
+            # of the matrix, so raw FETCH_SIZE + WRITE_SIZE is reported for these kernels
+            hbm = (f + w) * 1024.0
+            note = " (raw FETCH_SIZE, 8-byte loads)"
         traffic[name[2:]] = hbm
-        lines.append(f"| {name} | {t['launches']} ({t['effective']}) | {t['avg_us']:.1f} | {f:.1f} | {w:.1f} | {hbm / 1e6:.1f} |")
+        lines.append(f"| {name} | {t['launches']} ({t['effective']}) | {t['avg_us']:.1f} | {f:.1f} | {w:.1f} | {hbm / 1e6:.1f}{note} |")
     open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
