@@ -370,3 +370,29 @@ def test_nazareth_is_unbounded_on_gpu():
     from lp_files import load
     gf, ex, md, emd = load("burkardt/nazareth.mps")
     assert engine.Tableau(md).solve_relaxation() == engine.UNBOUNDED           # tests/burkardt/test.rs:149-157
+
+
+def test_c2_full_solve_both_engines_agree_to_optimality():
+    """Config C2 (2,000 x 2,000) solved to optimality (~5,900 pivots) by both engines: identical pivot
+    sequences over the whole solve, and the final basis checked against a numpy solve:
+    B x_B = rhs, x_B >= 0, basic reduced costs vanish, no negative reduced cost is left."""
+    m = n = 2000
+    md = dense_problem(m, n, 20250001)
+    traces, objs = [], []
+    for kind in (engine.ENGINE_TABLEAU, engine.ENGINE_REVISED):
+        t = engine.Tableau(md, engine=kind, trace_capacity=1 << 16)
+        assert t.solve_relaxation() == engine.OPTIMAL
+        basis, b, d = t.basis_indices(), t.b(), t.relative_costs()
+        a = np.hstack([md.dense, np.eye(m)])
+        x_b = np.linalg.solve(a[:, basis], md.b)
+        assert np.max(np.abs(x_b - b)) <= 1e-7 * max(1.0, np.max(np.abs(x_b)))
+        assert b.min() >= -1e-9
+        nonbasic = np.ones(len(d), dtype=bool)
+        nonbasic[basis] = False
+        assert d[nonbasic].min() >= -1e-9 and np.max(np.abs(d[basis])) <= 1e-9
+        c = np.concatenate([md.cost, np.zeros(m)])
+        assert abs(t.objective_function_value() - c[basis] @ x_b) <= 1e-9 * abs(c[basis] @ x_b)
+        traces.append(t.trace())
+        objs.append(t.objective_function_value())
+    assert traces[0] == traces[1] and len(traces[0]) > 1000
+    assert abs(objs[0] - objs[1]) <= 1e-11 * abs(objs[0])
