@@ -415,20 +415,16 @@ void Engine::enqueue_iteration_tableau(int rule) {
     const TableauView tv = tview();
     const DeferredUpdate du = deferred();
     const SelectPartials sp = tab_partials(rule);
-    prof_begin(RELP_K_SELECT_COLUMN);
-    launch_tab_select(tv, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_rec_, stream_);
-    prof_end();
+    // 3 launches: [PRICE's final reduction + tableau column] -> [ratio test + block bookkeeping] ->
+    // [tableau row / reduced costs / next PRICE partials  ||  W, b, basis]
     prof_begin(RELP_K_FTRAN);
-    launch_tab_column(tv, du, d_alpha_, d_rec_, stream_);
+    launch_tab_select_column(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_RATIO);
     launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_PRICE);
-    launch_tab_row_update(tv, du, sp, d_rec_, stream_);
-    prof_end();
-    prof_begin(RELP_K_UPDATE_W);
-    launch_tab_update_w_vectors(du, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+    launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
     if (++since_flush_ >= block_) enqueue_flush();
 }

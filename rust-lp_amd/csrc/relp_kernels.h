@@ -196,6 +196,13 @@ void launch_tab_update_vectors(int32_t m, const double* alpha, double* b, int32_
 void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const double* alpha, double* b,
                                  int32_t* basis_indices, uint8_t* in_basis, int32_t* trace, int64_t trace_cap,
                                  PivotRecord* rec, hipStream_t s);
+// launch_tab_select + launch_tab_column in one launch (every workgroup reduces the partials itself)
+void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
+                              double* alpha, PivotRecord* rec, hipStream_t s);
+// launch_tab_row_update + launch_tab_update_w_vectors in one launch (disjoint workgroup ranges)
+void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
+                           const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,
+                           int64_t trace_cap, PivotRecord* rec, hipStream_t s);
 // flush: T0 += W R0 with v_mfma_f64_16x16x4_f64 tiles
 void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s);
 // out[i, k] = T0[i, cols[k]] (row-major m x m): B^-1 from the identity columns

@@ -916,14 +916,14 @@ __global__ __launch_bounds__(kThreads) void k_tab_column(TableauView tv, Deferre
 
 // Row r of T before the pivot, the reduced-cost update and the next PRICE's partial argmin in one
 // pass over the stored columns.  When row r is new in the block its T0 row is appended to R0 here.
-__global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, DeferredUpdate du, SelectPartials sp,
-                                                             PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
+// `block` = index of this workgroup among the row-update workgroups.
+__device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const DeferredUpdate& du,
+                                                    const SelectPartials& sp, const PivotRecord* rec, int block) {
     __shared__ double s_wr[kMaxEta];
     const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r, q = rec->q, leaving = rec->leaving;
     if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
     __syncthreads();
-    const int c = tv.c_lo + blockIdx.x * kThreads + threadIdx.x;
+    const int c = tv.c_lo + block * kThreads + threadIdx.x;
     double key = INFINITY;
     int kj = 0x7fffffff;
     if (c < tv.c_hi) {
@@ -938,27 +938,30 @@ __global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, Def
         if (j == q) dn = 0.0;
         tv.d[c] = dn;
         if (j >= 0 && j < tv.n) {
-            const bool basic = (j == q) || (sp.in_basis[j] && j != leaving);   // flags are still the old ones
+            // correct for old AND new flags (the flags may be flipped concurrently by the W/vector part)
+            const bool basic = (j == q) || (sp.in_basis[j] && j != leaving);
             if (!basic && dn < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, dn); kj = j; }
         }
     }
-    block_partial_min(key, kj, sp, blockIdx.x);
+    block_partial_min(key, kj, sp, block);
 }
 
-// W <- E W  and  b, -obj, basis, flags, trace in one launch (both walk the m rows)
-__global__ __launch_bounds__(kThreads) void k_tab_update_w_vectors(DeferredUpdate du, int m,
-                                                                   const double* __restrict__ alpha,
-                                                                   double* __restrict__ b,
-                                                                   int32_t* __restrict__ basis_indices,
-                                                                   uint8_t* __restrict__ in_basis,
-                                                                   int32_t* __restrict__ trace, int64_t trace_cap,
-                                                                   PivotRecord* rec) {
+__global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, DeferredUpdate du, SelectPartials sp,
+                                                             PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
-    __shared__ double s_wr[kMaxEta];
+    tab_row_update_body(tv, du, sp, rec, blockIdx.x);
+}
+
+// W <- E W  and  b, -obj, basis, flags, trace (both walk the m rows)
+__device__ __forceinline__ void tab_update_w_vectors_body(const DeferredUpdate& du, int m, const double* __restrict__ alpha,
+                                                          double* __restrict__ b, int32_t* __restrict__ basis_indices,
+                                                          uint8_t* __restrict__ in_basis, int32_t* __restrict__ trace,
+                                                          int64_t trace_cap, PivotRecord* rec, int block) {
+    __shared__ double s_wr2[kMaxEta];
     const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r;
-    if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
+    if ((int)threadIdx.x < p_old) s_wr2[threadIdx.x] = du.wr[threadIdx.x];
     __syncthreads();
-    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int i = block * kThreads + threadIdx.x;
     const double ar = rec->alpha_r;
     const double br = rec->b_r / ar;
     if (i < m) {
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_w_vectors(DeferredUpdat
         const double u = (i == r) ? (1.0 / ar - 1.0) : (-a / ar);
         if (u != 0.0) {
             for (int j = 0; j < p_old; ++j) {
-                const double w = s_wr[j];
+                const double w = s_wr2[j];
                 if (w != 0.0) du.W[(int64_t)j * du.ld + i] = fma(u, w, du.W[(int64_t)j * du.ld + i]);
             }
         }
@@ -990,6 +993,103 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_w_vectors(DeferredUpdat
         }
         rec->iterations = it + 1;
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_tab_update_w_vectors(DeferredUpdate du, int m,
+                                                                   const double* __restrict__ alpha,
+                                                                   double* __restrict__ b,
+                                                                   int32_t* __restrict__ basis_indices,
+                                                                   uint8_t* __restrict__ in_basis,
+                                                                   int32_t* __restrict__ trace, int64_t trace_cap,
+                                                                   PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, rec, blockIdx.x);
+}
+
+// Both halves of the update in ONE launch: workgroups [0, nb_row) update the tableau row / reduced
+// costs / PRICE partials of their columns, workgroups [nb_row, ..) update W, b and the bookkeeping.
+// The halves touch disjoint data; the basis flags flipped by the second half are read by the first
+// through an expression that is the same for the old and the new flags.
+__global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, DeferredUpdate du, SelectPartials sp,
+                                                             int nb_row, int m, const double* __restrict__ alpha,
+                                                             double* __restrict__ b, int32_t* __restrict__ basis_indices,
+                                                             uint8_t* __restrict__ in_basis, int32_t* __restrict__ trace,
+                                                             int64_t trace_cap, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    if ((int)blockIdx.x < nb_row) tab_row_update_body(tv, du, sp, rec, blockIdx.x);
+    else tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, rec, blockIdx.x - nb_row);
+}
+
+// PRICE's final reduction and the tableau column in one launch: every workgroup reduces the (few)
+// partials to the same entering column q, then forms alpha = T0[:,q] + W R0[:,q] for its rows.
+__global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, DeferredUpdate du, SelectPartials sp,
+                                                                int count, double* __restrict__ alpha, PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_k1[kThreads / 64];
+    __shared__ int s_j[kThreads / 64];
+    __shared__ double s_vs[kMaxEta];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double k1 = INFINITY;
+    int bj = 0x7fffffff;
+    for (int t = threadIdx.x; t < count; t += kThreads) {
+        const double key = sp.k1[t];
+        const int j = sp.j[t];
+        if (key < k1 || (key == k1 && j < bj)) { k1 = key; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(k1, off, 64);
+        const int oj = __shfl_down(bj, off, 64);
+        if (ok < k1 || (ok == k1 && oj < bj)) { k1 = ok; bj = oj; }
+    }
+    if (lane == 0) { s_k1[wave] = k1; s_j[wave] = bj; }
+    __syncthreads();
+    k1 = s_k1[0]; bj = s_j[0];
+    for (int w = 1; w < kThreads / 64; ++w)
+        if (s_k1[w] < k1 || (s_k1[w] == k1 && s_j[w] < bj)) { k1 = s_k1[w]; bj = s_j[w]; }
+    __syncthreads();
+    if (bj != 0x7fffffff && sp.rule == 2 && sp.tol_tie > 0.0) {
+        // Dantzig tie band (see k_tab_select): slots inside the band are re-read, one column per thread
+        const double bound = k1 + sp.tol_tie * fmax(1.0, fabs(k1));
+        int lowest = 0x7fffffff;
+        for (int t = 0; t < count; ++t) {
+            if (!(sp.k1[t] <= bound)) continue;
+            const int c = tv.c_lo + t * kThreads + threadIdx.x;
+            const int j = c - tv.col_off;
+            if (c < tv.c_hi && j >= 0 && j < tv.n) {
+                const double v = tv.d[c];
+                if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
+        if (lane == 0) s_j[wave] = lowest;
+        __syncthreads();
+        bj = s_j[0];
+        for (int w = 1; w < kThreads / 64; ++w) bj = min(bj, s_j[w]);
+    }
+    if (bj == 0x7fffffff) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (sp.rule == 1) rec->last_selected = -1;
+        }
+        return;
+    }
+    const int cq = bj + tv.col_off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        rec->q = bj;
+        rec->d_q = tv.d[cq];
+        rec->key1 = k1;
+        if (sp.rule == 1) rec->last_selected = bj;
+    }
+    const int p = rec->n_eta;
+    if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
+    __syncthreads();
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= tv.m) return;
+    double a = tv.T0[(int64_t)cq * tv.ld_t + i];
+    for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
+    alpha[i] = a;
 }
 
 __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, double* __restrict__ b,
@@ -1432,6 +1532,21 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
                                  int32_t* basis_indices, uint8_t* in_basis, int32_t* trace, int64_t trace_cap,
                                  PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_update_w_vectors, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, alpha, b,
+                       basis_indices, in_basis, trace, trace_cap, rec);
+}
+
+void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
+                              double* alpha, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
+                       rec);
+}
+
+void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
+                           const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,
+                           int64_t trace_cap, PivotRecord* rec, hipStream_t s) {
+    const int nb_row = tv.c_hi > tv.c_lo ? tab_scan_blocks(tv.c_hi - tv.c_lo) : 0;
+    const int nb_w = cdiv(m, kThreads);
+    hipLaunchKernelGGL(k_tab_update_all, dim3(nb_row + nb_w), dim3(kThreads), 0, s, tv, du, sp, nb_row, m, alpha, b,
                        basis_indices, in_basis, trace, trace_cap, rec);
 }
 
