@@ -414,15 +414,34 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     __shared__ double s_bcast;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    // both operands are loaded unconditionally so that the loads of several rows overlap
+    // Each thread keeps its rows' ratios and leaving columns in registers (all loads issued at once, one
+    // memory round trip); both passes then run out of registers.  m > 16 * 1024 falls back to re-reading.
+    constexpr int kItems = 16;
+    const bool cached = m <= kItems * kSingleBlock;
+    double ratio_r[kItems];
+    int leave_r[kItems];
     double mn = INFINITY;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int i = threadIdx.x + k * kSingleBlock;
+            const bool in = i < m;
+            const double a = in ? alpha[i] : 0.0;
+            double bi = in ? b[i] : 0.0;
+            leave_r[k] = in ? basis_indices[i] : 0x7fffffff;
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            ratio_r[k] = (in && a > tol.pivot) ? bi / a : INFINITY;
+            mn = fmin(mn, ratio_r[k]);
+        }
+    } else {
 #pragma unroll 4
-    for (int i = threadIdx.x; i < m; i += kSingleBlock) {
-        const double a = alpha[i];
-        double bi = b[i];
-        if (fabs(bi) <= tol.zero) bi = 0.0;
-        const double ratio = (a > tol.pivot) ? bi / a : INFINITY;
-        mn = fmin(mn, ratio);
+        for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+            const double a = alpha[i];
+            double bi = b[i];
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            const double ratio = (a > tol.pivot) ? bi / a : INFINITY;
+            mn = fmin(mn, ratio);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
@@ -441,13 +460,21 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     }
     const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
     int best_leave = 0x7fffffff, best_row = -1;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            // ratio_r is +inf for rows that do not take part, so `<= bound` excludes them
+            if (ratio_r[k] <= bound && leave_r[k] < best_leave) { best_leave = leave_r[k]; best_row = threadIdx.x + k * kSingleBlock; }
+        }
+    } else {
 #pragma unroll 4
-    for (int i = threadIdx.x; i < m; i += kSingleBlock) {
-        const double a = alpha[i];
-        double bi = b[i];
-        const int lv = basis_indices[i];
-        if (fabs(bi) <= tol.zero) bi = 0.0;
-        if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
+        for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+            const double a = alpha[i];
+            double bi = b[i];
+            const int lv = basis_indices[i];
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1153,25 +1180,35 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
                 const int i = i_wave + b * 16 + lm;
                 acc[a][b][g] = (c < tv.c_hi && i < tv.m) ? tv.T0[(int64_t)c * tv.ld_t + i] : 0.0;
             }
-    for (int k0 = 0; k0 < p; k0 += 4) {
+    // operand fragments of step k0 + 4 are requested before the MFMAs of step k0 are issued, so their
+    // L2 latency (~1-2 us) overlaps the 8 x 64-cycle MFMAs instead of serialising with them
+    double af[kFlushMT], bf[kFlushNT], afn[kFlushMT], bfn[kFlushNT];
+    auto load_frags = [&](int k0, double* fa, double* fb) {
         const int k = k0 + lk;
         const bool kv = k < p;
-        double af[kFlushMT], bf[kFlushNT];
 #pragma unroll
         for (int a = 0; a < kFlushMT; ++a) {
             const int c = c_wave + a * 16 + lm;
-            af[a] = (kv && c < tv.c_hi) ? tv.R0[(int64_t)k * tv.ld_r + c] : 0.0;
+            fa[a] = (kv && c < tv.c_hi) ? tv.R0[(int64_t)k * tv.ld_r + c] : 0.0;
         }
 #pragma unroll
         for (int b = 0; b < kFlushNT; ++b) {
             const int i = i_wave + b * 16 + lm;
-            bf[b] = (kv && i < tv.m) ? du.W[(int64_t)k * du.ld + i] : 0.0;
+            fb[b] = (kv && i < tv.m) ? du.W[(int64_t)k * du.ld + i] : 0.0;
         }
+    };
+    load_frags(0, af, bf);
+    for (int k0 = 0; k0 < p; k0 += 4) {
+        load_frags(k0 + 4, afn, bfn);                 // k >= p yields zeros, no branch
 #pragma unroll
         for (int a = 0; a < kFlushMT; ++a)
 #pragma unroll
             for (int b = 0; b < kFlushNT; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < kFlushMT; ++a) af[a] = afn[a];
+#pragma unroll
+        for (int b = 0; b < kFlushNT; ++b) bf[b] = bfn[b];
     }
 #pragma unroll
     for (int a = 0; a < kFlushMT; ++a)
