@@ -1153,78 +1153,73 @@ __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, do
 // Flush: T0 += W R0 on the f64 matrix cores (v_mfma_f64_16x16x4_f64).  The MFMA computes the
 // transposed tile (R0' W')  so that the fast lane index of the accumulator runs along the rows of
 // T0, which are contiguous (column-major): stores are 128-byte segments.
-//   A operand (16 x 4): A[M][k] = R0[k][col(M)]      lane l: M = l & 15, k = l >> 4
-//   B operand (4 x 16): B[k][N] = W[row(N)][k]       lane l: N = l & 15, k = l >> 4
-//   D (16 x 16):        D[M][N] -> T0[row(N), col(M)], lane l holds N = l & 15, M = (l >> 4) + 4 g, g = 0..3
-template <int MT>
+//   A operand (16 x 4): A[M][k] = R0[k][c0 + M]      lane l: M = l & 15, k = l >> 4
+//   B operand (4 x 16): B[k][N] = W[i0 + N][k]       lane l: N = l & 15, k = l >> 4
+//   D (16 x 16):        D[M][N] -> T0[i0 + N, c0 + M], lane l holds N = l & 15, M = (l >> 4) + 4 g, g = 0..3
+// Wavefront tile 64 columns x 64 rows (4 x 4 MFMA tiles, 8 operand loads per 16 MFMAs), workgroup
+// 128 x 128.
+template <int MT, int NT>
 __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, DeferredUpdate du, const PivotRecord* rec) {
-    // Index maps (lm = lane & 15, lk = lane >> 4):
-    //   rows:    the two MFMA tiles b = 0, 1 of a wavefront hold the even / odd rows of a 32-row strip,
-    //            row(b, N) = i_wave + 2 N + b, so lane lm owns the adjacent rows 2 lm, 2 lm + 1 of every
-    //            column it touches: T0 and W are accessed 16 bytes per lane
-    //   columns: tiles a, a + 1 (a even) interleave likewise, col(a, M) = c_wave + 32 (a / 2) + 2 M + (a & 1),
-    //            so one 16-byte load of R0 feeds two A fragments
-    // Workgroup = 2 x 2 wavefronts = (32 MT) columns x 64 rows; blockIdx.x walks down the rows so that
-    // concurrently running workgroups stream contiguous memory.
-    static_assert(MT % 2 == 0, "column tiles come in interleaved pairs");
+    constexpr int kFlushMT = MT, kFlushNT = NT;
     const int p = rec->n_eta;
     if (p == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i_wave = blockIdx.x * 64 + (wave >> 1) * 32;
-    const int c_wave = tv.c_lo + blockIdx.y * (32 * MT) + (wave & 1) * (16 * MT);
+    const int c_wave = tv.c_lo + blockIdx.x * (2 * 16 * MT) + (wave & 1) * (16 * MT);   // first T0 column of this wavefront
+    const int i_wave = blockIdx.y * (2 * 16 * NT) + (wave >> 1) * (16 * NT);            // first T0 row
     if (c_wave >= tv.c_hi || i_wave >= tv.m) return;
     const int lm = lane & 15, lk = lane >> 4;
-    const int row = i_wave + 2 * lm;                       // and row + 1
-    const bool row_ok = row < (int)tv.ld_t;                 // ld_t is even and >= m; the pad row is harmless
-    double4_t acc[MT][2];
+    // the accumulators start as the T0 tile itself: all of its loads are in flight before the first MFMA
+    double4_t acc[kFlushMT][kFlushNT];
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int a = 0; a < kFlushMT; ++a)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = c_wave + 32 * (a >> 1) + 2 * (lk + 4 * g) + (a & 1);
-            double2 v = make_double2(0.0, 0.0);
-            if (row_ok && c < tv.c_hi) v = *reinterpret_cast<const double2*>(tv.T0 + (int64_t)c * tv.ld_t + row);
-            acc[a][0][g] = v.x;
-            acc[a][1][g] = v.y;
-        }
-    double af[MT], bf[2], afn[MT], bfn[2];
+        for (int b = 0; b < kFlushNT; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c_wave + a * 16 + lk + 4 * g;
+                const int i = i_wave + b * 16 + lm;
+                acc[a][b][g] = (c < tv.c_hi && i < tv.m) ? tv.T0[(int64_t)c * tv.ld_t + i] : 0.0;
+            }
+    // operand fragments of step k0 + 4 are requested before the MFMAs of step k0 are issued, so their
+    // L2 latency (~1-2 us) overlaps the 8 x 64-cycle MFMAs instead of serialising with them
+    double af[kFlushMT], bf[kFlushNT], afn[kFlushMT], bfn[kFlushNT];
     auto load_frags = [&](int k0, double* fa, double* fb) {
         const int k = k0 + lk;
         const bool kv = k < p;
 #pragma unroll
-        for (int ap = 0; ap < MT / 2; ++ap) {
-            const int c = c_wave + 32 * ap + 2 * lm;       // columns c, c + 1 (R0's pad column is zero)
-            double2 r = make_double2(0.0, 0.0);
-            if (kv && c < tv.c_hi) r = *reinterpret_cast<const double2*>(tv.R0 + (int64_t)k * tv.ld_r + c);
-            fa[2 * ap] = r.x;
-            fa[2 * ap + 1] = r.y;
+        for (int a = 0; a < kFlushMT; ++a) {
+            const int c = c_wave + a * 16 + lm;
+            fa[a] = (kv && c < tv.c_hi) ? tv.R0[(int64_t)k * tv.ld_r + c] : 0.0;
         }
-        double2 w = make_double2(0.0, 0.0);
-        if (kv && row_ok) w = *reinterpret_cast<const double2*>(du.W + (int64_t)k * du.ld + row);
-        fb[0] = w.x;
-        fb[1] = w.y;
+#pragma unroll
+        for (int b = 0; b < kFlushNT; ++b) {
+            const int i = i_wave + b * 16 + lm;
+            fb[b] = (kv && i < tv.m) ? du.W[(int64_t)k * du.ld + i] : 0.0;
+        }
     };
     load_frags(0, af, bf);
     for (int k0 = 0; k0 < p; k0 += 4) {
-        load_frags(k0 + 4, afn, bfn);                      // requested before this step's MFMAs; k >= p gives zeros
+        load_frags(k0 + 4, afn, bfn);                 // k >= p yields zeros, no branch
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[0], acc[a][0], 0, 0, 0);
-            acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[1], acc[a][1], 0, 0, 0);
-        }
+        for (int a = 0; a < kFlushMT; ++a)
 #pragma unroll
-        for (int a = 0; a < MT; ++a) af[a] = afn[a];
-        bf[0] = bfn[0];
-        bf[1] = bfn[1];
+            for (int b = 0; b < kFlushNT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < kFlushMT; ++a) af[a] = afn[a];
+#pragma unroll
+        for (int b = 0; b < kFlushNT; ++b) bf[b] = bfn[b];
     }
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int a = 0; a < kFlushMT; ++a)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = c_wave + 32 * (a >> 1) + 2 * (lk + 4 * g) + (a & 1);
-            if (row_ok && c < tv.c_hi)
-                *reinterpret_cast<double2*>(tv.T0 + (int64_t)c * tv.ld_t + row) = make_double2(acc[a][0][g], acc[a][1][g]);
-        }
+        for (int b = 0; b < kFlushNT; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c_wave + a * 16 + lk + 4 * g;
+                const int i = i_wave + b * 16 + lm;
+                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+            }
 }
 
 __global__ void k_tab_gather_columns(TableauView tv, const int32_t* __restrict__ cols, double* __restrict__ out) {
@@ -1593,10 +1588,10 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
 }
 
 void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
-    constexpr int MT = 4;              // wavefront tile 64 columns x 32 rows, workgroup 128 columns x 64 rows
+    constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
     if (tv.c_hi <= tv.c_lo) return;
-    dim3 grid(cdiv(tv.m, 64), cdiv(tv.c_hi - tv.c_lo, 32 * MT));     // x = row tiles (fastest), y = column tiles
-    hipLaunchKernelGGL((k_tab_flush<MT>), grid, dim3(kThreads), 0, s, tv, du, rec);
+    dim3 grid(cdiv(tv.c_hi - tv.c_lo, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
+    hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, rec);
 }
 
 void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s) {
