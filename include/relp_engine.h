@@ -111,7 +111,8 @@ typedef enum {
      * tableau column per pivot, and T0 is updated by an m x K x n GEMM on the f64 matrix cores every
      * update_block pivots (needs 8 m n bytes; same pivots as the revised engine up to f64 rounding).
      * Restrictions: no relp_from_basis, no sharding yet. */
-    RELP_ENGINE_TABLEAU = 1
+    RELP_ENGINE_TABLEAU = 1,
+    RELP_ENGINE_LU = 2        /* sparse LU of the basis + pending updates (Carry<_, LUDecomposition<_>>) */
 } relp_engine_kind_t;
 
 void relp_default_config(relp_config_t *cfg);

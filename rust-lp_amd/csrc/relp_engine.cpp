@@ -39,6 +39,7 @@ void Engine::free_all() {
     fr(d_part_k1_); fr(d_part_j_);
     fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
+    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_i_); fr(d_lu_d_); fr(d_lu_scratch_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
     prof_ev_.clear();
@@ -80,7 +81,7 @@ TableauView Engine::tview() const {
 SelectPartials Engine::tab_partials(int rule) const {
     SelectPartials sp;
     sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
-    sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+    sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.cols_per_slot = 8;
     return sp;
 }
 
@@ -217,7 +218,12 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     owns_stream_ = true;
     const int32_t n_local = col_hi_ - col_lo_;
-    if (md.format == RELP_FORMAT_DENSE) {
+    lu_ = cfg_.engine == RELP_ENGINE_LU;
+    if (lu_) {
+        if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+        relp_status_t lst = lu_load_matrix(md);
+        if (lst) return lst;
+    } else if (md.format == RELP_FORMAT_DENSE) {
         if (nr_normal_ > 0 && mc_ > 0 && !md.dense) return fail(RELP_E_ARG, "dense matrix missing");
         const int64_t src_ld = md.dense_ld > 0 ? md.dense_ld : mc_;
         if (src_ld < mc_) return fail(RELP_E_ARG, "dense_ld < nr_constraints");
@@ -254,7 +260,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     const int64_t rows_local = std::max(row_hi_ - row_lo_, 1);
     const bool want_tableau = cfg_.engine == RELP_ENGINE_TABLEAU;
     // the tableau engine reads B^-1 off the identity columns of T; the explicit inverse is not stored
-    HIP_TRY(dev_alloc(&dBinv_, want_tableau ? 16 : rows_local * ld_b_));
+    HIP_TRY(dev_alloc(&dBinv_, (want_tableau || lu_) ? 16 : rows_local * ld_b_));
     HIP_TRY(dev_alloc(&d_minus_pi_, ld_b_));
     HIP_TRY(dev_alloc(&d_b_, ld_b_));
     HIP_TRY(dev_alloc(&d_alpha_, ld_b_));
@@ -273,12 +279,18 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     HIP_TRY(dev_alloc(&d_rec_, 1));
     {
         const int64_t slots = price_structural_blocks(col_lo_, col_hi_) + (nr_artificial_ + nr_virtual_ + 255) / 256 + 8 +
-                              tab_scan_blocks(n_alloc_);
+                              tab_scan_blocks(n_alloc_) + price_csc_blocks(0, nr_normal_);
         HIP_TRY(dev_alloc(&d_part_k1_, slots));
         HIP_TRY(dev_alloc(&d_part_j_, slots));
     }
     block_ = cfg_.update_block < 0 ? (m_ >= 4096 ? 64 : 0) : std::min(cfg_.update_block, 128);
     tableau_ = cfg_.engine == RELP_ENGINE_TABLEAU;
+    if (lu_) {
+        // pivots between refactorisations (the reference refactors after 10 updates, lower_upper/mod.rs:199;
+        // here an update is one column of W, so longer blocks are cheap)
+        block_ = cfg_.update_block < 0 ? 64 : std::max(1, std::min(cfg_.update_block, 128));
+        HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
+    }
     if (tableau_) {
         if (block_ == 0) block_ = 64;                  // the tableau is always maintained in blocks
         n_store_ = n_alloc_;
@@ -348,7 +360,157 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     relp_status_t st = upload_rec();
     if (st) return st;
     HIP_TRY(hipDeviceSynchronize());   // hipMemset on the null stream vs. our non-blocking stream
+    if (lu_ && (st = lu_refactor())) return st;
     return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sparse LU engine: matrix in CSC, factors from the host (relp_lu.cpp), solves on the device
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::lu_load_matrix(const relp_matrix_data_t& md) {
+    hc_ptr_.assign(nr_normal_ + 1, 0);
+    hc_idx_.clear(); hc_val_.clear();
+    if (md.format == RELP_FORMAT_CSC) {
+        if (md.matrix_memory != RELP_MEM_HOST) return fail(RELP_E_UNSUPPORTED, "CSC input must be in host memory");
+        if (!md.col_ptr) return fail(RELP_E_ARG, "col_ptr missing");
+        for (int32_t j = 0; j < nr_normal_; ++j) {
+            for (int64_t p = md.col_ptr[j]; p < md.col_ptr[j + 1]; ++p) {
+                const int32_t i = md.row_idx[p];
+                if (i < 0 || i >= mc_) return fail(RELP_E_ARG, "row index out of range");
+                if (md.values[p] == 0.0) continue;
+                hc_idx_.push_back(i); hc_val_.push_back(md.values[p]);
+            }
+            hc_ptr_[j + 1] = (int64_t)hc_idx_.size();
+        }
+    } else if (md.format == RELP_FORMAT_DENSE) {
+        if (nr_normal_ > 0 && mc_ > 0 && !md.dense) return fail(RELP_E_ARG, "dense matrix missing");
+        const int64_t src_ld = md.dense_ld > 0 ? md.dense_ld : mc_;
+        if (src_ld < mc_) return fail(RELP_E_ARG, "dense_ld < nr_constraints");
+        std::vector<double> col(std::max(mc_, 1));
+        for (int32_t j = 0; j < nr_normal_; ++j) {
+            const double* src = md.dense + (int64_t)j * src_ld;
+            if (md.matrix_memory == RELP_MEM_DEVICE) {
+                HIP_TRY(hipMemcpy(col.data(), src, sizeof(double) * mc_, hipMemcpyDeviceToHost));
+                src = col.data();
+            }
+            for (int32_t i = 0; i < mc_; ++i)
+                if (src[i] != 0.0) { hc_idx_.push_back(i); hc_val_.push_back(src[i]); }
+            hc_ptr_[j + 1] = (int64_t)hc_idx_.size();
+        }
+    } else {
+        return fail(RELP_E_ARG, "unknown matrix format");
+    }
+    HIP_TRY(dev_alloc(&d_cptr_, nr_normal_ + 1));
+    HIP_TRY(dev_alloc(&d_cidx_, (int64_t)hc_idx_.size()));
+    HIP_TRY(dev_alloc(&d_cval_, (int64_t)hc_val_.size()));
+    HIP_TRY(hipMemcpy(d_cptr_, hc_ptr_.data(), sizeof(int64_t) * hc_ptr_.size(), hipMemcpyHostToDevice));
+    if (!hc_idx_.empty()) {
+        HIP_TRY(hipMemcpy(d_cidx_, hc_idx_.data(), sizeof(int32_t) * hc_idx_.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_cval_, hc_val_.data(), sizeof(double) * hc_val_.size(), hipMemcpyHostToDevice));
+    }
+    return RELP_OK;
+}
+
+// Refactorisation (lower_upper/mod.rs:199-202 + carry/mod.rs:602-614): B from the current basis
+// columns, P B Q = L U on the host, schedules to the device, W := empty.  Synchronises the stream.
+relp_status_t Engine::lu_refactor() {
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpyAsync(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<std::vector<std::pair<int32_t, double>>> cols(m_);
+    for (int32_t i = 0; i < m_; ++i) {
+        const int32_t j = basis[i];
+        auto& c = cols[i];
+        if (j < nr_artificial_) { c.emplace_back(column_to_row_[j], 1.0); continue; }
+        const int32_t p = j - nr_artificial_;
+        if (p < nr_normal_) {
+            for (int64_t e = hc_ptr_[p]; e < hc_ptr_[p + 1]; ++e) c.emplace_back(hc_idx_[e], hc_val_[e]);
+            if (bound_row_h_[p] >= 0) c.emplace_back(bound_row_h_[p], 1.0);
+        } else {
+            const int32_t v = p - nr_normal_;
+            if (v >= nr_virtual_) return fail(RELP_E_STATE, "basis column out of range");
+            c.emplace_back(vrow0_h_[v], (double)vsign_h_[v]);
+            if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
+        }
+    }
+    std::string msg;
+    if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
+    // pack: ints = rowperm, colperm, 4 x (ptr, idx, level_ptr, level_rows); doubles = 4 x (val, diag)
+    const TriangularSchedule* sch[4] = {&hlu_.Lf, &hlu_.Uf, &hlu_.Ub, &hlu_.Lb};
+    std::vector<int32_t> hi; std::vector<double> hd;
+    auto put_i = [&](const std::vector<int32_t>& v) { const int64_t o = (int64_t)hi.size(); hi.insert(hi.end(), v.begin(), v.end()); if (hi.size() & 1) hi.push_back(0); return o; };
+    auto put_d = [&](const std::vector<double>& v) { const int64_t o = (int64_t)hd.size(); hd.insert(hd.end(), v.begin(), v.end()); return o; };
+    const int64_t o_rp = put_i(hlu_.rowperm), o_cp = put_i(hlu_.colperm);
+    int64_t oi[4][4], od[4][2];
+    for (int k = 0; k < 4; ++k) {
+        oi[k][0] = put_i(sch[k]->ptr); oi[k][1] = put_i(sch[k]->idx); oi[k][2] = put_i(sch[k]->level_ptr); oi[k][3] = put_i(sch[k]->level_rows);
+        od[k][0] = put_d(sch[k]->val); od[k][1] = put_d(sch[k]->diag);
+    }
+    if ((int64_t)hi.size() > lu_i_cap_) {
+        if (d_lu_i_) HIP_TRY(hipFree(d_lu_i_));
+        lu_i_cap_ = (int64_t)hi.size() * 3 / 2 + 64;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_i_), sizeof(int32_t) * lu_i_cap_));
+    }
+    if ((int64_t)hd.size() > lu_d_cap_) {
+        if (d_lu_d_) HIP_TRY(hipFree(d_lu_d_));
+        lu_d_cap_ = (int64_t)hd.size() * 3 / 2 + 64;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_d_), sizeof(double) * lu_d_cap_));
+    }
+    HIP_TRY(hipMemcpyAsync(d_lu_i_, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, stream_));
+    if (!hd.empty()) HIP_TRY(hipMemcpyAsync(d_lu_d_, hd.data(), sizeof(double) * hd.size(), hipMemcpyHostToDevice, stream_));
+    dlu_.m = m_; dlu_.pad_ = 0;
+    dlu_.rowperm = d_lu_i_ + o_rp; dlu_.colperm = d_lu_i_ + o_cp;
+    DeviceSchedule* ds[4] = {&dlu_.Lf, &dlu_.Uf, &dlu_.Ub, &dlu_.Lb};
+    for (int k = 0; k < 4; ++k) {
+        ds[k]->ptr = d_lu_i_ + oi[k][0]; ds[k]->idx = d_lu_i_ + oi[k][1];
+        ds[k]->level_ptr = d_lu_i_ + oi[k][2]; ds[k]->level_rows = d_lu_i_ + oi[k][3];
+        ds[k]->val = d_lu_d_ + od[k][0]; ds[k]->diag = d_lu_d_ + od[k][1];
+        ds[k]->n_levels = (int32_t)sch[k]->level_ptr.size() - 1; ds[k]->pad_ = 0;
+    }
+    launch_flush_reset(deferred(), d_rec_, stream_);
+    HIP_TRY(hipStreamSynchronize(stream_));             // hi / hd are stack-owned
+    since_flush_ = 0;
+    ++lu_refactors_;
+    return RELP_OK;
+}
+
+// One pivot of the LU engine: CSC PRICE -> select + scatter a_q -> FTRAN (L, U solves) -> W correction
+// -> ratio test -> W update -> BTRAN for the pivot row -> b, -pi, basis.
+void Engine::enqueue_iteration_lu(int rule) {
+    const ColumnTable ct = table();
+    const DeferredUpdate du = deferred();
+    SelectPartials sp;
+    sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+    const int nb_struct = price_csc_blocks(0, nr_normal_);
+    sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.cols_per_slot = 256;
+    const int nb_virt = price_virtual_blocks(ct);
+    prof_begin(RELP_K_PRICE);
+    launch_price_csc(csc(), ct, d_minus_pi_, d_d_, 0, nr_normal_, phase_, sp, d_rec_, stream_);
+    SelectPartials spv = sp;
+    spv.offset = nb_struct;
+    launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_SELECT_COLUMN);
+    launch_select_partials_csc(sp, nb_struct + nb_virt, d_d_, csc(), ct, m_, d_aq_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_FTRAN);
+    launch_lu_ftran(dlu_, d_aq_, d_v_, d_lu_scratch_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_APPLY_W);
+    launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_RATIO);
+    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_W);
+    launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_VECTORS);
+    launch_lu_btran(dlu_, du, nullptr, -1, d_rho_, d_lu_scratch_, d_rec_, stream_);
+    launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
+                          stream_);
+    prof_end();
+    if (++since_flush_ >= block_) enqueue_flush();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,6 +565,11 @@ relp_status_t Engine::profile_read(int kernel_id, int64_t* launches, double* tot
 // PRICE over the owned structural columns and every virtual column with vector `vec` (= -pi).
 void Engine::enqueue_price(int cost_mode, const double* vec, const PivotRecord* rec, int32_t p_lo, int32_t p_hi) {
     const ColumnTable ct = table();
+    if (lu_) {
+        launch_price_csc(csc(), ct, vec, d_d_, 0, nr_normal_, cost_mode, SelectPartials{}, rec, stream_);
+        launch_price_virtual(ct, vec, d_d_, cost_mode, rec, stream_);
+        return;
+    }
     // dA_ holds the owned columns only: shift the base so that global column p indexes correctly
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     launch_price_structural(A, ld_a_, ct, vec, d_d_, p_lo, p_hi, cost_mode, rec, stream_);
@@ -432,6 +599,7 @@ void Engine::enqueue_iteration_tableau(int rule) {
 void Engine::enqueue_iteration(int rule) {
     struct Tick { int64_t& t; ~Tick() { ++t; } } tick{prof_tick_};
     if (tableau_) { enqueue_iteration_tableau(rule); return; }
+    if (lu_) { enqueue_iteration_lu(rule); return; }
     const ColumnTable ct = table();
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -441,7 +609,7 @@ void Engine::enqueue_iteration(int rule) {
     SelectPartials sp;
     sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
     const int nb_struct = price_structural_blocks(col_lo_, col_hi_);
-    sp.n = n; sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = col_lo_; sp.pad_ = 0;
+    sp.n = n; sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = col_lo_; sp.cols_per_slot = 8;
     const int nb_virt = price_virtual_blocks(ct);
     prof_begin(RELP_K_PRICE);
     launch_price_structural_sel(A, ld_a_, ct, d_minus_pi_, d_d_, col_lo_, col_hi_, phase_, sp, d_rec_, stream_);
@@ -497,6 +665,14 @@ void Engine::enqueue_iteration(int rule) {
 // (also after the loop froze): (B0inv, W, S) is consistent after every completed pivot.
 void Engine::enqueue_flush() {
     if (block_ == 0) return;
+    if (lu_) {
+        if (since_flush_ == 0) return;                 // the factors already describe the current basis
+        prof_begin(RELP_K_FLUSH);
+        const relp_status_t st = lu_refactor();
+        prof_end();
+        if (st && !lu_status_) lu_status_ = st;
+        return;
+    }
     if (tableau_) {
         // T0 += W R0 on the f64 matrix cores
         const DeferredUpdate dut = deferred();
@@ -532,7 +708,7 @@ relp_status_t Engine::select_primal_pivot_column(int rule, int32_t* found, int32
     if (tableau_) {
         SelectPartials sp;
         sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
-        sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+        sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.cols_per_slot = 8;
         launch_tab_scan(tview(), sp, d_rec_, stream_);
         launch_tab_select(tview(), sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_rec_, stream_);
     } else {
@@ -564,6 +740,10 @@ relp_status_t Engine::generate_column(int32_t column, double* out_m) {
     if ((st = upload_rec())) return st;
     if (tableau_) {
         launch_tab_column(tview(), deferred(), d_alpha_, d_rec_, stream_);
+    } else if (lu_) {
+        launch_build_column_csc(csc(), table(), m_, d_aq_, d_rec_, stream_);
+        launch_lu_ftran(dlu_, d_aq_, d_v_, d_lu_scratch_, d_rec_, stream_);
+        launch_apply_w(deferred(), m_, d_v_, d_alpha_, d_rec_, stream_);
     } else {
         enqueue_flush();                               // the step-wise calls work on the explicit inverse
         const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
@@ -605,7 +785,7 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
     HIP_TRY(hipMemcpy(&b_r, d_b_ + row, sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&lv, d_basis_ + row, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
-    if (!tableau_) enqueue_flush();
+    if (!tableau_ && !lu_) enqueue_flush();
     if ((st = download_rec())) return st;               // the flush may have reset the block counters
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->q = column; h_rec_->d_q = cost; h_rec_->r = row; h_rec_->leaving = lv; h_rec_->alpha_r = alpha_r; h_rec_->b_r = b_r;
@@ -616,7 +796,7 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
         SelectPartials sp;
         sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost;
         sp.rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
-        sp.n = tv.n; sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.pad_ = 0;
+        sp.n = tv.n; sp.offset = 0; sp.nb_struct = 0; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.cols_per_slot = 8;
         launch_eta_prepare(du, d_rec_, stream_);
         launch_tab_row_update(tv, du, sp, d_rec_, stream_);
         launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
@@ -624,6 +804,19 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
         if (++since_flush_ >= block_) enqueue_flush();
         HIP_TRY(hipStreamSynchronize(stream_));
         if (leaving) *leaving = lv;
+        return RELP_OK;
+    }
+    if (lu_) {
+        const DeferredUpdate du = deferred();
+        launch_eta_prepare(du, d_rec_, stream_);
+        launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+        launch_lu_btran(dlu_, du, nullptr, -1, d_rho_, d_lu_scratch_, d_rec_, stream_);
+        launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_,
+                              d_rec_, stream_);
+        if (++since_flush_ >= block_) enqueue_flush();
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (leaving) *leaving = lv;
+        if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
         return RELP_OK;
     }
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -654,6 +847,7 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     int64_t next_poll = phase_ == 1 ? 1 : cfg_.poll_interval;
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
         enqueue_iteration(rule);
+        if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
         if (it + 1 == next_poll) {
             next_poll += phase_ == 1 ? std::min<int64_t>(next_poll, cfg_.poll_interval) : cfg_.poll_interval;
             if ((st = download_rec())) return st;
@@ -719,6 +913,10 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
         if (tableau_) {
             launch_tab_row(tview(), deferred(), pivot_row, d_aq_big(), d_rec_, stream_);        // single GPU: all columns
             HIP_TRY(hipMemcpyAsync(tau.data(), d_aq_big(), sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+        } else if (lu_) {
+            launch_lu_btran(dlu_, deferred(), nullptr, pivot_row, d_rho_, d_lu_scratch_, nullptr, stream_);
+            enqueue_price(0, d_rho_, nullptr, 0, nr_normal_);
+            HIP_TRY(hipMemcpyAsync(tau.data(), d_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
         } else {
             double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
             enqueue_price(0, Binv + (int64_t)pivot_row * ld_b_, nullptr, col_lo_, col_hi_);
@@ -759,8 +957,12 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = cost_h_[basis[i]];
     if (cfg_.shard_count > 1)
         for (double v : w) if (v != 0.0) return fail(RELP_E_UNSUPPORTED, "sharded phase switch needs an all-slack basis");
+    if (lu_) for (auto& v : w) v = -v;                 // BTRAN with rhs -c_B gives -pi directly
     HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
-    if (tableau_) {
+    if (lu_) {
+        if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
+        launch_lu_btran(dlu_, deferred(), d_w_, -1, d_minus_pi_, d_lu_scratch_, nullptr, stream_);
+    } else if (tableau_) {
         // phase-2 reduced costs of every stored column: d = c - c_B' T (the artificial block keeps cost 0)
         cost_store_h_.assign(n_store_, 0.0);
         for (int32_t p = 0; p < nr_normal_; ++p) cost_store_h_[tab_na_ + p] = cost_h_[p];
@@ -798,7 +1000,8 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     for (int32_t r : rows) if (r >= mc_) return fail(RELP_E_STATE, "only constraint rows can be redundant");
     const int32_t mc_new = mc_ - (int32_t)rows.size();
     // B^-1 (or the tableau), b, basis
-    std::vector<double> Bh(tableau_ ? 1 : (size_t)m_ * ld_b_), b(m_);
+    const bool no_inv = tableau_ || lu_;
+    std::vector<double> Bh(no_inv ? 1 : (size_t)m_ * ld_b_), b(m_);
     std::vector<int32_t> basis(m_);
     if (tableau_) {
         // every stored column loses the rows; the columns that were the identity of those rows stay as
@@ -816,27 +1019,43 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
         idcol_h_ = idn;
         HIP_TRY(hipMemcpy(d_idcol_, idcol_h_.data(), sizeof(int32_t) * idcol_h_.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(d_pos_of_row_, 0xFF, sizeof(int32_t) * m_));
+    } else if (lu_) {
+        // the CSC matrix loses the rows; the factors are rebuilt below
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::vector<int64_t> np(nr_normal_ + 1, 0);
+        size_t o = 0;
+        for (int32_t j = 0; j < nr_normal_; ++j) {
+            for (int64_t e = hc_ptr_[j]; e < hc_ptr_[j + 1]; ++e)
+                if (map[hc_idx_[e]] >= 0) { hc_idx_[o] = map[hc_idx_[e]]; hc_val_[o] = hc_val_[e]; ++o; }
+            np[j + 1] = (int64_t)o;
+        }
+        hc_idx_.resize(o); hc_val_.resize(o); hc_ptr_ = np;
+        HIP_TRY(hipMemcpy(d_cptr_, hc_ptr_.data(), sizeof(int64_t) * hc_ptr_.size(), hipMemcpyHostToDevice));
+        if (o) {
+            HIP_TRY(hipMemcpy(d_cidx_, hc_idx_.data(), sizeof(int32_t) * o, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_cval_, hc_val_.data(), sizeof(double) * o, hipMemcpyHostToDevice));
+        }
     } else {
         HIP_TRY(hipMemcpy(Bh.data(), dBinv_, Bh.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
     HIP_TRY(hipMemcpy(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     const int64_t ld_new = ld_b_;
-    std::vector<double> Bn(tableau_ ? 1 : (size_t)m_ * ld_new, 0.0), bn(m_, 0.0);
+    std::vector<double> Bn(no_inv ? 1 : (size_t)m_ * ld_new, 0.0), bn(m_, 0.0);
     std::vector<int32_t> basisn(m_, 0);
     for (int32_t i = 0; i < m_; ++i) {
         if (map[i] < 0) continue;
-        if (!tableau_)
+        if (!no_inv)
             for (int32_t j = 0; j < m_; ++j) if (map[j] >= 0) Bn[(size_t)map[i] * ld_new + map[j]] = Bh[(size_t)i * ld_b_ + j];
         bn[map[i]] = b[i];
         basisn[map[i]] = basis[i];
     }
-    if (!tableau_) HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!no_inv) HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_b_, 0, sizeof(double) * ld_b_));
     HIP_TRY(hipMemcpy(d_b_, bn.data(), sizeof(double) * m_new, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_basis_, basisn.data(), sizeof(int32_t) * m_new, hipMemcpyHostToDevice));
     // A: drop the rows inside every structural column (the tableau engine no longer reads A)
-    if (nr_normal_ > 0 && !tableau_) {
+    if (nr_normal_ > 0 && !no_inv) {
         std::vector<double> Ah((size_t)ld_a_ * nr_normal_);
         HIP_TRY(hipMemcpy(Ah.data(), dA_, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<double> An((size_t)ld_a_ * nr_normal_, 0.0);
@@ -868,6 +1087,7 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     HIP_TRY(hipMemset(d_rho_, 0, sizeof(double) * ld_b_));
     HIP_TRY(hipMemset(d_minus_pi_, 0, sizeof(double) * ld_b_));
     HIP_TRY(hipDeviceSynchronize());
+    if (lu_) return lu_refactor();
     return RELP_OK;
 }
 
@@ -877,6 +1097,35 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     // signed permutation.  General warm starts need the dense inversion kernel (next round).
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
     if (tableau_) return fail(RELP_E_UNSUPPORTED, "from_basis in the tableau engine");
+    if (lu_) {
+        // any basis: factorise it, b = B^-1 rhs (FTRAN), -pi = -c_B' B^-1 (BTRAN), carry/mod.rs:428-463
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::vector<int32_t> basis(basis_columns, basis_columns + m_);
+        std::vector<uint8_t> flags(n_alloc_, 0);
+        for (int32_t v : basis) {
+            if (v < 0 || v >= n_provider_) return fail(RELP_E_ARG, "from_basis: column out of range");
+            if (flags[v]) return fail(RELP_E_SINGULAR, "from_basis: duplicate column");
+            flags[v] = 1;
+        }
+        nr_artificial_ = 0; phase_ = 2;
+        HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));
+        since_flush_ = 1;                              // force: the factors are stale
+        relp_status_t st = lu_refactor();
+        if (st) return st;
+        std::vector<double> w(ld_b_, 0.0), b(m_);
+        for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = -cost_h_[basis[i]];
+        HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_aq_, rhs_h_.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
+        launch_lu_ftran(dlu_, d_aq_, d_b_, d_lu_scratch_, nullptr, stream_);
+        launch_lu_btran(dlu_, deferred(), d_w_, -1, d_minus_pi_, d_lu_scratch_, nullptr, stream_);
+        HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+        if ((st = download_rec())) return st;
+        double objective = 0.0;
+        for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) objective += b[i] * cost_h_[basis[i]];
+        h_rec_->minus_objective = -objective; h_rec_->outcome = DEV_RUNNING; h_rec_->last_selected = -1; h_rec_->phase = 2;
+        return upload_rec();
+    }
     enqueue_flush();                                   // leaves the deferred state empty
     HIP_TRY(hipStreamSynchronize(stream_));
     std::vector<int32_t> basis(basis_columns, basis_columns + m_);
@@ -943,6 +1192,17 @@ relp_status_t Engine::get_basis_indices(int32_t* out) {
 
 relp_status_t Engine::get_basis_inverse(double* out) {
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "B^-1 is row-sharded");
+    if (lu_) {
+        // row i of B^-1 = BTRAN of e_i (with the pending W); test / debugging path
+        double* tmp = nullptr;
+        HIP_TRY(dev_alloc(&tmp, (int64_t)m_ * m_));
+        for (int32_t i = 0; i < m_; ++i)
+            launch_lu_btran(dlu_, deferred(), nullptr, i, tmp + (int64_t)i * m_, d_lu_scratch_, nullptr, stream_);
+        HIP_TRY(hipMemcpyAsync(out, tmp, sizeof(double) * m_ * m_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipFree(tmp));
+        return RELP_OK;
+    }
     enqueue_flush();
     if (tableau_) {
         // B^-1 = the tableau columns of the original identity columns
@@ -1050,6 +1310,7 @@ relp_status_t Engine::shard_pivot() {
 }
 
 relp_status_t Engine::shard_price(double* dev_candidate) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     if (tableau_) {
         // local PRICE result = the partial argmin the last row update left behind (or a scan of d);
@@ -1089,6 +1350,7 @@ relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t 
 }
 
 relp_status_t Engine::shard_ftran(double* dev_alpha_slice) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     prof_begin(RELP_K_FTRAN);
     launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, dev_alpha_slice, row_lo_, d_rec_, stream_);
@@ -1098,6 +1360,7 @@ relp_status_t Engine::shard_ftran(double* dev_alpha_slice) {
 }
 
 relp_status_t Engine::shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     if (block_ == 0) {
         prof_begin(RELP_K_RATIO);

@@ -18,6 +18,7 @@
 
 #include "../../include/relp_engine.h"
 #include "relp_kernels.h"
+#include "relp_lu.hpp"
 
 namespace relp {
 
@@ -133,6 +134,21 @@ class Engine {
     SelectPartials tab_partials(int rule) const;
     void enqueue_iteration_tableau(int rule);
     relp_status_t tableau_reprice();
+    // sparse LU engine (cfg.engine == RELP_ENGINE_LU): B^-1 = (I + W S') (L U)^-1, refactor every block_ pivots
+    bool lu_ = false;
+    std::vector<int64_t> hc_ptr_; std::vector<int32_t> hc_idx_; std::vector<double> hc_val_;   // host CSC of A
+    int64_t* d_cptr_ = nullptr; int32_t* d_cidx_ = nullptr; double* d_cval_ = nullptr;         // device CSC of A
+    LUFactors hlu_;
+    int32_t* d_lu_i_ = nullptr; int64_t lu_i_cap_ = 0;    // packed index arrays of the factors
+    double* d_lu_d_ = nullptr; int64_t lu_d_cap_ = 0;     // packed values
+    double* d_lu_scratch_ = nullptr;
+    DeviceLU dlu_{};
+    relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop
+    int64_t lu_refactors_ = 0;
+    DeviceCSC csc() const { return DeviceCSC{d_cptr_, d_cidx_, d_cval_}; }
+    relp_status_t lu_load_matrix(const relp_matrix_data_t& md);
+    relp_status_t lu_refactor();
+    void enqueue_iteration_lu(int rule);
     DeferredUpdate deferred() const;
     void enqueue_flush();
     int32_t n_alloc_ = 0;     // allocated tableau columns (artificial + provider)

@@ -82,8 +82,21 @@ struct SelectPartials {
     int32_t        nb_struct; // slots [0, nb_struct) belong to structural workgroups of 8 columns from p_lo
     double         tol_tie;   // SteepestDescent: columns within tol_tie*max(1,|min|) of the minimum tie
     int32_t        p_lo;      // first structural column priced by this rank
-    int32_t        pad_;
+    int32_t        cols_per_slot;  // structural columns behind one slot (8 dense PRICE, 256 CSC PRICE)
 };
+
+// ---- sparse LU engine (device side of relp_lu.hpp) ------------------------------------------------
+struct DeviceSchedule {
+    const int32_t* ptr; const int32_t* idx; const double* val; const double* diag;
+    const int32_t* level_ptr; const int32_t* level_rows; int32_t n_levels; int32_t pad_;
+};
+struct DeviceLU {
+    int32_t m; int32_t pad_;
+    const int32_t* rowperm;   // pivot step -> original row
+    const int32_t* colperm;   // pivot step -> basis position
+    DeviceSchedule Lf, Uf, Ub, Lb;
+};
+struct DeviceCSC { const int64_t* col_ptr; const int32_t* row_idx; const double* values; };
 
 // ---- launchers (all asynchronous on `s`) -------------------------------------------------------
 // cost_mode: 0 = no cost term (tableau row), 1 = phase-1 costs (artificial: 1), 2 = phase-2 costs
@@ -210,6 +223,24 @@ void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, doubl
 // tableau row `row` of the CURRENT T into out[0..n_store) (remove_artificial_basis_variables)
 void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row, double* out, const PivotRecord* rec,
                     hipStream_t s);
+
+// ---- sparse LU engine ------------------------------------------------------------------------------
+// PRICE over CSC columns (thread per column), partial argmin per 256 columns
+void launch_price_csc(const DeviceCSC& csc, const ColumnTable& ct, const double* vec, double* d, int32_t p_lo,
+                      int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec, hipStream_t s);
+int32_t price_csc_blocks(int32_t p_lo, int32_t p_hi);
+// k_select_partials with the entering column scattered from CSC instead of copied from dense A
+void launch_select_partials_csc(SelectPartials sp, int32_t count, const double* d, const DeviceCSC& csc,
+                                const ColumnTable& ct, int32_t m, double* aq, PivotRecord* rec, hipStream_t s);
+void launch_build_column_csc(const DeviceCSC& csc, const ColumnTable& ct, int32_t m, double* aq, const PivotRecord* rec,
+                             hipStream_t s);
+// FTRAN: v = (LU)^-1 aq  (one persistent workgroup, level-scheduled pull solves, work vector in LDS)
+void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* scratch, const PivotRecord* rec,
+                     hipStream_t s);
+// BTRAN: rho' = z' (LU)^-1 with z = e_r + sum_j W[r,j] e_S[j] (rhs == nullptr, r from rec or `row` >= 0)
+//        or z = rhs (dense, indexed by basis position)
+void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double* rhs, int32_t row, double* rho,
+                     double* scratch, const PivotRecord* rec, hipStream_t s);
 
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);

@@ -89,6 +89,27 @@ __device__ __forceinline__ double select_key(int rule, int n, const PivotRecord*
 
 // ------------------------------------------------------------------------------------------------
 // PRICE
+// Workgroup-level (key, j) minimum of one candidate per thread -> partial slot `slot`.
+__device__ __forceinline__ void block_partial_min(double key, int kj, SelectPartials sp, int slot) {
+    __shared__ double s_k[kThreads / 64];
+    __shared__ int s_j[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(key, off, 64);
+        const int oj = __shfl_down(kj, off, 64);
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k[wave] = key; s_j[wave] = kj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w)
+            if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
+        sp.k1[slot] = key;
+        sp.j[slot] = kj;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_price_structural(
     const double* __restrict__ A, int64_t ld_a, ColumnTable ct, const double* __restrict__ minus_pi,
@@ -177,8 +198,8 @@ __global__ __launch_bounds__(kThreads) void k_price_virtual(ColumnTable ct, cons
 __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials sp, int count,
                                                                   const double* __restrict__ d,
                                                                   const double* __restrict__ A, int64_t ld_a,
-                                                                  ColumnTable ct, int m, double* __restrict__ aq,
-                                                                  PivotRecord* rec) {
+                                                                  DeviceCSC csc, ColumnTable ct, int m,
+                                                                  double* __restrict__ aq, PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
     __shared__ double s_k1[kSingleBlock / 64];
     __shared__ int s_j[kSingleBlock / 64];
@@ -218,8 +239,8 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
         for (int t = threadIdx.x; t < count; t += kSingleBlock) {
             if (!(sp.k1[t] <= bound)) continue;
             if (t < sp.nb_struct) {
-                const int p0 = sp.p_lo + t * kVecPerBlock;
-                for (int u = 0; u < kVecPerBlock; ++u) {
+                const int p0 = sp.p_lo + t * sp.cols_per_slot;
+                for (int u = 0; u < sp.cols_per_slot; ++u) {
                     const int p = p0 + u;
                     if (p >= ct.nr_normal) break;
                     const int j = ct.nr_artificial + p;
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
     for (int i = threadIdx.x; i < m; i += kSingleBlock) {
         double v = 0.0;
         if (kind == 0) {
-            if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
+            if (i < ct.nr_constraints) v = A ? A[(int64_t)p * ld_a + i] : 0.0;
             else if (i == r0) v = 1.0;
         } else {
             if (i == r0) v = sgn;
@@ -283,7 +304,122 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
         }
         aq[i] = v;
     }
+    if (kind == 0 && !A) {
+        // sparse structural column: scatter its CSC entries over the zero fill
+        __syncthreads();
+        const int64_t s0 = csc.col_ptr[p], s1 = csc.col_ptr[p + 1];
+        for (int64_t e = s0 + threadIdx.x; e < s1; e += kSingleBlock) aq[csc.row_idx[e]] = csc.values[e];
+    }
 }
+
+// aq := tableau column rec->q built from the CSC matrix (k_build_column for the LU engine)
+__global__ void k_build_column_csc(DeviceCSC csc, ColumnTable ct, int m, double* __restrict__ aq, const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    // single workgroup: zero fill, then scatter
+    const int q = rec->q;
+    int kind = 1, p = 0, r0 = -1, r1 = -1;
+    double sgn = 1.0;
+    if (q < ct.nr_artificial) r0 = ct.column_to_row[q];
+    else {
+        p = q - ct.nr_artificial;
+        if (p < ct.nr_normal) { kind = 0; r0 = ct.bound_row[p]; }
+        else { const int vv = p - ct.nr_normal; r0 = ct.vrow0[vv]; r1 = ct.vrow1[vv]; sgn = (double)ct.vsign[vv]; }
+    }
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        double v = 0.0;
+        if (kind == 0) { if (i == r0) v = 1.0; }
+        else { if (i == r0) v = sgn; else if (i == r1) v = 1.0; }
+        aq[i] = v;
+    }
+    if (kind == 0) {
+        __syncthreads();
+        const int64_t s0 = csc.col_ptr[p], s1 = csc.col_ptr[p + 1];
+        for (int64_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) aq[csc.row_idx[e]] = csc.values[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sparse LU engine: CSC PRICE and the level-scheduled triangular solves
+// ------------------------------------------------------------------------------------------------
+// d_j = c_j + sum_i (-pi)_i a_ij over the stored entries of column j (vector/dense.rs:81-92), thread per
+// column; the workgroup's best (key, j) goes to the PRICE partials.
+__global__ __launch_bounds__(kThreads) void k_price_csc(DeviceCSC csc, ColumnTable ct, const double* __restrict__ vec,
+                                                        double* __restrict__ d, int p_lo, int p_hi, int cost_mode,
+                                                        SelectPartials sp, const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    const int p = p_lo + blockIdx.x * kThreads + threadIdx.x;
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (p < p_hi) {
+        double v = 0.0;
+        const int64_t s0 = csc.col_ptr[p], s1 = csc.col_ptr[p + 1];
+        for (int64_t e = s0; e < s1; ++e) v = fma(vec[csc.row_idx[e]], csc.values[e], v);
+        const int br = ct.bound_row[p];
+        if (br >= 0) v += vec[br];
+        if (cost_mode == 2) v += ct.cost[p];
+        const int j = ct.nr_artificial + p;
+        d[j] = v;
+        if (sp.k1 && !sp.in_basis[j] && v < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, v); kj = j; }
+    }
+    if (sp.k1) block_partial_min(key, kj, sp, sp.offset + blockIdx.x);
+}
+
+// x[k] := (x[k] - sum_e val[e] x[idx[e]]) / diag[k], level by level (rows of a level are independent)
+__device__ __forceinline__ void solve_schedule(const DeviceSchedule& s, double* x) {
+    for (int lev = 0; lev < s.n_levels; ++lev) {
+        const int t0 = s.level_ptr[lev], t1 = s.level_ptr[lev + 1];
+        for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+            const int k = s.level_rows[t];
+            double sum = x[k];
+            const int e0 = s.ptr[k], e1 = s.ptr[k + 1];
+            for (int e = e0; e < e1; ++e) sum = fma(-s.val[e], x[s.idx[e]], sum);
+            x[k] = sum / s.diag[k];
+        }
+        __syncthreads();
+    }
+}
+
+static constexpr int kLuLdsDoubles = 8192;   // work vector in LDS up to m = 8192 (64 KB)
+
+// FTRAN (lower_upper/mod.rs:157-190 without the update loop: the updates live in W): P a -> L -> U -> Q
+__global__ __launch_bounds__(kSingleBlock) void k_lu_ftran(DeviceLU lu, const double* __restrict__ aq,
+                                                           double* __restrict__ v, double* __restrict__ scratch,
+                                                           const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_x[kLuLdsDoubles];
+    double* x = lu.m <= kLuLdsDoubles ? s_x : scratch;
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) x[k] = aq[lu.rowperm[k]];
+    __syncthreads();
+    solve_schedule(lu.Lf, x);
+    solve_schedule(lu.Uf, x);
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) v[lu.colperm[k]] = x[k];
+}
+
+// BTRAN (lower_upper/mod.rs:204-222): z' B = c'  ->  U' t = Q' c, L' w = t, z = P' w
+__global__ __launch_bounds__(kSingleBlock) void k_lu_btran(DeviceLU lu, DeferredUpdate du, const double* __restrict__ rhs,
+                                                           int row, double* __restrict__ rho, double* __restrict__ scratch,
+                                                           const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    __shared__ double s_x[kLuLdsDoubles];
+    double* x = lu.m <= kLuLdsDoubles ? s_x : scratch;
+    const int r = row >= 0 ? row : rec->r;
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) {
+        const int cp = lu.colperm[k];
+        double c;
+        if (rhs) c = rhs[cp];
+        else {
+            // c = e_r + sum_j W[r, j] e_S[j]   (the pivot row of (I + W S') B0inv)
+            c = (cp == r) ? 1.0 : 0.0;
+            if (du.kmax > 0) { const int jt = du.pos_of_row[cp]; if (jt >= 0) c += du.W[(int64_t)jt * du.ld + r]; }
+        }
+        x[k] = c;
+    }
+    __syncthreads();
+    solve_schedule(lu.Ub, x);
+    solve_schedule(lu.Lb, x);
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) rho[lu.rowperm[k]] = x[k];
+}
+
 
 // Single-workgroup selection over the reduced costs.  key = (k1, j) lexicographic minimum:
 //   SteepestDescent: k1 = d_j (strict `<` => lowest j wins ties, pivot_rule.rs:118)
@@ -817,27 +953,6 @@ __global__ __launch_bounds__(kThreads) void k_tab_price_init(TableauView tv, con
     block_multi_dot(tv.T0, tv.ld_t, tv.m, v0, tv.c_hi, w, s_partial, dot);
     const int c = v0 + threadIdx.x;
     if (threadIdx.x < kVecPerBlock && c < tv.c_hi) tv.d[c] = cost_store[c] - dot;
-}
-
-// Workgroup-level (key, j) minimum of one candidate per thread -> partial slot `slot`.
-__device__ __forceinline__ void block_partial_min(double key, int kj, SelectPartials sp, int slot) {
-    __shared__ double s_k[kThreads / 64];
-    __shared__ int s_j[kThreads / 64];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ok = __shfl_down(key, off, 64);
-        const int oj = __shfl_down(kj, off, 64);
-        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_k[wave] = key; s_j[wave] = kj; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kThreads / 64; ++w)
-            if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
-        sp.k1[slot] = key;
-        sp.j[slot] = kj;
-    }
 }
 
 // one slot per 256 storage columns
@@ -1415,7 +1530,8 @@ void launch_price_virtual_sel(const ColumnTable& ct, const double* minus_pi, dou
 
 void launch_select_partials(SelectPartials sp, int32_t count, const double* d, const double* A, int64_t ld_a,
                             const ColumnTable& ct, int32_t m, double* aq, PivotRecord* rec, hipStream_t s) {
-    hipLaunchKernelGGL(k_select_partials, dim3(1), dim3(kSingleBlock), 0, s, sp, count, d, A, ld_a, ct, m, aq, rec);
+    hipLaunchKernelGGL(k_select_partials, dim3(1), dim3(kSingleBlock), 0, s, sp, count, d, A, ld_a, DeviceCSC{}, ct, m, aq,
+                       rec);
 }
 
 void launch_ratio_eta(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
@@ -1603,6 +1719,36 @@ void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row
                     hipStream_t s) {
     if (tv.c_hi <= tv.c_lo) return;
     hipLaunchKernelGGL(k_tab_row, dim3(tab_scan_blocks(tv.c_hi - tv.c_lo)), dim3(kThreads), 0, s, tv, du, row, out, rec);
+}
+
+int32_t price_csc_blocks(int32_t p_lo, int32_t p_hi) { return p_hi > p_lo ? cdiv(p_hi - p_lo, kThreads) : 0; }
+
+void launch_price_csc(const DeviceCSC& csc, const ColumnTable& ct, const double* vec, double* d, int32_t p_lo,
+                      int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec, hipStream_t s) {
+    const int blocks = price_csc_blocks(p_lo, p_hi);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_price_csc, dim3(blocks), dim3(kThreads), 0, s, csc, ct, vec, d, p_lo, p_hi, cost_mode, sp, rec);
+}
+
+void launch_select_partials_csc(SelectPartials sp, int32_t count, const double* d, const DeviceCSC& csc,
+                                const ColumnTable& ct, int32_t m, double* aq, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_partials, dim3(1), dim3(kSingleBlock), 0, s, sp, count, d, (const double*)nullptr,
+                       (int64_t)0, csc, ct, m, aq, rec);
+}
+
+void launch_build_column_csc(const DeviceCSC& csc, const ColumnTable& ct, int32_t m, double* aq, const PivotRecord* rec,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(k_build_column_csc, dim3(1), dim3(kSingleBlock), 0, s, csc, ct, m, aq, rec);
+}
+
+void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* scratch, const PivotRecord* rec,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_lu_ftran, dim3(1), dim3(kSingleBlock), 0, s, lu, aq, v, scratch, rec);
+}
+
+void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double* rhs, int32_t row, double* rho,
+                     double* scratch, const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_lu_btran, dim3(1), dim3(kSingleBlock), 0, s, lu, du, rhs, row, rho, scratch, rec);
 }
 
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {

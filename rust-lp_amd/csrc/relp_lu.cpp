@@ -1,0 +1,159 @@
+// relp_lu.cpp -- host-side sparse LU (P B Q = L U) with Markowitz-style pivoting and the level
+// schedules for the device triangular solves.  See relp_lu.hpp.
+#include "relp_lu.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <tuple>
+
+namespace relp {
+
+namespace {
+
+struct Entry { int32_t row, pos; double val; };   // L entry: (original row, pivot step of the column, factor)
+
+// rows[k] = list of (dependency, value); `ascending`: dependencies have smaller indices (solve 0..m-1),
+// otherwise larger (solve m-1..0).
+void build_schedule(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& rows,
+                    const std::vector<double>& diag, bool ascending, TriangularSchedule* s) {
+    s->ptr.assign(m + 1, 0);
+    for (int32_t k = 0; k < m; ++k) s->ptr[k + 1] = s->ptr[k] + (int32_t)rows[k].size();
+    s->idx.resize(s->ptr[m]);
+    s->val.resize(s->ptr[m]);
+    for (int32_t k = 0; k < m; ++k) {
+        int32_t o = s->ptr[k];
+        for (auto& e : rows[k]) { s->idx[o] = e.first; s->val[o] = e.second; ++o; }
+    }
+    s->diag = diag;
+    std::vector<int32_t> lev(m, 0);
+    int32_t nlev = 0;
+    auto visit = [&](int32_t k) {
+        int32_t l = 0;
+        for (auto& e : rows[k]) l = std::max(l, lev[e.first] + 1);
+        lev[k] = l;
+        nlev = std::max(nlev, l + 1);
+    };
+    if (ascending) for (int32_t k = 0; k < m; ++k) visit(k);
+    else for (int32_t k = m - 1; k >= 0; --k) visit(k);
+    s->level_ptr.assign(nlev + 1, 0);
+    for (int32_t k = 0; k < m; ++k) ++s->level_ptr[lev[k] + 1];
+    for (int32_t l = 0; l < nlev; ++l) s->level_ptr[l + 1] += s->level_ptr[l];
+    s->level_rows.resize(m);
+    std::vector<int32_t> fill(s->level_ptr.begin(), s->level_ptr.end() - 1);
+    for (int32_t k = 0; k < m; ++k) s->level_rows[fill[lev[k]]++] = k;
+}
+
+}  // namespace
+
+bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
+               std::string* err) {
+    std::vector<std::vector<std::pair<int32_t, double>>> rows(m);       // active submatrix, row major: (column, value)
+    std::vector<std::vector<int32_t>> colrows(m);                       // rows that (may) hold an entry of the column
+    std::vector<int32_t> ccount(m, 0);
+    for (int32_t j = 0; j < m; ++j)
+        for (auto& e : columns[j]) {
+            if (e.second == 0.0) continue;
+            rows[e.first].emplace_back(j, e.second);
+            colrows[j].push_back(e.first);
+            ++ccount[j];
+        }
+    std::vector<char> row_done(m, 0);
+    std::vector<int32_t> step_of_row(m, -1), step_of_col(m, -1);
+    out->m = m;
+    out->rowperm.assign(m, 0);
+    out->colperm.assign(m, 0);
+    std::vector<std::vector<std::pair<int32_t, double>>> urows(m);      // U row of step k: (original column, value)
+    std::vector<double> udiag(m, 1.0);
+    std::vector<Entry> lent;
+    std::vector<int32_t> mark(m, -1), pos(m, 0);
+    int32_t stamp = 0;
+
+    for (int32_t k = 0; k < m; ++k) {
+        // pivot row: the sparsest active row (ties: lowest index)
+        int32_t pi = -1;
+        for (int32_t i = 0; i < m; ++i) {
+            if (row_done[i]) continue;
+            if (rows[i].empty()) { if (err) *err = "singular basis (empty row during LU)"; return false; }
+            if (pi < 0 || rows[i].size() < rows[pi].size()) pi = i;
+        }
+        // pivot column inside it: the sparsest column among the numerically acceptable entries
+        double rmax = 0.0;
+        for (auto& e : rows[pi]) rmax = std::max(rmax, std::fabs(e.second));
+        int32_t pj = -1; double pv = 0.0;
+        for (auto& e : rows[pi]) {
+            if (std::fabs(e.second) < 1e-2 * rmax || e.second == 0.0) continue;
+            if (pj < 0 || ccount[e.first] < ccount[pj] || (ccount[e.first] == ccount[pj] && e.first < pj)) { pj = e.first; pv = e.second; }
+        }
+        if (pj < 0) { if (err) *err = "singular basis (no acceptable pivot)"; return false; }
+        out->rowperm[k] = pi; out->colperm[k] = pj;
+        step_of_row[pi] = k; step_of_col[pj] = k;
+        row_done[pi] = 1;
+        udiag[k] = pv;
+        for (auto& e : rows[pi]) { --ccount[e.first]; if (e.first != pj) urows[k].push_back(e); }
+        const std::vector<std::pair<int32_t, double>>& prow = urows[k];
+        // eliminate column pj from the other active rows
+        for (int32_t i : colrows[pj]) {
+            if (row_done[i]) continue;
+            auto& ri = rows[i];
+            double vij = 0.0; bool has = false;
+            for (auto& e : ri) if (e.first == pj) { vij = e.second; has = true; break; }
+            if (!has) continue;                                   // stale list entry
+            const double f = vij / pv;
+            lent.push_back(Entry{i, k, f});
+            ++stamp;
+            std::vector<std::pair<int32_t, double>> nr;
+            nr.reserve(ri.size() + prow.size());
+            for (auto& e : ri) {
+                if (e.first == pj) continue;
+                mark[e.first] = stamp; pos[e.first] = (int32_t)nr.size();
+                nr.push_back(e);
+            }
+            for (auto& e : prow) {
+                if (mark[e.first] == stamp) nr[pos[e.first]].second -= f * e.second;
+                else {
+                    mark[e.first] = stamp; pos[e.first] = (int32_t)nr.size();
+                    nr.emplace_back(e.first, -f * e.second);
+                    colrows[e.first].push_back(i);
+                    ++ccount[e.first];
+                }
+            }
+            size_t o = 0;
+            for (auto& e : nr) {
+                if (e.second == 0.0) { --ccount[e.first]; continue; }        // exact cancellation (decomposition/mod.rs:178)
+                nr[o++] = e;
+            }
+            nr.resize(o);
+            ri.swap(nr);
+        }
+        rows[pi].clear();
+    }
+
+    // L and U in pivot-step coordinates
+    std::vector<std::vector<std::pair<int32_t, double>>> lrows(m), lcols(m), urows_s(m), ucols(m);
+    for (auto& e : lent) {
+        const int32_t k = step_of_row[e.row];
+        lrows[k].emplace_back(e.pos, e.val);          // L[k, l], l < k
+        lcols[e.pos].emplace_back(k, e.val);          // column l of L: rows k > l
+    }
+    for (int32_t k = 0; k < m; ++k)
+        for (auto& e : urows[k]) {
+            const int32_t l = step_of_col[e.first];
+            urows_s[k].emplace_back(l, e.second);     // U[k, l], l > k
+            ucols[l].emplace_back(k, e.second);       // column l of U: rows k < l
+        }
+    for (auto& v : lrows) std::sort(v.begin(), v.end());
+    for (auto& v : lcols) std::sort(v.begin(), v.end());
+    for (auto& v : urows_s) std::sort(v.begin(), v.end());
+    for (auto& v : ucols) std::sort(v.begin(), v.end());
+    std::vector<double> ones(m, 1.0);
+    build_schedule(m, lrows, ones, true, &out->Lf);
+    build_schedule(m, urows_s, udiag, false, &out->Uf);
+    build_schedule(m, ucols, udiag, true, &out->Ub);
+    build_schedule(m, lcols, ones, false, &out->Lb);
+    out->nnz_l = (int64_t)lent.size();
+    out->nnz_u = 0;
+    for (auto& v : urows) out->nnz_u += (int64_t)v.size() + 1;
+    return true;
+}
+
+}  // namespace relp

@@ -1,0 +1,48 @@
+// relp_lu.hpp -- host-side sparse LU factorisation of the basis (P B Q = L U) and the level
+// schedules the device solves use.
+//
+// Reference: tableau/inverse_maintenance/carry/lower_upper/decomposition/mod.rs:27-138 (right-looking
+// elimination on a row-major working copy) and decomposition/pivoting.rs:45-81 (Markowitz: minimise
+// (row count - 1)(column count - 1)).  This runs at every refactorisation (lower_upper/mod.rs:199-202:
+// after more than 10 updates; carry/mod.rs:602-614 re-inverts from the original columns).
+// f64 differences, none of which changes a pivot decision of the simplex (B^-1 a_q is the same vector
+// up to rounding): the pivot search looks at the sparsest active row first and takes its sparsest
+// column among the entries within 1e-2 of the row maximum (threshold pivoting; the reference has exact
+// arithmetic and needs no threshold, and its exhaustive search over all remaining entries is O(nnz) per
+// step, pivoting.rs:59).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace relp {
+
+// One triangular factor in the "pull" form the device kernel uses: row k lists the entries
+// (idx, val) it must subtract before it is final, rows are grouped into levels (all rows of a level
+// depend only on rows of earlier levels).
+struct TriangularSchedule {
+    std::vector<int32_t> ptr;        // m + 1
+    std::vector<int32_t> idx;        // position (pivot step) of the other unknown
+    std::vector<double>  val;
+    std::vector<double>  diag;       // m (1.0 for the unit-diagonal factor)
+    std::vector<int32_t> level_ptr;  // n_levels + 1
+    std::vector<int32_t> level_rows; // rows sorted by level
+};
+
+struct LUFactors {
+    int32_t m = 0;
+    std::vector<int32_t> rowperm;    // pivot step k -> original row
+    std::vector<int32_t> colperm;    // pivot step k -> basis position (column of B)
+    TriangularSchedule Lf;           // FTRAN: L y = P a         (rows of L)
+    TriangularSchedule Uf;           // FTRAN: U x = y           (rows of U, solved from the back)
+    TriangularSchedule Ub;           // BTRAN: U' t = Q' c       (columns of U)
+    TriangularSchedule Lb;           // BTRAN: L' z = t          (columns of L, solved from the back)
+    int64_t nnz_l = 0, nnz_u = 0;
+};
+
+// columns[j] = sorted sparse column j of the basis matrix B (m columns over m rows).
+// Returns false (and a message) when B is numerically singular.
+bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
+               std::string* err);
+
+}  // namespace relp

@@ -35,7 +35,7 @@ OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded",
  K_UPDATE_W, K_FLUSH) = range(10)
 KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
                 "apply_w", "update_w", "flush"]
-ENGINE_REVISED, ENGINE_TABLEAU = 0, 1          # relp_engine_kind_t
+ENGINE_REVISED, ENGINE_TABLEAU, ENGINE_LU = 0, 1, 2   # relp_engine_kind_t
 FORMAT_CSC, FORMAT_DENSE = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 

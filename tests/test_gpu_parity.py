@@ -34,8 +34,10 @@ def dense_problem(m, n, seed):
 # deferred update folded in every K pivots (K = 3 forces frequent flushes and repeated pivot rows)
 BLOCKS = [0, 3, 64]
 # engine kinds: revised (explicit / deferred inverse) and the dense tableau (always blocked)
+# and the sparse LU engine (block = pivots between refactorisations; 1 = refactor at every pivot)
 KINDS = [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 3), (engine.ENGINE_REVISED, 64),
-         (engine.ENGINE_TABLEAU, 3), (engine.ENGINE_TABLEAU, 64)]
+         (engine.ENGINE_TABLEAU, 3), (engine.ENGINE_TABLEAU, 64),
+         (engine.ENGINE_LU, 1), (engine.ENGINE_LU, 3), (engine.ENGINE_LU, 64)]
 
 
 @pytest.mark.parametrize("kind,block", KINDS)
@@ -53,7 +55,8 @@ def test_dense_trace_matches_f64_oracle(m, n, seed, kind, block):
     assert ident <= 1e-8 and basic <= 1e-8 and min_b >= -1e-9
 
 
-@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 16), (engine.ENGINE_TABLEAU, 16)])
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 16), (engine.ENGINE_TABLEAU, 16),
+                                        (engine.ENGINE_LU, 11)])
 @pytest.mark.parametrize("m,n,seed", [(8, 8, 1), (32, 48, 7), (128, 128, 20250001)])
 def test_dense_trace_matches_exact_oracle(m, n, seed, kind, block):
     """Parity shadows of config C2: the f64 GPU pivot sequence equals the exact-rational trace."""
@@ -74,7 +77,8 @@ def test_dense_trace_matches_exact_oracle(m, n, seed, kind, block):
 
 
 @pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 5), (engine.ENGINE_REVISED, 64),
-                                        (engine.ENGINE_TABLEAU, 5), (engine.ENGINE_TABLEAU, 64)])
+                                        (engine.ENGINE_TABLEAU, 5), (engine.ENGINE_TABLEAU, 64),
+                                        (engine.ENGINE_LU, 1), (engine.ENGINE_LU, 5), (engine.ENGINE_LU, 64)])
 @pytest.mark.parametrize("m,n,seed", [(20, 30, 5), (60, 90, 2), (150, 220, 9)])
 def test_sparse_two_phase_matches_f64_oracle(m, n, seed, kind, block):
     """==, <=, >= rows and upper bounds: phase 1 (FirstProfitableWithMemory), the phase switch and
@@ -90,7 +94,8 @@ def test_sparse_two_phase_matches_f64_oracle(m, n, seed, kind, block):
         assert_state_close(t, ref)
 
 
-@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 4), (engine.ENGINE_TABLEAU, 4)])
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 4), (engine.ENGINE_TABLEAU, 4),
+                                        (engine.ENGINE_LU, 4)])
 def test_stepwise_api_matches_loop(kind, block):
     """The step-by-step entry points (select column / generate column / select row / bring into
     basis) walk the same path as relp_run."""
@@ -116,7 +121,7 @@ def test_stepwise_api_matches_loop(kind, block):
     assert abs(t.objective_function_value() - loop.objective_function_value()) <= 1e-12 * abs(loop.objective_function_value())
 
 
-@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU])
+@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU, engine.ENGINE_LU])
 def test_relative_costs_and_generate_element(kind):
     md = dense_problem(24, 36, 21)
     t = engine.Tableau(md, update_block=4, engine=kind)
@@ -323,7 +328,8 @@ def test_adlittle_gpu_pivot_sequence_equals_exact_trace():
     tr = []
     status, obj, sol = exact_solve(gf, emd, trace=tr.append)
     assert status == "optimal" and obj == Fr(24975305659811992079614961229, 120651674036153428931840)
-    for kind, block in ((engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 8), (engine.ENGINE_TABLEAU, 8)):
+    for kind, block in ((engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 8), (engine.ENGINE_TABLEAU, 8),
+                        (engine.ENGINE_LU, 11)):
         t = engine.Tableau(md, trace_capacity=4096, update_block=block, engine=kind)
         assert t.solve_relaxation() == engine.OPTIMAL
         assert t.trace() == [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
@@ -347,7 +353,7 @@ FILES = [("burkardt/afiro.mps", False, -406659 / 875, 1e-9), ("burkardt/testprob
          ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3), ("miplib/50v-10.mps", False, 2879.065687, 1e-3)]
 
 
-@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU])
+@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU, engine.ENGINE_LU])
 @pytest.mark.parametrize("path,fixed,objective,tol", FILES)
 def test_reference_problem_files_on_gpu(path, fixed, objective, tol, kind):
     """The reference's own problem files (tests/{burkardt,cook,netlib,miplib}) through the GPU engine:
@@ -355,7 +361,7 @@ def test_reference_problem_files_on_gpu(path, fixed, objective, tol, kind):
     reference's tolerance."""
     from lp_files import load
     gf, ex, md, emd = load(path, fixed=fixed)
-    t = engine.Tableau(md, trace_capacity=1 << 15, engine=kind, update_block=32 if kind == engine.ENGINE_TABLEAU else -1)
+    t = engine.Tableau(md, trace_capacity=1 << 15, engine=kind, update_block={engine.ENGINE_TABLEAU: 32, engine.ENGINE_LU: 11}.get(kind, -1))
     outcome = t.solve_relaxation()
     assert outcome == engine.OPTIMAL
     ref = relp_f64.OracleF64(md)
@@ -396,3 +402,65 @@ def test_c2_full_solve_both_engines_agree_to_optimality():
         objs.append(t.objective_function_value())
     assert traces[0] == traces[1] and len(traces[0]) > 1000
     assert abs(objs[0] - objs[1]) <= 1e-11 * abs(objs[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# Sparse LU engine (Carry<_, LUDecomposition<_>>)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path,fixed", [("burkardt/adlittle.mps", False), ("netlib/SC205.SIF", True), ("netlib/SHARE1B.SIF", True)])
+def test_lu_from_basis_restarts_at_the_optimum(path, fixed):
+    """InverseMaintener::from_basis (carry/mod.rs:428-463) with a general basis: the LU engine factorises
+    the optimal basis found by the revised engine and reports optimality without a single pivot, with the
+    same b, -pi and objective."""
+    from lp_files import load
+    gf, ex, md, emd = load(path, fixed=fixed)
+    first = engine.Tableau(md)
+    assert first.solve_relaxation() == engine.OPTIMAL
+    basis = first.basis_indices()
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=64)
+    if t.nr_rows() != first.nr_rows():
+        pytest.skip("phase 1 removed redundant rows: the basis refers to the reduced problem")
+    t.from_basis(basis)
+    done, outcome = t.run(1 << 20)
+    assert (done, outcome) == (0, engine.OPTIMAL)
+    assert abs(t.objective_function_value() - first.objective_function_value()) <= 1e-9 * max(1.0, abs(first.objective_function_value()))
+    np.testing.assert_allclose(t.b(), first.b(), rtol=1e-7, atol=1e-7 * max(1.0, np.max(np.abs(first.b()))))
+    scale = max(1.0, np.max(np.abs(first.minus_pi())))
+    np.testing.assert_allclose(t.minus_pi(), first.minus_pi(), rtol=1e-7, atol=1e-7 * scale)
+
+
+def test_lu_from_basis_mid_solve_continues_the_same_path():
+    """Warm start from an intermediate basis: the continuation walks the same pivots as the run it was
+    taken from (Dantzig's rule has no memory)."""
+    md = MatrixData.from_sparse_dict(synthetic.sparse_lp(60, 90, 2))
+    full = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=7, trace_capacity=4096)
+    assert full.run(1 << 20)[1] == engine.PHASE_ONE_DONE
+    start = len(full.trace())
+    assert full.run(10)[0] == 10
+    if full.nr_rows() != engine.Tableau(md, engine=engine.ENGINE_LU).nr_rows():
+        pytest.skip("rows were removed at the phase switch")
+    basis = full.basis_indices()
+    assert full.run(1 << 20)[1] == engine.OPTIMAL
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=7, trace_capacity=4096)
+    t.from_basis(basis)
+    assert t.run(1 << 20)[1] == engine.OPTIMAL
+    assert t.trace() == full.trace()[start + 10:]
+    assert abs(t.objective_function_value() - full.objective_function_value()) <= 1e-9 * max(1.0, abs(full.objective_function_value()))
+
+
+def test_lu_engine_large_sparse_matches_revised():
+    """A Netlib-shaped sparse LP (m = 1,500, n = 3,000, ~4 nonzeros per column): the LU engine and the
+    explicit-inverse engine walk the same two-phase pivot sequence; the oracle checks a bounded prefix."""
+    md = MatrixData.from_sparse_dict(synthetic.sparse_lp(1500, 3000, 77))
+    a = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=1 << 16)
+    b = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=0, trace_capacity=1 << 16)
+    oa, ob = a.solve_relaxation(), b.solve_relaxation()
+    assert oa == ob
+    ta, tb = a.trace(), b.trace()
+    assert ta == tb and len(ta) > 100
+    ref = relp_f64.OracleF64(md)
+    ref.run(200, through_phases=True)
+    k = len(ref.trace)
+    assert ta[:k] == ref.trace
+    if oa == engine.OPTIMAL:
+        assert abs(a.objective_function_value() - b.objective_function_value()) <= 1e-9 * max(1.0, abs(b.objective_function_value()))
