@@ -160,6 +160,10 @@ relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
 relp_status_t relp_flush(relp_engine_t *h);
 /* The block size K in effect (0 = explicit rank-1 updates). */
 int32_t       relp_update_block(const relp_engine_t *h);
+/* RELP_ENGINE_LU only: statistics of the current factorisation, out[8] = { refactorisations so far, m,
+ * nnz(L) (off-diagonal), nnz(U) (with diagonal), levels of the four solve schedules L, U (FTRAN) and
+ * U', L' (BTRAN) }.  Levels bound the length of the dependent chain of a triangular solve. */
+relp_status_t relp_lu_stats(const relp_engine_t *h, int64_t *out8);
 
 /* ---- state getters (InverseMaintener accessors, inverse_maintenance/mod.rs:200-266) ----------- */
 int32_t relp_nr_rows(const relp_engine_t *h);

@@ -39,7 +39,7 @@ void Engine::free_all() {
     fr(d_part_k1_); fr(d_part_j_);
     fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
-    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_i_); fr(d_lu_d_); fr(d_lu_scratch_);
+    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
     prof_ev_.clear();
@@ -337,7 +337,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     for (int32_t r = 0; r < m_; ++r) flags[basis[r]] = 1;
     HIP_TRY(up(d_in_basis_, flags.data(), flags.size()));
     // identity rows [row_lo, row_hi): local row i has its 1 in column row_lo + i (BasisInverse::identity)
-    if (row_hi_ > row_lo_ && !tableau_) launch_set_identity(dBinv_, ld_b_, row_lo_, row_hi_, stream_);
+    if (row_hi_ > row_lo_ && !tableau_ && !lu_) launch_set_identity(dBinv_, ld_b_, row_lo_, row_hi_, stream_);
     if (tableau_) {
         // T0 = the original matrix in row space (B = I), d = c - c_B' T0 with the phase-1 costs
         idcol_h_ = basis;                                    // the initial basis column of row k is e_k
@@ -435,42 +435,60 @@ relp_status_t Engine::lu_refactor() {
     }
     std::string msg;
     if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
-    // pack: ints = rowperm, colperm, 4 x (ptr, idx, level_ptr, level_rows); doubles = 4 x (val, diag)
+    // pack everything into one buffer (16-byte aligned pieces): rowperm, colperm, then per schedule the
+    // rows in solve order, the entry indices / values and the level offsets
     const TriangularSchedule* sch[4] = {&hlu_.Lf, &hlu_.Uf, &hlu_.Ub, &hlu_.Lb};
-    std::vector<int32_t> hi; std::vector<double> hd;
-    auto put_i = [&](const std::vector<int32_t>& v) { const int64_t o = (int64_t)hi.size(); hi.insert(hi.end(), v.begin(), v.end()); if (hi.size() & 1) hi.push_back(0); return o; };
-    auto put_d = [&](const std::vector<double>& v) { const int64_t o = (int64_t)hd.size(); hd.insert(hd.end(), v.begin(), v.end()); return o; };
-    const int64_t o_rp = put_i(hlu_.rowperm), o_cp = put_i(hlu_.colperm);
-    int64_t oi[4][4], od[4][2];
+    std::vector<char> buf;
+    auto put = [&](const void* src, size_t bytes) {
+        const size_t o = buf.size();
+        buf.resize(o + (bytes + 15) / 16 * 16);
+        if (bytes) std::memcpy(buf.data() + o, src, bytes);
+        return o;
+    };
+    const size_t o_rp = put(hlu_.rowperm.data(), sizeof(int32_t) * m_), o_cp = put(hlu_.colperm.data(), sizeof(int32_t) * m_);
+    size_t o_rows[4], o_idx[4], o_val[4], o_lp[4];
+    std::vector<LuRow> rows(m_);
     for (int k = 0; k < 4; ++k) {
-        oi[k][0] = put_i(sch[k]->ptr); oi[k][1] = put_i(sch[k]->idx); oi[k][2] = put_i(sch[k]->level_ptr); oi[k][3] = put_i(sch[k]->level_rows);
-        od[k][0] = put_d(sch[k]->val); od[k][1] = put_d(sch[k]->diag);
+        const TriangularSchedule& t = *sch[k];
+        for (int32_t i = 0; i < m_; ++i) {
+            const int32_t r = t.level_rows[i];
+            rows[i] = LuRow{r, t.ptr[r], t.ptr[r + 1], 0, 1.0 / t.diag[r]};
+        }
+        o_rows[k] = put(rows.data(), sizeof(LuRow) * m_);
+        o_idx[k] = put(t.idx.data(), sizeof(int32_t) * t.idx.size());
+        o_val[k] = put(t.val.data(), sizeof(double) * t.val.size());
+        o_lp[k] = put(t.level_ptr.data(), sizeof(int32_t) * t.level_ptr.size());
     }
-    if ((int64_t)hi.size() > lu_i_cap_) {
-        if (d_lu_i_) HIP_TRY(hipFree(d_lu_i_));
-        lu_i_cap_ = (int64_t)hi.size() * 3 / 2 + 64;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_i_), sizeof(int32_t) * lu_i_cap_));
+    if ((int64_t)buf.size() > lu_cap_) {
+        if (d_lu_buf_) HIP_TRY(hipFree(d_lu_buf_));
+        lu_cap_ = (int64_t)buf.size() * 3 / 2 + 256;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_buf_), (size_t)lu_cap_));
     }
-    if ((int64_t)hd.size() > lu_d_cap_) {
-        if (d_lu_d_) HIP_TRY(hipFree(d_lu_d_));
-        lu_d_cap_ = (int64_t)hd.size() * 3 / 2 + 64;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_d_), sizeof(double) * lu_d_cap_));
-    }
-    HIP_TRY(hipMemcpyAsync(d_lu_i_, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, stream_));
-    if (!hd.empty()) HIP_TRY(hipMemcpyAsync(d_lu_d_, hd.data(), sizeof(double) * hd.size(), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_lu_buf_, buf.data(), buf.size(), hipMemcpyHostToDevice, stream_));
     dlu_.m = m_; dlu_.pad_ = 0;
-    dlu_.rowperm = d_lu_i_ + o_rp; dlu_.colperm = d_lu_i_ + o_cp;
+    dlu_.rowperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rp);
+    dlu_.colperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_cp);
     DeviceSchedule* ds[4] = {&dlu_.Lf, &dlu_.Uf, &dlu_.Ub, &dlu_.Lb};
     for (int k = 0; k < 4; ++k) {
-        ds[k]->ptr = d_lu_i_ + oi[k][0]; ds[k]->idx = d_lu_i_ + oi[k][1];
-        ds[k]->level_ptr = d_lu_i_ + oi[k][2]; ds[k]->level_rows = d_lu_i_ + oi[k][3];
-        ds[k]->val = d_lu_d_ + od[k][0]; ds[k]->diag = d_lu_d_ + od[k][1];
-        ds[k]->n_levels = (int32_t)sch[k]->level_ptr.size() - 1; ds[k]->pad_ = 0;
+        ds[k]->rows = reinterpret_cast<const LuRow*>(d_lu_buf_ + o_rows[k]);
+        ds[k]->idx = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_idx[k]);
+        ds[k]->val = reinterpret_cast<const double*>(d_lu_buf_ + o_val[k]);
+        ds[k]->level_ptr = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lp[k]);
+        ds[k]->n_levels = (int32_t)sch[k]->level_ptr.size() - 1;
+        ds[k]->nnz = (int32_t)sch[k]->idx.size();
     }
     launch_flush_reset(deferred(), d_rec_, stream_);
-    HIP_TRY(hipStreamSynchronize(stream_));             // hi / hd are stack-owned
+    HIP_TRY(hipStreamSynchronize(stream_));             // buf is stack-owned
     since_flush_ = 0;
     ++lu_refactors_;
+    return RELP_OK;
+}
+
+relp_status_t Engine::lu_stats(int64_t* out8) const {
+    if (!lu_) return RELP_E_STATE;
+    out8[0] = lu_refactors_; out8[1] = hlu_.m; out8[2] = hlu_.nnz_l; out8[3] = hlu_.nnz_u;
+    out8[4] = (int64_t)hlu_.Lf.level_ptr.size() - 1; out8[5] = (int64_t)hlu_.Uf.level_ptr.size() - 1;
+    out8[6] = (int64_t)hlu_.Ub.level_ptr.size() - 1; out8[7] = (int64_t)hlu_.Lb.level_ptr.size() - 1;
     return RELP_OK;
 }
 
@@ -1289,6 +1307,7 @@ void Engine::shard_ranges(int32_t* col_lo, int32_t* col_hi, int32_t* row_lo, int
 // Tableau engine, one pivot after the candidates were exchanged: ratio test (replicated), row update
 // of the owned columns, W / b / basis update (replicated); the flush is local to the owned columns.
 relp_status_t Engine::shard_pivot() {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     if (!tableau_) return fail(RELP_E_STATE, "relp_shard_pivot is the tableau engine's step");
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     const TableauView tv = tview();
@@ -1342,6 +1361,7 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
 }
 
 relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t count) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     // tableau engine: the winner's payload is the entering tableau column (alpha) itself
     launch_select_candidate(dev_candidates, count, cand_len_, m_, tableau_ ? d_alpha_ : d_aq_, rule, cfg_.tol_tie, d_rec_,
@@ -1389,6 +1409,7 @@ relp_status_t Engine::shard_ratio(const double* dev_alpha_slices, int32_t count,
 }
 
 relp_status_t Engine::shard_flush_begin(double** dev_snapshot, int64_t* len) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     if (len) *len = 0;
     if (block_ == 0) return RELP_OK;
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -1401,6 +1422,7 @@ relp_status_t Engine::shard_flush_begin(double** dev_snapshot, int64_t* len) {
 }
 
 relp_status_t Engine::shard_flush_end() {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     if (block_ == 0) return RELP_OK;
     const DeferredUpdate du = deferred();
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
@@ -1413,6 +1435,7 @@ relp_status_t Engine::shard_flush_end() {
 }
 
 relp_status_t Engine::shard_update(const double* dev_rho) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
     prof_begin(RELP_K_UPDATE_VECTORS);
     launch_update_vectors(m_, d_alpha_, dev_rho, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,

@@ -44,6 +44,7 @@ class Engine {
     relp_status_t from_basis(const int32_t* basis_columns);
     relp_status_t flush();
     int32_t update_block() const { return block_; }
+    relp_status_t lu_stats(int64_t* out8) const;
     relp_status_t shard_flush_begin(double** dev_snapshot, int64_t* len);
     relp_status_t shard_flush_end();
 
@@ -139,8 +140,7 @@ class Engine {
     std::vector<int64_t> hc_ptr_; std::vector<int32_t> hc_idx_; std::vector<double> hc_val_;   // host CSC of A
     int64_t* d_cptr_ = nullptr; int32_t* d_cidx_ = nullptr; double* d_cval_ = nullptr;         // device CSC of A
     LUFactors hlu_;
-    int32_t* d_lu_i_ = nullptr; int64_t lu_i_cap_ = 0;    // packed index arrays of the factors
-    double* d_lu_d_ = nullptr; int64_t lu_d_cap_ = 0;     // packed values
+    char* d_lu_buf_ = nullptr; int64_t lu_cap_ = 0;       // packed factors (permutations, rows, entries, levels)
     double* d_lu_scratch_ = nullptr;
     DeviceLU dlu_{};
     relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop

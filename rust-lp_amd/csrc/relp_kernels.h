@@ -86,9 +86,14 @@ struct SelectPartials {
 };
 
 // ---- sparse LU engine (device side of relp_lu.hpp) ------------------------------------------------
+// One row of a triangular factor in solve order (rows of a level are contiguous): unknown k becomes
+// (x[k] - sum_{e in [e0, e1)} val[e] x[idx[e]]) * diag, diag = 1 / (diagonal entry).
+struct LuRow { int32_t k, e0, e1, pad_; double diag; };
 struct DeviceSchedule {
-    const int32_t* ptr; const int32_t* idx; const double* val; const double* diag;
-    const int32_t* level_ptr; const int32_t* level_rows; int32_t n_levels; int32_t pad_;
+    const LuRow* rows;          // m rows, level by level
+    const int32_t* idx; const double* val;
+    const int32_t* level_ptr;   // n_levels + 1 offsets into rows
+    int32_t n_levels; int32_t nnz;
 };
 struct DeviceLU {
     int32_t m; int32_t pad_;

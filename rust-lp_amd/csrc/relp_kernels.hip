@@ -15,6 +15,9 @@
 //   k_weighted_column_sums                 a10    carry/mod.rs:214-248
 #include "relp_kernels.h"
 
+#include <algorithm>
+#include <vector>
+
 #include <math.h>
 
 namespace relp {
@@ -236,11 +239,24 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
         // workgroups' columns are re-read (8 structural columns, or 256 virtual ones).
         const double bound = k1 + sp.tol_tie * fmax(1.0, fabs(k1));
         int lowest = 0x7fffffff;
+        // slots whose own minimum lies inside the band (normally one or two): listed, then scanned by
+        // the whole workgroup; a long list falls back to one thread per slot
+        constexpr int kListMax = 64;
+        __shared__ int s_list[kListMax];
+        __shared__ int s_cnt;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
         for (int t = threadIdx.x; t < count; t += kSingleBlock) {
             if (!(sp.k1[t] <= bound)) continue;
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < kListMax) s_list[pos] = t;
+        }
+        __syncthreads();
+        const int listed = s_cnt;
+        auto scan_slot = [&](int t, int u0, int ustep) {
             if (t < sp.nb_struct) {
                 const int p0 = sp.p_lo + t * sp.cols_per_slot;
-                for (int u = 0; u < sp.cols_per_slot; ++u) {
+                for (int u = u0; u < sp.cols_per_slot; u += ustep) {
                     const int p = p0 + u;
                     if (p >= ct.nr_normal) break;
                     const int j = ct.nr_artificial + p;
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
                 }
             } else {
                 const int v0 = (t - sp.nb_struct) * kThreads;
-                for (int u = 0; u < kThreads; ++u) {
+                for (int u = u0; u < kThreads; u += ustep) {
                     const int vt = v0 + u;
                     if (vt >= ct.nr_artificial + ct.nr_virtual) break;
                     const int j = vt < ct.nr_artificial ? vt : ct.nr_artificial + ct.nr_normal + (vt - ct.nr_artificial);
@@ -257,6 +273,12 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
                     if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
                 }
             }
+        };
+        if (listed <= kListMax) {
+            for (int i = 0; i < listed; ++i) scan_slot(s_list[i], threadIdx.x, kSingleBlock);
+        } else {
+            for (int t = threadIdx.x; t < count; t += kSingleBlock)
+                if (sp.k1[t] <= bound) scan_slot(t, 0, 1);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
@@ -364,45 +386,132 @@ __global__ __launch_bounds__(kThreads) void k_price_csc(DeviceCSC csc, ColumnTab
     if (sp.k1) block_partial_min(key, kj, sp, sp.offset + blockIdx.x);
 }
 
-// x[k] := (x[k] - sum_e val[e] x[idx[e]]) / diag[k], level by level (rows of a level are independent)
-__device__ __forceinline__ void solve_schedule(const DeviceSchedule& s, double* x) {
-    for (int lev = 0; lev < s.n_levels; ++lev) {
-        const int t0 = s.level_ptr[lev], t1 = s.level_ptr[lev + 1];
-        for (int t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-            const int k = s.level_rows[t];
-            double sum = x[k];
-            const int e0 = s.ptr[k], e1 = s.ptr[k + 1];
-            for (int e = e0; e < e1; ++e) sum = fma(-s.val[e], x[s.idx[e]], sum);
-            x[k] = sum / s.diag[k];
+// ---- level-scheduled triangular solves ---------------------------------------------------------------
+// One persistent workgroup of 256 threads.  The work vector lives in LDS; when the factor itself fits
+// next to it (the usual case for Netlib-sized bases) its rows and entries are staged into LDS first, so
+// that a level costs an LDS round trip and a barrier instead of a chain of dependent global loads.
+// 8 to 64 lanes share one row (coalesced entry loads, DPP reduction), and each group fetches its
+// first row of the NEXT level - row header and first entries do not depend on x - before it waits at
+// the barrier of the current one.
+static constexpr int kLuThreads = 256;          // 4 wavefronts: cheap barriers, 32 rows per pass
+static constexpr int kLuLdsBytes = 156 * 1024;        // of the CU's 160 KB
+
+__host__ __device__ inline int64_t lu_up16(int64_t b) { return (b + 15) / 16 * 16; }
+// bytes needed to hold a schedule (m rows, nnz entries) in LDS
+__host__ __device__ inline int64_t schedule_lds_bytes(int m, int64_t nnz, int n_levels) {
+    return lu_up16((int64_t)sizeof(LuRow) * m) + lu_up16(8 * nnz) + lu_up16(4 * nnz) + lu_up16(4 * ((int64_t)n_levels + 1));
+}
+
+// Sum over the 8 lanes of a group, result valid in the group's lane 0.  DPP row shifts (lane i reads lane
+// i + n inside its row of 16) instead of LDS-routed shuffles: the reduction sits on the critical path of
+// every level.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_row_shl(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the G lanes of a group (G = 8, 16, 32 or 64, uniform over the workgroup); valid in lane 0.
+__device__ __forceinline__ double group_sum(double v, int G) {
+    if (G >= 64) v += __shfl_down(v, 32, 64);
+    if (G >= 32) v += __shfl_down(v, 16, 64);
+    if (G >= 16) v += dpp_row_shl<0x108>(v);
+    v += dpp_row_shl<0x104>(v);
+    v += dpp_row_shl<0x102>(v);
+    v += dpp_row_shl<0x101>(v);
+    return v;
+}
+// Lanes per row for a level of `rows` rows: a level with few rows (the dense rows of the bump come one
+// per level) gets a whole wavefront per row.
+__device__ __forceinline__ int group_lanes(int rows) {
+    return rows <= kLuThreads / 64 ? 64 : rows <= kLuThreads / 32 ? 32 : rows <= kLuThreads / 16 ? 16 : 8;
+}
+
+// kStage: copy the schedule into LDS at `base` and solve from there; otherwise solve from global memory.
+template <bool kStage>
+__device__ __forceinline__ void solve_schedule(const DeviceSchedule& s, int m, char* base, double* x) {
+    const LuRow* rows = s.rows; const int32_t* idx = s.idx; const double* val = s.val; const int32_t* level_ptr = s.level_ptr;
+    if (kStage) {
+        LuRow* l_rows = reinterpret_cast<LuRow*>(base); base += lu_up16((int64_t)sizeof(LuRow) * m);
+        double* l_val = reinterpret_cast<double*>(base); base += lu_up16(8 * (int64_t)s.nnz);
+        int32_t* l_idx = reinterpret_cast<int32_t*>(base); base += lu_up16(4 * (int64_t)s.nnz);
+        int32_t* l_lp = reinterpret_cast<int32_t*>(base);
+        for (int e = threadIdx.x; e < s.nnz; e += blockDim.x) { l_val[e] = s.val[e]; l_idx[e] = s.idx[e]; }
+        for (int k = threadIdx.x; k < m; k += blockDim.x) l_rows[k] = s.rows[k];
+        for (int k = threadIdx.x; k <= s.n_levels; k += blockDim.x) l_lp[k] = s.level_ptr[k];
+        __syncthreads();
+        rows = l_rows; idx = l_idx; val = l_val; level_ptr = l_lp;
+    }
+    const int n_levels = s.n_levels;
+    const int tid = threadIdx.x;
+    // prefetched first row of the level about to be solved
+    int t0 = level_ptr[0], t1 = level_ptr[1];
+    int G = group_lanes(t1 - t0);
+    LuRow pr{0, 0, 0, 0, 1.0};
+    int pidx = 0; double pval = 0.0;
+    bool have = t0 + tid / G < t1;
+    if (have) {
+        pr = rows[t0 + tid / G];
+        if (pr.e0 + tid % G < pr.e1) { pidx = idx[pr.e0 + tid % G]; pval = val[pr.e0 + tid % G]; }
+    }
+    for (int lev = 0; lev < n_levels; ++lev) {
+        const LuRow cr = pr; const int cidx = pidx; const double cval = pval; const bool chave = have;
+        const int ct0 = t0, ct1 = t1, cG = G;
+        const int g = tid / cG, lane = tid % cG, ngroups = kLuThreads / cG;
+        if (lev + 1 < n_levels) {
+            t0 = t1; t1 = level_ptr[lev + 2];
+            G = group_lanes(t1 - t0);
+            have = t0 + tid / G < t1; pval = 0.0; pidx = 0;
+            if (have) {
+                pr = rows[t0 + tid / G];
+                if (pr.e0 + tid % G < pr.e1) { pidx = idx[pr.e0 + tid % G]; pval = val[pr.e0 + tid % G]; }
+            }
+        }
+        if (chave) {
+            double sum = (cr.e0 + lane < cr.e1) ? -cval * x[cidx] : 0.0;
+            for (int e = cr.e0 + lane + cG; e < cr.e1; e += cG) sum = fma(-val[e], x[idx[e]], sum);
+            sum = group_sum(sum, cG);
+            if (lane == 0) x[cr.k] = (x[cr.k] + sum) * cr.diag;
+        }
+        for (int t = ct0 + g + ngroups; t < ct1; t += ngroups) {
+            const LuRow r = rows[t];
+            double sum = 0.0;
+            for (int e = r.e0 + lane; e < r.e1; e += cG) sum = fma(-val[e], x[idx[e]], sum);
+            sum = group_sum(sum, cG);
+            if (lane == 0) x[r.k] = (x[r.k] + sum) * r.diag;
         }
         __syncthreads();
     }
 }
 
-static constexpr int kLuLdsDoubles = 8192;   // work vector in LDS up to m = 8192 (64 KB)
-
+// Dynamic LDS: [x : m doubles (kXLds)] [staged schedule].  The variant is chosen by the host from the
+// sizes (plan_lu_lds).
 // FTRAN (lower_upper/mod.rs:157-190 without the update loop: the updates live in W): P a -> L -> U -> Q
-__global__ __launch_bounds__(kSingleBlock) void k_lu_ftran(DeviceLU lu, const double* __restrict__ aq,
+template <bool kXLds, bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_ftran(DeviceLU lu, const double* __restrict__ aq,
                                                            double* __restrict__ v, double* __restrict__ scratch,
                                                            const PivotRecord* rec) {
     if (rec && rec->outcome != DEV_RUNNING) return;
-    __shared__ double s_x[kLuLdsDoubles];
-    double* x = lu.m <= kLuLdsDoubles ? s_x : scratch;
+    extern __shared__ __align__(16) char lds[];
+    double* x = kXLds ? reinterpret_cast<double*>(lds) : scratch;
+    char* base = lds + (kXLds ? lu_up16((int64_t)lu.m * 8) : 0);
     for (int k = threadIdx.x; k < lu.m; k += blockDim.x) x[k] = aq[lu.rowperm[k]];
     __syncthreads();
-    solve_schedule(lu.Lf, x);
-    solve_schedule(lu.Uf, x);
+    solve_schedule<kStage1>(lu.Lf, lu.m, base, x);
+    solve_schedule<kStage2>(lu.Uf, lu.m, base, x);
     for (int k = threadIdx.x; k < lu.m; k += blockDim.x) v[lu.colperm[k]] = x[k];
 }
 
 // BTRAN (lower_upper/mod.rs:204-222): z' B = c'  ->  U' t = Q' c, L' w = t, z = P' w
-__global__ __launch_bounds__(kSingleBlock) void k_lu_btran(DeviceLU lu, DeferredUpdate du, const double* __restrict__ rhs,
+template <bool kXLds, bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_btran(DeviceLU lu, DeferredUpdate du, const double* __restrict__ rhs,
                                                            int row, double* __restrict__ rho, double* __restrict__ scratch,
                                                            const PivotRecord* rec) {
     if (rec && rec->outcome != DEV_RUNNING) return;
-    __shared__ double s_x[kLuLdsDoubles];
-    double* x = lu.m <= kLuLdsDoubles ? s_x : scratch;
-    const int r = row >= 0 ? row : rec->r;
+    extern __shared__ __align__(16) char lds[];
+    double* x = kXLds ? reinterpret_cast<double*>(lds) : scratch;
+    char* base = lds + (kXLds ? lu_up16((int64_t)lu.m * 8) : 0);
+    const int r = rhs ? 0 : (row >= 0 ? row : rec->r);   // rec may be null when rhs or row is given
     for (int k = threadIdx.x; k < lu.m; k += blockDim.x) {
         const int cp = lu.colperm[k];
         double c;
@@ -415,8 +524,8 @@ __global__ __launch_bounds__(kSingleBlock) void k_lu_btran(DeviceLU lu, Deferred
         x[k] = c;
     }
     __syncthreads();
-    solve_schedule(lu.Ub, x);
-    solve_schedule(lu.Lb, x);
+    solve_schedule<kStage1>(lu.Ub, lu.m, base, x);
+    solve_schedule<kStage2>(lu.Lb, lu.m, base, x);
     for (int k = threadIdx.x; k < lu.m; k += blockDim.x) rho[lu.rowperm[k]] = x[k];
 }
 
@@ -1741,14 +1850,52 @@ void launch_build_column_csc(const DeviceCSC& csc, const ColumnTable& ct, int32_
     hipLaunchKernelGGL(k_build_column_csc, dim3(1), dim3(kSingleBlock), 0, s, csc, ct, m, aq, rec);
 }
 
+// LDS plan of one solve kernel: x first, then whichever schedule fits behind it
+struct LuLdsPlan { int x_in_lds, stage_first, stage_second; size_t bytes; };
+static LuLdsPlan plan_lu_lds(int m, const DeviceSchedule& a, const DeviceSchedule& b) {
+    LuLdsPlan p{0, 0, 0, 0};
+    int64_t used = 0;
+    if (lu_up16((int64_t)m * 8) <= kLuLdsBytes / 2) { p.x_in_lds = 1; used = lu_up16((int64_t)m * 8); }
+    const int64_t na = schedule_lds_bytes(m, a.nnz, a.n_levels), nb = schedule_lds_bytes(m, b.nnz, b.n_levels);
+    int64_t extra = 0;
+    if (p.x_in_lds && used + na <= kLuLdsBytes) { p.stage_first = 1; extra = na; }
+    if (p.x_in_lds && used + nb <= kLuLdsBytes) { p.stage_second = 1; extra = std::max(extra, nb); }
+    p.bytes = (size_t)(used + extra);
+    return p;
+}
+
+template <class K>
+static K pick_lu_variant(const LuLdsPlan& p, K v000, K v100, K v110, K v101, K v111) {
+    if (!p.x_in_lds) return v000;
+    if (p.stage_first && p.stage_second) return v111;
+    if (p.stage_first) return v110;
+    if (p.stage_second) return v101;
+    return v100;
+}
+
+static void allow_big_lds(const void* fn) {
+    static std::vector<const void*> done;
+    for (auto f : done) if (f == fn) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLuLdsBytes);
+    done.push_back(fn);
+}
+
 void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* scratch, const PivotRecord* rec,
                      hipStream_t s) {
-    hipLaunchKernelGGL(k_lu_ftran, dim3(1), dim3(kSingleBlock), 0, s, lu, aq, v, scratch, rec);
+    const LuLdsPlan p = plan_lu_lds(lu.m, lu.Lf, lu.Uf);
+    auto fn = pick_lu_variant(p, k_lu_ftran<false, false, false>, k_lu_ftran<true, false, false>,
+                              k_lu_ftran<true, true, false>, k_lu_ftran<true, false, true>, k_lu_ftran<true, true, true>);
+    allow_big_lds(reinterpret_cast<const void*>(fn));
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kLuThreads), p.bytes, s, lu, aq, v, scratch, rec);
 }
 
 void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double* rhs, int32_t row, double* rho,
                      double* scratch, const PivotRecord* rec, hipStream_t s) {
-    hipLaunchKernelGGL(k_lu_btran, dim3(1), dim3(kSingleBlock), 0, s, lu, du, rhs, row, rho, scratch, rec);
+    const LuLdsPlan p = plan_lu_lds(lu.m, lu.Ub, lu.Lb);
+    auto fn = pick_lu_variant(p, k_lu_btran<false, false, false>, k_lu_btran<true, false, false>,
+                              k_lu_btran<true, true, false>, k_lu_btran<true, false, true>, k_lu_btran<true, true, true>);
+    allow_big_lds(reinterpret_cast<const void*>(fn));
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kLuThreads), p.bytes, s, lu, du, rhs, row, rho, scratch, rec);
 }
 
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {

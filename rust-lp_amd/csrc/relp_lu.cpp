@@ -69,20 +69,42 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     int32_t stamp = 0;
 
     for (int32_t k = 0; k < m; ++k) {
-        // pivot row: the sparsest active row (ties: lowest index)
-        int32_t pi = -1;
+        // Markowitz search restricted to the sparsest active row and the sparsest active column
+        // (pivoting.rs:45-81 searches every remaining entry): candidate A = the entry of the sparsest row
+        // with the lowest column count, candidate B = the entry of the sparsest column with the lowest row
+        // count; the lower (r - 1)(c - 1) wins.  Entries below 1e-2 of their row's maximum are skipped.
+        int32_t ra = -1;
         for (int32_t i = 0; i < m; ++i) {
             if (row_done[i]) continue;
             if (rows[i].empty()) { if (err) *err = "singular basis (empty row during LU)"; return false; }
-            if (pi < 0 || rows[i].size() < rows[pi].size()) pi = i;
+            if (ra < 0 || rows[i].size() < rows[ra].size()) ra = i;
         }
-        // pivot column inside it: the sparsest column among the numerically acceptable entries
-        double rmax = 0.0;
-        for (auto& e : rows[pi]) rmax = std::max(rmax, std::fabs(e.second));
-        int32_t pj = -1; double pv = 0.0;
-        for (auto& e : rows[pi]) {
-            if (std::fabs(e.second) < 1e-2 * rmax || e.second == 0.0) continue;
-            if (pj < 0 || ccount[e.first] < ccount[pj] || (ccount[e.first] == ccount[pj] && e.first < pj)) { pj = e.first; pv = e.second; }
+        auto row_max = [&](int32_t i) { double mx = 0.0; for (auto& e : rows[i]) mx = std::max(mx, std::fabs(e.second)); return mx; };
+        int32_t pi = -1, pj = -1; double pv = 0.0; int64_t best = -1;
+        {
+            const double rmax = row_max(ra);
+            for (auto& e : rows[ra]) {
+                if (std::fabs(e.second) < 1e-2 * rmax || e.second == 0.0) continue;
+                if (pj < 0 || ccount[e.first] < ccount[pj] || (ccount[e.first] == ccount[pj] && e.first < pj)) { pj = e.first; pv = e.second; }
+            }
+            if (pj >= 0) { pi = ra; best = (int64_t)(rows[ra].size() - 1) * (ccount[pj] - 1); }
+        }
+        if (best != 0) {
+            int32_t cb = -1;
+            for (int32_t j = 0; j < m; ++j) {
+                if (step_of_col[j] >= 0 || ccount[j] <= 0) continue;
+                if (cb < 0 || ccount[j] < ccount[cb]) cb = j;
+            }
+            if (cb >= 0) {
+                for (int32_t i : colrows[cb]) {
+                    if (row_done[i]) continue;
+                    double v = 0.0; bool has = false;
+                    for (auto& e : rows[i]) if (e.first == cb) { v = e.second; has = true; break; }
+                    if (!has || v == 0.0 || std::fabs(v) < 1e-2 * row_max(i)) continue;
+                    const int64_t cost = (int64_t)(rows[i].size() - 1) * (ccount[cb] - 1);
+                    if (best < 0 || cost < best) { best = cost; pi = i; pj = cb; pv = v; }
+                }
+            }
         }
         if (pj < 0) { if (err) *err = "singular basis (no acceptable pivot)"; return false; }
         out->rowperm[k] = pi; out->colperm[k] = pj;

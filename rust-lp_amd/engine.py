@@ -82,6 +82,7 @@ _SIGNATURES = {
     "relp_from_basis": (C.c_int, [C.c_void_p, C.c_void_p]),
     "relp_flush": (C.c_int, [C.c_void_p]),
     "relp_update_block": (C.c_int32, [C.c_void_p]),
+    "relp_lu_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_shard_flush_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "relp_shard_flush_end": (C.c_int, [C.c_void_p]),
     "relp_nr_rows": (C.c_int32, [C.c_void_p]),
@@ -311,6 +312,13 @@ class Tableau:
 
     def update_block(self) -> int:
         return self._lib.relp_update_block(self._h)
+
+    def lu_stats(self) -> dict:
+        """Factor statistics of the LU engine (relp_lu_stats)."""
+        out = (C.c_int64 * 8)()
+        self._ck(self._lib.relp_lu_stats(self._h, out))
+        keys = ("refactorisations", "m", "nnz_l", "nnz_u", "levels_l", "levels_u", "levels_ut", "levels_lt")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def from_basis(self, basis_columns) -> None:
         arr = np.ascontiguousarray(basis_columns, dtype=np.int32)

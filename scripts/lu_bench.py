@@ -1,0 +1,42 @@
+"""Pivots per second of the three engines on sparse problems (synthetic Netlib-shaped LPs and the
+reference's own files).  Usage: python scripts/lu_bench.py [synth M N SEED | FILE] ..."""
+import sys
+import time
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import rust_lp_amd  # noqa: F401
+from rust_lp_amd import MatrixData, engine, synthetic
+
+
+def problems(argv):
+    i = 0
+    while i < len(argv):
+        if argv[i] == "synth":
+            m, n, s = map(int, argv[i + 1:i + 4])
+            yield f"synth{m}x{n}", MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, s))
+            i += 4
+        else:
+            from lp_files import load
+            gf, ex, md, emd = load(argv[i], fixed=argv[i].endswith(".SIF"))
+            yield argv[i], md
+            i += 1
+
+
+def main():
+    argv = sys.argv[1:] or ["synth", "400", "800", "77"]
+    for name, md in problems(argv):
+        for label, kw in (("lu64", dict(engine=engine.ENGINE_LU)), ("lu16", dict(engine=engine.ENGINE_LU, update_block=16)),
+                          ("revised", dict(engine=engine.ENGINE_REVISED, update_block=0)),
+                          ("tableau", dict(engine=engine.ENGINE_TABLEAU, update_block=32))):
+            t = engine.Tableau(md, **kw)
+            t0 = time.perf_counter()
+            oc = t.solve_relaxation()
+            dt = time.perf_counter() - t0
+            it = t.iterations()
+            extra = t.lu_stats() if label.startswith("lu") else ""
+            print(f"{name:28s} {label:8s} {engine.OUTCOME_NAMES[oc]:10s} pivots {it:7d}  {dt:8.3f} s  {it / dt:9.0f} it/s  "
+                  f"obj {t.objective_function_value():.9g} {extra}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

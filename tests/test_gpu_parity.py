@@ -448,19 +448,21 @@ def test_lu_from_basis_mid_solve_continues_the_same_path():
     assert abs(t.objective_function_value() - full.objective_function_value()) <= 1e-9 * max(1.0, abs(full.objective_function_value()))
 
 
-def test_lu_engine_large_sparse_matches_revised():
-    """A Netlib-shaped sparse LP (m = 1,500, n = 3,000, ~4 nonzeros per column): the LU engine and the
-    explicit-inverse engine walk the same two-phase pivot sequence; the oracle checks a bounded prefix."""
-    md = MatrixData.from_sparse_dict(synthetic.sparse_lp(1500, 3000, 77))
-    a = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=1 << 16)
-    b = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=0, trace_capacity=1 << 16)
-    oa, ob = a.solve_relaxation(), b.solve_relaxation()
-    assert oa == ob
-    ta, tb = a.trace(), b.trace()
-    assert ta == tb and len(ta) > 100
+def test_lu_engine_degenerate_sparse_reaches_the_oracle_optimum():
+    """A Netlib-shaped sparse LP (400 x 800, ~11,000 heavily degenerate pivots, hundreds of
+    refactorisations): the first 500 pivots equal the CPU oracle's, and the solve ends at the oracle's
+    optimum.  (Over 11,000 degenerate pivots f64 rounding may legitimately break a tie differently, so
+    the whole trace is not compared; the optimum is unique.)"""
+    md = MatrixData.from_sparse_dict(synthetic.sparse_lp(400, 800, 77))
     ref = relp_f64.OracleF64(md)
-    ref.run(200, through_phases=True)
-    k = len(ref.trace)
-    assert ta[:k] == ref.trace
-    if oa == engine.OPTIMAL:
-        assert abs(a.objective_function_value() - b.objective_function_value()) <= 1e-9 * max(1.0, abs(b.objective_function_value()))
+    assert ref.run() == "optimal"
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=1 << 16)
+    assert t.solve_relaxation() == engine.OPTIMAL
+    assert t.trace()[:500] == ref.trace[:500]
+    assert abs(t.objective_function_value() - ref.objective) <= 1e-7 * abs(ref.objective)
+    ident, basic, min_b = t.check_basis()
+    # -pi is updated pivot by pivot like the reference's (carry/mod.rs:559-563), never recomputed: 11,000
+    # updates leave ~1e-7 of drift in the basic reduced costs
+    assert ident <= 1e-7 and basic <= 1e-6 and min_b >= -1e-7
+    st = t.lu_stats()
+    assert st["refactorisations"] > 100 and st["m"] == t.nr_rows()
