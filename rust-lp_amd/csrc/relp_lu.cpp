@@ -72,22 +72,38 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
         // Markowitz search restricted to the sparsest active row and the sparsest active column
         // (pivoting.rs:45-81 searches every remaining entry): candidate A = the entry of the sparsest row
         // with the lowest column count, candidate B = the entry of the sparsest column with the lowest row
-        // count; the lower (r - 1)(c - 1) wins.  Entries below 1e-2 of their row's maximum are skipped.
+        // count; the lower (r - 1)(c - 1) wins.
         int32_t ra = -1;
         for (int32_t i = 0; i < m; ++i) {
             if (row_done[i]) continue;
             if (rows[i].empty()) { if (err) *err = "singular basis (empty row during LU)"; return false; }
             if (ra < 0 || rows[i].size() < rows[ra].size()) ra = i;
         }
-        auto row_max = [&](int32_t i) { double mx = 0.0; for (auto& e : rows[i]) mx = std::max(mx, std::fabs(e.second)); return mx; };
+        // threshold partial pivoting: a pivot must be at least kThreshold of the largest active entry of
+        // its column, which bounds every multiplier of L by 1 / kThreshold
+        auto col_max = [&](int32_t j) {
+            double mx = 0.0;
+            for (int32_t i : colrows[j]) {
+                if (row_done[i]) continue;
+                for (auto& e : rows[i]) if (e.first == j) { mx = std::max(mx, std::fabs(e.second)); break; }
+            }
+            return mx;
+        };
+        constexpr double kThreshold = 0.1;
         int32_t pi = -1, pj = -1; double pv = 0.0; int64_t best = -1;
         {
-            const double rmax = row_max(ra);
-            for (auto& e : rows[ra]) {
-                if (std::fabs(e.second) < 1e-2 * rmax || e.second == 0.0) continue;
-                if (pj < 0 || ccount[e.first] < ccount[pj] || (ccount[e.first] == ccount[pj] && e.first < pj)) { pj = e.first; pv = e.second; }
+            // candidate A: entries of the sparsest row, by ascending column count
+            std::vector<std::pair<int32_t, int32_t>> order;          // (column count, column)
+            for (auto& e : rows[ra]) if (e.second != 0.0) order.emplace_back(ccount[e.first], e.first);
+            std::sort(order.begin(), order.end());
+            for (auto& oc : order) {
+                double v = 0.0;
+                for (auto& e : rows[ra]) if (e.first == oc.second) { v = e.second; break; }
+                if (std::fabs(v) < kThreshold * col_max(oc.second)) continue;
+                pi = ra; pj = oc.second; pv = v;
+                best = (int64_t)(rows[ra].size() - 1) * (ccount[pj] - 1);
+                break;
             }
-            if (pj >= 0) { pi = ra; best = (int64_t)(rows[ra].size() - 1) * (ccount[pj] - 1); }
         }
         if (best != 0) {
             int32_t cb = -1;
@@ -96,14 +112,28 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
                 if (cb < 0 || ccount[j] < ccount[cb]) cb = j;
             }
             if (cb >= 0) {
+                const double cmax = col_max(cb);
                 for (int32_t i : colrows[cb]) {
                     if (row_done[i]) continue;
                     double v = 0.0; bool has = false;
                     for (auto& e : rows[i]) if (e.first == cb) { v = e.second; has = true; break; }
-                    if (!has || v == 0.0 || std::fabs(v) < 1e-2 * row_max(i)) continue;
+                    if (!has || v == 0.0 || std::fabs(v) < kThreshold * cmax) continue;
                     const int64_t cost = (int64_t)(rows[i].size() - 1) * (ccount[cb] - 1);
                     if (best < 0 || cost < best) { best = cost; pi = i; pj = cb; pv = v; }
                 }
+            }
+        }
+        if (pj < 0) {
+            // no entry of the sparsest row / column passes the threshold: take the largest entry of the
+            // sparsest row's best column (always acceptable)
+            double bestv = 0.0;
+            for (auto& e : rows[ra]) {
+                const int32_t j = e.first;
+                for (int32_t i : colrows[j]) {
+                    if (row_done[i]) continue;
+                    for (auto& f : rows[i]) if (f.first == j && std::fabs(f.second) > bestv) { bestv = std::fabs(f.second); pi = i; pj = j; pv = f.second; }
+                }
+                if (pj >= 0) break;
             }
         }
         if (pj < 0) { if (err) *err = "singular basis (no acceptable pivot)"; return false; }

@@ -5,11 +5,10 @@
 // elimination on a row-major working copy) and decomposition/pivoting.rs:45-81 (Markowitz: minimise
 // (row count - 1)(column count - 1)).  This runs at every refactorisation (lower_upper/mod.rs:199-202:
 // after more than 10 updates; carry/mod.rs:602-614 re-inverts from the original columns).
-// f64 differences, none of which changes a pivot decision of the simplex (B^-1 a_q is the same vector
-// up to rounding): the pivot search looks at the sparsest active row first and takes its sparsest
-// column among the entries within 1e-2 of the row maximum (threshold pivoting; the reference has exact
-// arithmetic and needs no threshold, and its exhaustive search over all remaining entries is O(nnz) per
-// step, pivoting.rs:59).
+// f64 differences, none of which changes what is computed (B^-1 a_q is the same vector up to rounding):
+// the Markowitz search is restricted to the sparsest active row and the sparsest active column (the
+// reference scans every remaining entry, pivoting.rs:59), and a pivot must be at least 0.1 of the largest
+// active entry of its column (threshold partial pivoting; exact arithmetic needs no threshold).
 #pragma once
 #include <cstdint>
 #include <string>
