@@ -1446,6 +1446,108 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
             }
 }
 
+// The same product with the operands staged through LDS.  A workgroup of WC x WR wavefronts owns a
+// (WC * 64 columns) x (WR * 32 rows) tile of T0; per chunk of KC pivots of the block it copies the
+// R0 rows (KC x TC) and W columns (KC x TR) it needs into LDS once (double-buffered, 16-byte global
+// loads issued one chunk ahead) and every wavefront takes its MFMA fragments from there.  Without this
+// each wavefront fetches its own operands from L2 / Infinity Cache: 48 KB per 32 KB of T0 traffic
+// (4.7 GB per flush at 10k x 20k against 3.2 GB of HBM traffic); with a 256 x 128 tile it is 12 KB.
+template <int WC, int WR, int KC>
+__global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, DeferredUpdate du, const PivotRecord* rec) {
+    constexpr int MT = 4, NT = 2;                     // wavefront tile: 64 columns x 32 rows
+    constexpr int TC = WC * 16 * MT, TR = WR * 16 * NT, NTHR = WC * WR * 64;
+    constexpr int RA = KC * TC / 2 / NTHR, RB = KC * TR / 2 / NTHR;
+    static_assert(RA * NTHR * 2 == KC * TC && RB * NTHR * 2 == KC * TR, "staging must divide evenly");
+    const int p = rec->n_eta;
+    if (p == 0) return;
+    __shared__ __align__(16) double As[2][KC][TC];
+    __shared__ __align__(16) double Bs[2][KC][TR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave % WC, wr = wave / WC;
+    // consecutive workgroups walk down the rows of the same 256 columns: T0 is column-major, so the
+    // workgroups in flight stream whole columns (sequential DRAM pages) and share one R0 chunk in L2
+    const int c_blk = tv.c_lo + blockIdx.y * TC, i_blk = blockIdx.x * TR;
+    const int c_wave = c_blk + wc * 16 * MT, i_wave = i_blk + wr * 16 * NT;
+    const bool active = c_wave < tv.c_hi && i_wave < tv.m;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int c_end = tv.c_lo + (int)tv.ld_r;         // R0 rows are readable up to their (even) pitch
+    double2 ra[RA], rb[RB];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < RA; ++u) {
+            const int idx = tid + NTHR * u, k = idx / (TC / 2), c = c_blk + 2 * (idx % (TC / 2));
+            ra[u] = (kc + k < p && c < c_end) ? *reinterpret_cast<const double2*>(tv.R0 + (int64_t)(kc + k) * tv.ld_r + c)
+                                              : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int idx = tid + NTHR * u, k = idx / (TR / 2), i = i_blk + 2 * (idx % (TR / 2));
+            rb[u] = (kc + k < p && i < (int)du.ld) ? *reinterpret_cast<const double2*>(du.W + (int64_t)(kc + k) * du.ld + i)
+                                                   : make_double2(0.0, 0.0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < RA; ++u) {
+            const int idx = tid + NTHR * u;
+            *reinterpret_cast<double2*>(&As[buf][idx / (TC / 2)][2 * (idx % (TC / 2))]) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int idx = tid + NTHR * u;
+            *reinterpret_cast<double2*>(&Bs[buf][idx / (TR / 2)][2 * (idx % (TR / 2))]) = rb[u];
+        }
+    };
+    gload(0);
+    // the accumulators start as the T0 tile itself
+    double4_t acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c_wave + a * 16 + lk + 4 * g;
+                const int i = i_wave + b * 16 + lm;
+                acc[a][b][g] = (active && c < tv.c_hi && i < tv.m) ? tv.T0[(int64_t)c * tv.ld_t + i] : 0.0;
+            }
+    lstore(0);
+    __syncthreads();
+    const int nchunks = (p + KC - 1) / KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) gload((ch + 1) * KC);
+        if (active) {
+            const int kmax = min(KC, p - ch * KC);
+            for (int k0 = 0; k0 < kmax; k0 += 4) {
+                double af[MT], bf[NT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) af[a] = As[buf][k0 + lk][wc * 16 * MT + a * 16 + lm];
+#pragma unroll
+                for (int b = 0; b < NT; ++b) bf[b] = Bs[buf][k0 + lk][wr * 16 * NT + b * 16 + lm];
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = c_wave + a * 16 + lk + 4 * g;
+                const int i = i_wave + b * 16 + lm;
+                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+            }
+}
+
 __global__ void k_tab_gather_columns(TableauView tv, const int32_t* __restrict__ cols, double* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)tv.m * tv.m;
@@ -1813,9 +1915,19 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
 }
 
 void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
-    constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
     if (tv.c_hi <= tv.c_lo) return;
-    dim3 grid(cdiv(tv.c_hi - tv.c_lo, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
+    const int ncols = tv.c_hi - tv.c_lo;
+    if ((int64_t)ncols * tv.m >= (1 << 16)) {
+        // LDS-staged operands: 8 wavefronts, 128 columns x 128 rows per workgroup, chunks of 16 pivots
+        // (64 KB of LDS, <= 128 VGPRs: two workgroups per CU, so one streams its T0 tile while the
+        // other one is in its MFMA loop)
+        constexpr int WC = 2, WR = 4, KC = 16;
+        dim3 grid(cdiv(tv.m, WR * 32), cdiv(ncols, WC * 64));
+        hipLaunchKernelGGL((k_tab_flush_lds<WC, WR, KC>), grid, dim3(WC * WR * 64), 0, s, tv, du, rec);
+        return;
+    }
+    constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
+    dim3 grid(cdiv(ncols, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
     hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, rec);
 }
 
