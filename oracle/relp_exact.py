@@ -25,6 +25,18 @@ from fractions import Fraction
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 F = Fraction
+
+def usize_sub(j: int, k: int) -> int:
+    """`j - k` on `usize` as the reference's integration tests see it: they are built with `--release`
+    (.github/workflows/main.yml:34-38), i.e. without overflow checks, so the subtraction wraps.  It
+    matters in one situation: an artificial variable that re-entered the basis in another row than its
+    own survives `remove_artificial_basis_variables` (the zero-level pivot is made in its ORIGINAL row,
+    phase_one.rs:236), and `basis_column -= nr_artificial` (carry/mod.rs:524, 663) turns its index into a
+    huge one.  That index classifies as the last column group (`column_type`, matrix_data.rs:198-222:
+    no cost), sorts last in Bland's tie-break, and the variable stays basic at value zero until the
+    ratio test removes it.  Netlib BOEING2 walks through this state on its way to the pinned optimum."""
+    return (j - k) % (1 << 64)
+
 ZERO = Fraction(0)
 ONE = Fraction(1)
 SparseVec = List[Tuple[int, Fraction]]
@@ -1050,7 +1062,7 @@ class Carry:
     @classmethod
     def from_artificial(cls, artificial: "Carry", provider, nr_artificial: int) -> "Carry":
         """carry/mod.rs:484-510."""
-        basis = [j - nr_artificial for j in artificial.basis_indices]
+        basis = [usize_sub(j, nr_artificial) for j in artificial.basis_indices]
         mp = cls.create_minus_pi_from_artificial(artificial.basis_inverse, provider, basis)
         mo = cls.create_minus_obj_from_artificial(provider, basis, artificial.b)
         return cls(mo, mp, artificial.b, basis, artificial.basis_inverse)
@@ -1061,7 +1073,7 @@ class Carry:
         """carry/mod.rs:512-547 (generic: re-invert) and :650-689 (``RemoveBasisPart``)."""
         basis = list(artificial.basis_indices)
         remove_indices(basis, rows_removed.filtered_rows())
-        basis = [j - nr_artificial for j in basis]
+        basis = [usize_sub(j, nr_artificial) for j in basis]
         if hasattr(artificial.basis_inverse, "remove_basis_part"):
             bi = artificial.basis_inverse
             bi.remove_basis_part(rows_removed.filtered_rows())
@@ -1184,7 +1196,7 @@ class Tableau:
     def from_artificial(cls, im: Carry, nr_artificial: int, basis, provider) -> "Tableau":
         """kind/non_artificial.rs:151-172."""
         return cls(Carry.from_artificial(im, provider, nr_artificial),
-                   [c - nr_artificial for c in basis], NonArtificial(provider))
+                   [usize_sub(c, nr_artificial) for c in basis], NonArtificial(provider))
 
     @classmethod
     def from_artificial_removing_rows(cls, BI, im: Carry, nr_artificial: int, basis, provider: RemoveRows):
@@ -1192,7 +1204,7 @@ class Tableau:
         basis = set(basis)
         for row in provider.filtered_rows():
             basis.remove(im.basis_indices[row])
-        cols = [j - nr_artificial for j in basis]
+        cols = [usize_sub(j, nr_artificial) for j in basis]
         return cls(Carry.from_artificial_remove_rows(BI, im, provider, nr_artificial), cols, NonArtificial(provider))
 
     # queries -------------------------------------------------------------------------------

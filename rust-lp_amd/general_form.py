@@ -15,9 +15,9 @@ Restates (file:line under /root/reference/src/):
   general_form/mod.rs:817-942             reshift, un-flip, recombine x+ - x-, objective = sum c_j x_j + fixed cost
                                           (NOT negated back for maximisation inputs, :861-863)
 
-**Presolve (general_form/mod.rs:333-478, presolve/**, ~3.9 k lines) is NOT restated yet**: the
-standardisation here starts from the un-presolved problem.  Optimal objective values are unaffected;
-the `MatrixData` (hence the pivot sequence) is the one of the un-presolved problem.
+Presolve (general_form/mod.rs:333-478, presolve/**) is restated in `presolve.py`; `standardize()` runs it
+first like the reference (`standardize(presolve=False)` keeps the un-presolved problem, which has the
+same optimum but another `MatrixData`).
 """
 from __future__ import annotations
 
@@ -29,6 +29,7 @@ import numpy as np
 
 from .matrix_data import MatrixData
 from .mps import MPS, MPSError
+from . import presolve as _presolve
 
 ZERO = Fraction(0)
 ONE = Fraction(1)
@@ -43,6 +44,15 @@ class Variable:
     shift: Fraction = ZERO
     flipped: bool = False
     integer: bool = False
+
+
+class Solved(Exception):
+    """Presolve determined every variable: `LinearProgramType::FiniteOptimum(solution)`
+    (general_form/mod.rs:354-356).  ``objective`` is the fixed cost, ``values`` maps names to values."""
+
+    def __init__(self, objective, values):
+        super().__init__("solved by presolve")
+        self.objective, self.values = objective, values
 
 
 class GeneralForm:
@@ -204,8 +214,77 @@ class GeneralForm:
             for v in self.variables:
                 v.cost = -v.cost
 
-    def standardize(self) -> None:
-        """general_form/mod.rs:307-314 WITHOUT the presolve step (see module docstring)."""
+    # ---- presolve (general_form/mod.rs:333-478, 727-800) -----------------------------------------
+    def presolve(self) -> None:
+        """Apply the reductions of `presolve.compute_presolve_changes`.  Raises `presolve.Infeasible` /
+        `presolve.Unbounded`, or `Solved` when every variable was determined (the reference returns
+        `Err(FiniteOptimum(solution))` and the simplex never runs)."""
+        ch = _presolve.compute_presolve_changes(self)
+        # update_values_that_remain, :405-437 (indices relative to the problem before any removal)
+        for i, v in ch["b"].items():
+            self.b[i] = v
+        for i, t in ch["constraints"].items():
+            self.constraint_types[i] = t
+        self.fixed_cost += ch["fixed_cost"]
+        for (j, sol) in ch["removed_variables"]:
+            orig = self.from_active_to_original[j]
+            self.original[orig] = (self.original[orig][0], ("removed", sol))
+        for (j, direction), value in ch["bounds"].items():
+            if direction == _presolve.LOWER:
+                self.variables[j].lower_bound = value
+            else:
+                self.variables[j].upper_bound = value
+        # remove_rows_and_columns, :439-478 (survivors keep their relative order)
+        gone_cols = {j for (j, _) in ch["removed_variables"]}
+        gone_rows = set(ch["constraints_marked_removed"])
+        if gone_cols:
+            keep = [j for j in range(len(self.variables)) if j not in gone_cols]
+            self.columns = [self.columns[j] for j in keep]
+            self.variables = [self.variables[j] for j in keep]
+            self.from_active_to_original = [self.from_active_to_original[j] for j in keep]
+            for new_index, orig in enumerate(self.from_active_to_original):
+                self.original[orig] = (self.original[orig][0], ("active", new_index))
+        if gone_rows:
+            new_row = {}
+            for i in range(len(self.b)):
+                if i not in gone_rows:
+                    new_row[i] = len(new_row)
+            self.columns = [[(new_row[i], v) for (i, v) in col if i not in gone_rows] for col in self.columns]
+            self.constraint_types = [t for i, t in enumerate(self.constraint_types) if i not in gone_rows]
+            self.b = [v for i, v in enumerate(self.b) if i not in gone_rows]
+        # compute_solution_where_possible, :727-750: functions of solved variables become values
+        memo: Dict[int, Optional[Fraction]] = {}
+
+        def value_of(k):
+            ref = self.original[k][1]
+            if ref[0] != "removed":
+                return None
+            if ref[1][0] == "solved":
+                return ref[1][1]
+            if k not in memo:
+                memo[k] = None
+                total = ZERO
+                for (other, coefficient) in ref[1][2]:
+                    v = value_of(other)
+                    if v is None:
+                        total = None
+                        break
+                    total += coefficient * v
+                memo[k] = None if total is None else ref[1][1] - total
+            return memo[k]
+        for k in range(len(self.original)):
+            ref = self.original[k][1]
+            if ref[0] == "removed" and ref[1][0] == "function":
+                v = value_of(k)
+                if v is not None:
+                    self.original[k] = (self.original[k][0], ("removed", ("solved", v)))
+        if all(ref[0] == "removed" and ref[1][0] == "solved" for (_, ref) in self.original):
+            raise Solved(self.fixed_cost, {name: ref[1][1] for (name, ref) in self.original})
+
+    def standardize(self, presolve: bool = True) -> None:
+        """general_form/mod.rs:307-314"""
+        if presolve:
+            self.presolve()
         self.transform_variables()
         self.make_b_non_negative()
         self.make_minimization_problem()
@@ -222,9 +301,9 @@ class GeneralForm:
         return self.counts
 
     # ---- MatrixData ---------------------------------------------------------------------------
-    def derive_matrix_data_exact(self):
+    def derive_matrix_data_exact(self, presolve: bool = True):
         """(columns, b, ranges, counts, costs, upper bounds) as exact data for oracle/relp_exact.MatrixData."""
-        self.standardize()
+        self.standardize(presolve=presolve)
         ne, nr, nl, ng = self.reorder_constraints_by_type()
         ranges = [t[1] for t in self.constraint_types[ne:ne + nr]]
         costs = [v.cost for v in self.variables]
@@ -263,10 +342,27 @@ class GeneralForm:
             if var.flipped:
                 v = -v
             values[j] = v
-        out = {}
-        for (name, ref) in self.original:
+        # compute_solution_value_with_bfs, :889-942
+        solved: Dict[int, object] = {}
+
+        def value_of(k):
+            if k in solved:
+                return solved[k]
+            ref = self.original[k][1]
             if ref[0] == "active":
-                out[name] = values[ref[1]]
+                v = values[ref[1]]
+            elif ref[0] == "free":
+                v = values[ref[1]] - values[ref[2]]
+            elif ref[1][0] == "solved":
+                v = ref[1][1] if isinstance(zero, Fraction) else float(ref[1][1])
             else:
-                out[name] = values[ref[1]] - values[ref[2]]
+                _, constant, coefficients = ref[1]
+                exact = isinstance(zero, Fraction)
+                total = zero
+                for (other, coefficient) in coefficients:
+                    total = total + value_of(other) * (coefficient if exact else float(coefficient))
+                v = (constant if exact else float(constant)) - total
+            solved[k] = v
+            return v
+        out = {name: value_of(k) for k, (name, _) in enumerate(self.original)}
         return cost, out

@@ -350,7 +350,8 @@ FILES = [("burkardt/afiro.mps", False, -406659 / 875, 1e-9), ("burkardt/testprob
          ("netlib/SCAGR7.SIF", True, -2.331389824e+06, 1e-1), ("netlib/SC205.SIF", True, -5.220206121e+01, 1e-5),
          ("netlib/SHARE2B.SIF", True, -4.157322407e+02, 1e-5), ("netlib/RECIPELP.SIF", True, -0.266616e3, 1e-2),
          ("netlib/LOTFI.SIF", True, -0.2526470606188e2, 1e-6), ("netlib/VTP-BASE.SIF", True, 0.1298314624613613e6, 1e-2),
-         ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3), ("miplib/50v-10.mps", False, 2879.065687, 1e-3)]
+         ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3), ("netlib/BORE3D.SIF", True, 0.13730803942084927e4, 1e-2),
+         ("miplib/50v-10.mps", False, 2879.065687, 1e-3)]
 
 
 # LOTFI's phase-1 bases reach cond(B) ~ 1e8 (measured at pivot 181): a reduced cost that is exactly 0
