@@ -211,9 +211,9 @@ def main():
             # the flush T0 += W R0 is the one kernel that streams the m x (n + m) tableau; at K = 64 its HBM time
             # (16 m n bytes) exceeds its MFMA time (2 m n K flops at 78.6 TFLOP/s), so it is priced against HBM
             fl = kernels["flush"]
-            roofline = {"kernel": "k_tab_flush", "bound": "hbm", "achieved": fl["GBps"], "peak": HBM_PEAK_GBS,
+            roofline = {"kernel": "k_tab_flush_lds", "bound": "hbm", "achieved": fl["GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(fl["GBps"] / HBM_PEAK_GBS, 4),
-                        "traffic": load_traffic(args.workload, "tab_flush"),
+                        "traffic": load_traffic(args.workload, "tab_flush_lds"),
                         "algorithmic_bytes_per_launch": res["alg_bytes"]["flush"],
                         "launches_per_pivot": 1.0 / max(res["block"], 1),
                         "mfma": {"achieved": fl.get("TFLOPs"), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s (f64 matrix)",

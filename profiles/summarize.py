@@ -61,10 +61,11 @@ def main():
         w = write.get(name, {}).get("value", 0.0)
         hbm = (2.0 * f + w) * 1024.0
         note = ""
-        if name in ("k_tab_flush", "k_flush_apply"):
+        if name in ("k_tab_flush", "k_tab_flush_lds", "k_flush_apply"):
             # 8-byte-per-lane loads: the x2 FETCH_SIZE correction is calibrated for 16-byte-per-lane streams only
             # (MI355X_MICROARCH.md section HBM: other widths uncalibrated); the raw figure already matches the bytes
-            # of the matrix, so raw FETCH_SIZE + WRITE_SIZE is reported for these kernels
+            # of the matrix, so raw FETCH_SIZE + WRITE_SIZE is reported for these kernels (k_tab_flush_lds reads its
+            # T0 tile 8 bytes per lane and under-reports further: treat its figure as a lower bound)
             hbm = (f + w) * 1024.0
             note = " (raw FETCH_SIZE, 8-byte loads)"
         traffic[name[2:]] = hbm
