@@ -266,7 +266,7 @@ static int32_t change_basis(oracle_engine_t *e, int32_t r, int32_t q, const svec
     int32_t leaving = e->basis_indices[r];
     e->basis_indices[r] = q;
     /* tableau/mod.rs:72-84 */
-    e->in_basis[leaving] = 0;
+    if (leaving < e->n_flags) e->in_basis[leaving] = 0;    /* a wrapped artificial has no flag */
     e->in_basis[q] = 1;
     return leaving;
 }
@@ -482,20 +482,29 @@ static void switch_to_phase_two(oracle_engine_t *e, const int32_t *rows_to_remov
             row->n = o;
         }
     }
-    for (int32_t r = 0; r < e->m; r++) e->basis_indices[r] -= na;
+    /* An artificial variable can survive remove_artificial_basis_variables: when it re-entered the basis in
+     * another row than its own, the zero-level pivot of phase_one.rs:236 is made in its ORIGINAL row and
+     * removes somebody else.  The reference's integration tests are release builds, where
+     * `basis_column -= nr_artificial` (carry/mod.rs:524, 663) then wraps to a huge usize: a column without
+     * cost that sorts last in Bland's tie-break and stays basic at value zero.  Same here, with the wrapped
+     * index squeezed into int32: artificial a becomes INT32_MAX - (na - 1 - a) (order preserved). */
+    for (int32_t r = 0; r < e->m; r++) {
+        if (e->basis_indices[r] < na) e->basis_indices[r] = INT32_MAX - (na - 1 - e->basis_indices[r]);
+        else e->basis_indices[r] -= na;
+    }
     e->phase = 2;
     e->nr_artificial = 0;
     int32_t n2 = md_nr_columns(e);
     memset(e->in_basis, 0, (size_t)e->n_flags);
-    for (int32_t r = 0; r < e->m; r++) e->in_basis[e->basis_indices[r]] = 1;
+    for (int32_t r = 0; r < e->m; r++) if (e->basis_indices[r] < e->n_flags) e->in_basis[e->basis_indices[r]] = 1;
     (void)n2;
     /* create_minus_pi_from_artificial, carry/mod.rs:214-248.  The reference builds every column of
      * B^-1 by a unit FTRAN and re-assembles rows; entry (i,j) of that is exactly rows[i][j], and the
      * accumulation order (i ascending, then j ascending) is kept. */
     for (int32_t j = 0; j < e->m; j++) e->minus_pi[j] = 0.0;
     for (int32_t i = 0; i < e->m; i++) {
+        if (e->basis_indices[i] >= e->nr_normal) continue;      /* cost None (slacks, wrapped artificials) */
         double c = md_cost_value(e, e->basis_indices[i]);
-        if (e->basis_indices[i] >= e->nr_normal) continue;      /* cost None */
         for (int64_t k = 0; k < e->rows[i].n; k++) e->minus_pi[e->rows[i].d[k].idx] += e->rows[i].d[k].val * c;
     }
     for (int32_t j = 0; j < e->m; j++) e->minus_pi[j] = -e->minus_pi[j];

@@ -422,6 +422,10 @@ relp_status_t Engine::lu_refactor() {
         const int32_t j = basis[i];
         auto& c = cols[i];
         if (j < nr_artificial_) { c.emplace_back(column_to_row_[j], 1.0); continue; }
+        if (j >= kWrappedArtificialBase) {                      // artificial that survived phase 1: still e_row
+            c.emplace_back(column_to_row_[wrapped_na_ - 1 - (INT32_MAX - j)], 1.0);
+            continue;
+        }
         const int32_t p = j - nr_artificial_;
         if (p < nr_normal_) {
             for (int64_t e = hc_ptr_[p]; e < hc_ptr_[p + 1]; ++e) c.emplace_back(hc_idx_[e], hc_val_[e]);
@@ -963,12 +967,23 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     const int32_t na = nr_artificial_;
-    for (auto& v : basis) v -= na;
+    // An artificial variable can survive remove_artificial_basis_variables: when it re-entered the basis in
+    // another row than its own, the zero-level pivot of phase_one.rs:236 is made in its ORIGINAL row.  In
+    // the reference's release-built integration tests `basis_column -= nr_artificial` (carry/mod.rs:524, 663)
+    // then wraps to a huge usize: a column without cost that sorts last in Bland's tie-break and stays basic
+    // at value zero until the ratio test removes it (Netlib BOEING2 walks through this state).  Same here
+    // with the wrapped index squeezed into int32, order preserved: INT32_MAX - (na - 1 - a).
+    for (auto& v : basis) v = v < na ? INT32_MAX - (na - 1 - v) : v - na;
+    wrapped_na_ = na;
     nr_artificial_ = 0;
     phase_ = 2;
     HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
     std::vector<uint8_t> flags(n_alloc_, 0);
-    for (int32_t v : basis) { if (v < 0 || v >= n_provider_) return fail(RELP_E_STATE, "artificial variable left in the basis"); flags[v] = 1; }
+    for (int32_t v : basis) {
+        if (v >= kWrappedArtificialBase) continue;
+        if (v < 0 || v >= n_provider_) return fail(RELP_E_STATE, "basis column out of range at the phase switch");
+        flags[v] = 1;
+    }
     HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));
     // -pi = -(c_B' B^-1) (create_minus_pi_from_artificial, carry/mod.rs:214-248), accumulated over rows in order
     std::vector<double> w(m_, 0.0), b(m_);
@@ -1279,11 +1294,12 @@ relp_status_t Engine::check_basis(double* max_identity_error, double* max_basic_
     std::vector<double> col(m_), d(nr_columns()), b(m_);
     double e1 = 0.0, e2 = 0.0, mb = std::numeric_limits<double>::infinity();
     for (int32_t i = 0; i < m_; ++i) {
+        if (basis[i] >= kWrappedArtificialBase) continue;       // no column to regenerate
         if ((st = generate_column(basis[i], col.data()))) return st;
         for (int32_t k = 0; k < m_; ++k) e1 = std::max(e1, std::fabs(col[k] - (k == i ? 1.0 : 0.0)));
     }
     if ((st = relative_costs(d.data()))) return st;
-    for (int32_t i = 0; i < m_; ++i) e2 = std::max(e2, std::fabs(d[basis[i]]));
+    for (int32_t i = 0; i < m_; ++i) if (basis[i] < kWrappedArtificialBase) e2 = std::max(e2, std::fabs(d[basis[i]]));
     if ((st = get_vector(0, b.data()))) return st;
     for (double v : b) mb = std::min(mb, v);
     if (max_identity_error) *max_identity_error = e1;

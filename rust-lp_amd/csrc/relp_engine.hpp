@@ -97,6 +97,7 @@ class Engine {
     int32_t nr_artificial_ = 0;
     std::vector<int32_t> column_to_row_;
     double initial_phase1_objective_ = 0.0;
+    int32_t wrapped_na_ = 0;      // nr_artificial at the phase switch (decodes wrapped artificial indices)
 
     // ---- device state ----
     double* dA_ = nullptr; int64_t ld_a_ = 0; bool owns_A_ = false;

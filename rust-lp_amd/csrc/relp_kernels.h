@@ -101,6 +101,10 @@ struct DeviceLU {
     const int32_t* colperm;   // pivot step -> basis position
     DeviceSchedule Lf, Uf, Ub, Lb;
 };
+// Column indices at or above this value are artificial variables that survived phase 1 (see
+// Engine::switch_to_phase_two): INT32_MAX - (na - 1 - a).  They have no flag, no cost and no column.
+static constexpr int32_t kWrappedArtificialBase = 0x40000000;
+
 struct DeviceCSC { const int64_t* col_ptr; const int32_t* row_idx; const double* values; };
 
 // ---- launchers (all asynchronous on `s`) -------------------------------------------------------

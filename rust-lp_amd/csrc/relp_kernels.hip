@@ -795,7 +795,7 @@ __global__ void k_update_vectors(int m, const double* __restrict__ alpha, const 
         const int q = rec->q, leaving = rec->leaving;
         rec->minus_objective = fma(-d_q, br, rec->minus_objective);
         basis_indices[r] = q;
-        in_basis[leaving] = 0;
+        if (leaving < kWrappedArtificialBase) in_basis[leaving] = 0;   // a wrapped artificial has no flag
         in_basis[q] = 1;
         const long long it = rec->iterations;
         if (trace && it < trace_cap) {
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void tab_update_w_vectors_body(const DeferredUpdate& 
         const int q = rec->q, leaving = rec->leaving;
         rec->minus_objective = fma(-rec->d_q, br, rec->minus_objective);
         basis_indices[r] = q;
-        in_basis[leaving] = 0;
+        if (leaving < kWrappedArtificialBase) in_basis[leaving] = 0;   // a wrapped artificial has no flag
         in_basis[q] = 1;
         const long long it = rec->iterations;
         if (trace && it < trace_cap) {
@@ -1361,7 +1361,7 @@ __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, do
         const int q = rec->q, leaving = rec->leaving;
         rec->minus_objective = fma(-rec->d_q, br, rec->minus_objective);
         basis_indices[r] = q;
-        in_basis[leaving] = 0;
+        if (leaving < kWrappedArtificialBase) in_basis[leaving] = 0;   // a wrapped artificial has no flag
         in_basis[q] = 1;
         const long long it = rec->iterations;
         if (trace && it < trace_cap) {

@@ -351,6 +351,7 @@ FILES = [("burkardt/afiro.mps", False, -406659 / 875, 1e-9), ("burkardt/testprob
          ("netlib/SHARE2B.SIF", True, -4.157322407e+02, 1e-5), ("netlib/RECIPELP.SIF", True, -0.266616e3, 1e-2),
          ("netlib/LOTFI.SIF", True, -0.2526470606188e2, 1e-6), ("netlib/VTP-BASE.SIF", True, 0.1298314624613613e6, 1e-2),
          ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3), ("netlib/BORE3D.SIF", True, 0.13730803942084927e4, 1e-2),
+         ("netlib/BOEING2.SIF", True, -0.31501872801520287e3, 1e-3),
          ("miplib/50v-10.mps", False, 2879.065687, 1e-3)]
 
 

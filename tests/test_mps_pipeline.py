@@ -122,12 +122,20 @@ def test_boeing2_exact_oracle_reaches_the_pinned_optimum():
     assert abs(float(obj) - (-0.31501872801520287870462195913263e3)) < 1e-3
 
 
-@pytest.mark.xfail(strict=True, reason="the f64 engines stop when an artificial variable is left in the basis after "
-                                       "phase 1 instead of emulating the reference's wrapped index")
-def test_boeing2_f64_oracle():
+def test_boeing2_f64_oracle_walks_the_exact_path():
+    """The f64 oracle keeps the surviving artificial like the release-built reference does (wrapped index,
+    squeezed into int32 with the order preserved) and walks the exact oracle's 416 pivots."""
     gf, ex, md, emd = load("netlib/BOEING2.SIF", fixed=True)
+    tr = []
+    status, obj, _ = exact_solve(gf, emd, trace=tr.append)
     ref = relp_f64.OracleF64(md)
-    assert ref.run(max_iters=20000) == "optimal"
+    assert ref.run(max_iters=20000) == status == "optimal"
+    assert abs(ref.objective + float(gf.fixed_cost) - float(obj)) < 1e-9 * abs(float(obj))
+    na = 123                                                   # artificial variables of the presolved problem
+
+    def squeeze(j):                                            # (a - na) mod 2^64  ->  INT32_MAX - (na - 1 - a)
+        return j if j < (1 << 62) else (1 << 31) - 1 - (na - 1 - (j - (1 << 64) + na))
+    assert ref.trace == [(e["phase"], e["entering"], e["row"], squeeze(e["leaving"])) for e in tr]
 
 
 @pytest.mark.parametrize("name", ["AFIRO", "SC50A", "SC50B"])
