@@ -652,7 +652,8 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
                                                         const double* __restrict__ b,
                                                         const int32_t* __restrict__ basis_indices, int m,
                                                         Tolerances tol, DeferredUpdate du, PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
+    const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
+    if (outcome != DEV_RUNNING) return;
     __shared__ double s_min[kSingleBlock / 64];
     __shared__ int s_leave[kSingleBlock / 64];
     __shared__ int s_row[kSingleBlock / 64];
@@ -740,7 +741,6 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     }
     if (du.kmax <= 0) return;
     // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
-    const int p = rec->n_eta;
     __syncthreads();
     const int r = s_row[0];
     for (int j = threadIdx.x; j < p; j += kSingleBlock) du.wr[j] = du.W[(int64_t)j * du.ld + r];
@@ -1168,13 +1168,18 @@ __global__ __launch_bounds__(kThreads) void k_tab_column(TableauView tv, Deferre
 // Row r of T before the pivot, the reduced-cost update and the next PRICE's partial argmin in one
 // pass over the stored columns.  When row r is new in the block its T0 row is appended to R0 here.
 // `block` = index of this workgroup among the row-update workgroups.
+// `R` is the workgroup's snapshot of the PivotRecord (one cache line, fetched once at kernel start: reading
+// it field by field between stores costs a dependent memory round trip each time).
 __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const DeferredUpdate& du,
-                                                    const SelectPartials& sp, const PivotRecord* rec, int block) {
+                                                    const SelectPartials& sp, const PivotRecord& R, int block) {
     __shared__ double s_wr[kMaxEta];
-    const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r, q = rec->q, leaving = rec->leaving;
-    if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.wr[threadIdx.x];
-    __syncthreads();
+    const PivotRecord* rec = &R;
+    const int p_old = R.n_eta_old, jt = R.eta_target, r = R.r, q = R.q, leaving = R.leaving;
+    // fetched without waiting for p_old (entries beyond it are never used)
+    if ((int)threadIdx.x < du.kmax) s_wr[threadIdx.x] = du.wr[threadIdx.x];
     const int c = tv.c_lo + block * kThreads + threadIdx.x;
+    const double d_old = c < tv.c_hi ? tv.d[c] : 0.0;
+    __syncthreads();
     double key = INFINITY;
     int kj = 0x7fffffff;
     if (c < tv.c_hi) {
@@ -1183,9 +1188,9 @@ __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const
         else { base = tv.T0[(int64_t)c * tv.ld_t + r]; tv.R0[(int64_t)jt * tv.ld_r + c] = base; }
         double row = base;
         for (int j = 0; j < p_old; ++j) row = fma(s_wr[j], tv.R0[(int64_t)j * tv.ld_r + c], row);
-        const double theta = rec->d_q / rec->alpha_r;
+        const double theta = R.d_q / R.alpha_r;
         const int j = c - tv.col_off;
-        double dn = fma(-theta, row, tv.d[c]);
+        double dn = fma(-theta, row, d_old);
         if (j == q) dn = 0.0;
         tv.d[c] = dn;
         if (j >= 0 && j < tv.n) {
@@ -1199,24 +1204,28 @@ __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const
 
 __global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, DeferredUpdate du, SelectPartials sp,
                                                              PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
-    tab_row_update_body(tv, du, sp, rec, blockIdx.x);
+    const PivotRecord R = *rec;
+    if (R.outcome != DEV_RUNNING) return;
+    tab_row_update_body(tv, du, sp, R, blockIdx.x);
 }
 
 // W <- E W  and  b, -obj, basis, flags, trace (both walk the m rows)
 __device__ __forceinline__ void tab_update_w_vectors_body(const DeferredUpdate& du, int m, const double* __restrict__ alpha,
                                                           double* __restrict__ b, int32_t* __restrict__ basis_indices,
                                                           uint8_t* __restrict__ in_basis, int32_t* __restrict__ trace,
-                                                          int64_t trace_cap, PivotRecord* rec, int block) {
+                                                          int64_t trace_cap, const PivotRecord& R, PivotRecord* rec,
+                                                          int block) {
     __shared__ double s_wr2[kMaxEta];
-    const int p_old = rec->n_eta_old, jt = rec->eta_target, r = rec->r;
-    if ((int)threadIdx.x < p_old) s_wr2[threadIdx.x] = du.wr[threadIdx.x];
-    __syncthreads();
+    const int p_old = R.n_eta_old, jt = R.eta_target, r = R.r;
+    if ((int)threadIdx.x < du.kmax) s_wr2[threadIdx.x] = du.wr[threadIdx.x];
     const int i = block * kThreads + threadIdx.x;
-    const double ar = rec->alpha_r;
-    const double br = rec->b_r / ar;
+    const double a_i = i < m ? alpha[i] : 0.0;
+    const double b_i = i < m ? b[i] : 0.0;
+    __syncthreads();
+    const double ar = R.alpha_r;
+    const double br = R.b_r / ar;
     if (i < m) {
-        const double a = alpha[i];
+        const double a = a_i;
         const double u = (i == r) ? (1.0 / ar - 1.0) : (-a / ar);
         if (u != 0.0) {
             for (int j = 0; j < p_old; ++j) {
@@ -1227,17 +1236,17 @@ __device__ __forceinline__ void tab_update_w_vectors_body(const DeferredUpdate& 
         double* tgt = du.W + (int64_t)jt * du.ld + i;
         if (jt < p_old) *tgt += u; else *tgt = u;
         if (i == r) b[i] = br;
-        else if (a != 0.0) b[i] = fma(-a, br, b[i]);
+        else if (a != 0.0) b[i] = fma(-a, br, b_i);
     }
     if (i == 0) {
-        const int q = rec->q, leaving = rec->leaving;
-        rec->minus_objective = fma(-rec->d_q, br, rec->minus_objective);
+        const int q = R.q, leaving = R.leaving;
+        rec->minus_objective = fma(-R.d_q, br, R.minus_objective);
         basis_indices[r] = q;
         if (leaving < kWrappedArtificialBase) in_basis[leaving] = 0;   // a wrapped artificial has no flag
         in_basis[q] = 1;
-        const long long it = rec->iterations;
+        const long long it = R.iterations;
         if (trace && it < trace_cap) {
-            trace[0 * trace_cap + it] = rec->phase;
+            trace[0 * trace_cap + it] = R.phase;
             trace[1 * trace_cap + it] = q;
             trace[2 * trace_cap + it] = r;
             trace[3 * trace_cap + it] = leaving;
@@ -1253,8 +1262,9 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_w_vectors(DeferredUpdat
                                                                    uint8_t* __restrict__ in_basis,
                                                                    int32_t* __restrict__ trace, int64_t trace_cap,
                                                                    PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
-    tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, rec, blockIdx.x);
+    const PivotRecord R = *rec;
+    if (R.outcome != DEV_RUNNING) return;
+    tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, R, rec, blockIdx.x);
 }
 
 // Both halves of the update in ONE launch: workgroups [0, nb_row) update the tableau row / reduced
@@ -1266,16 +1276,18 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, Def
                                                              double* __restrict__ b, int32_t* __restrict__ basis_indices,
                                                              uint8_t* __restrict__ in_basis, int32_t* __restrict__ trace,
                                                              int64_t trace_cap, PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
-    if ((int)blockIdx.x < nb_row) tab_row_update_body(tv, du, sp, rec, blockIdx.x);
-    else tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, rec, blockIdx.x - nb_row);
+    const PivotRecord R = *rec;
+    if (R.outcome != DEV_RUNNING) return;
+    if ((int)blockIdx.x < nb_row) tab_row_update_body(tv, du, sp, R, blockIdx.x);
+    else tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, R, rec, blockIdx.x - nb_row);
 }
 
 // PRICE's final reduction and the tableau column in one launch: every workgroup reduces the (few)
 // partials to the same entering column q, then forms alpha = T0[:,q] + W R0[:,q] for its rows.
 __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, DeferredUpdate du, SelectPartials sp,
                                                                 int count, double* __restrict__ alpha, PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
+    const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
+    if (outcome != DEV_RUNNING) return;
     __shared__ double s_k1[kThreads / 64];
     __shared__ int s_j[kThreads / 64];
     __shared__ double s_vs[kMaxEta];
@@ -1333,12 +1345,12 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
         rec->key1 = k1;
         if (sp.rule == 1) rec->last_selected = bj;
     }
-    const int p = rec->n_eta;
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
-    __syncthreads();
     const int i = blockIdx.x * kThreads + threadIdx.x;
+    const double t0 = i < tv.m ? tv.T0[(int64_t)cq * tv.ld_t + i] : 0.0;     // in flight together with the R0 column
+    __syncthreads();
     if (i >= tv.m) return;
-    double a = tv.T0[(int64_t)cq * tv.ld_t + i];
+    double a = t0;
     for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
     alpha[i] = a;
 }
