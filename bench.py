@@ -106,6 +106,12 @@ def main():
                     help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: anything a library prints there on the way (RCCL writes its
+    # version banner to stdout at communicator creation) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import rust_lp_amd  # noqa: F401
@@ -260,7 +266,8 @@ def main():
             out["revised_engine"] = secondary
         if world == 1:
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(m, n, seed, W, K)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if sharded:
         dist.destroy_process_group()
 

@@ -1329,14 +1329,10 @@ relp_status_t Engine::shard_pivot() {
     const TableauView tv = tview();
     const DeferredUpdate du = deferred();
     const SelectPartials sp = tab_partials(rule);
-    prof_begin(RELP_K_RATIO);
-    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
-    prof_end();
+    // the ratio test ran in relp_shard_select_column; tableau row / reduced costs / PRICE partials of the
+    // owned columns and W, b, basis (replicated) in one launch
     prof_begin(RELP_K_PRICE);
-    launch_tab_row_update(tv, du, sp, d_rec_, stream_);
-    prof_end();
-    prof_begin(RELP_K_UPDATE_W);
-    launch_tab_update_w_vectors(du, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+    launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
     tab_partials_valid_ = true;
     if (++since_flush_ >= block_) enqueue_flush();
@@ -1353,12 +1349,10 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
         const TableauView tv = tview();
         const SelectPartials sp = tab_partials(rule);
         if (!tab_partials_valid_) { launch_tab_scan(tv, sp, d_rec_, stream_); tab_partials_valid_ = true; }
-        prof_begin(RELP_K_SELECT_COLUMN);
-        launch_tab_select(tv, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_rec_, stream_);
-        prof_end();
+        // PRICE's final reduction over the local partials + the local winner's tableau column, written
+        // straight into the candidate message
         prof_begin(RELP_K_FTRAN);
-        launch_tab_column(tv, deferred(), d_aq_, d_rec_, stream_);
-        launch_pack_candidate(d_aq_, m_, dev_candidate, d_rec_, stream_);
+        launch_tab_select_column_msg(tv, deferred(), sp, tab_scan_blocks(sc_hi_ - sc_lo_), dev_candidate, d_rec_, stream_);
         prof_end();
         return RELP_OK;
     }
@@ -1379,9 +1373,15 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
 relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t count) {
     if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
-    // tableau engine: the winner's payload is the entering tableau column (alpha) itself
-    launch_select_candidate(dev_candidates, count, cand_len_, m_, tableau_ ? d_alpha_ : d_aq_, rule, cfg_.tol_tie, d_rec_,
-                            stream_);
+    if (tableau_) {
+        // the winner's payload is the entering tableau column (alpha) itself: pick it and run the ratio test
+        prof_begin(RELP_K_RATIO);
+        launch_select_candidate_ratio(dev_candidates, count, cand_len_, m_, d_alpha_, d_b_, d_basis_, rule, tolerances(),
+                                      deferred(), d_rec_, stream_);
+        prof_end();
+        return RELP_OK;
+    }
+    launch_select_candidate(dev_candidates, count, cand_len_, m_, d_aq_, rule, cfg_.tol_tie, d_rec_, stream_);
     return RELP_OK;
 }
 

@@ -221,6 +221,13 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 // launch_tab_select + launch_tab_column in one launch (every workgroup reduces the partials itself)
 void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                               double* alpha, PivotRecord* rec, hipStream_t s);
+// sharded engines: this rank's candidate message [key, j, d_j, alpha(m)] instead of the record
+void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
+                                  double* msg, PivotRecord* rec, hipStream_t s);
+// winner among the gathered candidates + ratio test + block bookkeeping in one launch (tableau engine)
+void launch_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
+                                   const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
+                                   const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
 // launch_tab_row_update + launch_tab_update_w_vectors in one launch (disjoint workgroup ranges)
 void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
                            const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,

@@ -648,29 +648,29 @@ __global__ __launch_bounds__(kThreads) void k_ftran(const double* __restrict__ B
 // RATIO TEST (single workgroup; two passes: strict minimum, then Bland tie-break on the leaving
 // column among rows within the tie band -- identical to tableau/mod.rs:221-247 for zero tolerances)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict__ alpha,
-                                                        const double* __restrict__ b,
-                                                        const int32_t* __restrict__ basis_indices, int m,
-                                                        Tolerances tol, DeferredUpdate du, PivotRecord* rec) {
-    const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
-    if (outcome != DEV_RUNNING) return;
-    __shared__ double s_min[kSingleBlock / 64];
-    __shared__ int s_leave[kSingleBlock / 64];
-    __shared__ int s_row[kSingleBlock / 64];
+// Body of the ratio test for a workgroup of BS threads that keeps up to ITEMS rows per thread in
+// registers.  `p` = rec->n_eta read by the caller together with the outcome.  Ends with the block
+// bookkeeping of the deferred update.
+template <int BS, int ITEMS>
+__device__ __forceinline__ void ratio_body(const double* alpha, const double* b, const int32_t* basis_indices, int m,
+                                           const Tolerances& tol, const DeferredUpdate& du, int p, PivotRecord* rec) {
+    __shared__ double s_min[BS / 64];
+    __shared__ int s_leave[BS / 64];
+    __shared__ int s_row[BS / 64];
     __shared__ double s_bcast;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     // Each thread keeps its rows' ratios and leaving columns in registers (all loads issued at once, one
     // memory round trip); both passes then run out of registers.  m > 16 * 1024 falls back to re-reading.
-    constexpr int kItems = 16;
-    const bool cached = m <= kItems * kSingleBlock;
+    constexpr int kItems = ITEMS;
+    const bool cached = m <= kItems * BS;
     double ratio_r[kItems];
     int leave_r[kItems];
     double mn = INFINITY;
     if (cached) {
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
-            const int i = threadIdx.x + k * kSingleBlock;
+            const int i = threadIdx.x + k * BS;
             const bool in = i < m;
             const double a = in ? alpha[i] : 0.0;
             double bi = in ? b[i] : 0.0;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
         }
     } else {
 #pragma unroll 4
-        for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+        for (int i = threadIdx.x; i < m; i += BS) {
             const double a = alpha[i];
             double bi = b[i];
             if (fabs(bi) <= tol.zero) bi = 0.0;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         double g = s_min[0];
-        for (int w = 1; w < kSingleBlock / 64; ++w) g = fmin(g, s_min[w]);
+        for (int w = 1; w < BS / 64; ++w) g = fmin(g, s_min[w]);
         s_bcast = g;
     }
     __syncthreads();
@@ -710,11 +710,11 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             // ratio_r is +inf for rows that do not take part, so `<= bound` excludes them
-            if (ratio_r[k] <= bound && leave_r[k] < best_leave) { best_leave = leave_r[k]; best_row = threadIdx.x + k * kSingleBlock; }
+            if (ratio_r[k] <= bound && leave_r[k] < best_leave) { best_leave = leave_r[k]; best_row = threadIdx.x + k * BS; }
         }
     } else {
 #pragma unroll 4
-        for (int i = threadIdx.x; i < m; i += kSingleBlock) {
+        for (int i = threadIdx.x; i < m; i += BS) {
             const double a = alpha[i];
             double bi = b[i];
             const int lv = basis_indices[i];
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     if (lane == 0) { s_leave[wave] = best_leave; s_row[wave] = best_row; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kSingleBlock / 64; ++w)
+        for (int w = 1; w < BS / 64; ++w)
             if (s_leave[w] < best_leave) { best_leave = s_leave[w]; best_row = s_row[w]; }
         rec->r = best_row;
         rec->leaving = best_leave;
@@ -743,13 +743,22 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict
     // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
     __syncthreads();
     const int r = s_row[0];
-    for (int j = threadIdx.x; j < p; j += kSingleBlock) du.wr[j] = du.W[(int64_t)j * du.ld + r];
+    for (int j = threadIdx.x; j < p; j += BS) du.wr[j] = du.W[(int64_t)j * du.ld + r];
     if (threadIdx.x == 0) {
         int jt = du.pos_of_row[r];
         rec->n_eta_old = p;
         if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
         rec->eta_target = jt;
     }
+}
+
+__global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict__ alpha,
+                                                        const double* __restrict__ b,
+                                                        const int32_t* __restrict__ basis_indices, int m,
+                                                        Tolerances tol, DeferredUpdate du, PivotRecord* rec) {
+    const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
+    if (outcome != DEV_RUNNING) return;
+    ratio_body<kSingleBlock, 16>(alpha, b, basis_indices, m, tol, du, p, rec);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1284,8 +1293,11 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, Def
 
 // PRICE's final reduction and the tableau column in one launch: every workgroup reduces the (few)
 // partials to the same entering column q, then forms alpha = T0[:,q] + W R0[:,q] for its rows.
+// `msg` (sharded engines): the candidate message [key, j, d_j, alpha(m)] of this rank is written instead
+// of the record; a rank without a candidate sends key = +inf and stays RUNNING (another rank may have one).
 __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, DeferredUpdate du, SelectPartials sp,
-                                                                int count, double* __restrict__ alpha, PivotRecord* rec) {
+                                                                int count, double* __restrict__ alpha, double* msg,
+                                                                PivotRecord* rec) {
     const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
     if (outcome != DEV_RUNNING) return;
     __shared__ double s_k1[kThreads / 64];
@@ -1332,7 +1344,11 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
         for (int w = 1; w < kThreads / 64; ++w) bj = min(bj, s_j[w]);
     }
     if (bj == 0x7fffffff) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (msg) {
+            const int i = blockIdx.x * kThreads + threadIdx.x;
+            if (i < tv.m) alpha[i] = 0.0;
+            if (i == 0) { msg[0] = INFINITY; msg[1] = 0.0; msg[2] = 0.0; }
+        } else if (blockIdx.x == 0 && threadIdx.x == 0) {
             rec->outcome = DEV_NO_CANDIDATE;
             if (sp.rule == 1) rec->last_selected = -1;
         }
@@ -1340,10 +1356,13 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
     }
     const int cq = bj + tv.col_off;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        rec->q = bj;
-        rec->d_q = tv.d[cq];
-        rec->key1 = k1;
-        if (sp.rule == 1) rec->last_selected = bj;
+        if (msg) { msg[0] = k1; msg[1] = (double)bj; msg[2] = tv.d[cq]; }
+        else {
+            rec->q = bj;
+            rec->d_q = tv.d[cq];
+            rec->key1 = k1;
+            if (sp.rule == 1) rec->last_selected = bj;
+        }
     }
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
     const int i = blockIdx.x * kThreads + threadIdx.x;
@@ -1686,6 +1705,47 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_candidate(const double*
     for (int i = threadIdx.x; i < m; i += kSingleBlock) aq[i] = msgs[win * msg_len + 3 + i];
 }
 
+// The winner among the gathered candidates, its tableau column, and the ratio test on it in one
+// single-workgroup launch (tableau engine: the candidate's payload IS alpha).
+__global__ __launch_bounds__(kSingleBlock) void k_select_candidate_ratio(const double* __restrict__ msgs, int count,
+                                                                         int64_t msg_len, int m, double* alpha,
+                                                                         const double* b, const int32_t* basis_indices,
+                                                                         int rule, Tolerances tol, DeferredUpdate du,
+                                                                         PivotRecord* rec) {
+    const int outcome = rec->outcome, p = rec->n_eta;
+    if (outcome != DEV_RUNNING) return;
+    __shared__ int s_win;
+    if (threadIdx.x == 0) {
+        int win = -1; double k1 = INFINITY; double kj = 0.0;
+        for (int g = 0; g < count; ++g) {
+            const double a = msgs[g * msg_len + 0], j = msgs[g * msg_len + 1];
+            if (a < k1 || (a == k1 && win >= 0 && j < kj)) { k1 = a; kj = j; win = g; }
+        }
+        if (win >= 0 && rule == 2 && tol.tie > 0.0) {
+            const double bound = k1 + tol.tie * fmax(1.0, fabs(k1));
+            for (int g = 0; g < count; ++g) {
+                const double a = msgs[g * msg_len + 0], j = msgs[g * msg_len + 1];
+                if (a <= bound && j < kj) { kj = j; win = g; }
+            }
+        }
+        s_win = win;
+        if (win < 0) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (rule == 1) rec->last_selected = -1;
+        } else {
+            rec->q = (int)msgs[win * msg_len + 1];
+            rec->d_q = msgs[win * msg_len + 2];
+            if (rule == 1) rec->last_selected = rec->q;
+        }
+    }
+    __syncthreads();
+    const int win = s_win;
+    if (win < 0) return;
+    for (int i = threadIdx.x; i < m; i += kSingleBlock) alpha[i] = msgs[win * msg_len + 3 + i];
+    __syncthreads();                                   // alpha was written by this workgroup: visible to it
+    ratio_body<kSingleBlock, 16>(alpha, b, basis_indices, m, tol, du, p, rec);
+}
+
 __global__ void k_gather_alpha(const double* __restrict__ slices, int count, int stride, int m,
                                double* __restrict__ alpha, const PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
@@ -1914,7 +1974,13 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                               double* alpha, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       rec);
+                       (double*)nullptr, rec);
+}
+
+void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
+                                  double* msg, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
+                       msg, rec);
 }
 
 void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
@@ -2025,6 +2091,13 @@ void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double*
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_candidate, dim3(cdiv(m, 256)), dim3(256), 0, s, aq, m, msg, rec);
     hipLaunchKernelGGL(k_clear_no_candidate, dim3(1), dim3(1), 0, s, rec);
+}
+
+void launch_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
+                                   const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
+                                   const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_candidate_ratio, dim3(1), dim3(kSingleBlock), 0, s, msgs, count, msg_len, m, alpha, b,
+                       basis_indices, rule, tol, du, rec);
 }
 
 void launch_select_candidate(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* aq,
