@@ -27,6 +27,7 @@ ranks, ONE all-gather of [key, j, d_j, alpha(m)] candidates per pivot over RCCL,
 import argparse
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -62,7 +63,19 @@ def cpu_baseline(m, n, seed, warmup, steps, budget_s=20.0):
     return {"value": done / dt if dt > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": f"{done} pivots (iterations {warmup}..{warmup + done}) of the same {m}x{n} LP, "
                       f"oracle/relp_f64.c (f64 restatement of Carry<_, BasisInverseRows>), {dt:.1f} s",
-            "nproc": os.cpu_count()}
+            "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+            "reference_toolchain": "cargo " + ("present (not used: the crate needs a 2021 nightly and crates.io)"
+                                               if shutil.which("cargo") else "absent on this host")}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def kernel_table(prof, alg_bytes, alg_flops):
