@@ -1,0 +1,214 @@
+// relp_device_common.h -- device helpers shared by the three kernel files (constants, wavefront and
+// workgroup reductions, the PRICE key, the ratio-test body).  Included by relp_kernels_*.hip only.
+#pragma once
+#include "relp_kernels.h"
+
+#include <math.h>
+
+namespace relp {
+
+static constexpr int kThreads = 256;     // 4 wavefronts
+static constexpr int kVecPerBlock = 8;   // vectors (columns of A / rows of B^-1) per workgroup
+static constexpr int kSingleBlock = 1024;
+
+// ------------------------------------------------------------------------------------------------
+// Wavefront (64 lanes) and workgroup reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Dot products of kVecPerBlock contiguous vectors (stride ld) with one shared vector x.
+// Thread t streams 16-byte pairs k = 2t, 2t + 512, ...; all 8 loads of one step are independent.
+// Vectors beyond `v_hi` are clamped (duplicate loads, results discarded) so there is no branch in
+// the stream.  result[v] is valid for threads < kVecPerBlock after the call.
+__device__ __forceinline__ void block_multi_dot(const double* __restrict__ M, int64_t ld, int len,
+                                                int v0, int v_hi, const double* __restrict__ x,
+                                                double* s_partial /* [4][kVecPerBlock] */,
+                                                double& result) {
+    const int t = threadIdx.x;
+    double acc[kVecPerBlock];
+    const double* base[kVecPerBlock];
+#pragma unroll
+    for (int v = 0; v < kVecPerBlock; ++v) {
+        acc[v] = 0.0;
+        int vi = v0 + v;
+        if (vi >= v_hi) vi = v_hi - 1;
+        base[v] = M + (int64_t)vi * ld;
+    }
+    const int len2 = len & ~1;
+    for (int k = 2 * t; k < len2; k += 2 * kThreads) {
+        const double2 xv = *reinterpret_cast<const double2*>(x + k);
+#pragma unroll
+        for (int v = 0; v < kVecPerBlock; ++v) {
+            const double2 a = *reinterpret_cast<const double2*>(base[v] + k);
+            acc[v] = fma(a.x, xv.x, acc[v]);
+            acc[v] = fma(a.y, xv.y, acc[v]);
+        }
+    }
+    if ((len & 1) && t == 0) {
+        const double xl = x[len - 1];
+#pragma unroll
+        for (int v = 0; v < kVecPerBlock; ++v) acc[v] = fma(base[v][len - 1], xl, acc[v]);
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int v = 0; v < kVecPerBlock; ++v) {
+        const double w = wave_sum(acc[v]);
+        if (lane == 0) s_partial[wave * kVecPerBlock + v] = w;
+    }
+    __syncthreads();
+    if (t < kVecPerBlock) {
+        result = (s_partial[0 * kVecPerBlock + t] + s_partial[1 * kVecPerBlock + t]) +
+                 (s_partial[2 * kVecPerBlock + t] + s_partial[3 * kVecPerBlock + t]);
+    }
+}
+
+// Selection key of a candidate column (smaller wins, ties by smaller j):
+//   SteepestDescent: d_j (pivot_rule.rs:118); FirstProfitable[WithMemory]: position in the search order (:88)
+__device__ __forceinline__ double select_key(int rule, int n, const PivotRecord* rec, int j, double d_j) {
+    if (rule == 2) return d_j;
+    const int last = (rule == 1 && rec) ? rec->last_selected : -1;
+    if (last >= 0) return (double)(j >= last ? j - last : j - last + n);
+    return (double)j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PRICE
+// Workgroup-level (key, j) minimum of one candidate per thread -> partial slot `slot`.
+__device__ __forceinline__ void block_partial_min(double key, int kj, SelectPartials sp, int slot) {
+    __shared__ double s_k[kThreads / 64];
+    __shared__ int s_j[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(key, off, 64);
+        const int oj = __shfl_down(kj, off, 64);
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k[wave] = key; s_j[wave] = kj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w)
+            if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
+        sp.k1[slot] = key;
+        sp.j[slot] = kj;
+    }
+}
+
+static constexpr int kMaxEta = 128;
+
+// ------------------------------------------------------------------------------------------------
+// RATIO TEST (single workgroup; two passes: strict minimum, then Bland tie-break on the leaving
+// column among rows within the tie band -- identical to tableau/mod.rs:221-247 for zero tolerances)
+// ------------------------------------------------------------------------------------------------
+// Body of the ratio test for a workgroup of BS threads that keeps up to ITEMS rows per thread in
+// registers.  `p` = rec->n_eta read by the caller together with the outcome.  Ends with the block
+// bookkeeping of the deferred update.
+template <int BS, int ITEMS>
+__device__ __forceinline__ void ratio_body(const double* alpha, const double* b, const int32_t* basis_indices, int m,
+                                           const Tolerances& tol, const DeferredUpdate& du, int p, PivotRecord* rec) {
+    __shared__ double s_min[BS / 64];
+    __shared__ int s_leave[BS / 64];
+    __shared__ int s_row[BS / 64];
+    __shared__ double s_bcast;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // Each thread keeps its rows' ratios and leaving columns in registers (all loads issued at once, one
+    // memory round trip); both passes then run out of registers.  m > 16 * 1024 falls back to re-reading.
+    constexpr int kItems = ITEMS;
+    const bool cached = m <= kItems * BS;
+    double ratio_r[kItems];
+    int leave_r[kItems];
+    double mn = INFINITY;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int i = threadIdx.x + k * BS;
+            const bool in = i < m;
+            const double a = in ? alpha[i] : 0.0;
+            double bi = in ? b[i] : 0.0;
+            leave_r[k] = in ? basis_indices[i] : 0x7fffffff;
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            ratio_r[k] = (in && a > tol.pivot) ? bi / a : INFINITY;
+            mn = fmin(mn, ratio_r[k]);
+        }
+    } else {
+#pragma unroll 4
+        for (int i = threadIdx.x; i < m; i += BS) {
+            const double a = alpha[i];
+            double bi = b[i];
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            const double ratio = (a > tol.pivot) ? bi / a : INFINITY;
+            mn = fmin(mn, ratio);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if (lane == 0) s_min[wave] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = s_min[0];
+        for (int w = 1; w < BS / 64; ++w) g = fmin(g, s_min[w]);
+        s_bcast = g;
+    }
+    __syncthreads();
+    const double gmin = s_bcast;
+    if (gmin == INFINITY) {
+        if (threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
+        return;
+    }
+    const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
+    int best_leave = 0x7fffffff, best_row = -1;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            // ratio_r is +inf for rows that do not take part, so `<= bound` excludes them
+            if (ratio_r[k] <= bound && leave_r[k] < best_leave) { best_leave = leave_r[k]; best_row = threadIdx.x + k * BS; }
+        }
+    } else {
+#pragma unroll 4
+        for (int i = threadIdx.x; i < m; i += BS) {
+            const double a = alpha[i];
+            double bi = b[i];
+            const int lv = basis_indices[i];
+            if (fabs(bi) <= tol.zero) bi = 0.0;
+            if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ol = __shfl_down(best_leave, off, 64);
+        const int orow = __shfl_down(best_row, off, 64);
+        if (ol < best_leave) { best_leave = ol; best_row = orow; }
+    }
+    if (lane == 0) { s_leave[wave] = best_leave; s_row[wave] = best_row; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BS / 64; ++w)
+            if (s_leave[w] < best_leave) { best_leave = s_leave[w]; best_row = s_row[w]; }
+        rec->r = best_row;
+        rec->leaving = best_leave;
+        rec->alpha_r = alpha[best_row];
+        rec->b_r = b[best_row];
+        s_row[0] = best_row;
+    }
+    if (du.kmax <= 0) return;
+    // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
+    __syncthreads();
+    const int r = s_row[0];
+    for (int j = threadIdx.x; j < p; j += BS) du.wr[j] = du.W[(int64_t)j * du.ld + r];
+    if (threadIdx.x == 0) {
+        int jt = du.pos_of_row[r];
+        rec->n_eta_old = p;
+        if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
+        rec->eta_target = jt;
+    }
+}
+
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace relp

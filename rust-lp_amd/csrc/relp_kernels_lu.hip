@@ -1,0 +1,241 @@
+// relp_kernels_lu.hip -- kernels of the sparse LU engine (RELP_ENGINE_LU): CSC PRICE and the
+// level-scheduled, LDS-resident triangular solves (FTRAN / BTRAN).  Reference rows a4 (LU), a8:
+// carry/lower_upper/mod.rs:157-222.
+#include "relp_device_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace relp {
+
+// ------------------------------------------------------------------------------------------------
+// Sparse LU engine: CSC PRICE and the level-scheduled triangular solves
+// ------------------------------------------------------------------------------------------------
+// d_j = c_j + sum_i (-pi)_i a_ij over the stored entries of column j (vector/dense.rs:81-92), thread per
+// column; the workgroup's best (key, j) goes to the PRICE partials.
+__global__ __launch_bounds__(kThreads) void k_price_csc(DeviceCSC csc, ColumnTable ct, const double* __restrict__ vec,
+                                                        double* __restrict__ d, int p_lo, int p_hi, int cost_mode,
+                                                        SelectPartials sp, const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    const int p = p_lo + blockIdx.x * kThreads + threadIdx.x;
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (p < p_hi) {
+        double v = 0.0;
+        const int64_t s0 = csc.col_ptr[p], s1 = csc.col_ptr[p + 1];
+        for (int64_t e = s0; e < s1; ++e) v = fma(vec[csc.row_idx[e]], csc.values[e], v);
+        const int br = ct.bound_row[p];
+        if (br >= 0) v += vec[br];
+        if (cost_mode == 2) v += ct.cost[p];
+        const int j = ct.nr_artificial + p;
+        d[j] = v;
+        if (sp.k1 && !sp.in_basis[j] && v < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, v); kj = j; }
+    }
+    if (sp.k1) block_partial_min(key, kj, sp, sp.offset + blockIdx.x);
+}
+
+// ---- level-scheduled triangular solves ---------------------------------------------------------------
+// One persistent workgroup of 256 threads.  The work vector lives in LDS; when the factor itself fits
+// next to it (the usual case for Netlib-sized bases) its rows and entries are staged into LDS first, so
+// that a level costs an LDS round trip and a barrier instead of a chain of dependent global loads.
+// 8 to 64 lanes share one row (coalesced entry loads, DPP reduction), and each group fetches its
+// first row of the NEXT level - row header and first entries do not depend on x - before it waits at
+// the barrier of the current one.
+static constexpr int kLuThreads = 256;          // 4 wavefronts: cheap barriers, 32 rows per pass
+static constexpr int kLuLdsBytes = 156 * 1024;        // of the CU's 160 KB
+
+__host__ __device__ inline int64_t lu_up16(int64_t b) { return (b + 15) / 16 * 16; }
+// bytes needed to hold a schedule (m rows, nnz entries) in LDS
+__host__ __device__ inline int64_t schedule_lds_bytes(int m, int64_t nnz, int n_levels) {
+    return lu_up16((int64_t)sizeof(LuRow) * m) + lu_up16(8 * nnz) + lu_up16(4 * nnz) + lu_up16(4 * ((int64_t)n_levels + 1));
+}
+
+// Sum over the 8 lanes of a group, result valid in the group's lane 0.  DPP row shifts (lane i reads lane
+// i + n inside its row of 16) instead of LDS-routed shuffles: the reduction sits on the critical path of
+// every level.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_row_shl(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the G lanes of a group (G = 8, 16, 32 or 64, uniform over the workgroup); valid in lane 0.
+__device__ __forceinline__ double group_sum(double v, int G) {
+    if (G >= 64) v += __shfl_down(v, 32, 64);
+    if (G >= 32) v += __shfl_down(v, 16, 64);
+    if (G >= 16) v += dpp_row_shl<0x108>(v);
+    v += dpp_row_shl<0x104>(v);
+    v += dpp_row_shl<0x102>(v);
+    v += dpp_row_shl<0x101>(v);
+    return v;
+}
+// Lanes per row for a level of `rows` rows: a level with few rows (the dense rows of the bump come one
+// per level) gets a whole wavefront per row.
+__device__ __forceinline__ int group_lanes(int rows) {
+    return rows <= kLuThreads / 64 ? 64 : rows <= kLuThreads / 32 ? 32 : rows <= kLuThreads / 16 ? 16 : 8;
+}
+
+// kStage: copy the schedule into LDS at `base` and solve from there; otherwise solve from global memory.
+template <bool kStage>
+__device__ __forceinline__ void solve_schedule(const DeviceSchedule& s, int m, char* base, double* x) {
+    const LuRow* rows = s.rows; const int32_t* idx = s.idx; const double* val = s.val; const int32_t* level_ptr = s.level_ptr;
+    if (kStage) {
+        LuRow* l_rows = reinterpret_cast<LuRow*>(base); base += lu_up16((int64_t)sizeof(LuRow) * m);
+        double* l_val = reinterpret_cast<double*>(base); base += lu_up16(8 * (int64_t)s.nnz);
+        int32_t* l_idx = reinterpret_cast<int32_t*>(base); base += lu_up16(4 * (int64_t)s.nnz);
+        int32_t* l_lp = reinterpret_cast<int32_t*>(base);
+        for (int e = threadIdx.x; e < s.nnz; e += blockDim.x) { l_val[e] = s.val[e]; l_idx[e] = s.idx[e]; }
+        for (int k = threadIdx.x; k < m; k += blockDim.x) l_rows[k] = s.rows[k];
+        for (int k = threadIdx.x; k <= s.n_levels; k += blockDim.x) l_lp[k] = s.level_ptr[k];
+        __syncthreads();
+        rows = l_rows; idx = l_idx; val = l_val; level_ptr = l_lp;
+    }
+    const int n_levels = s.n_levels;
+    const int tid = threadIdx.x;
+    // prefetched first row of the level about to be solved
+    int t0 = level_ptr[0], t1 = level_ptr[1];
+    int G = group_lanes(t1 - t0);
+    LuRow pr{0, 0, 0, 0, 1.0};
+    int pidx = 0; double pval = 0.0;
+    bool have = t0 + tid / G < t1;
+    if (have) {
+        pr = rows[t0 + tid / G];
+        if (pr.e0 + tid % G < pr.e1) { pidx = idx[pr.e0 + tid % G]; pval = val[pr.e0 + tid % G]; }
+    }
+    for (int lev = 0; lev < n_levels; ++lev) {
+        const LuRow cr = pr; const int cidx = pidx; const double cval = pval; const bool chave = have;
+        const int ct0 = t0, ct1 = t1, cG = G;
+        const int g = tid / cG, lane = tid % cG, ngroups = kLuThreads / cG;
+        if (lev + 1 < n_levels) {
+            t0 = t1; t1 = level_ptr[lev + 2];
+            G = group_lanes(t1 - t0);
+            have = t0 + tid / G < t1; pval = 0.0; pidx = 0;
+            if (have) {
+                pr = rows[t0 + tid / G];
+                if (pr.e0 + tid % G < pr.e1) { pidx = idx[pr.e0 + tid % G]; pval = val[pr.e0 + tid % G]; }
+            }
+        }
+        if (chave) {
+            double sum = (cr.e0 + lane < cr.e1) ? -cval * x[cidx] : 0.0;
+            for (int e = cr.e0 + lane + cG; e < cr.e1; e += cG) sum = fma(-val[e], x[idx[e]], sum);
+            sum = group_sum(sum, cG);
+            if (lane == 0) x[cr.k] = (x[cr.k] + sum) * cr.diag;
+        }
+        for (int t = ct0 + g + ngroups; t < ct1; t += ngroups) {
+            const LuRow r = rows[t];
+            double sum = 0.0;
+            for (int e = r.e0 + lane; e < r.e1; e += cG) sum = fma(-val[e], x[idx[e]], sum);
+            sum = group_sum(sum, cG);
+            if (lane == 0) x[r.k] = (x[r.k] + sum) * r.diag;
+        }
+        __syncthreads();
+    }
+}
+
+// Dynamic LDS: [x : m doubles (kXLds)] [staged schedule].  The variant is chosen by the host from the
+// sizes (plan_lu_lds).
+// FTRAN (lower_upper/mod.rs:157-190 without the update loop: the updates live in W): P a -> L -> U -> Q
+template <bool kXLds, bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_ftran(DeviceLU lu, const double* __restrict__ aq,
+                                                           double* __restrict__ v, double* __restrict__ scratch,
+                                                           const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    extern __shared__ __align__(16) char lds[];
+    double* x = kXLds ? reinterpret_cast<double*>(lds) : scratch;
+    char* base = lds + (kXLds ? lu_up16((int64_t)lu.m * 8) : 0);
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) x[k] = aq[lu.rowperm[k]];
+    __syncthreads();
+    solve_schedule<kStage1>(lu.Lf, lu.m, base, x);
+    solve_schedule<kStage2>(lu.Uf, lu.m, base, x);
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) v[lu.colperm[k]] = x[k];
+}
+
+// BTRAN (lower_upper/mod.rs:204-222): z' B = c'  ->  U' t = Q' c, L' w = t, z = P' w
+template <bool kXLds, bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_btran(DeviceLU lu, DeferredUpdate du, const double* __restrict__ rhs,
+                                                           int row, double* __restrict__ rho, double* __restrict__ scratch,
+                                                           const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    extern __shared__ __align__(16) char lds[];
+    double* x = kXLds ? reinterpret_cast<double*>(lds) : scratch;
+    char* base = lds + (kXLds ? lu_up16((int64_t)lu.m * 8) : 0);
+    const int r = rhs ? 0 : (row >= 0 ? row : rec->r);   // rec may be null when rhs or row is given
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) {
+        const int cp = lu.colperm[k];
+        double c;
+        if (rhs) c = rhs[cp];
+        else {
+            // c = e_r + sum_j W[r, j] e_S[j]   (the pivot row of (I + W S') B0inv)
+            c = (cp == r) ? 1.0 : 0.0;
+            if (du.kmax > 0) { const int jt = du.pos_of_row[cp]; if (jt >= 0) c += du.W[(int64_t)jt * du.ld + r]; }
+        }
+        x[k] = c;
+    }
+    __syncthreads();
+    solve_schedule<kStage1>(lu.Ub, lu.m, base, x);
+    solve_schedule<kStage2>(lu.Lb, lu.m, base, x);
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) rho[lu.rowperm[k]] = x[k];
+}
+
+
+// Single-workgroup selection over the reduced costs.  key = (k1, j) lexicographic minimum:
+//   SteepestDescent: k1 = d_j (strict `<` => lowest j wins ties, pivot_rule.rs:118)
+//   FirstProfitable[WithMemory]: k1 = position of j in the search order (pivot_rule.rs:88)
+int32_t price_csc_blocks(int32_t p_lo, int32_t p_hi) { return p_hi > p_lo ? cdiv(p_hi - p_lo, kThreads) : 0; }
+
+void launch_price_csc(const DeviceCSC& csc, const ColumnTable& ct, const double* vec, double* d, int32_t p_lo,
+                      int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec, hipStream_t s) {
+    const int blocks = price_csc_blocks(p_lo, p_hi);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_price_csc, dim3(blocks), dim3(kThreads), 0, s, csc, ct, vec, d, p_lo, p_hi, cost_mode, sp, rec);
+}
+
+struct LuLdsPlan { int x_in_lds, stage_first, stage_second; size_t bytes; };
+static LuLdsPlan plan_lu_lds(int m, const DeviceSchedule& a, const DeviceSchedule& b) {
+    LuLdsPlan p{0, 0, 0, 0};
+    int64_t used = 0;
+    if (lu_up16((int64_t)m * 8) <= kLuLdsBytes / 2) { p.x_in_lds = 1; used = lu_up16((int64_t)m * 8); }
+    const int64_t na = schedule_lds_bytes(m, a.nnz, a.n_levels), nb = schedule_lds_bytes(m, b.nnz, b.n_levels);
+    int64_t extra = 0;
+    if (p.x_in_lds && used + na <= kLuLdsBytes) { p.stage_first = 1; extra = na; }
+    if (p.x_in_lds && used + nb <= kLuLdsBytes) { p.stage_second = 1; extra = std::max(extra, nb); }
+    p.bytes = (size_t)(used + extra);
+    return p;
+}
+
+template <class K>
+static K pick_lu_variant(const LuLdsPlan& p, K v000, K v100, K v110, K v101, K v111) {
+    if (!p.x_in_lds) return v000;
+    if (p.stage_first && p.stage_second) return v111;
+    if (p.stage_first) return v110;
+    if (p.stage_second) return v101;
+    return v100;
+}
+
+static void allow_big_lds(const void* fn) {
+    static std::vector<const void*> done;
+    for (auto f : done) if (f == fn) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLuLdsBytes);
+    done.push_back(fn);
+}
+
+void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* scratch, const PivotRecord* rec,
+                     hipStream_t s) {
+    const LuLdsPlan p = plan_lu_lds(lu.m, lu.Lf, lu.Uf);
+    auto fn = pick_lu_variant(p, k_lu_ftran<false, false, false>, k_lu_ftran<true, false, false>,
+                              k_lu_ftran<true, true, false>, k_lu_ftran<true, false, true>, k_lu_ftran<true, true, true>);
+    allow_big_lds(reinterpret_cast<const void*>(fn));
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kLuThreads), p.bytes, s, lu, aq, v, scratch, rec);
+}
+
+void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double* rhs, int32_t row, double* rho,
+                     double* scratch, const PivotRecord* rec, hipStream_t s) {
+    const LuLdsPlan p = plan_lu_lds(lu.m, lu.Ub, lu.Lb);
+    auto fn = pick_lu_variant(p, k_lu_btran<false, false, false>, k_lu_btran<true, false, false>,
+                              k_lu_btran<true, true, false>, k_lu_btran<true, false, true>, k_lu_btran<true, true, true>);
+    allow_big_lds(reinterpret_cast<const void*>(fn));
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kLuThreads), p.bytes, s, lu, du, rhs, row, rho, scratch, rec);
+}
+
+
+}  // namespace relp

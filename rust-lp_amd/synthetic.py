@@ -2,7 +2,7 @@
 
 Every number is an integer-defined rational, produced by a counter-based SplitMix64 so that the
 exact oracle (Fractions), the f64 CPU oracle, the numpy host path and the on-device fill kernel
-(``relp_synth_fill_dense`` in csrc/relp_kernels.hip) all see the same data:
+(``relp_synth_fill_dense`` in csrc/relp_kernels_revised.hip) all see the same data:
 
   x(stream, idx) = mix(seed + stream * 0xD1B54A32D192ED03 + (idx + 1) * 0x9E3779B97F4A7C15)  (mod 2^64)
   A[i, j] = (1 + x(0, j*m + i) % 999) / 1000             in [0.001, 0.999]
