@@ -70,7 +70,7 @@ def sparse_lp(m: int, n: int, seed: int, nnz_per_col: int = 6, frac_eq: float = 
     All data are small integers (exact in f64 and as Fractions).  Built around a feasible point
     x0 >= 0 (so phase 1 succeeds) with strictly positive costs (so phase 2 is bounded):
       rows [0, n_eq) are ==, then n_le rows <=, then n_ge rows >= (the MatrixData order, no ranges);
-      A entries in [-9, 9] \ {0}; == and >= rows are sign-flipped where needed so that b >= 0.
+      A entries in [-9, 9] without 0; == and >= rows are sign-flipped where needed so that b >= 0.
     Returns CSC arrays over the m constraint rows, b, c and upper bounds (+inf = none).
     """
     idx = np.arange(n * nnz_per_col, dtype=np.uint64)
