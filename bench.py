@@ -78,6 +78,53 @@ def cpu_model():
     return "unknown"
 
 
+def sparse_path(events, with_cpu):
+    """The sparse path (BASELINE.json configs[2]): Netlib 25FV47 through the build's MPS reader, presolve and
+    standardisation, solved to optimality by the LU engine (host Markowitz refactorisation every 64 pivots,
+    level-scheduled FTRAN / BTRAN in LDS, CSC PRICE).  The whole solve is timed; it is latency-bound (the
+    factors are a few hundred KB), so the HBM figure is reported for what it is."""
+    from rust_lp_amd import engine, general_form, mps
+    path = os.path.join(ROOT, "tests", "golden", "mps", "netlib", "25FV47.SIF")
+    if not os.path.exists(path):
+        return None
+    gf = general_form.GeneralForm.from_mps(mps.import_file(path, True))
+    md = gf.to_matrix_data(gf.derive_matrix_data_exact())
+    tol = dict(tol_pivot=1e-5, tol_cost=1e-7)            # see tests/test_gpu_parity.py, config C3
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, **tol)
+    if events:
+        t.profile_enable(True, 40000, 8)
+    t0 = time.perf_counter()
+    outcome = t.solve_relaxation()
+    dt = time.perf_counter() - t0
+    its = t.iterations()
+    stats = t.lu_stats()
+    prof = t.profile_read() if events else {}
+    obj = t.objective_function_value() + float(gf.fixed_cost)
+    t.close()
+    out = {"workload": f"Netlib 25FV47 after presolve: {stats['m']} rows, {md.nr_normal} structural columns, "
+                       f"{len(md.values)} nonzeros; FirstProfitableWithMemory / SteepestDescent, whole two-phase solve",
+           "engine": "lu", "outcome": engine.OUTCOME_NAMES.get(outcome), "objective": obj, "reference_objective": 5.5018459e+03,
+           "pivots": its, "value": its / dt, "unit": "iterations/s", "seconds": dt, "tolerances": tol,
+           "refactorisations": stats["refactorisations"],
+           "last_factor": {k: stats[k] for k in ("nnz_l", "nnz_u", "levels_l", "levels_u")}}
+    if prof:
+        kt = {name: {"launches": cnt, "avg_us": round(ms * 1e3 / cnt, 3)} for name, (cnt, ms) in prof.items() if cnt}
+        out["kernels"] = kt
+        if "ftran" in kt:
+            factor_bytes = 12.0 * (stats["nnz_l"] + stats["nnz_u"]) + 40.0 * stats["m"]
+            out["ftran_GBps"] = round(factor_bytes / (kt["ftran"]["avg_us"] * 1e-6) / 1e9, 3)
+            out["ftran_note"] = "12 (nnz L + nnz U) + 40 m bytes of the last factor / average FTRAN time: dependency-bound"
+    if with_cpu:
+        from oracle import relp_f64
+        ref = relp_f64.OracleF64(md, **tol)
+        c0 = time.perf_counter()
+        ref.run(max_iters=3000, record=False)
+        cdt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": 3000 / cdt, "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"first 3000 pivots of the same LP, oracle/relp_f64.c, {cdt:.1f} s"}
+    return out
+
+
 def kernel_table(prof, alg_bytes, alg_flops):
     kernels = {}
     for name, (cnt, ms) in prof.items():
@@ -112,6 +159,7 @@ def main():
                     help="default = tableau as the measured engine (+ the revised engine's numbers at N = 1)")
     ap.add_argument("--update-block", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-path (LU engine, Netlib 25FV47) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
@@ -259,6 +307,10 @@ def main():
                      "ftran_traffic": load_traffic(args.workload, "ftran"),
                      "objective_after_run": r2["objective"]}
 
+    sparse = None
+    if args.engine == "default" and not sharded and rank == 0 and not args.no_sparse:
+        sparse = sparse_path(events, not args.no_cpu_baseline)
+
     if rank == 0:
         out = {
             "metric": "simplex iterations/sec", "value": K / dt, "unit": "iterations/s", "n_gpus": world,
@@ -277,6 +329,8 @@ def main():
         }
         if secondary is not None:
             out["revised_engine"] = secondary
+        if sparse is not None:
+            out["sparse_engine"] = sparse
         if world == 1:
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(m, n, seed, W, K)
         sys.stdout.flush()
