@@ -508,3 +508,50 @@ def test_25fv47_reaches_the_netlib_optimum(kind, block):
     assert t.trace()[:300] == ref.trace
     ident, basic, min_b = t.check_basis()
     assert ident <= 1e-6 and min_b >= -1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# Full size of the north-star workload: 10,000 x 10,000 dense (bench.py's default)
+# ------------------------------------------------------------------------------------------------
+def test_dense10k_full_size_engines_agree_and_match_the_cpu_oracle_prefix():
+    """The LP bench.py measures, generated in HBM by relp_synth_fill_dense (bit-identical to the numpy
+    generator).  Too large for a CPU solve, so: the first 40 pivots equal the CPU oracle's, the tableau and
+    the revised engine walk the same 320 pivots (5 flushes of the blocked update each), and the
+    size-independent invariants hold afterwards."""
+    import ctypes as C
+    lib = engine.load_library()
+    m = n = 10000
+    seed = 20250002
+    lp = synthetic.dense_lp(m, n, seed)
+    md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"])
+    ref = relp_f64.OracleF64(md.ensure_csc())
+    ref.run(40)
+    ptr = C.c_void_p()
+    assert lib.relp_device_alloc(C.byref(ptr), m * n * 8) == 0
+    assert lib.relp_synth_fill_dense(ptr, m, m, n, seed, 0, None) == 0
+    counts = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=md.b, cost=md.cost, upper_bound=md.upper_bound)
+    traces = []
+    for kind in (engine.ENGINE_TABLEAU, engine.ENGINE_REVISED):
+        t = engine.Tableau(counts, engine=kind, device_dense_ptr=ptr.value, device_dense_ld=m, trace_capacity=1024)
+        assert t.update_block() == 64
+        assert t.run(1)[1] == engine.PHASE_ONE_DONE
+        objs = []
+        for _ in range(5):
+            done, outcome = t.run(64)
+            assert done == 64 and outcome == engine.RUNNING
+            objs.append(t.objective_function_value())
+        assert all(b <= a + 1e-9 for a, b in zip(objs, objs[1:]))         # monotone objective
+        tr = t.trace()
+        assert tr[:40] == ref.trace
+        b = t.b()
+        basis = t.basis_indices()
+        assert b.min() >= -1e-8 and len(set(basis.tolist())) == m
+        d = t.relative_costs()
+        assert np.max(np.abs(d[basis])) <= 1e-7                           # basic reduced costs vanish
+        # objective = c_B . x_B
+        c = np.concatenate([md.cost, np.zeros(m)])
+        assert abs(c[basis] @ b - objs[-1]) <= 1e-9 * abs(objs[-1])
+        traces.append(tr)
+        t.close()
+    assert traces[0] == traces[1] and len(traces[0]) == 320
+    assert lib.relp_device_free(ptr) == 0
