@@ -299,14 +299,33 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
         // Dantzig tie band (see k_tab_select): slots inside the band are re-read, one column per thread
         const double bound = k1 + sp.tol_tie * fmax(1.0, fabs(k1));
         int lowest = 0x7fffffff;
-        for (int t = 0; t < count; ++t) {
+        // the slots whose own minimum is inside the band (normally one or two) are listed first, so the
+        // scan does not walk all `count` slots one dependent load after the other
+        constexpr int kListMax = 32;
+        __shared__ int s_list[kListMax];
+        __shared__ int s_cnt;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < count; t += kThreads) {
             if (!(sp.k1[t] <= bound)) continue;
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < kListMax) s_list[pos] = t;
+        }
+        __syncthreads();
+        const int listed = s_cnt;
+        auto scan_slot = [&](int t) {
             const int c = tv.c_lo + t * kThreads + threadIdx.x;
             const int j = c - tv.col_off;
             if (c < tv.c_hi && j >= 0 && j < tv.n) {
                 const double v = tv.d[c];
                 if (!sp.in_basis[j] && v < -sp.tol_cost && v <= bound && j < lowest) lowest = j;
             }
+        };
+        if (listed <= kListMax) {
+            for (int i = 0; i < listed; ++i) scan_slot(s_list[i]);
+        } else {
+            for (int t = 0; t < count; ++t)
+                if (sp.k1[t] <= bound) scan_slot(t);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
