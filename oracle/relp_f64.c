@@ -552,6 +552,8 @@ int32_t oracle_m(const oracle_engine_t *e) { return e->m; }
 int32_t oracle_n(const oracle_engine_t *e) { return kind_nr_columns(e); }
 int32_t oracle_phase(const oracle_engine_t *e) { return e->phase; }
 int32_t oracle_nr_artificial(const oracle_engine_t *e) { return e->nr_artificial; }
+int32_t oracle_nr_filtered_rows(const oracle_engine_t *e) { return e->nr_filtered; }
+void oracle_get_filtered_rows(const oracle_engine_t *e, int32_t *out) { for (int32_t k = 0; k < e->nr_filtered; k++) out[k] = e->filtered[k]; }
 double  oracle_objective(const oracle_engine_t *e) { return -e->minus_objective; }
 void oracle_get_b(const oracle_engine_t *e, double *out) { memcpy(out, e->b, sizeof(double) * (size_t)e->m); }
 void oracle_get_minus_pi(const oracle_engine_t *e, double *out) { memcpy(out, e->minus_pi, sizeof(double) * (size_t)e->m); }

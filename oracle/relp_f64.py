@@ -54,12 +54,13 @@ def lib():
         L.oracle_run.restype = C.c_int
         L.oracle_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.POINTER(C.c_int64)]
-        for name in ("oracle_m", "oracle_n", "oracle_phase", "oracle_nr_artificial"):
+        for name in ("oracle_m", "oracle_n", "oracle_phase", "oracle_nr_artificial", "oracle_nr_filtered_rows"):
             getattr(L, name).restype = C.c_int32
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_objective.restype = C.c_double
         L.oracle_objective.argtypes = [C.c_void_p]
-        for name in ("oracle_get_b", "oracle_get_minus_pi", "oracle_get_basis", "oracle_get_basis_inverse"):
+        for name in ("oracle_get_b", "oracle_get_minus_pi", "oracle_get_basis", "oracle_get_basis_inverse",
+                     "oracle_get_filtered_rows"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_basis_inverse_nnz.restype = C.c_int64
         L.oracle_basis_inverse_nnz.argtypes = [C.c_void_p]
@@ -118,6 +119,13 @@ class OracleF64:
     n = property(lambda self: lib().oracle_n(self._h))
     phase = property(lambda self: lib().oracle_phase(self._h))
     nr_artificial = property(lambda self: lib().oracle_nr_artificial(self._h))
+
+    def filtered_rows(self):
+        """Rows removed as redundant at the phase switch."""
+        k = lib().oracle_nr_filtered_rows(self._h)
+        out = np.zeros(max(k, 1), dtype=np.int32)
+        lib().oracle_get_filtered_rows(self._h, out.ctypes.data)
+        return out[:k].tolist()
     objective = property(lambda self: lib().oracle_objective(self._h))
     basis_inverse_nnz = property(lambda self: lib().oracle_basis_inverse_nnz(self._h))
 

@@ -70,6 +70,9 @@ int32_t oracle_m(const oracle_engine_t *e);           /* rows of the current tab
 int32_t oracle_n(const oracle_engine_t *e);           /* columns of the current tableau (incl. artificials) */
 int32_t oracle_phase(const oracle_engine_t *e);       /* 1 or 2 */
 int32_t oracle_nr_artificial(const oracle_engine_t *e);
+/* rows removed as redundant at the phase switch (indices as the reference pushes them, phase_one.rs:252) */
+int32_t oracle_nr_filtered_rows(const oracle_engine_t *e);
+void oracle_get_filtered_rows(const oracle_engine_t *e, int32_t *out);
 double  oracle_objective(const oracle_engine_t *e);
 void    oracle_get_b(const oracle_engine_t *e, double *out);
 void    oracle_get_minus_pi(const oracle_engine_t *e, double *out);

@@ -433,7 +433,7 @@ relp_status_t Engine::lu_refactor() {
         } else {
             const int32_t v = p - nr_normal_;
             if (v >= nr_virtual_) return fail(RELP_E_STATE, "basis column out of range");
-            c.emplace_back(vrow0_h_[v], (double)vsign_h_[v]);
+            if (vrow0_h_[v] >= 0) c.emplace_back(vrow0_h_[v], (double)vsign_h_[v]);   // -1: its row was removed
             if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
         }
     }
@@ -1100,7 +1100,8 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     // descriptors: every remaining row index shifts down (column/into_filtered, matrix_data.rs:592-614)
     auto remap = [&](std::vector<int32_t>& v) { for (auto& x : v) if (x >= 0) x = map[x]; };
     remap(bound_row_h_); remap(vrow0_h_); remap(vrow1_h_);
-    for (auto x : vrow0_h_) if (x < 0) return fail(RELP_E_STATE, "a slack row cannot be redundant");
+    // a slack whose row disappears keeps its column index and becomes an empty column (vrow0 = -1), as
+    // Column::into_filtered does (matrix_data.rs:592-614)
     for (auto& x : column_to_row_) x = map[x] >= 0 ? map[x] : 0;
     HIP_TRY(hipMemcpy(d_bound_row_, bound_row_h_.data(), sizeof(int32_t) * nr_normal_, hipMemcpyHostToDevice));
     if (nr_virtual_) {
@@ -1170,6 +1171,7 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
         const int32_t v = p - nr_normal_;
         if (vrow1_h_[v] >= 0) return fail(RELP_E_UNSUPPORTED, "from_basis: range slack in basis");
         const int32_t row = vrow0_h_[v];
+        if (row < 0) return fail(RELP_E_SINGULAR, "from_basis: empty column in the basis");
         if (seen[row]) return fail(RELP_E_SINGULAR, "from_basis: duplicate pivot row");
         seen[row] = 1;
         // column i of B is sign * e_row  =>  row i of B^-1 is sign * e_row'

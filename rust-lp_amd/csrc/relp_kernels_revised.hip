@@ -71,7 +71,9 @@ __global__ __launch_bounds__(kThreads) void k_price_virtual(ColumnTable ct, cons
     } else {
         const int v = t - ct.nr_artificial;
         if (v < ct.nr_virtual) {
-            double s = (double)ct.vsign[v] * minus_pi[ct.vrow0[v]];
+            // a slack whose row was removed as redundant (RemoveRows) is an empty column: vrow0 = -1
+            const int r0 = ct.vrow0[v];
+            double s = r0 >= 0 ? (double)ct.vsign[v] * minus_pi[r0] : 0.0;
             const int r1 = ct.vrow1[v];
             if (r1 >= 0) s += minus_pi[r1];
             j = ct.nr_artificial + ct.nr_normal + v;              // slack cost is None (zero)
