@@ -555,3 +555,45 @@ def test_dense10k_full_size_engines_agree_and_match_the_cpu_oracle_prefix():
         t.close()
     assert traces[0] == traces[1] and len(traces[0]) == 320
     assert lib.relp_device_free(ptr) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# Randomised differential test (a fixed slice of scripts/fuzz_gpu.py)
+# ------------------------------------------------------------------------------------------------
+def test_random_mixed_lps_every_engine_matches_the_oracle():
+    """120 random LPs with ==, <=, >= rows, bounds and rank deficiencies (rows removed at the phase switch,
+    including rows that own a slack: its column becomes empty, matrix_data.rs:592-614), random engine and
+    block length: outcome, pivot trace, objective and b equal the f64 oracle's.  Cases in which the reference
+    removes a non-redundant row (it pushes the artificial's INDEX, phase_one.rs:252, which differs from its row
+    for >= rows) have no defined answer outside the explicit-inverse back end and are checked on the revised
+    engine only - see scripts/fuzz_gpu.py."""
+    rng = np.random.default_rng(20250003)
+    kinds = [(engine.ENGINE_REVISED, (0, 1, 3, 7, 64)), (engine.ENGINE_TABLEAU, (1, 2, 5, 64)), (engine.ENGINE_LU, (1, 2, 6, 64))]
+    checked = removed = 0
+    for case in range(120):
+        m, n = int(rng.integers(4, 80)), int(rng.integers(4, 120))
+        md = MatrixData.from_sparse_dict(synthetic.sparse_lp(
+            m, n, 7000 + case, nnz_per_col=int(rng.integers(2, 7)), frac_eq=float(rng.uniform(0, 0.5)),
+            frac_ge=float(rng.uniform(0, 0.4)), frac_bounded=float(rng.uniform(0, 0.6))))
+        kind, blocks = kinds[int(rng.integers(0, 3))]
+        block = int(blocks[int(rng.integers(0, len(blocks)))])
+        ref = relp_f64.OracleF64(md)
+        status = ref.run(200000)
+        rows = ref.filtered_rows()
+        removed += bool(rows)
+        if any(r >= md.nr_eq + md.nr_range for r in rows):
+            kind, block = engine.ENGINE_REVISED, block if kind == engine.ENGINE_REVISED else 0
+        t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 16)
+        try:
+            outcome = engine.OUTCOME_NAMES[t.solve_relaxation()]
+        except engine.RelpError as e:
+            assert kind == engine.ENGINE_LU and "singular" in str(e) and rows, (case, str(e))
+            continue
+        assert outcome == status, case
+        assert t.trace() == ref.trace, case
+        if status == "optimal":
+            assert abs(t.objective_function_value() - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), case
+            assert np.max(np.abs(t.b() - ref.b())) <= VEC_TOL * max(1.0, np.max(np.abs(ref.b()))), case
+        checked += 1
+        t.close()
+    assert checked >= 110 and removed >= 5
