@@ -82,7 +82,7 @@ class MatrixData:
 
     @classmethod
     def from_sparse_dict(cls, d) -> "MatrixData":
-        """From ``synthetic.sparse_lp``."""
+        """From ``synthetic.sparse_lp`` / ``synthetic.mixed_lp``."""
         return cls(nr_normal=d["n"], nr_eq=d["nr_eq"], nr_range=d.get("nr_range", 0), nr_le=d["nr_le"],
-                   nr_ge=d["nr_ge"], b=d["b"], cost=d["c"], upper_bound=d["ub"],
+                   nr_ge=d["nr_ge"], b=d["b"], cost=d["c"], upper_bound=d["ub"], ranges=d.get("ranges", np.zeros(0)),
                    col_ptr=d["col_ptr"], row_idx=d["row_idx"], values=d["values"])

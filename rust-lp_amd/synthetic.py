@@ -115,3 +115,66 @@ def sparse_lp(m: int, n: int, seed: int, nnz_per_col: int = 6, frac_eq: float = 
         "values": np.array(values, dtype=np.float64), "b": b.astype(np.float64),
         "c": c.astype(np.float64), "ub": ub,
     }
+
+
+def mixed_lp(m: int, n: int, seed: int, nnz_per_col: int = 4, frac_eq: float = 0.2, frac_range: float = 0.15,
+             frac_ge: float = 0.15, frac_bounded: float = 0.3, frac_negative_cost: float = 0.0,
+             infeasible: bool = False) -> Dict[str, object]:
+    """Random LP in `MatrixData` form with every row kind ([== | range | <= | >=]), upper-bounded variables,
+    optionally negative costs (phase 2 may be unbounded) and optionally a contradictory pair of equality rows
+    (phase 1 ends infeasible).  Small integer data; feasible around a point x0 >= 0 unless ``infeasible``.
+    Test generator (numpy `Generator`, deterministic in ``seed``); same dictionary layout as `sparse_lp`
+    plus ``ranges`` (width r of `b - r <= a.x <= b` per range row)."""
+    rng = np.random.default_rng(seed)
+    n_eq, n_rg, n_ge = int(m * frac_eq), int(m * frac_range), int(m * frac_ge)
+    if infeasible:
+        n_eq = max(n_eq, 2)
+    n_le = m - n_eq - n_rg - n_ge
+    assert n_le >= 0
+    x0 = rng.integers(0, 4, size=n)
+    cols = []
+    for j in range(n):
+        rows = rng.integers(0, m, size=nnz_per_col)
+        vals = rng.integers(-9, 10, size=nnz_per_col)
+        vals[vals == 0] = 1
+        cols.append({int(r): int(v) for r, v in zip(rows, vals)})
+    if infeasible:                                           # row 1 := row 0, right-hand sides differ below
+        for col in cols:
+            col.pop(1, None)
+            if 0 in col:
+                col[1] = col[0]
+    ax0 = np.zeros(m, dtype=np.int64)
+    for j, col in enumerate(cols):
+        for r, v in col.items():
+            ax0[r] += v * x0[j]
+    lo_ge = n_eq + n_rg + n_le
+    flip = np.ones(m, dtype=np.int64)
+    for i in list(range(n_eq + n_rg)) + list(range(lo_ge, m)):
+        if ax0[i] < 0:
+            flip[i] = -1
+    if infeasible:
+        flip[1] = flip[0]
+    ax0 = ax0 * flip
+    slack = rng.integers(0, 5, size=m)
+    b = ax0.copy()
+    ranges = np.zeros(n_rg, dtype=np.float64)
+    for k in range(n_rg):
+        i = n_eq + k
+        b[i] = ax0[i] + slack[i]
+        ranges[k] = slack[i] + int(rng.integers(0, 4)) + 1
+    b[n_eq + n_rg:lo_ge] = np.maximum(ax0[n_eq + n_rg:lo_ge], 0) + slack[n_eq + n_rg:lo_ge]
+    b[lo_ge:] = np.maximum(ax0[lo_ge:] - slack[lo_ge:], 0)
+    if infeasible:
+        b[1] = b[0] + 1
+    col_ptr, row_idx, values = [0], [], []
+    for col in cols:
+        for r in sorted(col):
+            row_idx.append(r)
+            values.append(col[r] * int(flip[r]))
+        col_ptr.append(len(row_idx))
+    c = rng.integers(1, 21, size=n).astype(np.float64)
+    c[rng.random(n) < frac_negative_cost] *= -1.0
+    ub = np.where(rng.random(n) < frac_bounded, (x0 + 2).astype(np.float64), np.inf)
+    return {"m": m, "n": n, "nr_eq": n_eq, "nr_range": n_rg, "nr_le": n_le, "nr_ge": n_ge,
+            "col_ptr": np.array(col_ptr, dtype=np.int64), "row_idx": np.array(row_idx, dtype=np.int32),
+            "values": np.array(values, dtype=np.float64), "b": b.astype(np.float64), "c": c, "ub": ub, "ranges": ranges}

@@ -30,12 +30,20 @@ for case in range(N):
         lp = synthetic.dense_lp(m, n, seed)
         md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"])
         what = f"dense {m}x{n}"
-    else:
+    elif rng.random() < 0.5:
         m, n = int(rng.integers(4, 80)), int(rng.integers(4, 120))
         md = MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, seed, nnz_per_col=int(rng.integers(2, 7)),
                                                             frac_eq=float(rng.uniform(0, 0.5)), frac_ge=float(rng.uniform(0, 0.4)),
                                                             frac_bounded=float(rng.uniform(0, 0.6))))
         what = f"sparse {m}x{n}"
+    else:
+        # every row kind incl. ranges, negative costs (unbounded outcomes), contradictory rows (infeasible)
+        m, n = int(rng.integers(6, 70)), int(rng.integers(4, 100))
+        md = MatrixData.from_sparse_dict(synthetic.mixed_lp(
+            m, n, seed, nnz_per_col=int(rng.integers(2, 6)), frac_eq=float(rng.uniform(0, 0.3)),
+            frac_range=float(rng.uniform(0, 0.3)), frac_ge=float(rng.uniform(0, 0.3)), frac_bounded=float(rng.uniform(0, 0.6)),
+            frac_negative_cost=float(rng.choice([0.0, 0.0, 0.1, 0.3])), infeasible=bool(rng.random() < 0.15)))
+        what = f"mixed {m}x{n}"
     ref = relp_f64.OracleF64(md.ensure_csc() if md.col_ptr is None else md)
     status = ref.run(200000)
     stats[status if status in stats else "other"] += 1

@@ -597,3 +597,38 @@ def test_random_mixed_lps_every_engine_matches_the_oracle():
         checked += 1
         t.close()
     assert checked >= 110 and removed >= 5
+
+
+def test_random_lps_with_ranges_unbounded_and_infeasible_outcomes():
+    """100 random LPs from `synthetic.mixed_lp`: every row kind including ranges (two-entry slack columns,
+    range-bound rows), bounded variables, negative costs (some LPs are unbounded) and contradictory equality
+    rows (some are infeasible).  Outcome and pivot trace equal the f64 oracle's on a random engine."""
+    rng = np.random.default_rng(20250004)
+    kinds = [(engine.ENGINE_REVISED, (0, 1, 3, 7, 64)), (engine.ENGINE_TABLEAU, (1, 2, 5, 64)), (engine.ENGINE_LU, (1, 2, 6, 64))]
+    seen = {"optimal": 0, "unbounded": 0, "infeasible": 0}
+    for case in range(100):
+        m, n = int(rng.integers(6, 70)), int(rng.integers(4, 100))
+        md = MatrixData.from_sparse_dict(synthetic.mixed_lp(
+            m, n, 9000 + case, nnz_per_col=int(rng.integers(2, 6)), frac_eq=float(rng.uniform(0, 0.3)),
+            frac_range=float(rng.uniform(0, 0.3)), frac_ge=float(rng.uniform(0, 0.3)), frac_bounded=float(rng.uniform(0, 0.6)),
+            frac_negative_cost=float(rng.choice([0.0, 0.0, 0.1, 0.3])), infeasible=bool(rng.random() < 0.15)))
+        kind, blocks = kinds[int(rng.integers(0, 3))]
+        block = int(blocks[int(rng.integers(0, len(blocks)))])
+        ref = relp_f64.OracleF64(md)
+        status = ref.run(200000)
+        seen[status] += 1
+        rows = ref.filtered_rows()
+        if any(r >= md.nr_eq + md.nr_range for r in rows):
+            kind, block = engine.ENGINE_REVISED, block if kind == engine.ENGINE_REVISED else 0
+        t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 16)
+        try:
+            outcome = engine.OUTCOME_NAMES[t.solve_relaxation()]
+        except engine.RelpError as e:
+            assert kind == engine.ENGINE_LU and "singular" in str(e) and rows, (case, str(e))
+            continue
+        assert outcome == status, case
+        assert t.trace() == ref.trace, case
+        if status == "optimal":
+            assert abs(t.objective_function_value() - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), case
+        t.close()
+    assert min(seen.values()) >= 3, seen
