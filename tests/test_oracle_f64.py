@@ -72,3 +72,32 @@ def test_generator_is_deterministic_and_rational():
     nums = synthetic.dense_numerators(16, 24, 5)
     assert nums["A_num"].min() >= 1 and nums["A_num"].max() <= 999
     assert (a["b"] > 0).all() and (a["c"] < 0).all()
+
+
+def test_f64_oracle_equals_exact_on_random_lps_with_every_row_kind_and_outcome():
+    """60 small LPs from `synthetic.mixed_lp` (ranges, bounds, negative costs, contradictory rows): status and
+    pivot trace of the C oracle equal the exact oracle's, including the rows removed at the phase switch and the
+    wrapped index of a surviving artificial (`usize_sub`)."""
+    rng = np.random.default_rng(11)
+    seen = {"optimal": 0, "unbounded": 0, "infeasible": 0}
+    removed = 0
+    for case in range(60):
+        m, n = int(rng.integers(6, 28)), int(rng.integers(4, 36))
+        md = MatrixData.from_sparse_dict(synthetic.mixed_lp(
+            m, n, 300 + case, nnz_per_col=int(rng.integers(2, 5)), frac_eq=float(rng.uniform(0, 0.3)),
+            frac_range=float(rng.uniform(0, 0.3)), frac_ge=float(rng.uniform(0, 0.3)), frac_bounded=float(rng.uniform(0, 0.6)),
+            frac_negative_cost=float(rng.choice([0.0, 0.0, 0.1, 0.3])), infeasible=bool(rng.random() < 0.15)))
+        ref = relp_f64.OracleF64(md)
+        status = ref.run(100000)
+        removed += bool(ref.filtered_rows())
+        tr = []
+        out = ox.solve_relaxation(to_exact(md), trace=tr.append)
+        assert out["status"] == status, case
+        seen[status] += 1
+        exact = [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
+        squeezed = [(p, q, r, lv if lv < (1 << 62) else None) for (p, q, r, lv) in exact]
+        got = [(p, q, r, lv if lv < (1 << 30) else None) for (p, q, r, lv) in ref.trace]
+        assert got == squeezed, case
+        if status == "optimal":
+            assert abs(ref.objective - float(out["objective"])) <= 1e-9 * max(1.0, abs(float(out["objective"]))), case
+    assert min(seen.values()) >= 3 and removed >= 2, (seen, removed)
