@@ -21,12 +21,17 @@ bool Engine::hip_ok(hipError_t e, const char* what) {
     return false;
 }
 
+// Zero-initialised device buffer.  hipMemset runs on the null stream, which does not order with the
+// engine's non-blocking stream: the device is synchronised before the buffer is handed out, so a kernel
+// enqueued on stream_ right afterwards cannot be overtaken by the memset.
 template <class T>
 static hipError_t dev_alloc(T** p, int64_t count) {
     if (count < 1) count = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
     if (e != hipSuccess) return e;
-    return hipMemset(*p, 0, (size_t)count * sizeof(T));
+    e = hipMemset(*p, 0, (size_t)count * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipDeviceSynchronize();
 }
 
 void Engine::free_all() {
@@ -703,6 +708,17 @@ void Engine::enqueue_flush() {
         launch_flush_reset(dut, d_rec_, stream_);
         prof_end();
         since_flush_ = 0;
+        // The reduced costs are only ever updated (d -= theta * row); every few flushes they are recomputed
+        // from the flushed tableau, d = c - c_B' T0, so that rounding does not pile up over thousands of
+        // pivots (one extra pass over T0 per kRepriceEveryFlushes * K pivots).
+        if (++flushes_since_reprice_ >= kRepriceEveryFlushes) {
+            flushes_since_reprice_ = 0;
+            const TableauView tv = tview();
+            const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+            launch_tab_basis_costs(tv, d_basis_, d_cost_store_, d_w_, stream_);
+            launch_tab_price_init(tv, d_w_, d_cost_store_, stream_);
+            launch_tab_scan(tv, tab_partials(rule), d_rec_, stream_);
+        }
         return;
     }
     const DeferredUpdate du = deferred();

@@ -129,6 +129,8 @@ class Engine {
     int32_t tab_na_ = 0;                 // original number of artificial columns (their block is kept)
     int32_t sc_lo_ = 0, sc_hi_ = 0;      // storage columns owned by this rank (sharded tableau)
     bool tab_partials_valid_ = false;    // the PRICE partials describe the current d
+    static constexpr int kRepriceEveryFlushes = 8;
+    int32_t flushes_since_reprice_ = 0;
     std::vector<int32_t> idcol_h_;
     std::vector<double> cost_store_h_;
     TableauView tview() const;

@@ -201,6 +201,9 @@ void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, cons
 // d[c] = cost[c] - w . T0[:,c] for every stored column (w = cost of the basic variable of each row)
 void launch_tab_price_init(const TableauView& tv, const double* w, const double* cost_store, hipStream_t s);
 // partial argmin over d (one slot per 256 columns) -- used when the loop is (re)entered
+// w[i] = cost of the basic variable of row i; with launch_tab_price_init it recomputes d from T0
+void launch_tab_basis_costs(const TableauView& tv, const int32_t* basis_indices, const double* cost_store, double* w,
+                            hipStream_t s);
 void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s);
 int32_t tab_scan_blocks(int32_t n_owned_columns);
 // entering column from the partials (no column build: the tableau column is read directly)

@@ -45,6 +45,16 @@ __global__ __launch_bounds__(kThreads) void k_tab_price_init(TableauView tv, con
     if (threadIdx.x < kVecPerBlock && c < tv.c_hi) tv.d[c] = cost_store[c] - dot;
 }
 
+// w[i] = cost of the variable that is basic in row i (current phase), for re-pricing d from T0
+__global__ void k_tab_basis_costs(const int32_t* __restrict__ basis_indices, const double* __restrict__ cost_store,
+                                  int col_off, int n_store, int m, double* __restrict__ w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int j = basis_indices[i];
+    const int c = j + col_off;
+    w[i] = (j < kWrappedArtificialBase && c >= 0 && c < n_store) ? cost_store[c] : 0.0;
+}
+
 // one slot per 256 storage columns
 __global__ __launch_bounds__(kThreads) void k_tab_scan(TableauView tv, SelectPartials sp, const PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
@@ -603,6 +613,12 @@ void launch_tab_price_init(const TableauView& tv, const double* w, const double*
     if (tv.c_hi <= tv.c_lo) return;
     hipLaunchKernelGGL(k_tab_price_init, dim3(cdiv(tv.c_hi - tv.c_lo, kVecPerBlock)), dim3(kThreads), 0, s, tv, w,
                        cost_store);
+}
+
+void launch_tab_basis_costs(const TableauView& tv, const int32_t* basis_indices, const double* cost_store, double* w,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_basis_costs, dim3(cdiv(tv.m, 256)), dim3(256), 0, s, basis_indices, cost_store, tv.col_off,
+                       tv.n_store, tv.m, w);
 }
 
 void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s) {

@@ -8,7 +8,7 @@ by index surgery (carry/mod.rs:650-689), and what follows is no longer the LP (H
 reference's result on such cases).  The revised engine reproduces that literally and is checked against the
 oracle; the tableau engine and the LU engine (like the reference's own LU back end, which re-inverts from the
 filtered columns, carry/mod.rs:512-547) continue from a different state, so those cases are only counted.
-Usage: python scripts/fuzz_gpu.py [N_CASES] [SEED0]"""
+Usage: python scripts/fuzz_gpu.py [N_CASES] [SEED0] [SIZE_SCALE]"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -18,6 +18,7 @@ from oracle import relp_f64
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # multiplies the problem sizes (multi-workgroup kernels)
 rng = np.random.default_rng(seed0)
 KINDS = [(engine.ENGINE_REVISED, (0, 1, 3, 7, 64)), (engine.ENGINE_TABLEAU, (1, 2, 5, 64)), (engine.ENGINE_LU, (1, 2, 6, 64))]
 bad = 0
@@ -26,19 +27,19 @@ stats = {"optimal": 0, "unbounded": 0, "infeasible": 0, "other": 0}
 for case in range(N):
     seed = seed0 + case
     if rng.random() < 0.5:
-        m, n = int(rng.integers(2, 70)), int(rng.integers(2, 90))
+        m, n = SCALE * int(rng.integers(2, 70)), SCALE * int(rng.integers(2, 90))
         lp = synthetic.dense_lp(m, n, seed)
         md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"])
         what = f"dense {m}x{n}"
     elif rng.random() < 0.5:
-        m, n = int(rng.integers(4, 80)), int(rng.integers(4, 120))
+        m, n = SCALE * int(rng.integers(4, 80)), SCALE * int(rng.integers(4, 120))
         md = MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, seed, nnz_per_col=int(rng.integers(2, 7)),
                                                             frac_eq=float(rng.uniform(0, 0.5)), frac_ge=float(rng.uniform(0, 0.4)),
                                                             frac_bounded=float(rng.uniform(0, 0.6))))
         what = f"sparse {m}x{n}"
     else:
         # every row kind incl. ranges, negative costs (unbounded outcomes), contradictory rows (infeasible)
-        m, n = int(rng.integers(6, 70)), int(rng.integers(4, 100))
+        m, n = SCALE * int(rng.integers(6, 70)), SCALE * int(rng.integers(4, 100))
         md = MatrixData.from_sparse_dict(synthetic.mixed_lp(
             m, n, seed, nnz_per_col=int(rng.integers(2, 6)), frac_eq=float(rng.uniform(0, 0.3)),
             frac_range=float(rng.uniform(0, 0.3)), frac_ge=float(rng.uniform(0, 0.3)), frac_bounded=float(rng.uniform(0, 0.6)),
@@ -55,23 +56,30 @@ for case in range(N):
         continue
     try:
         t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 16)
-        oc = engine.OUTCOME_NAMES[t.solve_relaxation()]
-        ok = oc == status and t.trace() == ref.trace
+        oc = engine.OUTCOME_NAMES[t.solve_relaxation(max_iters=20 * len(ref.trace) + 1000)]     # bounded: no endless cycling
+        tr = t.trace()
+        first = next((i for i, (x, y) in enumerate(zip(tr, ref.trace)) if x != y), None)
+        detail = f"first trace difference at {first} of {len(tr)} gpu pivots"
+        if oc == status == "optimal":
+            detail += f", objective gpu {t.objective_function_value():.12g} oracle {ref.objective:.12g}"
+        ok = oc == status and tr == ref.trace
         if ok and status == "optimal":
             ok = abs(t.objective_function_value() - ref.objective) <= 1e-9 * max(1.0, abs(ref.objective))
             ok = ok and np.max(np.abs(t.b() - ref.b())) <= 1e-7 * max(1.0, np.max(np.abs(ref.b())))
         t.close()
     except Exception as e:          # noqa: BLE001
-        ok, oc = False, f"exception {e}"
+        ok, oc, detail = False, f"exception {e}", ""
         if kind == engine.ENGINE_LU and "singular" in str(e) and ref.filtered_rows():
             # the stuck artificial had re-entered in a foreign basis position: the index surgery removes the
             # wrong position; the reference's LU back end would fail in `invert` on the same matrix
             undefined += 1
             continue
+    if case % 25 == 24:
+        print(f"... {case + 1} cases, {bad} mismatches so far", flush=True)
     if not ok:
         bad += 1
         print(f"MISMATCH case {case} seed {seed} {what} kind {kind} block {block}: gpu {oc} vs oracle {status} "
-              f"({len(ref.trace)} pivots)", flush=True)
+              f"({len(ref.trace)} pivots) {detail}", flush=True)
 print(f"{N} cases, {bad} mismatches, {undefined} skipped (wrong-row removal, undefined outside the revised engine), "
       f"oracle outcomes {stats}")
 sys.exit(1 if bad else 0)
