@@ -934,6 +934,7 @@ relp_status_t Engine::finish_phase_one(int32_t* outcome) {
 
 // phase_one.rs:223-260 (pivots "at zero level"; pushes the artificial index like the reference)
 relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& rows_to_remove) {
+    HIP_TRY(hipStreamSynchronize(stream_));            // null-stream copies below vs. kernels on stream_
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     std::vector<int32_t> arts;
@@ -979,6 +980,9 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
 relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_remove) {
     relp_status_t st;
     if (cfg_.shard_count == 1) enqueue_flush();     // zero-level pivots may have left updates pending
+    // the host-side copies below go through the null stream, which does not order with stream_: everything
+    // enqueued so far (the flush, a possible re-pricing that uses d_w_) must have finished first
+    HIP_TRY(hipStreamSynchronize(stream_));
     if (!rows_to_remove.empty() && (st = remove_rows(rows_to_remove))) return st;
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
