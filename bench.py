@@ -181,6 +181,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: RELP_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo for the
+    # exchange (RCCL refuses two ranks on one device); the multi-rank code path is otherwise the same
+    rehearse = os.environ.get("RELP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
@@ -192,7 +197,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     m, n, seed = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
