@@ -1,0 +1,178 @@
+// relp_engine_shard.cpp -- Engine: the entry points of the sharded (multi-GPU) engines.
+#include "relp_engine_internal.hpp"
+
+namespace relp {
+
+// ------------------------------------------------------------------------------------------------
+// Shards.  Everything is enqueued on stream_; the caller interleaves the
+// RCCL collectives on the same stream, so there is no host sync inside a pivot.
+// ------------------------------------------------------------------------------------------------
+void Engine::shard_ranges(int32_t* col_lo, int32_t* col_hi, int32_t* row_lo, int32_t* row_hi, int32_t* stride) const {
+    if (col_lo) *col_lo = col_lo_;
+    if (col_hi) *col_hi = col_hi_;
+    if (row_lo) *row_lo = row_lo_;
+    if (row_hi) *row_hi = row_hi_;
+    if (stride) *stride = row_stride_;
+}
+
+// Tableau engine, one pivot after the candidates were exchanged: ratio test (replicated), row update
+// of the owned columns, W / b / basis update (replicated); the flush is local to the owned columns.
+relp_status_t Engine::shard_pivot() {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    if (!tableau_) return fail(RELP_E_STATE, "relp_shard_pivot is the tableau engine's step");
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    const TableauView tv = tview();
+    const DeferredUpdate du = deferred();
+    const SelectPartials sp = tab_partials(rule);
+    // the ratio test ran in relp_shard_select_column; tableau row / reduced costs / PRICE partials of the
+    // owned columns and W, b, basis (replicated) in one launch
+    prof_begin(RELP_K_PRICE);
+    launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+    prof_end();
+    tab_partials_valid_ = true;
+    if (++since_flush_ >= block_) enqueue_flush();
+    ++prof_tick_;
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_price(double* dev_candidate) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    if (tableau_) {
+        // local PRICE result = the partial argmin the last row update left behind (or a scan of d);
+        // the candidate message carries the tableau column alpha itself
+        const TableauView tv = tview();
+        const SelectPartials sp = tab_partials(rule);
+        if (!tab_partials_valid_) { launch_tab_scan(tv, sp, d_rec_, stream_); tab_partials_valid_ = true; }
+        // PRICE's final reduction over the local partials + the local winner's tableau column, written
+        // straight into the candidate message
+        prof_begin(RELP_K_FTRAN);
+        launch_tab_select_column_msg(tv, deferred(), sp, tab_scan_blocks(sc_hi_ - sc_lo_), dev_candidate, d_rec_, stream_);
+        prof_end();
+        return RELP_OK;
+    }
+    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+    prof_begin(RELP_K_PRICE);
+    enqueue_price(phase_, d_minus_pi_, d_rec_, col_lo_, col_hi_);
+    prof_end();
+    prof_begin(RELP_K_SELECT_COLUMN);
+    launch_select_column(d_d_, d_in_basis_, nr_columns(), rule, cfg_.tol_cost, cfg_.tol_tie, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_BUILD_COLUMN);
+    launch_build_column(A, ld_a_, table(), m_, d_aq_, d_rec_, stream_);
+    launch_pack_candidate(d_aq_, m_, dev_candidate, d_rec_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t count) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    if (tableau_) {
+        // the winner's payload is the entering tableau column (alpha) itself: pick it and run the ratio test
+        prof_begin(RELP_K_RATIO);
+        launch_select_candidate_ratio(dev_candidates, count, cand_len_, m_, d_alpha_, d_b_, d_basis_, rule, tolerances(),
+                                      deferred(), d_rec_, stream_);
+        prof_end();
+        return RELP_OK;
+    }
+    launch_select_candidate(dev_candidates, count, cand_len_, m_, d_aq_, rule, cfg_.tol_tie, d_rec_, stream_);
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_ftran(double* dev_alpha_slice) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FTRAN);
+    launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, dev_alpha_slice, row_lo_, d_rec_, stream_);
+    launch_pad_slice(dev_alpha_slice, row_hi_ - row_lo_, row_stride_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    if (block_ == 0) {
+        prof_begin(RELP_K_RATIO);
+        launch_gather_alpha(dev_alpha_slices, count, row_stride_, m_, d_alpha_, d_rec_, stream_);
+        launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+        launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, dev_rho, d_rec_, stream_);
+        prof_end();
+        return RELP_OK;
+    }
+    // deferred: the slices hold v = B0inv a_q; W is replicated, so every rank forms the full alpha,
+    // updates its copy of W and contributes the rows of B0inv it owns to rho (SUM over ranks).
+    const DeferredUpdate du = deferred();
+    prof_begin(RELP_K_APPLY_W);
+    launch_gather_alpha(dev_alpha_slices, count, row_stride_, m_, d_v_, d_rec_, stream_);
+    launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_RATIO);
+    launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    prof_end();
+    prof_begin(RELP_K_UPDATE_W);
+    launch_eta_prepare(du, d_rec_, stream_);
+    launch_update_w(du, m_, d_alpha_, d_rec_, stream_);
+    launch_rho_deferred(du, Binv, ld_b_, m_, row_lo_, row_hi_, dev_rho, d_rec_, stream_);
+    prof_end();
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_flush_begin(double** dev_snapshot, int64_t* len) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    if (len) *len = 0;
+    if (block_ == 0) return RELP_OK;
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FLUSH);
+    launch_flush_snapshot(deferred(), Binv, ld_b_, row_lo_, row_hi_, d_rec_, stream_);
+    prof_end();
+    if (dev_snapshot) *dev_snapshot = d_R_;
+    if (len) *len = ld_b_ * block_;
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_flush_end() {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    if (block_ == 0) return RELP_OK;
+    const DeferredUpdate du = deferred();
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_FLUSH);
+    launch_flush_apply(du, Binv, ld_b_, m_, row_lo_, row_hi_, d_rec_, stream_);
+    launch_flush_reset(du, d_rec_, stream_);
+    prof_end();
+    since_flush_ = 0;
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_update(const double* dev_rho) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    double* Binv = dBinv_ - (int64_t)row_lo_ * ld_b_;
+    prof_begin(RELP_K_UPDATE_VECTORS);
+    launch_update_vectors(m_, d_alpha_, dev_rho, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_,
+                          stream_);
+    prof_end();
+    if (block_ == 0) {
+        prof_begin(RELP_K_UPDATE_INVERSE);
+        launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, dev_rho, d_rec_, stream_);
+        prof_end();
+    } else {
+        ++since_flush_;
+    }
+    return RELP_OK;
+}
+
+relp_status_t Engine::poll(int32_t* outcome, int64_t* iterations) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    if (iterations) *iterations = h_rec_->iterations;
+    int32_t oc = RELP_RUNNING;
+    if (h_rec_->outcome == DEV_NO_CANDIDATE) {
+        if (phase_ == 2) oc = RELP_OPTIMAL;
+        else if ((st = finish_phase_one(&oc))) return st;
+    } else if (h_rec_->outcome == DEV_NO_ROW) oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
+    if (outcome) *outcome = oc;
+    return RELP_OK;
+}
+
+}  // namespace relp
