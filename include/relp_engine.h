@@ -111,7 +111,7 @@ typedef enum {
     /* dense tableau T = B^-1 [A | slacks] kept as (I + W S') T0: PRICE is one tableau row, FTRAN one
      * tableau column per pivot, and T0 is updated by an m x K x n GEMM on the f64 matrix cores every
      * update_block pivots (needs 8 m n bytes; same pivots as the revised engine up to f64 rounding).
-     * Restrictions: no relp_from_basis, no sharding yet. */
+     * Restrictions: no relp_from_basis (column-sharded across GPUs through relp_shard_*). */
     RELP_ENGINE_TABLEAU = 1,
     RELP_ENGINE_LU = 2        /* sparse LU of the basis + pending updates (Carry<_, LUDecomposition<_>>) */
 } relp_engine_kind_t;
@@ -155,11 +155,14 @@ relp_status_t relp_run(relp_engine_t *h, int64_t max_iters, int64_t *iterations_
  * (phase_one.rs:223-260), phase switch (kind/non_artificial.rs:151-220), phase 2. */
 relp_status_t relp_solve_relaxation(relp_engine_t *h, int64_t max_iters, int32_t *outcome);
 /* InverseMaintener::from_basis (carry/mod.rs:428-463): warm start from provider column indices,
- * one per row; switches to phase 2. */
+ * one per row; switches to phase 2.  RELP_ENGINE_LU: any basis (factorise, b = FTRAN(rhs), -pi = BTRAN(-c_B));
+ * RELP_ENGINE_REVISED: bases of slack columns (the inverse is a signed permutation); RELP_ENGINE_TABLEAU:
+ * RELP_E_UNSUPPORTED. */
 relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
-/* Fold every pending deferred update into the explicit inverse (no-op when update_block = 0). */
+/* Fold every pending deferred update into the stored representation: B0^-1 += W (S' B0^-1) (revised), T0 += W R0
+ * (tableau), refactorisation (LU).  No-op when update_block = 0. */
 relp_status_t relp_flush(relp_engine_t *h);
-/* The block size K in effect (0 = explicit rank-1 updates). */
+/* The block size K in effect (0 = explicit rank-1 updates; LU engine: pivots between refactorisations). */
 int32_t       relp_update_block(const relp_engine_t *h);
 /* RELP_ENGINE_LU only: statistics of the current factorisation, out[8] = { refactorisations so far, m,
  * nnz(L) (off-diagonal), nnz(U) (with diagonal), levels of the four solve schedules L, U (FTRAN) and
