@@ -955,9 +955,8 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
 }
 
 relp_status_t Engine::from_basis(const int32_t* basis_columns) {
-    // InverseMaintener::from_basis (carry/mod.rs:428-463).  Supported today: a basis made of unit
-    // columns only (slack bases, two_phase/mod.rs:103-111 `FullInitialBasis`), whose inverse is a
-    // signed permutation.  General warm starts need the dense inversion kernel (next round).
+    // InverseMaintener::from_basis (carry/mod.rs:428-463): any basis on the LU and the revised engine (the
+    // latter inverts on the host; slack bases are a signed permutation and take a shortcut).
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
     if (tableau_) return fail(RELP_E_UNSUPPORTED, "from_basis in the tableau engine");
     if (lu_) {
@@ -992,33 +991,78 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     enqueue_flush();                                   // leaves the deferred state empty
     HIP_TRY(hipStreamSynchronize(stream_));
     std::vector<int32_t> basis(basis_columns, basis_columns + m_);
-    std::vector<double> Bn((size_t)m_ * ld_b_, 0.0), b(m_, 0.0);
-    std::vector<uint8_t> seen(m_, 0);
+    std::vector<double> Bn((size_t)m_ * ld_b_, 0.0), b(m_, 0.0), minus_pi(ld_b_, 0.0);
+    double objective = 0.0;
+    bool unit_basis = true;
     for (int32_t i = 0; i < m_; ++i) {
         const int32_t p = basis[i];
-        if (p < nr_normal_ || p >= n_provider_) return fail(RELP_E_UNSUPPORTED, "from_basis: only slack bases are supported yet");
-        const int32_t v = p - nr_normal_;
-        if (vrow1_h_[v] >= 0) return fail(RELP_E_UNSUPPORTED, "from_basis: range slack in basis");
-        const int32_t row = vrow0_h_[v];
-        if (row < 0) return fail(RELP_E_SINGULAR, "from_basis: empty column in the basis");
-        if (seen[row]) return fail(RELP_E_SINGULAR, "from_basis: duplicate pivot row");
-        seen[row] = 1;
-        // column i of B is sign * e_row  =>  row i of B^-1 is sign * e_row'
-        Bn[(size_t)i * ld_b_ + row] = (double)vsign_h_[v];
-        b[i] = (double)vsign_h_[v] * rhs_h_[row];
+        if (p < 0 || p >= n_provider_) return fail(RELP_E_ARG, "from_basis: column out of range");
+        if (p < nr_normal_ || vrow1_h_[p - nr_normal_] >= 0) unit_basis = false;
+    }
+    if (unit_basis) {
+        // slack basis (two_phase/mod.rs:103-111 `FullInitialBasis`): the inverse is a signed permutation
+        std::vector<uint8_t> seen(m_, 0);
+        for (int32_t i = 0; i < m_; ++i) {
+            const int32_t v = basis[i] - nr_normal_;
+            const int32_t row = vrow0_h_[v];
+            if (row < 0) return fail(RELP_E_SINGULAR, "from_basis: empty column in the basis");
+            if (seen[row]) return fail(RELP_E_SINGULAR, "from_basis: duplicate pivot row");
+            seen[row] = 1;
+            // column i of B is sign * e_row  =>  row i of B^-1 is sign * e_row'
+            Bn[(size_t)i * ld_b_ + row] = (double)vsign_h_[v];
+            b[i] = (double)vsign_h_[v] * rhs_h_[row];
+        }
+    } else {
+        // any basis: factorise it on the host (relp_lu.cpp) and form the rows of B^-1 by unit BTRANs,
+        // O(m (m + nnz(L) + nnz(U))) - the one-off `BasisInverseRows::invert` of the reference
+        // (basis_inverse_rows.rs:103-129: LU-invert, then m unit solves)
+        std::vector<std::vector<std::pair<int32_t, double>>> cols(m_);
+        std::vector<double> colbuf(std::max(mc_, 1));
+        for (int32_t i = 0; i < m_; ++i) {
+            const int32_t p = basis[i];
+            auto& c = cols[i];
+            if (p < nr_normal_) {
+                HIP_TRY(hipMemcpy(colbuf.data(), dA_ + (int64_t)(p - col_lo_) * ld_a_, sizeof(double) * mc_, hipMemcpyDeviceToHost));
+                for (int32_t r = 0; r < mc_; ++r) if (colbuf[r] != 0.0) c.emplace_back(r, colbuf[r]);
+                if (bound_row_h_[p] >= 0) c.emplace_back(bound_row_h_[p], 1.0);
+            } else {
+                const int32_t v = p - nr_normal_;
+                if (vrow0_h_[v] >= 0) c.emplace_back(vrow0_h_[v], (double)vsign_h_[v]);
+                if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
+            }
+        }
+        LUFactors f;
+        std::string msg;
+        if (!lu_factor(m_, cols, &f, &msg)) return fail(RELP_E_SINGULAR, "from_basis: " + msg);
+        std::vector<double> unit(m_, 0.0), row;
+        for (int32_t i = 0; i < m_; ++i) {
+            unit[i] = 1.0;
+            lu_btran_host(f, unit, &row);
+            unit[i] = 0.0;
+            double bi = 0.0;
+            const double cost = basis[i] < nr_normal_ ? cost_h_[basis[i]] : 0.0;
+            for (int32_t k = 0; k < m_; ++k) {
+                const double v = row[k];
+                if (v == 0.0) continue;
+                Bn[(size_t)i * ld_b_ + k] = v;
+                bi += v * rhs_h_[k];
+                minus_pi[k] -= cost * v;                 // -pi = -(c_B' B^-1), carry/mod.rs:214-248
+            }
+            b[i] = bi;
+            objective += cost * bi;
+        }
     }
     HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_b_, b.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
-    std::vector<double> zeros(ld_b_, 0.0);
-    HIP_TRY(hipMemcpy(d_minus_pi_, zeros.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_minus_pi_, minus_pi.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice));
     std::vector<uint8_t> flags(n_alloc_, 0);
     for (int32_t v : basis) flags[v] = 1;
     HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));
     nr_artificial_ = 0; phase_ = 2;
     relp_status_t st = download_rec();
     if (st) return st;
-    h_rec_->minus_objective = 0.0; h_rec_->outcome = DEV_RUNNING; h_rec_->last_selected = -1; h_rec_->phase = 2;
+    h_rec_->minus_objective = -objective; h_rec_->outcome = DEV_RUNNING; h_rec_->last_selected = -1; h_rec_->phase = 2;
     return upload_rec();
 }
 

@@ -208,4 +208,35 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     return true;
 }
 
+namespace {
+void solve_schedule_host(const TriangularSchedule& s, std::vector<double>& x) {
+    const int32_t nl = (int32_t)s.level_ptr.size() - 1;
+    for (int32_t l = 0; l < nl; ++l)
+        for (int32_t t = s.level_ptr[l]; t < s.level_ptr[l + 1]; ++t) {
+            const int32_t k = s.level_rows[t];
+            double sum = x[k];
+            for (int32_t e = s.ptr[k]; e < s.ptr[k + 1]; ++e) sum -= s.val[e] * x[s.idx[e]];
+            x[k] = sum / s.diag[k];
+        }
+}
+}  // namespace
+
+void lu_ftran_host(const LUFactors& f, const std::vector<double>& a, std::vector<double>* x) {
+    std::vector<double> w(f.m);
+    for (int32_t k = 0; k < f.m; ++k) w[k] = a[f.rowperm[k]];
+    solve_schedule_host(f.Lf, w);
+    solve_schedule_host(f.Uf, w);
+    x->assign(f.m, 0.0);
+    for (int32_t k = 0; k < f.m; ++k) (*x)[f.colperm[k]] = w[k];
+}
+
+void lu_btran_host(const LUFactors& f, const std::vector<double>& c, std::vector<double>* z) {
+    std::vector<double> w(f.m);
+    for (int32_t k = 0; k < f.m; ++k) w[k] = c[f.colperm[k]];
+    solve_schedule_host(f.Ub, w);
+    solve_schedule_host(f.Lb, w);
+    z->assign(f.m, 0.0);
+    for (int32_t k = 0; k < f.m; ++k) (*z)[f.rowperm[k]] = w[k];
+}
+
 }  // namespace relp

@@ -44,4 +44,9 @@ struct LUFactors {
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err);
 
+// Host-side solves with the factors (warm starts, tests): x <- B^-1 a (x indexed by basis position on
+// return, a by original row) and z' <- c' B^-1 (c indexed by basis position, z by original row).
+void lu_ftran_host(const LUFactors& f, const std::vector<double>& a, std::vector<double>* x);
+void lu_btran_host(const LUFactors& f, const std::vector<double>& c, std::vector<double>* z);
+
 }  // namespace relp

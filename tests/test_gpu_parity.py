@@ -420,17 +420,18 @@ def test_c2_full_solve_both_engines_agree_to_optimality():
 # ------------------------------------------------------------------------------------------------
 # Sparse LU engine (Carry<_, LUDecomposition<_>>)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", [engine.ENGINE_LU, engine.ENGINE_REVISED])
 @pytest.mark.parametrize("path,fixed", [("burkardt/adlittle.mps", False), ("netlib/SC205.SIF", True), ("netlib/SHARE1B.SIF", True)])
-def test_lu_from_basis_restarts_at_the_optimum(path, fixed):
-    """InverseMaintener::from_basis (carry/mod.rs:428-463) with a general basis: the LU engine factorises
-    the optimal basis found by the revised engine and reports optimality without a single pivot, with the
-    same b, -pi and objective."""
+def test_from_basis_restarts_at_the_optimum(path, fixed, kind):
+    """InverseMaintener::from_basis (carry/mod.rs:428-463) with a general basis: the LU engine factorises the
+    optimal basis found by a cold solve (the revised engine inverts it on the host) and reports optimality
+    without a single pivot, with the same b, -pi and objective."""
     from lp_files import load
     gf, ex, md, emd = load(path, fixed=fixed)
     first = engine.Tableau(md)
     assert first.solve_relaxation() == engine.OPTIMAL
     basis = first.basis_indices()
-    t = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=64)
+    t = engine.Tableau(md, engine=kind, trace_capacity=64)
     if t.nr_rows() != first.nr_rows():
         pytest.skip("phase 1 removed redundant rows: the basis refers to the reduced problem")
     t.from_basis(basis)
@@ -442,7 +443,8 @@ def test_lu_from_basis_restarts_at_the_optimum(path, fixed):
     np.testing.assert_allclose(t.minus_pi(), first.minus_pi(), rtol=1e-7, atol=1e-7 * scale)
 
 
-def test_lu_from_basis_mid_solve_continues_the_same_path():
+@pytest.mark.parametrize("kind", [engine.ENGINE_LU, engine.ENGINE_REVISED])
+def test_from_basis_mid_solve_continues_the_same_path(kind):
     """Warm start from an intermediate basis: the continuation walks the same pivots as the run it was
     taken from (Dantzig's rule has no memory)."""
     md = MatrixData.from_sparse_dict(synthetic.sparse_lp(60, 90, 2))
@@ -454,7 +456,7 @@ def test_lu_from_basis_mid_solve_continues_the_same_path():
         pytest.skip("rows were removed at the phase switch")
     basis = full.basis_indices()
     assert full.run(1 << 20)[1] == engine.OPTIMAL
-    t = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=7, trace_capacity=4096)
+    t = engine.Tableau(md, engine=kind, update_block=7, trace_capacity=4096)
     t.from_basis(basis)
     assert t.run(1 << 20)[1] == engine.OPTIMAL
     assert t.trace() == full.trace()[start + 10:]
