@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-path (LU engine, Netlib 25FV47) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--event-stride", type=int, default=4,
+    ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
