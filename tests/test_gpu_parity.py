@@ -634,3 +634,19 @@ def test_random_lps_with_ranges_unbounded_and_infeasible_outcomes():
             assert abs(t.objective_function_value() - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), case
         t.close()
     assert min(seen.values()) >= 3, seen
+
+
+def test_edge_case_lps_on_every_engine():
+    """tests/edge_lps.py: 1 x 1 problems, empty columns, an all-zero right-hand side, zero costs, duplicate and
+    contradictory equalities, a range row, bounds only - outcome, trace and objective equal the oracle's."""
+    from edge_lps import CASES
+    for name, problem in CASES.items():
+        ref = relp_f64.OracleF64(problem.ensure_csc())
+        status = ref.run(10000)
+        for kind, block in ((engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 4), (engine.ENGINE_TABLEAU, 4), (engine.ENGINE_LU, 4)):
+            t = engine.Tableau(problem, engine=kind, update_block=block, trace_capacity=256)
+            assert engine.OUTCOME_NAMES[t.solve_relaxation(max_iters=1000)] == status, (name, kind)
+            assert t.trace() == ref.trace, (name, kind)
+            if status == "optimal":
+                assert abs(t.objective_function_value() - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), (name, kind)
+            t.close()

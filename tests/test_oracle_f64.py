@@ -101,3 +101,15 @@ def test_f64_oracle_equals_exact_on_random_lps_with_every_row_kind_and_outcome()
         if status == "optimal":
             assert abs(ref.objective - float(out["objective"])) <= 1e-9 * max(1.0, abs(float(out["objective"]))), case
     assert min(seen.values()) >= 3 and removed >= 2, (seen, removed)
+
+
+def test_f64_oracle_equals_exact_on_the_edge_cases():
+    from edge_lps import CASES
+    for name, problem in CASES.items():
+        md = problem.ensure_csc()
+        ref = relp_f64.OracleF64(md)
+        status = ref.run(10000)
+        tr = []
+        out = ox.solve_relaxation(to_exact(md), trace=tr.append)
+        assert out["status"] == status, name
+        assert ref.trace == [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr], name
