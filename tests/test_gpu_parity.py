@@ -650,3 +650,25 @@ def test_edge_case_lps_on_every_engine():
             if status == "optimal":
                 assert abs(t.objective_function_value() - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), (name, kind)
             t.close()
+
+
+@pytest.mark.parametrize("name,objective", [("model_data_1", 123 / 38), ("model_data_3_1", 70.0), ("model_data_3_2", 180.0),
+                                            ("model_data_3_3", 245.0), ("model_data_3_4", 2250.0), ("model_data_4", 7.0),
+                                            ("model_data_6", 28.0)])
+def test_unicamp_files_on_every_engine(name, objective):
+    """tests/unicamp/test.rs (the reference solves these with `Carry<_, LUDecomposition<_>>`): exact optimum pins
+    on all three GPU engines, pivot sequence equal to the oracle's.  Presolve may solve a file completely."""
+    from lp_files import load
+    from rust_lp_amd import general_form
+    try:
+        gf, ex, md, emd = load(f"unicamp/{name}.mps")
+    except general_form.Solved as solved:
+        assert abs(float(solved.objective) - objective) <= 1e-9 * max(1.0, abs(objective))
+        return
+    ref = relp_f64.OracleF64(md)
+    status = ref.run()
+    for kind in (engine.ENGINE_LU, engine.ENGINE_REVISED, engine.ENGINE_TABLEAU):
+        t = engine.Tableau(md, engine=kind, trace_capacity=4096)
+        assert engine.OUTCOME_NAMES[t.solve_relaxation()] == status == "optimal"
+        assert t.trace() == ref.trace
+        assert abs(t.objective_function_value() + float(gf.fixed_cost) - objective) <= 1e-9 * max(1.0, abs(objective))
