@@ -82,12 +82,25 @@ UNICAMP = [("model_data_1", Fr(123, 38)), ("model_data_3_1", 70), ("model_data_3
            ("model_data_3_4", 2250), ("model_data_4", 7), ("model_data_6", 28)]
 
 
+# full solutions the reference compares with `assert_eq!` (tests/unicamp/test.rs:40-101)
+UNICAMP_VALUES = {
+    "model_data_3_1": {"SUP1": Fr(200, 3), "SUP2": Fr(100, 3), "SUP3": Fr(100)},
+    "model_data_3_2": {"SUP1": Fr(25), "SUP2": Fr(75)},
+    "model_data_3_3": {"SUP1": Fr(100), "SUP2": Fr(150)},
+    "model_data_3_4": {"RAW1": Fr(5), "RAW2": Fr(3), "RAW3": Fr(4), "PRODUCT": Fr(500)},
+    "model_data_4": {"COL01": Fr(1), "COL02": Fr(2), "COL03": Fr(2)},
+}
+
+
 @pytest.mark.parametrize("name,objective", UNICAMP)
 def test_unicamp(name, objective):
-    """tests/unicamp/test.rs (the non-ignored cases), `Carry<_, LUDecomposition<_>>`."""
+    """tests/unicamp/test.rs (the non-ignored cases), `Carry<_, LUDecomposition<_>>`: exact objective, and the
+    exact variable values where the reference asserts them (presolve + standardisation + reconstruction)."""
     gf, ex, md, emd = load(f"unicamp/{name}.mps")
-    status, obj, _ = exact_solve(gf, emd, ox.LUDecomposition)
+    status, obj, sol = exact_solve(gf, emd, ox.LUDecomposition)
     assert (status, obj) == ("optimal", objective)
+    if name in UNICAMP_VALUES:
+        assert sol == UNICAMP_VALUES[name]
 
 
 NETLIB = [("AFIRO", -464.75314, 1e-3), ("SC50A", -6.457507706e+01, 1e-5), ("SC50B", -70, 1e-10),
