@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <queue>
 #include <tuple>
 
 namespace relp {
@@ -67,31 +69,72 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     std::vector<Entry> lent;
     std::vector<int32_t> mark(m, -1), pos(m, 0);
     int32_t stamp = 0;
+    // Singletons first: most of an LP basis is triangular (slacks, bound rows).  A column with one active
+    // entry is a fill-free pivot that always passes the threshold; a row with one active entry is fill-free
+    // and is taken when it passes it.  Both are served from stacks, so the O(m) searches below only run on
+    // the "bump" that is left.
+    std::vector<int32_t> col_single, row_single;
+    for (int32_t j = 0; j < m; ++j) if (ccount[j] == 1) col_single.push_back(j);
+    for (int32_t i = 0; i < m; ++i) if (rows[i].size() == 1) row_single.push_back(i);
+    // lazy min-heaps of (count, index) for the sparsest active row / column of the bump: an entry is stale
+    // when the line is done or its count has changed since it was pushed (every change pushes a fresh one)
+    using Item = std::pair<int32_t, int32_t>;
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> row_heap, col_heap;
+    for (int32_t i = 0; i < m; ++i) row_heap.emplace((int32_t)rows[i].size(), i);
+    for (int32_t j = 0; j < m; ++j) col_heap.emplace(ccount[j], j);
+    // largest active |entry| of column j; the scan also drops the stale members of colrows[j] (finished rows,
+    // rows that lost the entry, duplicates), so the lists stay as short as the columns are
+    std::vector<int32_t> seen_stamp(m, -1);
+    int32_t seen_tick = 0;
+    auto col_max_of = [&](int32_t j) {
+        double mx = 0.0;
+        ++seen_tick;
+        size_t o = 0;
+        auto& list = colrows[j];
+        for (size_t t = 0; t < list.size(); ++t) {
+            const int32_t i = list[t];
+            if (row_done[i] || seen_stamp[i] == seen_tick) continue;
+            for (auto& e : rows[i]) if (e.first == j) { mx = std::max(mx, std::fabs(e.second)); seen_stamp[i] = seen_tick; list[o++] = i; break; }
+        }
+        list.resize(o);
+        return mx;
+    };
 
     for (int32_t k = 0; k < m; ++k) {
+        int32_t spi = -1, spj = -1; double spv = 0.0;
+        while (!col_single.empty() && spj < 0) {
+            const int32_t j = col_single.back(); col_single.pop_back();
+            if (step_of_col[j] >= 0 || ccount[j] != 1) continue;
+            for (int32_t i : colrows[j]) {
+                if (row_done[i]) continue;
+                for (auto& e : rows[i]) if (e.first == j && e.second != 0.0) { spi = i; spj = j; spv = e.second; break; }
+                if (spj >= 0) break;
+            }
+        }
+        while (!row_single.empty() && spj < 0) {
+            const int32_t i = row_single.back(); row_single.pop_back();
+            if (row_done[i] || rows[i].size() != 1) continue;
+            const int32_t j = rows[i][0].first; const double v = rows[i][0].second;
+            if (v != 0.0 && std::fabs(v) >= 0.1 * col_max_of(j)) { spi = i; spj = j; spv = v; }
+        }
         // Markowitz search restricted to the sparsest active row and the sparsest active column
         // (pivoting.rs:45-81 searches every remaining entry): candidate A = the entry of the sparsest row
         // with the lowest column count, candidate B = the entry of the sparsest column with the lowest row
         // count; the lower (r - 1)(c - 1) wins.
         int32_t ra = -1;
-        for (int32_t i = 0; i < m; ++i) {
-            if (row_done[i]) continue;
-            if (rows[i].empty()) { if (err) *err = "singular basis (empty row during LU)"; return false; }
-            if (ra < 0 || rows[i].size() < rows[ra].size()) ra = i;
+        if (spj < 0) {
+            while (!row_heap.empty() && (row_done[row_heap.top().second] ||
+                                         (int32_t)rows[row_heap.top().second].size() != row_heap.top().first)) row_heap.pop();
+            if (row_heap.empty()) { if (err) *err = "singular basis (no active row)"; return false; }
+            ra = row_heap.top().second;
+            if (rows[ra].empty()) { if (err) *err = "singular basis (empty row during LU)"; return false; }
         }
         // threshold partial pivoting: a pivot must be at least kThreshold of the largest active entry of
         // its column, which bounds every multiplier of L by 1 / kThreshold
-        auto col_max = [&](int32_t j) {
-            double mx = 0.0;
-            for (int32_t i : colrows[j]) {
-                if (row_done[i]) continue;
-                for (auto& e : rows[i]) if (e.first == j) { mx = std::max(mx, std::fabs(e.second)); break; }
-            }
-            return mx;
-        };
+        auto& col_max = col_max_of;
         constexpr double kThreshold = 0.1;
-        int32_t pi = -1, pj = -1; double pv = 0.0; int64_t best = -1;
-        {
+        int32_t pi = spi, pj = spj; double pv = spv; int64_t best = spj >= 0 ? 0 : -1;
+        if (spj < 0) {
             // candidate A: entries of the sparsest row, by ascending column count
             std::vector<std::pair<int32_t, int32_t>> order;          // (column count, column)
             for (auto& e : rows[ra]) if (e.second != 0.0) order.emplace_back(ccount[e.first], e.first);
@@ -107,10 +150,9 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
         }
         if (best != 0) {
             int32_t cb = -1;
-            for (int32_t j = 0; j < m; ++j) {
-                if (step_of_col[j] >= 0 || ccount[j] <= 0) continue;
-                if (cb < 0 || ccount[j] < ccount[cb]) cb = j;
-            }
+            while (!col_heap.empty() && (step_of_col[col_heap.top().second] >= 0 || ccount[col_heap.top().second] != col_heap.top().first ||
+                                         col_heap.top().first <= 0)) col_heap.pop();
+            if (!col_heap.empty()) cb = col_heap.top().second;
             if (cb >= 0) {
                 const double cmax = col_max(cb);
                 for (int32_t i : colrows[cb]) {
@@ -123,7 +165,7 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
                 }
             }
         }
-        if (pj < 0) {
+        if (pj < 0 && ra >= 0) {
             // no entry of the sparsest row / column passes the threshold: take the largest entry of the
             // sparsest row's best column (always acceptable)
             double bestv = 0.0;
@@ -141,7 +183,11 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
         step_of_row[pi] = k; step_of_col[pj] = k;
         row_done[pi] = 1;
         udiag[k] = pv;
-        for (auto& e : rows[pi]) { --ccount[e.first]; if (e.first != pj) urows[k].push_back(e); }
+        for (auto& e : rows[pi]) {
+            if (--ccount[e.first] == 1) col_single.push_back(e.first);
+            col_heap.emplace(ccount[e.first], e.first);
+            if (e.first != pj) urows[k].push_back(e);
+        }
         const std::vector<std::pair<int32_t, double>>& prow = urows[k];
         // eliminate column pj from the other active rows
         for (int32_t i : colrows[pj]) {
@@ -167,15 +213,22 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
                     nr.emplace_back(e.first, -f * e.second);
                     colrows[e.first].push_back(i);
                     ++ccount[e.first];
+                    col_heap.emplace(ccount[e.first], e.first);
                 }
             }
             size_t o = 0;
             for (auto& e : nr) {
-                if (e.second == 0.0) { --ccount[e.first]; continue; }        // exact cancellation (decomposition/mod.rs:178)
+                if (e.second == 0.0) {                                       // exact cancellation (decomposition/mod.rs:178)
+                    if (--ccount[e.first] == 1) col_single.push_back(e.first);
+                    col_heap.emplace(ccount[e.first], e.first);
+                    continue;
+                }
                 nr[o++] = e;
             }
             nr.resize(o);
             ri.swap(nr);
+            if (ri.size() == 1) row_single.push_back(i);
+            row_heap.emplace((int32_t)ri.size(), i);
         }
         rows[pi].clear();
     }
