@@ -1,4 +1,4 @@
-"""Solve the 10,000 x 10,000 bench LP to optimality on the tableau and the revised engine and compare
+"""Usage: soak_dense10k.py [M [N [SEED]]].  Solve the 10,000 x 10,000 bench LP (or M x N) to optimality on the tableau and the revised engine and compare
 (objective, pivot count, trace prefix); report residuals of the final tableau state."""
 import ctypes as C
 import sys
@@ -8,8 +8,9 @@ import numpy as np
 import rust_lp_amd  # noqa: F401
 from rust_lp_amd import MatrixData, engine, synthetic
 
-m = n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-seed = 20250002
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else m
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 20250002
 lib = engine.load_library()
 b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64)) / 4000.0
 c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64)) / 1000.0
