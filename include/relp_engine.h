@@ -85,8 +85,8 @@ typedef struct {
     int32_t phase_one_rule;       /* relp_pivot_rule_t */
     int32_t phase_two_rule;
     double  tol_cost;             /* candidate iff d_j < -tol_cost          (pivot_rule.rs:56,81,117) */
-    double  tol_pivot;            /* ratio test iff alpha_i > tol_pivot      (tableau/mod.rs:227); default 1e-7,
-                                   * the other tolerances 1e-9 (tol_zero 1e-11) */
+    double  tol_pivot;            /* ratio test iff alpha_i > tol_pivot      (tableau/mod.rs:227).  Defaults:
+                                   * tol_cost = tol_pivot = tol_feas = 1e-7, tol_tie = 1e-9, tol_zero = 1e-11 */
     double  tol_zero;             /* |b_i| <= tol_zero reads as 0 in the ratio */
     double  tol_tie;              /* ratio ties: <= min + tol_tie*max(1,|min|), smallest leaving column wins
                                      (tableau/mod.rs:229-239) */

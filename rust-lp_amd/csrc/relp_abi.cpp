@@ -17,7 +17,7 @@ void relp_default_config(relp_config_t* cfg) {
     cfg->device = -1;
     cfg->phase_one_rule = RELP_RULE_FIRST_PROFITABLE_WITH_MEMORY;   // phase_one.rs:55,97
     cfg->phase_two_rule = RELP_RULE_STEEPEST_DESCENT;               // two_phase/mod.rs:44,101
-    cfg->tol_cost = 1e-9; cfg->tol_pivot = 1e-7; cfg->tol_zero = 1e-11; cfg->tol_tie = 1e-9; cfg->tol_feas = 1e-9;
+    cfg->tol_cost = 1e-7; cfg->tol_pivot = 1e-7; cfg->tol_zero = 1e-11; cfg->tol_tie = 1e-9; cfg->tol_feas = 1e-7;
     cfg->poll_interval = 64;
     cfg->trace_capacity = 0;
     cfg->shard_rank = 0; cfg->shard_count = 1;
