@@ -273,7 +273,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     if (lu_) {
         // pivots between refactorisations (the reference refactors after 10 updates, lower_upper/mod.rs:199;
         // here an update is one column of W, so longer blocks are cheap)
-        block_ = cfg_.update_block < 0 ? 64 : std::max(1, std::min(cfg_.update_block, 128));
+        block_ = cfg_.update_block < 0 ? 128 : std::max(1, std::min(cfg_.update_block, 128));
         HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
     }
     if (tableau_) {

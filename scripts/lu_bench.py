@@ -25,7 +25,7 @@ def problems(argv):
 def main():
     argv = sys.argv[1:] or ["synth", "400", "800", "77"]
     for name, md in problems(argv):
-        for label, kw in (("lu64", dict(engine=engine.ENGINE_LU)), ("lu128", dict(engine=engine.ENGINE_LU, update_block=128)),
+        for label, kw in (("lu128", dict(engine=engine.ENGINE_LU)), ("lu64", dict(engine=engine.ENGINE_LU, update_block=64)),
                           ("lu16", dict(engine=engine.ENGINE_LU, update_block=16)),
                           ("revised", dict(engine=engine.ENGINE_REVISED, update_block=0)),
                           ("tableau", dict(engine=engine.ENGINE_TABLEAU, update_block=32))):

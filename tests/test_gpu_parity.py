@@ -480,7 +480,7 @@ def test_lu_engine_degenerate_sparse_reaches_the_oracle_optimum():
     # updates leave ~1e-7 of drift in the basic reduced costs
     assert ident <= 1e-7 and basic <= 1e-6 and min_b >= -1e-7
     st = t.lu_stats()
-    assert st["refactorisations"] > 100 and st["m"] == t.nr_rows()
+    assert st["refactorisations"] > 50 and st["m"] == t.nr_rows()
 
 
 # ------------------------------------------------------------------------------------------------
