@@ -560,7 +560,7 @@ def test_dense10k_full_size_engines_agree_and_match_the_cpu_oracle_prefix():
 
 
 # ------------------------------------------------------------------------------------------------
-# Randomised differential test (a fixed slice of scripts/fuzz_gpu.py)
+# Randomised differential test (a fixed slice of tests/tools/fuzz_gpu.py)
 # ------------------------------------------------------------------------------------------------
 def test_random_mixed_lps_every_engine_matches_the_oracle():
     """120 random LPs with ==, <=, >= rows, bounds and rank deficiencies (rows removed at the phase switch,
@@ -568,7 +568,7 @@ def test_random_mixed_lps_every_engine_matches_the_oracle():
     block length: outcome, pivot trace, objective and b equal the f64 oracle's.  Cases in which the reference
     removes a non-redundant row (it pushes the artificial's INDEX, phase_one.rs:252, which differs from its row
     for >= rows) have no defined answer outside the explicit-inverse back end and are checked on the revised
-    engine only - see scripts/fuzz_gpu.py."""
+    engine only - see tests/tools/fuzz_gpu.py."""
     rng = np.random.default_rng(20250003)
     kinds = [(engine.ENGINE_REVISED, (0, 1, 3, 7, 64)), (engine.ENGINE_TABLEAU, (1, 2, 5, 64)), (engine.ENGINE_LU, (1, 2, 6, 64))]
     checked = removed = 0

@@ -1,7 +1,8 @@
-"""Re-run one case of scripts/fuzz_gpu.py verbosely (same random stream) and compare with HiGHS:
-   python scripts/fuzz_case.py SEED0 CASE [SIZE_SCALE]"""
+"""Re-run one case of tests/tools/fuzz_gpu.py verbosely (same random stream) and compare with HiGHS:
+   python tests/tools/fuzz_case.py SEED0 CASE [SIZE_SCALE]"""
 import sys
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
 import numpy as np
 import rust_lp_amd  # noqa: F401
 from rust_lp_amd import MatrixData, engine, synthetic

@@ -8,9 +8,10 @@ by index surgery (carry/mod.rs:650-689), and what follows is no longer the LP (H
 reference's result on such cases).  The revised engine reproduces that literally and is checked against the
 oracle; the tableau engine and the LU engine (like the reference's own LU back end, which re-inverts from the
 filtered columns, carry/mod.rs:512-547) continue from a different state, so those cases are only counted.
-Usage: python scripts/fuzz_gpu.py [N_CASES] [SEED0] [SIZE_SCALE]"""
+Usage: python tests/tools/fuzz_gpu.py [N_CASES] [SEED0] [SIZE_SCALE]"""
 import sys
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
 import numpy as np
 import rust_lp_amd  # noqa: F401
 from rust_lp_amd import MatrixData, engine, synthetic

@@ -1,6 +1,6 @@
 """Randomised run of the sharded entry points (G engines on one GPU, exchanges done with torch ops): calls
 tests/test_gpu_parity.py::test_shard_entry_points_on_one_gpu with random world sizes, LP sizes, engines and
-block lengths.  Usage: python scripts/fuzz_shards.py [N_CASES] [SEED]"""
+block lengths.  Usage: python tests/tools/fuzz_shards.py [N_CASES] [SEED]"""
 import sys
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
