@@ -3,9 +3,17 @@ reference's own files).  Usage: python scripts/lu_bench.py [synth M N SEED | FIL
 import sys
 import time
 sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
 import rust_lp_amd  # noqa: F401
 from rust_lp_amd import MatrixData, engine, synthetic
+
+
+def load_file(rel):
+    """MPS / SIF fixture -> presolved, standardised f64 MatrixData (the product path, no oracle involved)."""
+    import os
+    from rust_lp_amd import general_form, mps
+    path = os.path.join("tests", "golden", "mps", rel)
+    gf = general_form.GeneralForm.from_mps(mps.import_file(path, rel.endswith(".SIF")))
+    return gf.to_matrix_data(gf.derive_matrix_data_exact())
 
 
 def problems(argv):
@@ -16,9 +24,7 @@ def problems(argv):
             yield f"synth{m}x{n}", MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, s))
             i += 4
         else:
-            from lp_files import load
-            gf, ex, md, emd = load(argv[i], fixed=argv[i].endswith(".SIF"))
-            yield argv[i], md
+            yield argv[i], load_file(argv[i])
             i += 1
 
 

@@ -2,7 +2,6 @@
 `lu_profile.py synth M N SEED` for a synthetic sparse LP."""
 import sys
 sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
 import rust_lp_amd  # noqa: F401
 from rust_lp_amd import MatrixData, engine, synthetic
 
@@ -10,8 +9,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "synth":
     m, n, seed = (int(v) for v in sys.argv[2:5])
     md, kw = MatrixData.from_sparse_dict(synthetic.sparse_lp(m, n, seed)), {}
 else:
-    from lp_files import load
-    gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
+    import os
+    from rust_lp_amd import general_form, mps
+    gf = general_form.GeneralForm.from_mps(mps.import_file(os.path.join("tests", "golden", "mps", "netlib", "25FV47.SIF"), True))
+    md = gf.to_matrix_data(gf.derive_matrix_data_exact())
     kw = dict(tol_pivot=1e-5, tol_cost=1e-7)
 t = engine.Tableau(md, engine=engine.ENGINE_LU, **kw)
 print(engine.OUTCOME_NAMES[t.solve_relaxation()], t.iterations(), t.lu_stats())
