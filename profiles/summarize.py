@@ -6,7 +6,7 @@ FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
 
 Launches that ran as no-ops (the loop kernels return at once when the PivotRecord says the loop
 ended) are excluded from the per-kernel averages: a launch counts when its duration is at least
-half of that kernel's longest launch.
+half of that kernel's 90th-percentile launch (not the longest: one slow outlier would hide the rest).
 """
 import collections
 import csv
@@ -29,7 +29,8 @@ def per_kernel(path, value_col=None):
         agg[name].append((dur, val))
     out = {}
     for name, rows in agg.items():
-        mx = max(d for d, _ in rows)
+        durs = sorted(d for d, _ in rows)
+        mx = durs[min(len(durs) - 1, int(0.9 * len(durs)))]
         eff = [(d, v) for d, v in rows if d >= 0.5 * mx]
         out[name] = {"launches": len(rows), "effective": len(eff),
                      "avg_us": statistics.mean(d for d, _ in eff) / 1e3,

@@ -104,6 +104,45 @@ static constexpr int kMaxEta = 128;
 // RATIO TEST (single workgroup; two passes: strict minimum, then Bland tie-break on the leaving
 // column among rows within the tie band -- identical to tableau/mod.rs:221-247 for zero tolerances)
 // ------------------------------------------------------------------------------------------------
+// Last step of the ratio test: every thread brings its best (leaving column, row) among the rows inside the
+// tie band; the workgroup's minimum leaving column wins (Bland, tableau/mod.rs:229-239), the record is
+// written and the block bookkeeping of the deferred update (row r of W saved, slot of W chosen) is done.
+template <int BS>
+__device__ __forceinline__ void ratio_commit(int best_leave, int best_row, const double* alpha, const double* b,
+                                             const DeferredUpdate& du, int p, PivotRecord* rec) {
+    __shared__ int s_cl[BS / 64];
+    __shared__ int s_cr[BS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ol = __shfl_down(best_leave, off, 64);
+        const int orow = __shfl_down(best_row, off, 64);
+        if (ol < best_leave) { best_leave = ol; best_row = orow; }
+    }
+    if (lane == 0) { s_cl[wave] = best_leave; s_cr[wave] = best_row; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BS / 64; ++w)
+            if (s_cl[w] < best_leave) { best_leave = s_cl[w]; best_row = s_cr[w]; }
+        rec->r = best_row;
+        rec->leaving = best_leave;
+        rec->alpha_r = alpha[best_row];
+        rec->b_r = b[best_row];
+        s_cr[0] = best_row;
+    }
+    if (du.kmax <= 0) return;
+    // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
+    __syncthreads();
+    const int r = s_cr[0];
+    for (int j = threadIdx.x; j < p; j += BS) du.wr[j] = du.W[(int64_t)j * du.ld + r];
+    if (threadIdx.x == 0) {
+        int jt = du.pos_of_row[r];
+        rec->n_eta_old = p;
+        if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
+        rec->eta_target = jt;
+    }
+}
+
 // Body of the ratio test for a workgroup of BS threads that keeps up to ITEMS rows per thread in
 // registers.  `p` = rec->n_eta read by the caller together with the outcome.  Ends with the block
 // bookkeeping of the deferred update.
@@ -111,8 +150,6 @@ template <int BS, int ITEMS>
 __device__ __forceinline__ void ratio_body(const double* alpha, const double* b, const int32_t* basis_indices, int m,
                                            const Tolerances& tol, const DeferredUpdate& du, int p, PivotRecord* rec) {
     __shared__ double s_min[BS / 64];
-    __shared__ int s_leave[BS / 64];
-    __shared__ int s_row[BS / 64];
     __shared__ double s_bcast;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -178,34 +215,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
             if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int ol = __shfl_down(best_leave, off, 64);
-        const int orow = __shfl_down(best_row, off, 64);
-        if (ol < best_leave) { best_leave = ol; best_row = orow; }
-    }
-    if (lane == 0) { s_leave[wave] = best_leave; s_row[wave] = best_row; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < BS / 64; ++w)
-            if (s_leave[w] < best_leave) { best_leave = s_leave[w]; best_row = s_row[w]; }
-        rec->r = best_row;
-        rec->leaving = best_leave;
-        rec->alpha_r = alpha[best_row];
-        rec->b_r = b[best_row];
-        s_row[0] = best_row;
-    }
-    if (du.kmax <= 0) return;
-    // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
-    __syncthreads();
-    const int r = s_row[0];
-    for (int j = threadIdx.x; j < p; j += BS) du.wr[j] = du.W[(int64_t)j * du.ld + r];
-    if (threadIdx.x == 0) {
-        int jt = du.pos_of_row[r];
-        rec->n_eta_old = p;
-        if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
-        rec->eta_target = jt;
-    }
+    ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
 }
 
 

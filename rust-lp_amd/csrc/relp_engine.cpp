@@ -22,7 +22,7 @@ void Engine::free_all() {
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
     fr(d_part_k1_); fr(d_part_j_);
-    fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_);
+    fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
     fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
@@ -287,6 +287,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         HIP_TRY(dev_alloc(&dR0_, ld_r_ * (block_ + 1)));        // + one scratch row (d_aq_big)
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
         HIP_TRY(dev_alloc(&d_idcol_, m_));
+        HIP_TRY(dev_alloc(&d_rmin_, m_ / 256 + 2));
     }
     if (block_ > 0) {
         HIP_TRY(dev_alloc(&d_v_, ld_b_));
@@ -421,10 +422,11 @@ void Engine::enqueue_iteration_tableau(int rule) {
     // 3 launches: [PRICE's final reduction + tableau column] -> [ratio test + block bookkeeping] ->
     // [tableau row / reduced costs / next PRICE partials  ||  W, b, basis]
     prof_begin(RELP_K_FTRAN);
-    launch_tab_select_column(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_rec_, stream_);
+    launch_tab_select_column_rmin(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_b_, tolerances(), d_rmin_,
+                                  d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_RATIO);
-    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
+    launch_ratio_blocks(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rmin_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_PRICE);
     launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);

@@ -224,6 +224,13 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 // launch_tab_select + launch_tab_column in one launch (every workgroup reduces the partials itself)
 void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                               double* alpha, PivotRecord* rec, hipStream_t s);
+// single-GPU loop: also leaves the minimum ratio of every block of 256 rows in `rmin`, and the ratio test that
+// starts from those minima (re-reads only the row blocks inside the tie band)
+void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
+                                   double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
+                                   hipStream_t s);
+void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
+                         const DeferredUpdate& du, const double* rmin, PivotRecord* rec, hipStream_t s);
 // sharded engines: this rank's candidate message [key, j, d_j, alpha(m)] instead of the record
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                   double* msg, PivotRecord* rec, hipStream_t s);

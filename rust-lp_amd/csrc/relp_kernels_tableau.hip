@@ -277,9 +277,12 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, Def
 // partials to the same entering column q, then forms alpha = T0[:,q] + W R0[:,q] for its rows.
 // `msg` (sharded engines): the candidate message [key, j, d_j, alpha(m)] of this rank is written instead
 // of the record; a rank without a candidate sends key = +inf and stays RUNNING (another rank may have one).
+// `rmin` (single-GPU loop): the minimum ratio b_i / alpha_i over this workgroup's 256 rows, for
+// k_ratio_blocks.
 __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, DeferredUpdate du, SelectPartials sp,
                                                                 int count, double* __restrict__ alpha, double* msg,
-                                                                PivotRecord* rec) {
+                                                                const double* __restrict__ b, Tolerances tol,
+                                                                double* __restrict__ rmin, PivotRecord* rec) {
     const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
     if (outcome != DEV_RUNNING) return;
     __shared__ double s_k1[kThreads / 64];
@@ -368,11 +371,83 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
     const int i = blockIdx.x * kThreads + threadIdx.x;
     const double t0 = i < tv.m ? tv.T0[(int64_t)cq * tv.ld_t + i] : 0.0;     // in flight together with the R0 column
+    const double b_i = (rmin && i < tv.m) ? b[i] : 0.0;
     __syncthreads();
-    if (i >= tv.m) return;
-    double a = t0;
-    for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
-    alpha[i] = a;
+    double ratio = INFINITY;
+    if (i < tv.m) {
+        double a = t0;
+        for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
+        alpha[i] = a;
+        // the same expression as the ratio test's first pass (ratio_body), so min over the block minima is
+        // bit for bit the minimum over all rows
+        const double bz = fabs(b_i) <= tol.zero ? 0.0 : b_i;
+        if (a > tol.pivot) ratio = bz / a;
+    }
+    if (!rmin) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ratio = fmin(ratio, __shfl_down(ratio, off, 64));
+    if (lane == 0) s_k1[wave] = ratio;
+    __syncthreads();
+    if (threadIdx.x == 0) rmin[blockIdx.x] = fmin(fmin(s_k1[0], s_k1[1]), fmin(s_k1[2], s_k1[3]));
+}
+
+// Ratio test from the per-block minima of k_tab_select_column: the global minimum is the minimum of the block
+// minima, and a row inside the tie band lives in a block whose own minimum is inside the band, so only those
+// blocks' rows (usually one or two blocks of 256) are read again.  Same result as k_ratio.
+__global__ __launch_bounds__(kSingleBlock) void k_ratio_blocks(const double* __restrict__ alpha, const double* __restrict__ b,
+                                                               const int32_t* __restrict__ basis_indices, int m,
+                                                               Tolerances tol, DeferredUpdate du,
+                                                               const double* __restrict__ rmin, int nblk, PivotRecord* rec) {
+    const int outcome = rec->outcome, p = rec->n_eta;
+    if (outcome != DEV_RUNNING) return;
+    __shared__ double s_min[kSingleBlock / 64];
+    __shared__ double s_bcast;
+    constexpr int kListMax = 64;
+    __shared__ int s_list[kListMax];
+    __shared__ int s_cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mn = INFINITY;
+    for (int t = threadIdx.x; t < nblk; t += kSingleBlock) mn = fmin(mn, rmin[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if (lane == 0) s_min[wave] = mn;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = s_min[0];
+        for (int w = 1; w < kSingleBlock / 64; ++w) g = fmin(g, s_min[w]);
+        s_bcast = g;
+    }
+    __syncthreads();
+    const double gmin = s_bcast;
+    if (gmin == INFINITY) {
+        if (threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
+        return;
+    }
+    const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
+    for (int t = threadIdx.x; t < nblk; t += kSingleBlock) {
+        if (!(rmin[t] <= bound)) continue;
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < kListMax) s_list[pos] = t;
+    }
+    __syncthreads();
+    const int listed = s_cnt;
+    const bool use_list = listed <= kListMax;
+    const int total = (use_list ? listed : nblk) * kThreads;
+    int best_leave = 0x7fffffff, best_row = -1;
+    for (int idx = threadIdx.x; idx < total; idx += kSingleBlock) {
+        const int t = use_list ? s_list[idx / kThreads] : idx / kThreads;
+        const int i = t * kThreads + idx % kThreads;
+        if (i >= m) continue;
+        const double a = alpha[i];
+        double bi = b[i];
+        if (fabs(bi) <= tol.zero) bi = 0.0;
+        if (a > tol.pivot && bi / a <= bound) {
+            const int lv = basis_indices[i];
+            if (lv < best_leave) { best_leave = lv; best_row = i; }
+        }
+    }
+    ratio_commit<kSingleBlock>(best_leave, best_row, alpha, b, du, p, rec);
 }
 
 __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, double* __restrict__ b,
@@ -658,13 +733,26 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                               double* alpha, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       (double*)nullptr, rec);
+                       (double*)nullptr, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec);
+}
+
+void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
+                                   double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
+                       (double*)nullptr, b, tol, rmin, rec);
+}
+
+void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
+                         const DeferredUpdate& du, const double* rmin, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_ratio_blocks, dim3(1), dim3(kSingleBlock), 0, s, alpha, b, basis_indices, m, tol, du, rmin,
+                       cdiv(m, kThreads), rec);
 }
 
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                   double* msg, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
-                       msg, rec);
+                       msg, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec);
 }
 
 void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
