@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
+    ap.add_argument("--shard-loop", default="native", choices=["native", "python"],
+                    help="N > 1: pivot loop inside the library calling RCCL itself, or the Python loop over torch.distributed")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
     args = ap.parse_args()
@@ -211,6 +213,8 @@ def main():
     nums_b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
     nums_c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
 
+    loop_kind = {}
+
     def measure(kind):
         """Build the engine of `kind` on the synthetic LP (generated in HBM) and time K pivots."""
         md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=nums_b / 4000.0, cost=nums_c / 1000.0,
@@ -238,8 +242,18 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         else:
-            from rust_lp_amd.sharded import ShardedPivotLoop
-            loop = ShardedPivotLoop(t, dist, dev)
+            from rust_lp_amd.sharded import NativeShardedLoop, ShardedPivotLoop
+            loop = None
+            if not rehearse and args.shard_loop == "native":
+                # the loop inside the library, RCCL called from C++ on the engine's stream
+                try:
+                    loop = NativeShardedLoop(t, dist, dev)
+                    loop_kind[kind] = "native (relp_shard_run, RCCL from C++)"
+                except engine.RelpError as e:             # agreed on by all ranks (all-reduce MIN inside)
+                    print(f"[bench] native sharded loop unavailable: {e}", file=sys.stderr)
+            if loop is None:
+                loop = ShardedPivotLoop(t, dist, dev)
+                loop_kind[kind] = "python (torch.distributed collectives)"
             oc = loop.finish_phase_one()
             assert oc == engine.PHASE_ONE_DONE
             done, oc = loop.run(W)
@@ -335,6 +349,8 @@ def main():
             "objective_after_run": res["objective"],
             "reference_iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
         }
+        if sharded:
+            out["config"]["shard_loop"] = loop_kind.get(primary)
         if secondary is not None:
             out["revised_engine"] = secondary
         if sparse is not None:

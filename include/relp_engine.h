@@ -219,7 +219,9 @@ relp_status_t relp_shard_ranges(const relp_engine_t *h, int32_t *col_lo, int32_t
 /* columns [lo, hi) of the structural block owned by `rank` of `count` (what relp_engine_create
  * expects in `dense` when cfg.shard_count > 1) */
 void          relp_shard_column_range(int32_t nr_normal, int32_t rank, int32_t count, int32_t *lo, int32_t *hi);
-/* message length in doubles of one PRICE candidate: [key, j, d_j, a_j (m entries, tableau row space)] */
+/* message length in doubles of one PRICE candidate: [key, j, d_j, a_j (m entries, tableau row space)]; the
+ * tableau engine appends the minimum ratio b_i / alpha_i of every block of 256 rows (the receiver's ratio test
+ * starts from those) */
 int64_t       relp_shard_candidate_len(const relp_engine_t *h);
 /* length in doubles of the rho buffer (m rounded up to the B^-1 row pitch) */
 int64_t       relp_shard_rho_len(const relp_engine_t *h);
@@ -249,6 +251,27 @@ relp_status_t relp_shard_flush_begin(relp_engine_t *h, double **dev_snapshot, in
 relp_status_t relp_shard_flush_end(relp_engine_t *h);
 /* outcome poll (one small device->host copy) */
 relp_status_t relp_poll(relp_engine_t *h, int32_t *outcome, int64_t *iterations);
+
+/* ---- native multi-GPU loop: the same per-pivot sequence as above, enqueued by the library itself with the
+ * collectives called through two hooks between its kernels, on the engine's stream (no Python and no host
+ * sync inside a pivot; the host polls the outcome every cfg.poll_interval pivots like relp_run).  The hooks
+ * return 0 on success. */
+typedef int (*relp_allgather_fn)(void *ctx, const void *dev_send, void *dev_recv, int64_t bytes_per_rank, void *hip_stream);
+typedef int (*relp_allreduce_sum_fn)(void *ctx, double *dev_buf, int64_t count, void *hip_stream);
+relp_status_t relp_shard_set_collectives(relp_engine_t *h, relp_allgather_fn allgather, relp_allreduce_sum_fn allreduce_sum,
+                                         void *ctx);
+/* phase_one::primal / phase_two::primal across ranks: up to max_iters basis changes of the current phase.  Every
+ * rank must call it with the same arguments; every rank takes the same decisions from the same gathered data,
+ * so *done and *outcome agree on all ranks. */
+relp_status_t relp_shard_run(relp_engine_t *h, int64_t max_iters, int64_t *done, int32_t *outcome);
+/* RCCL as the collectives: rank 0 makes a unique id (ncclGetUniqueId, 128 bytes), the caller hands it to every
+ * rank (any channel; bench.py broadcasts it with torch.distributed), and each rank attaches a communicator of
+ * cfg.shard_count ranks on the engine's device (ncclCommInitRank), which installs ncclAllGather / ncclAllReduce
+ * as the hooks.  librccl.so.1 is taken from the process if already loaded (PyTorch ships one), else dlopen'ed.
+ * RELP_E_UNSUPPORTED when no RCCL library can be loaded. */
+#define RELP_RCCL_ID_BYTES 128
+relp_status_t relp_rccl_unique_id(uint8_t id[RELP_RCCL_ID_BYTES]);
+relp_status_t relp_rccl_attach(relp_engine_t *h, const uint8_t id[RELP_RCCL_ID_BYTES]);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,13 @@ relp_status_t relp_shard_flush_begin(relp_engine_t* h, double** snap, int64_t* l
     return h ? H(h).shard_flush_begin(snap, len) : RELP_E_ARG;
 }
 relp_status_t relp_shard_flush_end(relp_engine_t* h) { return h ? H(h).shard_flush_end() : RELP_E_ARG; }
+relp_status_t relp_shard_set_collectives(relp_engine_t* h, relp_allgather_fn ag, relp_allreduce_sum_fn ar, void* ctx) {
+    return h ? H(h).shard_set_collectives(ag, ar, ctx) : RELP_E_ARG;
+}
+relp_status_t relp_shard_run(relp_engine_t* h, int64_t max_iters, int64_t* done, int32_t* outcome) {
+    return h ? H(h).shard_run(max_iters, done, outcome) : RELP_E_ARG;
+}
+relp_status_t relp_rccl_attach(relp_engine_t* h, const uint8_t* id) { return (h && id) ? H(h).rccl_attach(id) : RELP_E_ARG; }
 
 int32_t relp_nr_rows(const relp_engine_t* h) { return h ? H(h).nr_rows() : -1; }
 int32_t relp_nr_columns(const relp_engine_t* h) { return h ? H(h).nr_columns() : -1; }

@@ -218,6 +218,64 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
     ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
 }
 
+// Ratio test of a workgroup of BS threads from the minimum ratio of every block of kThreads rows (`rmin`, nblk
+// entries, written by the kernel that formed alpha): the global minimum is the minimum of the block minima, and
+// a row inside the tie band lives in a block whose own minimum is inside the band, so only those blocks' rows
+// (usually one or two blocks) are read again.  Same result as ratio_body.  `p` = rec->n_eta read by the caller.
+template <int BS>
+__device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alpha, const double* __restrict__ b,
+                                                  const int32_t* __restrict__ basis_indices, int m, const Tolerances& tol,
+                                                  const DeferredUpdate& du, const double* __restrict__ rmin, int nblk, int p,
+                                                  PivotRecord* rec) {
+    __shared__ double s_min[BS / 64];
+    __shared__ double s_bcast;
+    constexpr int kListMax = 64;
+    __shared__ int s_list[kListMax];
+    __shared__ int s_cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mn = INFINITY;
+    for (int t = threadIdx.x; t < nblk; t += BS) mn = fmin(mn, rmin[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if (lane == 0) s_min[wave] = mn;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = s_min[0];
+        for (int w = 1; w < BS / 64; ++w) g = fmin(g, s_min[w]);
+        s_bcast = g;
+    }
+    __syncthreads();
+    const double gmin = s_bcast;
+    if (gmin == INFINITY) {
+        if (threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
+        return;
+    }
+    const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
+    for (int t = threadIdx.x; t < nblk; t += BS) {
+        if (!(rmin[t] <= bound)) continue;
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < kListMax) s_list[pos] = t;
+    }
+    __syncthreads();
+    const int listed = s_cnt;
+    const bool use_list = listed <= kListMax;
+    const int total = (use_list ? listed : nblk) * kThreads;
+    int best_leave = 0x7fffffff, best_row = -1;
+    for (int idx = threadIdx.x; idx < total; idx += BS) {
+        const int t = use_list ? s_list[idx / kThreads] : idx / kThreads;
+        const int i = t * kThreads + idx % kThreads;
+        if (i >= m) continue;
+        const double a = alpha[i];
+        double bi = b[i];
+        if (fabs(bi) <= tol.zero) bi = 0.0;
+        if (a > tol.pivot && bi / a <= bound) {
+            const int lv = basis_indices[i];
+            if (lv < best_leave) { best_leave = lv; best_row = i; }
+        }
+    }
+    ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -23,6 +23,7 @@ void Engine::free_all() {
     fr(d_in_basis_); fr(d_rec_);
     fr(d_part_k1_); fr(d_part_j_);
     fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
+    fr(d_msg_cand_); fr(d_msg_cands_); fr(d_msg_slice_); fr(d_msg_slices_); fr(d_msg_rho_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
     fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_);
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
@@ -32,7 +33,7 @@ void Engine::free_all() {
     stream_ = nullptr;
 }
 
-Engine::~Engine() { free_all(); }
+Engine::~Engine() { rccl_release(); free_all(); }
 
 ColumnTable Engine::table() const {
     ColumnTable ct;
@@ -148,7 +149,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         row_stride_ = (int32_t)round_up((m_ + G - 1) / G, 2);
         row_lo_ = std::min(m_, g * row_stride_);
         row_hi_ = std::min(m_, row_lo_ + row_stride_);
-        cand_len_ = round_up(3 + (int64_t)m_, 2);
+        cand_len_ = candidate_len_for(m_);
     }
     const bool want_tableau_early = cfg_.engine == RELP_ENGINE_TABLEAU;
 
@@ -945,7 +946,7 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     m_ = m_new; mc_ = mc_new;
     row_lo_ = 0; row_hi_ = m_;
     row_stride_ = (int32_t)round_up(m_, 2);
-    cand_len_ = round_up(3 + (int64_t)m_, 2);
+    cand_len_ = candidate_len_for(m_);
     // stale tails of the m-vectors must be zero for the 16-byte loads
     HIP_TRY(hipMemset(d_alpha_, 0, sizeof(double) * ld_b_));
     HIP_TRY(hipMemset(d_aq_, 0, sizeof(double) * ld_b_));

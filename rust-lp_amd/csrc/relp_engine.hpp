@@ -76,6 +76,9 @@ class Engine {
     relp_status_t shard_ratio(const double* dev_alpha_slices, int32_t count, double* dev_rho);
     relp_status_t shard_update(const double* dev_rho);
     relp_status_t shard_pivot();
+    relp_status_t shard_set_collectives(relp_allgather_fn ag, relp_allreduce_sum_fn ar, void* ctx);
+    relp_status_t shard_run(int64_t max_iters, int64_t* done, int32_t* outcome);
+    relp_status_t rccl_attach(const uint8_t* id);
     relp_status_t poll(int32_t* outcome, int64_t* iterations);
 
     const char* last_error() const { return err_.c_str(); }
@@ -159,7 +162,24 @@ class Engine {
 
     // ---- shards ----
     int32_t col_lo_ = 0, col_hi_ = 0, row_lo_ = 0, row_hi_ = 0, row_stride_ = 0;
+    // [key, j, d_j, column (m)] and, tableau engine, the minimum ratio of every block of 256 rows
+    int64_t candidate_len_for(int32_t m) const {
+        return round_up_even(3 + (int64_t)m + (cfg_.engine == RELP_ENGINE_TABLEAU ? (m + 255) / 256 : 0));
+    }
+    static int64_t round_up_even(int64_t v) { return (v + 1) & ~int64_t(1); }
     int64_t cand_len_ = 0;
+    // native multi-GPU loop: collective hooks and the message buffers they exchange
+    relp_allgather_fn coll_allgather_ = nullptr;
+    relp_allreduce_sum_fn coll_allreduce_ = nullptr;
+    void* coll_ctx_ = nullptr;
+    void* rccl_comm_ = nullptr;          // ncclComm_t owned by this engine (relp_rccl_attach)
+    double* d_msg_cand_ = nullptr;       // this rank's candidate / all ranks' candidates
+    double* d_msg_cands_ = nullptr;
+    double* d_msg_slice_ = nullptr;      // revised engine: alpha slice / all slices, rho
+    double* d_msg_slices_ = nullptr;
+    double* d_msg_rho_ = nullptr;
+    relp_status_t shard_iteration();
+    void rccl_release();
 
     // ---- profiling ----
     bool prof_on_ = false;

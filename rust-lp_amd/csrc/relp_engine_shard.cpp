@@ -47,7 +47,8 @@ relp_status_t Engine::shard_price(double* dev_candidate) {
         // PRICE's final reduction over the local partials + the local winner's tableau column, written
         // straight into the candidate message
         prof_begin(RELP_K_FTRAN);
-        launch_tab_select_column_msg(tv, deferred(), sp, tab_scan_blocks(sc_hi_ - sc_lo_), dev_candidate, d_rec_, stream_);
+        launch_tab_select_column_msg(tv, deferred(), sp, tab_scan_blocks(sc_hi_ - sc_lo_), dev_candidate, d_b_, tolerances(), d_rec_,
+                                     stream_);
         prof_end();
         return RELP_OK;
     }
@@ -71,8 +72,9 @@ relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t 
     if (tableau_) {
         // the winner's payload is the entering tableau column (alpha) itself: pick it and run the ratio test
         prof_begin(RELP_K_RATIO);
-        launch_select_candidate_ratio(dev_candidates, count, cand_len_, m_, d_alpha_, d_b_, d_basis_, rule, tolerances(),
-                                      deferred(), d_rec_, stream_);
+        if (count > 64) return fail(RELP_E_UNSUPPORTED, "at most 64 shards");
+        launch_tab_select_candidate_ratio(dev_candidates, count, cand_len_, m_, d_alpha_, d_b_, d_basis_, rule, tolerances(),
+                                          deferred(), d_rec_, stream_);
         prof_end();
         return RELP_OK;
     }
@@ -159,6 +161,76 @@ relp_status_t Engine::shard_update(const double* dev_rho) {
     } else {
         ++since_flush_;
     }
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Native loop over the shard steps: the library enqueues kernels and collectives itself.
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::shard_set_collectives(relp_allgather_fn ag, relp_allreduce_sum_fn ar, void* ctx) {
+    if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
+    if (!ag || (!tableau_ && !ar)) return fail(RELP_E_ARG, "collective hooks missing");
+    coll_allgather_ = ag; coll_allreduce_ = ar; coll_ctx_ = ctx;
+    const int64_t g = std::max(cfg_.shard_count, 1);
+    if (!d_msg_cand_) {
+        HIP_TRY(dev_alloc(&d_msg_cand_, cand_len_));
+        HIP_TRY(dev_alloc(&d_msg_cands_, cand_len_ * g));
+        if (!tableau_) {
+            HIP_TRY(dev_alloc(&d_msg_slice_, row_stride_));
+            HIP_TRY(dev_alloc(&d_msg_slices_, (int64_t)row_stride_ * g));
+            HIP_TRY(dev_alloc(&d_msg_rho_, rho_len()));
+        }
+    }
+    return RELP_OK;
+}
+
+// one pivot: the steps of rust-lp_amd/sharded.py `_iteration`, same order, same buffers
+relp_status_t Engine::shard_iteration() {
+    relp_status_t st;
+    const int32_t g = std::max(cfg_.shard_count, 1);
+    if ((st = shard_price(d_msg_cand_))) return st;
+    if (coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_))
+        return fail(RELP_E_HIP, "all-gather of the PRICE candidates failed");
+    if ((st = shard_select_column(d_msg_cands_, g))) return st;
+    if (tableau_) return shard_pivot();
+    if ((st = shard_ftran(d_msg_slice_))) return st;
+    if (coll_allgather_(coll_ctx_, d_msg_slice_, d_msg_slices_, row_stride_ * (int64_t)sizeof(double), stream_))
+        return fail(RELP_E_HIP, "all-gather of the FTRAN slices failed");
+    if ((st = shard_ratio(d_msg_slices_, g, d_msg_rho_))) return st;
+    if (coll_allreduce_(coll_ctx_, d_msg_rho_, rho_len(), stream_)) return fail(RELP_E_HIP, "all-reduce of the pivot row failed");
+    if ((st = shard_update(d_msg_rho_))) return st;
+    if (block_ > 0 && since_flush_ >= block_) {
+        double* snap = nullptr; int64_t len = 0;
+        if ((st = shard_flush_begin(&snap, &len))) return st;
+        if (len > 0) {
+            if (coll_allreduce_(coll_ctx_, snap, len, stream_)) return fail(RELP_E_HIP, "all-reduce of the flush snapshot failed");
+            if ((st = shard_flush_end())) return st;
+        }
+        since_flush_ = 0;
+    }
+    return RELP_OK;
+}
+
+relp_status_t Engine::shard_run(int64_t max_iters, int64_t* done, int32_t* outcome) {
+    if (!coll_allgather_) return fail(RELP_E_STATE, "relp_shard_run needs relp_shard_set_collectives / relp_rccl_attach first");
+    int32_t oc = RELP_RUNNING; int64_t start = 0, it = 0;
+    relp_status_t st = poll(&oc, &start);
+    if (st) return st;
+    it = start;
+    // every rank polls after the same pivot counts (the outcome is replicated), so the ranks leave the
+    // loop together and the collectives stay matched; phase 1 polls at 1, 2, 4, ... like relp_run
+    int64_t chunk = phase_ == 1 ? 1 : cfg_.poll_interval;
+    for (int64_t left = max_iters; left > 0 && oc == RELP_RUNNING;) {
+        const int64_t n = std::min(left, chunk);
+        for (int64_t k = 0; k < n; ++k)
+            if ((st = shard_iteration())) return st;
+        left -= n;
+        if ((st = poll(&oc, &it))) return st;
+        chunk = std::min<int64_t>(chunk * 2, cfg_.poll_interval);
+    }
+    if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
+    if (done) *done = it - start;
+    if (outcome) *outcome = oc;
     return RELP_OK;
 }
 

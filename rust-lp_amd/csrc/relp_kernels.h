@@ -231,9 +231,14 @@ void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& 
                                    hipStream_t s);
 void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
                          const DeferredUpdate& du, const double* rmin, PivotRecord* rec, hipStream_t s);
-// sharded engines: this rank's candidate message [key, j, d_j, alpha(m)] instead of the record
+// sharded engines: this rank's candidate message [key, j, d_j, alpha (m), minimum ratio per block of 256 rows
+// (cdiv(m, 256))] instead of the record, and the choice among the gathered messages + ratio test from the
+// winner's block minima
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
-                                  double* msg, PivotRecord* rec, hipStream_t s);
+                                  double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s);
+void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
+                                       const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
+                                       const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
 // winner among the gathered candidates + ratio test + block bookkeeping in one launch (tableau engine)
 void launch_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
                                    const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,

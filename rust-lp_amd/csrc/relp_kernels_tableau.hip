@@ -391,63 +391,63 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
     if (threadIdx.x == 0) rmin[blockIdx.x] = fmin(fmin(s_k1[0], s_k1[1]), fmin(s_k1[2], s_k1[3]));
 }
 
-// Ratio test from the per-block minima of k_tab_select_column: the global minimum is the minimum of the block
-// minima, and a row inside the tie band lives in a block whose own minimum is inside the band, so only those
-// blocks' rows (usually one or two blocks of 256) are read again.  Same result as k_ratio.
+// Ratio test from the per-block minima of k_tab_select_column (ratio_blocks_body): one workgroup.
 __global__ __launch_bounds__(kSingleBlock) void k_ratio_blocks(const double* __restrict__ alpha, const double* __restrict__ b,
                                                                const int32_t* __restrict__ basis_indices, int m,
                                                                Tolerances tol, DeferredUpdate du,
                                                                const double* __restrict__ rmin, int nblk, PivotRecord* rec) {
     const int outcome = rec->outcome, p = rec->n_eta;
     if (outcome != DEV_RUNNING) return;
-    __shared__ double s_min[kSingleBlock / 64];
-    __shared__ double s_bcast;
-    constexpr int kListMax = 64;
-    __shared__ int s_list[kListMax];
-    __shared__ int s_cnt;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double mn = INFINITY;
-    for (int t = threadIdx.x; t < nblk; t += kSingleBlock) mn = fmin(mn, rmin[t]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
-    if (lane == 0) s_min[wave] = mn;
-    if (threadIdx.x == 0) s_cnt = 0;
+    ratio_blocks_body<kSingleBlock>(alpha, b, basis_indices, m, tol, du, rmin, nblk, p, rec);
+}
+
+// Sharded engines: the winner among the gathered candidates [key, j, d_j, alpha (m), block minima of the
+// ratios], its tableau column copied for the update launch, and the ratio test on it from the block minima the
+// sender computed -- one single-workgroup launch.  Same choice rules as k_select_candidate.
+__global__ __launch_bounds__(kSingleBlock) void k_tab_select_candidate_ratio(const double* __restrict__ msgs, int count,
+                                                                             int64_t msg_len, int m, double* __restrict__ alpha,
+                                                                             const double* __restrict__ b,
+                                                                             const int32_t* __restrict__ basis_indices,
+                                                                             int rule, Tolerances tol, DeferredUpdate du,
+                                                                             PivotRecord* rec) {
+    const int outcome = rec->outcome, p = rec->n_eta;
+    if (outcome != DEV_RUNNING) return;
+    constexpr int kMaxRanks = 64;
+    __shared__ double s_key[kMaxRanks], s_idx[kMaxRanks];
+    __shared__ int s_win;
+    for (int g = threadIdx.x; g < count && g < kMaxRanks; g += kSingleBlock) {       // all heads in one round trip
+        s_key[g] = msgs[g * msg_len + 0];
+        s_idx[g] = msgs[g * msg_len + 1];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double g = s_min[0];
-        for (int w = 1; w < kSingleBlock / 64; ++w) g = fmin(g, s_min[w]);
-        s_bcast = g;
-    }
-    __syncthreads();
-    const double gmin = s_bcast;
-    if (gmin == INFINITY) {
-        if (threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
-        return;
-    }
-    const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
-    for (int t = threadIdx.x; t < nblk; t += kSingleBlock) {
-        if (!(rmin[t] <= bound)) continue;
-        const int pos = atomicAdd(&s_cnt, 1);
-        if (pos < kListMax) s_list[pos] = t;
-    }
-    __syncthreads();
-    const int listed = s_cnt;
-    const bool use_list = listed <= kListMax;
-    const int total = (use_list ? listed : nblk) * kThreads;
-    int best_leave = 0x7fffffff, best_row = -1;
-    for (int idx = threadIdx.x; idx < total; idx += kSingleBlock) {
-        const int t = use_list ? s_list[idx / kThreads] : idx / kThreads;
-        const int i = t * kThreads + idx % kThreads;
-        if (i >= m) continue;
-        const double a = alpha[i];
-        double bi = b[i];
-        if (fabs(bi) <= tol.zero) bi = 0.0;
-        if (a > tol.pivot && bi / a <= bound) {
-            const int lv = basis_indices[i];
-            if (lv < best_leave) { best_leave = lv; best_row = i; }
+        int win = -1; double k1 = INFINITY; double kj = 0.0;
+        for (int g = 0; g < count; ++g) {
+            const double a = s_key[g], j = s_idx[g];
+            if (a < k1 || (a == k1 && win >= 0 && j < kj)) { k1 = a; kj = j; win = g; }
+        }
+        if (win >= 0 && rule == 2 && tol.tie > 0.0) {
+            const double bound = k1 + tol.tie * fmax(1.0, fabs(k1));
+            for (int g = 0; g < count; ++g)
+                if (s_key[g] <= bound && s_idx[g] < kj) { kj = s_idx[g]; win = g; }
+        }
+        s_win = win;
+        if (win < 0) {
+            rec->outcome = DEV_NO_CANDIDATE;
+            if (rule == 1) rec->last_selected = -1;
+        } else {
+            rec->q = (int)s_idx[win];
+            rec->d_q = msgs[win * msg_len + 2];
+            if (rule == 1) rec->last_selected = rec->q;
         }
     }
-    ratio_commit<kSingleBlock>(best_leave, best_row, alpha, b, du, p, rec);
+    __syncthreads();
+    const int win = s_win;
+    if (win < 0) return;
+    const double* __restrict__ col = msgs + win * msg_len + 3;
+    for (int i = threadIdx.x; i < m; i += kSingleBlock) alpha[i] = col[i];            // for the update launch
+    // the ratio test reads the column from the message itself, not from the copy above
+    ratio_blocks_body<kSingleBlock>(col, b, basis_indices, m, tol, du, col + m, (m + kThreads - 1) / kThreads, p, rec);
 }
 
 __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, double* __restrict__ b,
@@ -750,9 +750,16 @@ void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* ba
 }
 
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
-                                  double* msg, PivotRecord* rec, hipStream_t s) {
+                                  double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
-                       msg, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec);
+                       msg, b, tol, msg + 3 + tv.m, rec);
+}
+
+void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
+                                       const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
+                                       const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_select_candidate_ratio, dim3(1), dim3(kSingleBlock), 0, s, msgs, count, msg_len, m, alpha, b,
+                       basis_indices, rule, tol, du, rec);
 }
 
 void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,

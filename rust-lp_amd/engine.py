@@ -36,6 +36,8 @@ OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded",
 KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
                 "apply_w", "update_w", "flush"]
 ENGINE_REVISED, ENGINE_TABLEAU, ENGINE_LU = 0, 1, 2   # relp_engine_kind_t
+# relp_status_t
+E_ARG, E_HIP, E_ZERO_PIVOT, E_SINGULAR, E_STATE, E_UNSUPPORTED, E_ALLOC = -1, -2, -3, -4, -5, -6, -7
 FORMAT_CSC, FORMAT_DENSE = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -115,6 +117,10 @@ _SIGNATURES = {
     "relp_shard_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "relp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "relp_shard_pivot": (C.c_int, [C.c_void_p]),
+    "relp_shard_set_collectives": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "relp_shard_run": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "relp_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "relp_rccl_attach": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     "relp_shard_plan": (C.c_int, [C.POINTER(_MatrixData), C.POINTER(Config), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 

@@ -4,7 +4,8 @@
 
 Per pivot, with G ranks and m rows (all messages are device buffers, no host sync):
   1. local PRICE over the owned columns            -> candidate [key, j, d_j, a_j (m)]
-     all-gather of the G candidates                   (8 * (m + 3) B per rank)
+     all-gather of the G candidates                   (8 * (m + 3) B per rank; the tableau engine appends
+                                                       its m/256 block minima of the ratio test)
      every rank picks the same winner: min key, then min j   (pivot_rule.rs:118 first-wins)
   2. local FTRAN slice alpha[rows of this rank]     -> all-gather of the G slices (8 * m / G B per rank)
      every rank runs the same ratio test on the full alpha (b, basis are replicated)
@@ -13,6 +14,10 @@ Per pivot, with G ranks and m rows (all messages are device buffers, no host syn
   4. every rank updates its rows of B^-1 and its replicas of b, -pi, -obj, basis.
 RCCL has no MINLOC, so step 1 gathers (key, j) pairs instead of emulating it with two
 all-reduces.  The messages are <= 80 KB at m = 10,000: latency-bound on xGMI, not bandwidth-bound.
+
+Two drivers of the same steps: `ShardedPivotLoop` issues the collectives through ``torch.distributed``
+from Python (any backend; the gloo tests run it); `NativeShardedLoop` hands the loop to the library
+(`relp_shard_run`), which calls RCCL itself between its kernels -- no interpreter in the pivot.
 """
 from __future__ import annotations
 
@@ -169,4 +174,48 @@ class ShardedPivotLoop:
 
     def finish_phase_one(self) -> int:
         """With a full slack basis phase 1 has no candidate: one PRICE proves it and switches."""
+        return self.run(1)[1]
+
+
+class NativeShardedLoop:
+    """The same loop inside the library: `relp_shard_run` enqueues kernels and RCCL collectives on the engine's
+    stream (include/relp_engine.h, "native multi-GPU loop").  ``torch.distributed`` only carries the 128-byte
+    RCCL unique id from rank 0 to the other ranks and the agreement that every rank attached."""
+
+    ID_BYTES = 128
+
+    def __init__(self, tableau: "_engine.Tableau", dist, device):
+        import torch
+        self.t = tableau
+        self.lib = _engine.load_library()
+        self.h = tableau.handle
+        self.dist = dist
+        on_device = dist.get_backend() == "nccl"
+        buf_dev = device if on_device else "cpu"
+        ident = (C.c_uint8 * self.ID_BYTES)()
+        status = 0
+        if dist.get_rank() == 0:
+            status = self.lib.relp_rccl_unique_id(ident)
+        msg = torch.tensor([status & 0xFF] + list(ident), dtype=torch.uint8, device=buf_dev)
+        dist.broadcast(msg, 0)
+        msg = msg.cpu()
+        if int(msg[0]) != 0:
+            raise _engine.RelpError("relp_rccl_unique_id failed on rank 0: no RCCL library")
+        for k in range(self.ID_BYTES):
+            ident[k] = int(msg[1 + k])
+        st = self.lib.relp_rccl_attach(self.h, ident)
+        ok = torch.tensor([1 if st == 0 else 0], dtype=torch.int32, device=buf_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            detail = self.lib.relp_last_error(self.h).decode() if st != 0 else "another rank failed"
+            raise _engine.RelpError(f"relp_rccl_attach failed ({st}): {detail}")
+
+    def run(self, max_iters: int) -> Tuple[int, int]:
+        done, oc = C.c_int64(), C.c_int32()
+        st = self.lib.relp_shard_run(self.h, max_iters, C.byref(done), C.byref(oc))
+        if st != 0:
+            raise _engine.RelpError(f"relp_shard_run failed ({st}): {self.lib.relp_last_error(self.h).decode()}")
+        return done.value, oc.value
+
+    def finish_phase_one(self) -> int:
         return self.run(1)[1]

@@ -315,6 +315,41 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, kind, block):
         np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_TABLEAU, 64), (engine.ENGINE_TABLEAU, 5), (engine.ENGINE_REVISED, 0),
+                                        (engine.ENGINE_REVISED, 4)])
+def test_native_shard_loop_with_rccl_on_one_rank(kind, block):
+    """`relp_shard_run` (the loop inside the library, RCCL called from C++ between the kernels) on a
+    communicator of one rank: same pivot sequence as the unsharded engine.  The exchange logic for G > 1 is the
+    same shard entry points the test above drives with G engines; this one covers the native driver and the
+    RCCL adaptor (`relp_rccl_unique_id`, `relp_rccl_attach`)."""
+    import ctypes as C
+    import torch  # noqa: F401  (PyTorch's librccl.so.1 is then in the process; the adaptor takes that one)
+    m, n, seed = 96, 130, 29
+    lp = synthetic.dense_lp(m, n, seed)
+    full = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"])
+    single = engine.Tableau(full, trace_capacity=4096)
+    assert single.solve_relaxation() == engine.OPTIMAL
+    lib = engine.load_library()
+    cfg = engine.default_config(shard_rank=0, shard_count=1, engine=kind, update_block=block, trace_capacity=4096,
+                                poll_interval=16)
+    t = engine.Tableau(MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]), config=cfg)
+    done, oc = C.c_int64(), C.c_int32()
+    assert lib.relp_shard_run(t.handle, 1, C.byref(done), C.byref(oc)) == engine.E_STATE     # no collectives yet
+    ident = (C.c_uint8 * 128)()
+    assert lib.relp_rccl_unique_id(ident) == 0
+    assert lib.relp_rccl_attach(t.handle, ident) == 0, lib.relp_last_error(t.handle).decode()
+    assert lib.relp_shard_run(t.handle, 1, C.byref(done), C.byref(oc)) == 0
+    assert oc.value == engine.PHASE_ONE_DONE and done.value == 0
+    assert lib.relp_shard_run(t.handle, 7, C.byref(done), C.byref(oc)) == 0                  # bounded call
+    assert oc.value == engine.RUNNING and done.value == 7
+    assert lib.relp_shard_run(t.handle, 1 << 20, C.byref(done), C.byref(oc)) == 0
+    assert oc.value == engine.OPTIMAL and done.value == len(single.trace()) - 7
+    assert t.trace() == single.trace()
+    assert abs(t.objective_function_value() - single.objective_function_value()) <= 1e-9 * abs(single.objective_function_value())
+    np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
+    t.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # File-driven configs (MPS reader + standardisation feed the engine; SURVEY 8f rows 1-3)
 # ------------------------------------------------------------------------------------------------
