@@ -142,6 +142,9 @@ relp_status_t relp_generate_column(relp_engine_t *h, int32_t column, double *out
 relp_status_t relp_generate_element(relp_engine_t *h, int32_t row, int32_t column, double *out);
 /* Tableau::select_primal_pivot_row (tableau/mod.rs:221-247) on the last generated column. */
 relp_status_t relp_select_primal_pivot_row(relp_engine_t *h, int32_t *found, int32_t *row);
+/* The same ratio test on a column the caller supplies (dense, m entries, host memory), the reference's signature
+ * `select_primal_pivot_row(&self, column: &SparseVector)`; leaves the last generated column untouched. */
+relp_status_t relp_select_primal_pivot_row_of(relp_engine_t *h, const double *column_m, int32_t *found, int32_t *row);
 /* Tableau::bring_into_basis (tableau/mod.rs:47-60) -> Carry::change_basis (carry/mod.rs:549-570):
  * consumes the last generated column; returns the leaving column. */
 relp_status_t relp_bring_into_basis(relp_engine_t *h, int32_t column, int32_t row, double relative_cost,

@@ -51,6 +51,9 @@ relp_status_t relp_generate_element(relp_engine_t* h, int32_t row, int32_t colum
 relp_status_t relp_select_primal_pivot_row(relp_engine_t* h, int32_t* found, int32_t* row) {
     return h ? H(h).select_primal_pivot_row(found, row) : RELP_E_ARG;
 }
+relp_status_t relp_select_primal_pivot_row_of(relp_engine_t* h, const double* column, int32_t* found, int32_t* row) {
+    return (h && column) ? H(h).select_primal_pivot_row_of(column, found, row) : RELP_E_ARG;
+}
 relp_status_t relp_bring_into_basis(relp_engine_t* h, int32_t column, int32_t row, double cost, int32_t* leaving) {
     return h ? H(h).bring_into_basis(column, row, cost, leaving) : RELP_E_ARG;
 }

@@ -626,6 +626,18 @@ relp_status_t Engine::select_primal_pivot_row(int32_t* found, int32_t* row) {
     return upload_rec();
 }
 
+relp_status_t Engine::select_primal_pivot_row_of(const double* column, int32_t* found, int32_t* row) {
+    HIP_TRY(hipMemcpyAsync(d_aq_, column, sizeof(double) * m_, hipMemcpyHostToDevice, stream_));
+    launch_ratio(d_aq_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+    relp_status_t st = download_rec();
+    if (st) return st;
+    const bool ok = h_rec_->outcome == DEV_RUNNING;
+    if (found) *found = ok ? 1 : 0;
+    if (ok && row) *row = h_rec_->r;
+    h_rec_->outcome = DEV_RUNNING;
+    return upload_rec();
+}
+
 relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost, int32_t* leaving) {
     if (column < 0 || column >= nr_columns() || row < 0 || row >= m_) return fail(RELP_E_ARG, "index out of range");
     relp_status_t st = download_rec();

@@ -36,6 +36,7 @@ class Engine {
     relp_status_t generate_column(int32_t column, double* out_m);
     relp_status_t generate_element(int32_t row, int32_t column, double* out);
     relp_status_t select_primal_pivot_row(int32_t* found, int32_t* row);
+    relp_status_t select_primal_pivot_row_of(const double* column, int32_t* found, int32_t* row);
     relp_status_t bring_into_basis(int32_t column, int32_t row, double cost, int32_t* leaving);
 
     // loops

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "relp_generate_column": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "relp_generate_element": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "relp_select_primal_pivot_row": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "relp_select_primal_pivot_row_of": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "relp_bring_into_basis": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_int32)]),
     "relp_run": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "relp_solve_relaxation": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
@@ -290,9 +291,18 @@ class Tableau:
         self._ck(self._lib.relp_generate_element(self._h, i, j, C.byref(v)))
         return v.value
 
-    def select_primal_pivot_row(self) -> Optional[int]:
+    def select_primal_pivot_row(self, column=None) -> Optional[int]:
+        """tableau/mod.rs:221-247.  Without an argument: on the last generated column (device resident);
+        with a dense column of m entries: the reference's signature."""
         found, row = C.c_int32(), C.c_int32()
-        self._ck(self._lib.relp_select_primal_pivot_row(self._h, C.byref(found), C.byref(row)))
+        if column is None:
+            self._ck(self._lib.relp_select_primal_pivot_row(self._h, C.byref(found), C.byref(row)))
+        else:
+            col = np.ascontiguousarray(column, dtype=np.float64)
+            if col.shape != (self.nr_rows(),):
+                raise ValueError("column must have nr_rows() entries")
+            self._ck(self._lib.relp_select_primal_pivot_row_of(self._h, col.ctypes.data_as(C.POINTER(C.c_double)),
+                                                              C.byref(found), C.byref(row)))
         return row.value if found.value else None
 
     def bring_into_basis(self, column: int, row: int, cost: float) -> int:
