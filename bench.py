@@ -80,7 +80,7 @@ def cpu_model():
 
 def sparse_path(events, with_cpu):
     """The sparse path (BASELINE.json configs[2]): Netlib 25FV47 through the build's MPS reader, presolve and
-    standardisation, solved to optimality by the LU engine (host Markowitz refactorisation every 64 pivots,
+    standardisation, solved to optimality by the LU engine (host Markowitz refactorisation every 128 pivots,
     level-scheduled FTRAN / BTRAN in LDS, CSC PRICE).  The whole solve is timed; it is latency-bound (the
     factors are a few hundred KB), so the HBM figure is reported for what it is."""
     from rust_lp_amd import engine, general_form, mps
@@ -114,6 +114,15 @@ def sparse_path(events, with_cpu):
             factor_bytes = 12.0 * (stats["nnz_l"] + stats["nnz_u"]) + 40.0 * stats["m"]
             out["ftran_GBps"] = round(factor_bytes / (kt["ftran"]["avg_us"] * 1e-6) / 1e9, 3)
             out["ftran_note"] = "12 (nnz L + nnz U) + 40 m bytes of the last factor / average FTRAN time: dependency-bound"
+    # the same LP on the explicit-inverse engine (m = 790: B^-1 is 5 MB, the dense kernels are at their latency floor)
+    t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=0, **tol)
+    t0 = time.perf_counter()
+    outcome2 = t.solve_relaxation()
+    dt2 = time.perf_counter() - t0
+    out["explicit_inverse_engine"] = {"outcome": engine.OUTCOME_NAMES.get(outcome2), "pivots": t.iterations(),
+                                      "value": t.iterations() / dt2, "unit": "iterations/s", "seconds": dt2,
+                                      "objective": t.objective_function_value() + float(gf.fixed_cost)}
+    t.close()
     if with_cpu:
         from oracle import relp_f64
         ref = relp_f64.OracleF64(md, **tol)

@@ -121,25 +121,34 @@ __device__ __forceinline__ void ratio_commit(int best_leave, int best_row, const
     }
     if (lane == 0) { s_cl[wave] = best_leave; s_cr[wave] = best_row; }
     __syncthreads();
+    // every thread finishes the reduction itself (BS / 64 LDS words): no second barrier, and everything the
+    // epilogue reads from memory -- alpha_r, b_r, row r of W, the slot of row r -- goes out in ONE round trip
+    best_leave = s_cl[0]; best_row = s_cr[0];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w)
+        if (s_cl[w] < best_leave) { best_leave = s_cl[w]; best_row = s_cr[w]; }
+    const int r = best_row;
+    const bool deferred = du.kmax > 0;
+    double a_r = 0.0, b_r = 0.0;
+    int jt = 0;
     if (threadIdx.x == 0) {
-        for (int w = 1; w < BS / 64; ++w)
-            if (s_cl[w] < best_leave) { best_leave = s_cl[w]; best_row = s_cr[w]; }
-        rec->r = best_row;
-        rec->leaving = best_leave;
-        rec->alpha_r = alpha[best_row];
-        rec->b_r = b[best_row];
-        s_cr[0] = best_row;
+        a_r = alpha[r];
+        b_r = b[r];
+        if (deferred) jt = du.pos_of_row[r];
     }
-    if (du.kmax <= 0) return;
     // deferred update bookkeeping (k_eta_prepare): save row r of W, choose the column that receives u
-    __syncthreads();
-    const int r = s_cr[0];
-    for (int j = threadIdx.x; j < p; j += BS) du.wr[j] = du.W[(int64_t)j * du.ld + r];
+    if (deferred)
+        for (int j = threadIdx.x; j < p; j += BS) du.wr[j] = du.W[(int64_t)j * du.ld + r];
     if (threadIdx.x == 0) {
-        int jt = du.pos_of_row[r];
-        rec->n_eta_old = p;
-        if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
-        rec->eta_target = jt;
+        rec->r = r;
+        rec->leaving = best_leave;
+        rec->alpha_r = a_r;
+        rec->b_r = b_r;
+        if (deferred) {
+            rec->n_eta_old = p;
+            if (jt < 0) { jt = p; du.S[p] = r; du.pos_of_row[r] = p; rec->n_eta = p + 1; }
+            rec->eta_target = jt;
+        }
     }
 }
 
@@ -226,15 +235,16 @@ template <int BS>
 __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alpha, const double* __restrict__ b,
                                                   const int32_t* __restrict__ basis_indices, int m, const Tolerances& tol,
                                                   const DeferredUpdate& du, const double* __restrict__ rmin, int nblk, int p,
-                                                  PivotRecord* rec) {
+                                                  PivotRecord* rec, double first = INFINITY, bool have_first = false) {
     __shared__ double s_min[BS / 64];
     __shared__ double s_bcast;
     constexpr int kListMax = 64;
     __shared__ int s_list[kListMax];
     __shared__ int s_cnt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double mn = INFINITY;
-    for (int t = threadIdx.x; t < nblk; t += BS) mn = fmin(mn, rmin[t]);
+    // `first` = rmin[threadIdx.x] when the caller loaded it together with the record (have_first)
+    double mn = have_first ? first : INFINITY;
+    for (int t = threadIdx.x + (have_first ? BS : 0); t < nblk; t += BS) mn = fmin(mn, rmin[t]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
     if (lane == 0) s_min[wave] = mn;

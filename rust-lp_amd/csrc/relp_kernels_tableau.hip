@@ -283,15 +283,19 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
                                                                 int count, double* __restrict__ alpha, double* msg,
                                                                 const double* __restrict__ b, Tolerances tol,
                                                                 double* __restrict__ rmin, PivotRecord* rec) {
-    const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both
+    const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both ...
+    // ... and for the first PRICE partial and b of this thread's row, which do not depend on the record
+    double k1 = INFINITY;
+    int bj = 0x7fffffff;
+    if ((int)threadIdx.x < count) { k1 = sp.k1[threadIdx.x]; bj = sp.j[threadIdx.x]; }
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const double b_i = (rmin && i < tv.m) ? b[i] : 0.0;
     if (outcome != DEV_RUNNING) return;
     __shared__ double s_k1[kThreads / 64];
     __shared__ int s_j[kThreads / 64];
     __shared__ double s_vs[kMaxEta];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double k1 = INFINITY;
-    int bj = 0x7fffffff;
-    for (int t = threadIdx.x; t < count; t += kThreads) {
+    for (int t = threadIdx.x + kThreads; t < count; t += kThreads) {
         const double key = sp.k1[t];
         const int j = sp.j[t];
         if (key < k1 || (key == k1 && j < bj)) { k1 = key; bj = j; }
@@ -349,7 +353,6 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
     }
     if (bj == 0x7fffffff) {
         if (msg) {
-            const int i = blockIdx.x * kThreads + threadIdx.x;
             if (i < tv.m) alpha[i] = 0.0;
             if (i == 0) { msg[0] = INFINITY; msg[1] = 0.0; msg[2] = 0.0; }
         } else if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -369,9 +372,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
         }
     }
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
-    const int i = blockIdx.x * kThreads + threadIdx.x;
     const double t0 = i < tv.m ? tv.T0[(int64_t)cq * tv.ld_t + i] : 0.0;     // in flight together with the R0 column
-    const double b_i = (rmin && i < tv.m) ? b[i] : 0.0;
     __syncthreads();
     double ratio = INFINITY;
     if (i < tv.m) {
@@ -397,8 +398,9 @@ __global__ __launch_bounds__(kSingleBlock) void k_ratio_blocks(const double* __r
                                                                Tolerances tol, DeferredUpdate du,
                                                                const double* __restrict__ rmin, int nblk, PivotRecord* rec) {
     const int outcome = rec->outcome, p = rec->n_eta;
+    const double first = (int)threadIdx.x < nblk ? rmin[threadIdx.x] : INFINITY;      // same round trip as the record
     if (outcome != DEV_RUNNING) return;
-    ratio_blocks_body<kSingleBlock>(alpha, b, basis_indices, m, tol, du, rmin, nblk, p, rec);
+    ratio_blocks_body<kSingleBlock>(alpha, b, basis_indices, m, tol, du, rmin, nblk, p, rec, first, true);
 }
 
 // Sharded engines: the winner among the gathered candidates [key, j, d_j, alpha (m), block minima of the

@@ -239,7 +239,7 @@ def test_dense_2000_properties():
 
 @pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_REVISED, 4), (engine.ENGINE_TABLEAU, 4),
                                         (engine.ENGINE_TABLEAU, 64)])
-@pytest.mark.parametrize("world,m,n,seed", [(2, 48, 64, 17), (3, 61, 45, 23)])
+@pytest.mark.parametrize("world,m,n,seed", [(2, 48, 64, 17), (3, 61, 45, 23), (8, 40, 300, 31)])
 def test_shard_entry_points_on_one_gpu(world, m, n, seed, kind, block):
     """`relp_shard_*` with G engines in one process on one GPU: the exchange steps (all-gather of
     candidates; for the revised engine also the all-gather of alpha slices and the SUM all-reduce of
@@ -592,6 +592,38 @@ def test_dense10k_full_size_engines_agree_and_match_the_cpu_oracle_prefix():
         t.close()
     assert traces[0] == traces[1] and len(traces[0]) == 320
     assert lib.relp_device_free(ptr) == 0
+
+
+@pytest.mark.parametrize("degenerate_rows", ["all", "most", "few"])
+def test_ratio_test_from_block_minima_on_many_degenerate_rows(degenerate_rows):
+    """17,000 rows = 67 blocks of 256: the tableau engine's ratio test starts from the per-block minimum ratios
+    (k_ratio_blocks) and re-reads only the blocks inside the tie band.  With b = 0 on all / most rows every block
+    is inside the band (more than the 64 the block list holds: the kernel then walks all blocks), with b = 0 on a
+    few rows a handful are.  The revised engine's ratio test scans every row (k_ratio); both must walk the same
+    pivots, and the leaving column must be the smallest one among the tied rows (tableau/mod.rs:229-239)."""
+    m, n, seed = 17000, 24, 41
+    lp = synthetic.dense_lp(m, n, seed)
+    b = lp["b"].copy()
+    rng = np.random.default_rng(5)
+    if degenerate_rows == "all":
+        b[:] = 0.0
+    elif degenerate_rows == "most":
+        b[rng.random(m) < 0.97] = 0.0
+    else:
+        b[rng.choice(m, size=9, replace=False)] = 0.0
+    traces, objs = [], []
+    for kind, block in ((engine.ENGINE_TABLEAU, 64), (engine.ENGINE_TABLEAU, 3), (engine.ENGINE_REVISED, 0)):
+        t = engine.Tableau(MatrixData.from_dense_le(lp["A"], b, lp["c"]), engine=kind, update_block=block, trace_capacity=4096)
+        assert t.solve_relaxation() == engine.OPTIMAL
+        traces.append(t.trace())
+        objs.append(t.objective_function_value())
+        t.close()
+    assert traces[0] == traces[1] == traces[2] and len(traces[0]) >= 1
+    assert max(objs) - min(objs) <= 1e-9 * max(1.0, abs(objs[0]))
+    if degenerate_rows == "all":
+        assert abs(objs[0]) <= 1e-12                       # x = 0 is the only feasible point
+        # every row ties at ratio 0 in the first pivot: the smallest leaving column is row 0's slack
+        assert traces[0][0][2] == 0 and traces[0][0][3] == n
 
 
 # ------------------------------------------------------------------------------------------------
