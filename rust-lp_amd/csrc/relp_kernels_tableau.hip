@@ -415,11 +415,12 @@ __global__ __launch_bounds__(kSingleBlock) void k_tab_select_candidate_ratio(con
     const int outcome = rec->outcome, p = rec->n_eta;
     if (outcome != DEV_RUNNING) return;
     constexpr int kMaxRanks = 64;
-    __shared__ double s_key[kMaxRanks], s_idx[kMaxRanks];
+    __shared__ double s_key[kMaxRanks], s_idx[kMaxRanks], s_dq[kMaxRanks];
     __shared__ int s_win;
     for (int g = threadIdx.x; g < count && g < kMaxRanks; g += kSingleBlock) {       // all heads in one round trip
         s_key[g] = msgs[g * msg_len + 0];
         s_idx[g] = msgs[g * msg_len + 1];
+        s_dq[g] = msgs[g * msg_len + 2];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -439,17 +440,32 @@ __global__ __launch_bounds__(kSingleBlock) void k_tab_select_candidate_ratio(con
             if (rule == 1) rec->last_selected = -1;
         } else {
             rec->q = (int)s_idx[win];
-            rec->d_q = msgs[win * msg_len + 2];
-            if (rule == 1) rec->last_selected = rec->q;
+            rec->d_q = s_dq[win];
+            if (rule == 1) rec->last_selected = (int)s_idx[win];
         }
     }
     __syncthreads();
     const int win = s_win;
     if (win < 0) return;
     const double* __restrict__ col = msgs + win * msg_len + 3;
-    for (int i = threadIdx.x; i < m; i += kSingleBlock) alpha[i] = col[i];            // for the update launch
-    // the ratio test reads the column from the message itself, not from the copy above
-    ratio_blocks_body<kSingleBlock>(col, b, basis_indices, m, tol, du, col + m, (m + kThreads - 1) / kThreads, p, rec);
+    // the winner's block minima and its column (copied for the update launch) leave in the same round trip; the
+    // copy is stored after the ratio test, which reads the column from the message itself
+    const int nblk = (m + kThreads - 1) / kThreads;
+    const double first = (int)threadIdx.x < nblk ? col[m + threadIdx.x] : INFINITY;
+    constexpr int kCopy = 16;
+    double cp[kCopy];
+#pragma unroll
+    for (int u = 0; u < kCopy; ++u) {
+        const int i = threadIdx.x + u * kSingleBlock;
+        cp[u] = i < m ? col[i] : 0.0;
+    }
+    ratio_blocks_body<kSingleBlock>(col, b, basis_indices, m, tol, du, col + m, nblk, p, rec, first, true);
+#pragma unroll
+    for (int u = 0; u < kCopy; ++u) {
+        const int i = threadIdx.x + u * kSingleBlock;
+        if (i < m) alpha[i] = cp[u];
+    }
+    for (int i = threadIdx.x + kCopy * kSingleBlock; i < m; i += kSingleBlock) alpha[i] = col[i];
 }
 
 __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, double* __restrict__ b,
