@@ -21,6 +21,10 @@ from Python (any backend; the gloo tests run it); `NativeShardedLoop` hands the 
 """
 from __future__ import annotations
 
+# Import order: a process that mixes this package with PyTorch must import torch BEFORE the first engine is
+# created (PyTorch ships its own HIP runtime; if librelp_engine.so has already brought in the system one, torch
+# finds "No HIP GPUs").  bench.py and the tests do.
+
 import ctypes as C
 from typing import Tuple
 

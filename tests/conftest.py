@@ -9,3 +9,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# PyTorch ships its own HIP runtime.  A process that lets librelp_engine.so bring in the system one first and
+# imports torch afterwards ends up with two runtimes, and torch then reports "No HIP GPUs are available".  The
+# tests that exchange device buffers through torch (shard tests) need torch's to be the one: import it first.
+try:
+    import torch  # noqa: F401,E402
+except ImportError:
+    pass

@@ -315,6 +315,67 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, kind, block):
         np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
 
 
+def _native_ranks(world, make_md, kind, block, poll_interval=16):
+    """G engines on one GPU, each driven by `relp_shard_run` on its own thread with the in-process collectives
+    of tests/shard_threads.py; returns [(outcome of phase 1, pivots, outcome, trace, objective, b)] per rank."""
+    import ctypes as C
+    import torch
+    from shard_threads import ThreadRank, ThreadWorld, run_ranks
+    lib = engine.load_library()
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)                          # initialise torch's HIP state on the main thread
+    torch.cuda.synchronize()
+    shared = ThreadWorld(world)
+    tabs, ranks = [], []
+    for r in range(world):
+        cfg = engine.default_config(shard_rank=r, shard_count=world, engine=kind, update_block=block, trace_capacity=1 << 14,
+                                    poll_interval=poll_interval)
+        t = engine.Tableau(make_md(cfg), config=cfg)
+        tabs.append(t)
+        ranks.append(ThreadRank(shared, r, lib, t.handle, torch, dev))
+
+    def body(r):
+        t = tabs[r]
+        done, oc = C.c_int64(), C.c_int32()
+        assert lib.relp_shard_run(t.handle, 1 << 20, C.byref(done), C.byref(oc)) == 0, (lib.relp_last_error(t.handle).decode(), shared.errors)
+        first = oc.value
+        total = done.value
+        if first == engine.PHASE_ONE_DONE:
+            assert lib.relp_shard_run(t.handle, 1 << 20, C.byref(done), C.byref(oc)) == 0, lib.relp_last_error(t.handle).decode()
+            total += done.value
+        return first, total, oc.value, t.trace(), t.objective_function_value(), t.b()
+    out = run_ranks(world, body)
+    assert not shared.errors, shared.errors
+    assert all(rk.calls["allgather"] > 0 for rk in ranks)
+    for t in tabs:
+        t.close()
+    return out
+
+
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_TABLEAU, 64), (engine.ENGINE_TABLEAU, 4), (engine.ENGINE_REVISED, 0),
+                                        (engine.ENGINE_REVISED, 4)])
+@pytest.mark.parametrize("world,m,n,seed", [(2, 48, 64, 17), (3, 61, 45, 23), (5, 90, 140, 3)])
+def test_native_shard_loop_with_several_ranks_on_one_gpu(world, m, n, seed, kind, block):
+    """The loop inside the library (`relp_shard_run`) with G > 1: one thread per rank, collectives through the
+    `relp_shard_set_collectives` hooks (tests/shard_threads.py stands in for RCCL, which refuses two ranks on one
+    device).  Every rank walks the single-engine pivot sequence."""
+    import torch  # noqa: F401  (before the first engine: PyTorch's HIP runtime has to be the one in the process)
+    lp = synthetic.dense_lp(m, n, seed)
+    single = engine.Tableau(MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]), trace_capacity=1 << 14)
+    assert single.solve_relaxation() == engine.OPTIMAL
+
+    def make_md(cfg):
+        md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=lp["b"], cost=lp["c"], upper_bound=np.full(n, np.inf))
+        lo, hi = engine.shard_plan(md, cfg)
+        md.dense = np.asfortranarray(lp["A"][:, lo:hi]) if hi > lo else np.zeros((m, 1), order="F")
+        return md
+    for first, total, oc, trace, obj, b in _native_ranks(world, make_md, kind, block):
+        assert first == engine.PHASE_ONE_DONE and oc == engine.OPTIMAL
+        assert trace == single.trace() and total == len(trace)
+        assert abs(obj - single.objective_function_value()) <= 1e-9 * abs(single.objective_function_value())
+        np.testing.assert_allclose(b, single.b(), rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("kind,block", [(engine.ENGINE_TABLEAU, 64), (engine.ENGINE_TABLEAU, 5), (engine.ENGINE_REVISED, 0),
                                         (engine.ENGINE_REVISED, 4)])
 def test_native_shard_loop_with_rccl_on_one_rank(kind, block):
