@@ -111,7 +111,9 @@ typedef enum {
     /* dense tableau T = B^-1 [A | slacks] kept as (I + W S') T0: PRICE is one tableau row, FTRAN one
      * tableau column per pivot, and T0 is updated by an m x K x n GEMM on the f64 matrix cores every
      * update_block pivots (needs 8 m n bytes; same pivots as the revised engine up to f64 rounding).
-     * Restrictions: no relp_from_basis (column-sharded across GPUs through relp_shard_*). */
+     * Restrictions: no relp_from_basis.  Column-sharded across GPUs through relp_shard_* / relp_shard_run: both
+     * phases, artificial removal and redundant-row removal included (the revised engine shards only LPs with a full
+     * slack basis). */
     RELP_ENGINE_TABLEAU = 1,
     RELP_ENGINE_LU = 2        /* sparse LU of the basis + pending updates (Carry<_, LUDecomposition<_>>) */
 } relp_engine_kind_t;

@@ -50,6 +50,7 @@ struct oracle_engine {
     int32_t col_start[7], row_start[7];
     /* rank-deficient view (filter/generic_wrapper.rs:51): sorted rows deleted from the provider */
     int32_t nr_filtered; int32_t *filtered;
+    int32_t nr_zero_level;                  /* pivots made by remove_artificial_basis_variables */
 
     oracle_config_t cfg;
 
@@ -353,6 +354,7 @@ oracle_engine_t *oracle_create(const oracle_matrix_data_t *md, const oracle_conf
     e->col_start[0] = e->row_start[0] = 0;
     for (int g = 0; g < 6; g++) { e->col_start[g + 1] = e->col_start[g] + camt[g]; e->row_start[g + 1] = e->row_start[g] + ramt[g]; }
     e->nr_filtered = 0; e->filtered = NULL;
+    e->nr_zero_level = 0;
     sv_init(&e->scratch_col); sv_init(&e->scratch_alpha);
 
     /* Tableau::<_, Partially<_>>::new, partially.rs:125-206 */
@@ -449,6 +451,7 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
             generate_column(e, q, &alpha);
             int32_t leaving = change_basis(e, pivot_row, q, &alpha, cost);
             record(n_done, cap, tp, te, tr, tl, 1, q, pivot_row, leaving);
+            e->nr_zero_level++;
         } else {
             rows_to_remove[nrem++] = a;                     /* NB: the artificial index (phase_one.rs:252) */
         }
@@ -553,6 +556,7 @@ int32_t oracle_n(const oracle_engine_t *e) { return kind_nr_columns(e); }
 int32_t oracle_phase(const oracle_engine_t *e) { return e->phase; }
 int32_t oracle_nr_artificial(const oracle_engine_t *e) { return e->nr_artificial; }
 int32_t oracle_nr_filtered_rows(const oracle_engine_t *e) { return e->nr_filtered; }
+int32_t oracle_nr_zero_level_pivots(const oracle_engine_t *e) { return e->nr_zero_level; }
 void oracle_get_filtered_rows(const oracle_engine_t *e, int32_t *out) { for (int32_t k = 0; k < e->nr_filtered; k++) out[k] = e->filtered[k]; }
 double  oracle_objective(const oracle_engine_t *e) { return -e->minus_objective; }
 void oracle_get_b(const oracle_engine_t *e, double *out) { memcpy(out, e->b, sizeof(double) * (size_t)e->m); }

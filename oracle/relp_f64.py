@@ -54,7 +54,8 @@ def lib():
         L.oracle_run.restype = C.c_int
         L.oracle_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.POINTER(C.c_int64)]
-        for name in ("oracle_m", "oracle_n", "oracle_phase", "oracle_nr_artificial", "oracle_nr_filtered_rows"):
+        for name in ("oracle_m", "oracle_n", "oracle_phase", "oracle_nr_artificial", "oracle_nr_filtered_rows",
+                     "oracle_nr_zero_level_pivots"):
             getattr(L, name).restype = C.c_int32
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_objective.restype = C.c_double
@@ -119,6 +120,7 @@ class OracleF64:
     n = property(lambda self: lib().oracle_n(self._h))
     phase = property(lambda self: lib().oracle_phase(self._h))
     nr_artificial = property(lambda self: lib().oracle_nr_artificial(self._h))
+    nr_zero_level_pivots = property(lambda self: lib().oracle_nr_zero_level_pivots(self._h))
 
     def filtered_rows(self):
         """Rows removed as redundant at the phase switch."""

@@ -72,6 +72,8 @@ int32_t oracle_phase(const oracle_engine_t *e);       /* 1 or 2 */
 int32_t oracle_nr_artificial(const oracle_engine_t *e);
 /* rows removed as redundant at the phase switch (indices as the reference pushes them, phase_one.rs:252) */
 int32_t oracle_nr_filtered_rows(const oracle_engine_t *e);
+/* pivots made at zero level to drive basic artificial variables out at the end of phase 1 (phase_one.rs:236-250) */
+int32_t oracle_nr_zero_level_pivots(const oracle_engine_t *e);
 void oracle_get_filtered_rows(const oracle_engine_t *e, int32_t *out);
 double  oracle_objective(const oracle_engine_t *e);
 void    oracle_get_b(const oracle_engine_t *e, double *out);

@@ -164,8 +164,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     for (int32_t k = 0; k < nr_range_; ++k) { real_row.push_back(row_start[5] + k); real_col.push_back(col_start5 + k); }
     const int32_t nr_real = (int32_t)real_row.size();
     nr_artificial_ = m_ - nr_real;
-    if (cfg_.shard_count > 1 && nr_artificial_ > 0)
-        return fail(RELP_E_UNSUPPORTED, "sharded engine needs a full slack basis (no artificial variables)");
+    if (cfg_.shard_count > 1 && nr_artificial_ > 0 && !want_tableau_early)
+        return fail(RELP_E_UNSUPPORTED, "the sharded revised engine needs a full slack basis (no artificial variables); "
+                                        "the sharded tableau engine runs both phases");
     column_to_row_.assign(nr_artificial_, 0);
     {
         int32_t i = 0;
@@ -718,7 +719,6 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     }
     if ((st = download_rec())) return st;
     if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
-    if (done) *done = h_rec_->iterations - start;
     int32_t oc = RELP_RUNNING;
     if (h_rec_->outcome == DEV_NO_CANDIDATE) {
         if (phase_ == 2) oc = RELP_OPTIMAL;
@@ -726,6 +726,7 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     } else if (h_rec_->outcome == DEV_NO_ROW) {
         oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
     }
+    if (done) *done = h_rec_->iterations - start;          // includes the zero-level pivots of the phase boundary
     if (outcome) *outcome = oc;
     return RELP_OK;
 }
@@ -748,8 +749,9 @@ relp_status_t Engine::finish_phase_one(int32_t* outcome) {
     const double obj = -h_rec_->minus_objective;
     if (std::fabs(obj) > cfg_.tol_feas * std::max(1.0, initial_phase1_objective_)) { *outcome = RELP_INFEASIBLE; return RELP_OK; }
     std::vector<int32_t> rows_to_remove;
-    if (cfg_.shard_count == 1) enqueue_flush();        // the phase boundary works on the explicit inverse
-    relp_status_t st = remove_artificial_basis_variables(rows_to_remove);
+    if (cfg_.shard_count == 1 || tableau_) enqueue_flush();        // the phase boundary works on the explicit inverse
+    relp_status_t st = (cfg_.shard_count > 1 && tableau_) ? remove_artificial_basis_variables_sharded(rows_to_remove)
+                                                          : remove_artificial_basis_variables(rows_to_remove);
     if (st) return st;
     if ((st = switch_to_phase_two(rows_to_remove))) return st;
     *outcome = RELP_PHASE_ONE_DONE;
@@ -803,7 +805,7 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
 // kind/non_artificial.rs:151-220, carry/mod.rs:484-510 (+ :650-689 when rows are removed)
 relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_remove) {
     relp_status_t st;
-    if (cfg_.shard_count == 1) enqueue_flush();     // zero-level pivots may have left updates pending
+    if (cfg_.shard_count == 1 || tableau_) enqueue_flush();     // zero-level pivots may have left updates pending
     // the host-side copies below go through the null stream, which does not order with stream_: everything
     // enqueued so far (the flush, a possible re-pricing that uses d_w_) must have finished first
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -832,7 +834,7 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     // -pi = -(c_B' B^-1) (create_minus_pi_from_artificial, carry/mod.rs:214-248), accumulated over rows in order
     std::vector<double> w(m_, 0.0), b(m_);
     for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = cost_h_[basis[i]];
-    if (cfg_.shard_count > 1)
+    if (cfg_.shard_count > 1 && !tableau_)
         for (double v : w) if (v != 0.0) return fail(RELP_E_UNSUPPORTED, "sharded phase switch needs an all-slack basis");
     if (lu_) for (auto& v : w) v = -v;                 // BTRAN with rhs -c_B gives -pi directly
     HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
@@ -865,7 +867,7 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
 // Rank-deficient problems (filter/generic_wrapper.rs:51, carry/mod.rs:650-689, basis_inverse_rows.rs:190-204):
 // delete the given rows (and the same columns of B^-1) everywhere.  Rare, host round trip.
 relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
-    if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "row removal in sharded mode");
+    if (cfg_.shard_count > 1 && !tableau_) return fail(RELP_E_UNSUPPORTED, "row removal in the sharded revised engine");
     std::vector<int32_t> map(m_, 0);   // old row -> new row, -1 = removed
     {
         size_t f = 0; int32_t out = 0;
@@ -885,7 +887,8 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
         // (never priced) artificial columns.  Column by column to bound the host buffer.
         HIP_TRY(hipStreamSynchronize(stream_));
         std::vector<double> col(ld_t_), coln(ld_t_);
-        for (int32_t c = 0; c < n_store_; ++c) {
+        const int32_t n_owned = sc_hi_ - sc_lo_;           // the stored columns of this rank (all of them unsharded)
+        for (int32_t c = 0; c < n_owned; ++c) {
             HIP_TRY(hipMemcpy(col.data(), dT0_ + (int64_t)c * ld_t_, sizeof(double) * m_, hipMemcpyDeviceToHost));
             std::fill(coln.begin(), coln.end(), 0.0);
             for (int32_t i = 0; i < m_; ++i) if (map[i] >= 0) coln[map[i]] = col[i];

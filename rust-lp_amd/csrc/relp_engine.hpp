@@ -180,6 +180,7 @@ class Engine {
     double* d_msg_slices_ = nullptr;
     double* d_msg_rho_ = nullptr;
     relp_status_t shard_iteration();
+    relp_status_t remove_artificial_basis_variables_sharded(std::vector<int32_t>& rows_to_remove);
     void rccl_release();
 
     // ---- profiling ----

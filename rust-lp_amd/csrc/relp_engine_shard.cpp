@@ -74,7 +74,7 @@ relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t 
         prof_begin(RELP_K_RATIO);
         if (count > 64) return fail(RELP_E_UNSUPPORTED, "at most 64 shards");
         launch_tab_select_candidate_ratio(dev_candidates, count, cand_len_, m_, d_alpha_, d_b_, d_basis_, rule, tolerances(),
-                                          deferred(), d_rec_, stream_);
+                                          deferred(), -1, d_rec_, stream_);
         prof_end();
         return RELP_OK;
     }
@@ -167,6 +167,47 @@ relp_status_t Engine::shard_update(const double* dev_rho) {
 // ------------------------------------------------------------------------------------------------
 // Native loop over the shard steps: the library enqueues kernels and collectives itself.
 // ------------------------------------------------------------------------------------------------
+// phase_one.rs:223-260 for the sharded tableau engine.  The basis is replicated, so every rank walks the same
+// sorted list of basic artificial variables; for each one the ranks exchange their first eligible column of the
+// artificial's row through the same candidate message and all-gather as a PRICE step, the lowest column wins on
+// every rank and enters in that row at zero level.  No eligible column anywhere: the row is redundant.
+relp_status_t Engine::remove_artificial_basis_variables_sharded(std::vector<int32_t>& rows_to_remove) {
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    std::vector<int32_t> arts;
+    for (int32_t v : basis) if (v < nr_artificial_) arts.push_back(v);
+    if (arts.empty()) return RELP_OK;
+    if (!coll_allgather_)
+        return fail(RELP_E_STATE, "artificial variables are still basic after phase 1: the sharded engine pivots them out "
+                                  "through the collective hooks (relp_shard_set_collectives / relp_rccl_attach)");
+    std::sort(arts.begin(), arts.end());
+    relp_status_t st;
+    const int32_t g = std::max(cfg_.shard_count, 1);
+    for (int32_t a : arts) {
+        const int32_t pivot_row = column_to_row_[a];
+        if ((st = download_rec())) return st;
+        h_rec_->outcome = DEV_RUNNING;
+        if ((st = upload_rec())) return st;
+        const TableauView tv = tview();
+        const DeferredUpdate du = deferred();
+        const SelectPartials sp = tab_partials(RELP_RULE_FIRST_PROFITABLE);        // key = column index
+        launch_tab_zero_level_scan(tv, du, sp, pivot_row, nr_artificial_, tolerances(), d_rec_, stream_);
+        launch_tab_select_column_msg(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_msg_cand_, d_b_, tolerances(), d_rec_, stream_);
+        if (coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_))
+            return fail(RELP_E_HIP, "all-gather of the zero-level candidates failed");
+        launch_tab_select_candidate_ratio(d_msg_cands_, g, cand_len_, m_, d_alpha_, d_b_, d_basis_, RELP_RULE_FIRST_PROFITABLE,
+                                          tolerances(), du, pivot_row, d_rec_, stream_);
+        if ((st = download_rec())) return st;
+        if (h_rec_->outcome == DEV_NO_CANDIDATE) { rows_to_remove.push_back(a); continue; }
+        if (h_rec_->alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
+        launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
+        tab_partials_valid_ = false;
+        if (++since_flush_ >= block_) enqueue_flush();
+    }
+    return RELP_OK;
+}
+
 relp_status_t Engine::shard_set_collectives(relp_allgather_fn ag, relp_allreduce_sum_fn ar, void* ctx) {
     if (lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine is not sharded");
     if (!ag || (!tableau_ && !ar)) return fail(RELP_E_ARG, "collective hooks missing");
@@ -237,12 +278,12 @@ relp_status_t Engine::shard_run(int64_t max_iters, int64_t* done, int32_t* outco
 relp_status_t Engine::poll(int32_t* outcome, int64_t* iterations) {
     relp_status_t st = download_rec();
     if (st) return st;
-    if (iterations) *iterations = h_rec_->iterations;
     int32_t oc = RELP_RUNNING;
     if (h_rec_->outcome == DEV_NO_CANDIDATE) {
         if (phase_ == 2) oc = RELP_OPTIMAL;
         else if ((st = finish_phase_one(&oc))) return st;
     } else if (h_rec_->outcome == DEV_NO_ROW) oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
+    if (iterations) *iterations = h_rec_->iterations;      // after the phase boundary: it may have pivoted at zero level
     if (outcome) *outcome = oc;
     return RELP_OK;
 }

@@ -236,9 +236,14 @@ void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* ba
 // winner's block minima
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                   double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s);
+// forced_row >= 0: the winner enters in that row at zero level (no ratio test), phase_one.rs:246-250
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
                                        const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
-                                       const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
+                                       const DeferredUpdate& du, int32_t forced_row, PivotRecord* rec, hipStream_t s);
+// sharded removal of basic artificial variables: PRICE partials (key = column index) of the owned columns that may
+// replace the variable basic in `row` at zero level
+void launch_tab_zero_level_scan(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t row,
+                                int32_t nr_artificial, Tolerances tol, const PivotRecord* rec, hipStream_t s);
 // winner among the gathered candidates + ratio test + block bookkeeping in one launch (tableau engine)
 void launch_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
                                    const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_tab_select_candidate_ratio(con
                                                                              const double* __restrict__ b,
                                                                              const int32_t* __restrict__ basis_indices,
                                                                              int rule, Tolerances tol, DeferredUpdate du,
-                                                                             PivotRecord* rec) {
+                                                                             int forced_row, PivotRecord* rec) {
     const int outcome = rec->outcome, p = rec->n_eta;
     if (outcome != DEV_RUNNING) return;
     constexpr int kMaxRanks = 64;
@@ -451,6 +451,12 @@ __global__ __launch_bounds__(kSingleBlock) void k_tab_select_candidate_ratio(con
     // the winner's block minima and its column (copied for the update launch) leave in the same round trip; the
     // copy is stored after the ratio test, which reads the column from the message itself
     const int nblk = (m + kThreads - 1) / kThreads;
+    if (forced_row >= 0) {
+        // zero-level pivot in a given row (phase_one.rs:246-250): no ratio test, the variable basic there leaves
+        for (int i = threadIdx.x; i < m; i += kSingleBlock) alpha[i] = col[i];
+        ratio_commit<kSingleBlock>(basis_indices[forced_row], forced_row, col, b, du, p, rec);
+        return;
+    }
     const double first = (int)threadIdx.x < nblk ? col[m + threadIdx.x] : INFINITY;
     constexpr int kCopy = 16;
     double cp[kCopy];
@@ -694,6 +700,28 @@ __global__ __launch_bounds__(kThreads) void k_tab_row(TableauView tv, DeferredUp
     out[c - tv.c_lo] = v;
 }
 
+// phase_one.rs:236-244 for the sharded engine: among the owned columns, the candidates to replace a basic
+// artificial variable at zero level in tableau row `row` -- non-basic, not artificial, reduced cost 0, tableau
+// entry != 0 -- as PRICE partials with key = column index (the first one wins, like FirstProfitable).
+__global__ __launch_bounds__(kThreads) void k_tab_zero_level_scan(TableauView tv, DeferredUpdate du, SelectPartials sp, int row,
+                                                                  int nr_artificial, Tolerances tol, const PivotRecord* rec) {
+    const int outcome = rec->outcome, p = rec->n_eta;
+    if (outcome != DEV_RUNNING) return;
+    __shared__ double s_w[kMaxEta];
+    if ((int)threadIdx.x < p) s_w[threadIdx.x] = du.W[(int64_t)threadIdx.x * du.ld + row];
+    __syncthreads();
+    const int c = tv.c_lo + blockIdx.x * kThreads + threadIdx.x;
+    const int j = c - tv.col_off;
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (c < tv.c_hi && j >= nr_artificial && j < tv.n && !sp.in_basis[j] && fabs(tv.d[c]) <= tol.cost) {
+        double v = tv.T0[(int64_t)c * tv.ld_t + row];
+        for (int k = 0; k < p; ++k) v = fma(s_w[k], tv.R0[(int64_t)k * tv.ld_r + c], v);
+        if (fabs(v) > tol.pivot) { key = (double)j; kj = j; }
+    }
+    block_partial_min(key, kj, sp, blockIdx.x);
+}
+
 int32_t tab_scan_blocks(int32_t n_owned_columns) { return cdiv(n_owned_columns, kThreads); }
 
 void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s) {
@@ -775,9 +803,16 @@ void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& d
 
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
                                        const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
-                                       const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
+                                       const DeferredUpdate& du, int32_t forced_row, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_candidate_ratio, dim3(1), dim3(kSingleBlock), 0, s, msgs, count, msg_len, m, alpha, b,
-                       basis_indices, rule, tol, du, rec);
+                       basis_indices, rule, tol, du, forced_row, rec);
+}
+
+void launch_tab_zero_level_scan(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t row,
+                                int32_t nr_artificial, Tolerances tol, const PivotRecord* rec, hipStream_t s) {
+    if (tv.c_hi <= tv.c_lo) return;
+    hipLaunchKernelGGL(k_tab_zero_level_scan, dim3(tab_scan_blocks(tv.c_hi - tv.c_lo)), dim3(kThreads), 0, s, tv, du, sp, row,
+                       nr_artificial, tol, rec);
 }
 
 void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,

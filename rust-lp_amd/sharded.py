@@ -38,13 +38,16 @@ class HipShardOps:
         self.t = tableau
         self.lib = _engine.load_library()
         self.h = tableau.handle
+        self.refresh_lengths()
+        self.update_block = self.lib.relp_update_block(self.h)
+        self.tableau = int(tableau.config.engine) == _engine.ENGINE_TABLEAU
+
+    def refresh_lengths(self):
         lo, hi, rlo, rhi, stride = (C.c_int32() for _ in range(5))
         self.lib.relp_shard_ranges(self.h, C.byref(lo), C.byref(hi), C.byref(rlo), C.byref(rhi), C.byref(stride))
         self.row_stride = stride.value
         self.candidate_len = self.lib.relp_shard_candidate_len(self.h)
         self.rho_len = self.lib.relp_shard_rho_len(self.h)
-        self.update_block = self.lib.relp_update_block(self.h)
-        self.tableau = int(tableau.config.engine) == _engine.ENGINE_TABLEAU
 
     def _ck(self, st):
         if st != 0:
@@ -95,6 +98,14 @@ class HipShardOps:
         self._ck(self.lib.relp_shard_flush_end(self.h))
 
 
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class ShardedPivotLoop:
     """phase_one::primal / phase_two::primal (phase_one.rs:125, phase_two.rs:22) across ranks."""
 
@@ -107,12 +118,7 @@ class ShardedPivotLoop:
         self.device = device
         self.poll_interval = max(1, poll_interval)
         o = self.ops
-        f64 = torch.float64
-        self.cand = torch.zeros(o.candidate_len, dtype=f64, device=device)
-        self.cands = torch.zeros(o.candidate_len * self.world, dtype=f64, device=device)
-        self.slice = torch.zeros(o.row_stride, dtype=f64, device=device)
-        self.slices = torch.zeros(o.row_stride * self.world, dtype=f64, device=device)
-        self.rho = torch.zeros(o.rho_len, dtype=f64, device=device)
+        self._alloc_buffers()
         self._block = int(getattr(o, "update_block", 0))
         self._since_flush = 0
         self.stream = None
@@ -120,6 +126,71 @@ class ShardedPivotLoop:
             # collectives are ordered against the current stream: put the kernels on it too
             self.stream = torch.cuda.Stream(device=device)
             o.set_stream(self.stream.cuda_stream)
+        if isinstance(o, HipShardOps):
+            self._install_hooks()
+
+    def _install_hooks(self):
+        """The library's own collective steps (the removal of basic artificial variables at the end of phase 1,
+        `relp_shard_run`) call back into ``torch.distributed`` through `relp_shard_set_collectives`."""
+        torch, dist, world, device = self.torch, self.dist, self.world, self.device
+        on_device = dist.get_backend() == "nccl"
+
+        def view(ptr, n):
+            iface = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 3}
+            return torch.as_tensor(type("_DevBuf", (), {"__cuda_array_interface__": iface})(), device=device)
+
+        def on_stream():
+            return torch.cuda.stream(self.stream) if self.stream is not None else _NullContext()
+
+        self.hook_calls = 0
+
+        def allgather(ctx, send, recv, nbytes, stream):
+            try:
+                self.hook_calls += 1
+                n = nbytes // 8
+                with on_stream():
+                    src, dst = view(send, n), view(recv, n * world)
+                    if on_device:
+                        dist.all_gather_into_tensor(dst, src)
+                    else:                                           # gloo: staged through host memory
+                        host = torch.empty(n * world, dtype=torch.float64)
+                        dist.all_gather_into_tensor(host, src.cpu())
+                        dst.copy_(host)
+                return 0
+            except Exception:                                       # noqa: BLE001  (reported through the status code)
+                return 1
+
+        def allreduce(ctx, buf, count, stream):
+            try:
+                with on_stream():
+                    t = view(buf, count)
+                    if on_device:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    else:
+                        host = t.cpu()
+                        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                        t.copy_(host)
+                return 0
+            except Exception:                                       # noqa: BLE001
+                return 1
+
+        self._hook_allgather = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(allgather)
+        self._hook_allreduce = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(allreduce)
+        o = self.ops
+        o._ck(o.lib.relp_shard_set_collectives(o.h, C.cast(self._hook_allgather, C.c_void_p),
+                                               C.cast(self._hook_allreduce, C.c_void_p), None))
+
+    def _alloc_buffers(self):
+        """Message buffers; their lengths follow the number of rows (redundant rows are removed at the phase switch)."""
+        o, torch, device = self.ops, self.torch, self.device
+        if hasattr(o, "refresh_lengths"):
+            o.refresh_lengths()
+        f64 = torch.float64
+        self.cand = torch.zeros(o.candidate_len, dtype=f64, device=device)
+        self.cands = torch.zeros(o.candidate_len * self.world, dtype=f64, device=device)
+        self.slice = torch.zeros(o.row_stride, dtype=f64, device=device)
+        self.slices = torch.zeros(o.row_stride * self.world, dtype=f64, device=device)
+        self.rho = torch.zeros(o.rho_len, dtype=f64, device=device)
 
     def _iteration(self):
         o, d = self.ops, self.dist
@@ -172,13 +243,26 @@ class ShardedPivotLoop:
             left -= chunk
             oc, it = self.ops.poll()
             if oc != _engine.RUNNING:
+                if oc == _engine.PHASE_ONE_DONE:
+                    self._alloc_buffers()
                 return it - start, oc
         oc, it = self.ops.poll()
+        if oc == _engine.PHASE_ONE_DONE:
+            self._alloc_buffers()
         return it - start, oc
 
     def finish_phase_one(self) -> int:
         """With a full slack basis phase 1 has no candidate: one PRICE proves it and switches."""
         return self.run(1)[1]
+
+    def solve_relaxation(self, max_iters: int = 1 << 40) -> Tuple[int, int]:
+        """Both phases (two_phase/mod.rs:30-76): returns (pivots, outcome).  The tableau engine runs phase 1 on any
+        `MatrixData`; the revised engine needs a full slack basis."""
+        done, oc = self.run(max_iters)
+        if oc == _engine.PHASE_ONE_DONE:
+            more, oc = self.run(max_iters - done)
+            done += more
+        return done, oc
 
 
 class NativeShardedLoop:

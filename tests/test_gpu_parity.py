@@ -2,6 +2,8 @@
 inputs.  Index work (pivot sequence, basis) must be identical; f64 values within the tolerances
 written here: |dobj|/|obj| <= 1e-9, |db|_inf <= 1e-7 * max(1, |b|_inf).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -315,7 +317,7 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, kind, block):
         np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
 
 
-def _native_ranks(world, make_md, kind, block, poll_interval=16):
+def _native_ranks(world, make_md, kind, block, poll_interval=16, return_calls=False):
     """G engines on one GPU, each driven by `relp_shard_run` on its own thread with the in-process collectives
     of tests/shard_threads.py; returns [(outcome of phase 1, pivots, outcome, trace, objective, b)] per rank."""
     import ctypes as C
@@ -345,6 +347,8 @@ def _native_ranks(world, make_md, kind, block, poll_interval=16):
             total += done.value
         return first, total, oc.value, t.trace(), t.objective_function_value(), t.b()
     out = run_ranks(world, body)
+    if return_calls:
+        out = [o + (rk.calls["allgather"],) for o, rk in zip(out, ranks)]
     assert not shared.errors, shared.errors
     assert all(rk.calls["allgather"] > 0 for rk in ranks)
     for t in tabs:
@@ -374,6 +378,97 @@ def test_native_shard_loop_with_several_ranks_on_one_gpu(world, m, n, seed, kind
         assert trace == single.trace() and total == len(trace)
         assert abs(obj - single.objective_function_value()) <= 1e-9 * abs(single.objective_function_value())
         np.testing.assert_allclose(b, single.b(), rtol=1e-9, atol=1e-9)
+
+
+def test_sharded_tableau_runs_both_phases_on_general_lps():
+    """LPs with ==, >= rows and bounded variables (artificial variables, phase 1, zero-level pivots that remove
+    basic artificials, phase switch) on the column-sharded tableau engine, 2 to 4 ranks through the native loop:
+    every rank ends with the single-engine outcome, pivot sequence and objective, rank-deficient cases (redundant
+    rows removed from every rank's columns at the phase switch) included."""
+    import ctypes as C
+    import torch  # noqa: F401
+    rng = np.random.default_rng(77)
+    checked = removed = 0
+    outcomes = set()
+    for case in range(48):
+        m, n = int(rng.integers(8, 60)), int(rng.integers(6, 90))
+        if case % 4 == 3:                                      # every row kind incl. ranges; some infeasible
+            d = synthetic.mixed_lp(m, n, 8100 + case, nnz_per_col=int(rng.integers(2, 6)), frac_negative_cost=0.1,
+                                   infeasible=(case % 8 == 7))
+        else:
+            d = synthetic.sparse_lp(m, n, 8100 + case, nnz_per_col=int(rng.integers(2, 6)), frac_eq=float(rng.uniform(0.1, 0.5)),
+                                    frac_ge=float(rng.uniform(0, 0.4)), frac_bounded=float(rng.uniform(0, 0.5)))
+            d.setdefault("ranges", np.zeros(0))
+            if case % 6 == 5:
+                d["c"] = -d["c"]                              # unbounded / other ends
+        full = MatrixData.from_sparse_dict(d)
+        ref = relp_f64.OracleF64(full)
+        status = ref.run(200000)
+        single = engine.Tableau(full, engine=engine.ENGINE_TABLEAU, update_block=4, trace_capacity=1 << 14)
+        single_outcome = single.solve_relaxation()
+        dense = np.zeros((m, n))
+        for j in range(n):
+            for e in range(d["col_ptr"][j], d["col_ptr"][j + 1]):
+                dense[d["row_idx"][e], j] = d["values"][e]
+        world = int(rng.integers(2, 5))
+
+        def make_md(cfg, d=d, dense=dense, m=m, n=n):
+            md = MatrixData(nr_normal=n, nr_eq=d["nr_eq"], nr_range=d["nr_range"], nr_le=d["nr_le"], nr_ge=d["nr_ge"], b=d["b"],
+                            cost=d["c"], upper_bound=d["ub"], ranges=d["ranges"])
+            lo, hi = engine.shard_plan(md, cfg)
+            md.dense = np.asfortranarray(dense[:, lo:hi]) if hi > lo else np.zeros((m, 1), order="F")
+            return md
+        # rows removed at the phase switch: when one of them is not an == / range row the reference deletes a
+        # non-redundant row (see test_random_mixed_lps_...): defined by the tableau engine itself only
+        rows = ref.filtered_rows()
+        quirk = any(r >= d["nr_eq"] + d["nr_range"] for r in rows)
+        results = _native_ranks(world, make_md, engine.ENGINE_TABLEAU, int(rng.choice([2, 5, 64])), poll_interval=int(rng.choice([3, 16])))
+        for first, total, oc, trace, obj, b in results:
+            assert (oc if first == engine.PHASE_ONE_DONE else first) == single_outcome, case
+            assert trace == single.trace(), case
+            if single_outcome == engine.OPTIMAL:
+                assert abs(obj - single.objective_function_value()) <= OBJ_RTOL * max(1.0, abs(obj)), case
+                np.testing.assert_allclose(b, single.b(), rtol=1e-9, atol=1e-9)
+            if not quirk:
+                assert engine.OUTCOME_NAMES[single_outcome] == status and trace == ref.trace, case
+                if status == "optimal":
+                    assert abs(obj - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), case
+                    assert np.max(np.abs(b - ref.b())) <= VEC_TOL * max(1.0, np.max(np.abs(ref.b()))), case
+        outcomes.add(status)
+        removed += bool(rows)
+        checked += 1
+        single.close()
+    assert checked == 48 and removed >= 5 and {"optimal", "infeasible", "unbounded"} <= outcomes, (checked, removed, outcomes)
+
+
+@pytest.mark.parametrize("path,fixed", [("netlib/BOEING2.SIF", True), ("netlib/BORE3D.SIF", True)])
+def test_python_sharded_loop_two_processes_general_lp(path, fixed):
+    """`ShardedPivotLoop` (collectives from Python through torch.distributed, gloo) in two processes that share the
+    GPU, on files of the reference with ==, range and >= rows: phase 1, the removal of basic artificial variables
+    (BOEING2: the library calls back into torch.distributed through the collective hooks), redundant rows removed
+    (BORE3D: the message buffers shrink with the rows), phase switch, phase 2."""
+    import torch.multiprocessing as mp
+    from lp_files import load
+    from shard_gloo_worker import gloo_rank
+    gf, ex, md, emd = load(path, fixed=fixed)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run(400000) == "optimal"
+    assert ref.nr_zero_level_pivots > 0 or ref.filtered_rows()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 300)
+    procs = [ctx.Process(target=gloo_rank, args=(r, world, port, path, fixed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, done, oc, trace, obj, hook_calls in results:
+        assert (hook_calls > 0) == (ref.nr_zero_level_pivots > 0 or bool(ref.filtered_rows()))
+        assert oc == engine.OPTIMAL and trace == ref.trace and done == len(trace)
+        assert abs(obj - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective))
 
 
 @pytest.mark.parametrize("kind,block", [(engine.ENGINE_TABLEAU, 64), (engine.ENGINE_TABLEAU, 5), (engine.ENGINE_REVISED, 0),
@@ -459,6 +554,37 @@ FILES = [("burkardt/afiro.mps", False, -406659 / 875, 1e-9), ("burkardt/testprob
 # BORE3D: cond(B) ~ 1e6 with entries up to 2.6e2 at pivot 117.
 TRACE_EXEMPT = {("netlib/LOTFI.SIF", engine.ENGINE_LU), ("netlib/SHARE1B.SIF", engine.ENGINE_LU),
                 ("netlib/BORE3D.SIF", engine.ENGINE_LU)}
+
+
+@pytest.mark.parametrize("path,fixed,objective,tol,world", [
+    ("netlib/BOEING2.SIF", True, -0.31501872801520287e3, 1e-3, 3),     # a zero-level pivot; an artificial survives it
+    ("miplib/50v-10.mps", False, 2879.065687, 1e-3, 4),                 # config C5: 1,647 bound rows, one redundant row
+    ("netlib/BORE3D.SIF", True, 0.13730803942084927e4, 1e-2, 2),        # two redundant rows
+    ("burkardt/adlittle.mps", False, 24975305659811992079614961229 / 120651674036153428931840, 1e-9, 8)])
+def test_reference_problem_files_on_the_sharded_tableau_engine(path, fixed, objective, tol, world):
+    """BASELINE config C5 (MIPLIB relaxation with sharded pricing) and other files of the reference on the
+    column-sharded tableau engine, through the native loop: both phases, the removal of basic artificial variables
+    through the candidate exchange, redundant rows deleted on every rank.  Pivot sequence of the f64 oracle, the
+    reference's objective pin."""
+    import torch  # noqa: F401
+    from lp_files import load
+    gf, ex, md, emd = load(path, fixed=fixed)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run() == "optimal"
+    full = md.ensure_dense()
+    dense = np.array(full.dense)
+
+    def make_md(cfg):
+        part = MatrixData(nr_normal=md.nr_normal, nr_eq=md.nr_eq, nr_range=md.nr_range, nr_le=md.nr_le, nr_ge=md.nr_ge, b=md.b,
+                          cost=md.cost, upper_bound=md.upper_bound, ranges=md.ranges)
+        lo, hi = engine.shard_plan(part, cfg)
+        part.dense = np.asfortranarray(dense[:, lo:hi]) if hi > lo else np.zeros((dense.shape[0], 1), order="F")
+        return part
+    for first, total, oc, trace, obj, b in _native_ranks(world, make_md, engine.ENGINE_TABLEAU, 32):
+        assert first == engine.PHASE_ONE_DONE and oc == engine.OPTIMAL
+        assert trace == ref.trace and total == len(trace)
+        got = obj + float(gf.fixed_cost)
+        assert abs(got - objective) < max(tol, 1e-9 * abs(objective))
 
 
 @pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU, engine.ENGINE_LU])
