@@ -60,9 +60,24 @@ __device__ __forceinline__ double dpp_row_shl(double v) {
     return __hiloint2double(hi, lo);
 }
 // Sum over the G lanes of a group (G = 8, 16, 32 or 64, uniform over the workgroup); valid in lane 0.
+// The two steps that cross rows of 16 lanes use the gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap,
+// register to register) instead of LDS-routed shuffles: lane i receives lane i + 32 / i + 16 for the lanes that
+// matter (i < 32 / the first row of each half), the same summation order as with __shfl_down.
+__device__ __forceinline__ double lane_plus_32(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double lane_plus_16(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
 __device__ __forceinline__ double group_sum(double v, int G) {
-    if (G >= 64) v += __shfl_down(v, 32, 64);
-    if (G >= 32) v += __shfl_down(v, 16, 64);
+    if (G >= 64) v += lane_plus_32(v);
+    if (G >= 32) v += lane_plus_16(v);
     if (G >= 16) v += dpp_row_shl<0x108>(v);
     v += dpp_row_shl<0x104>(v);
     v += dpp_row_shl<0x102>(v);
