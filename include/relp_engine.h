@@ -161,8 +161,9 @@ relp_status_t relp_run(relp_engine_t *h, int64_t max_iters, int64_t *iterations_
 relp_status_t relp_solve_relaxation(relp_engine_t *h, int64_t max_iters, int32_t *outcome);
 /* InverseMaintener::from_basis (carry/mod.rs:428-463): warm start from provider column indices,
  * one per row; switches to phase 2.  RELP_ENGINE_LU: any basis (factorise, b = FTRAN(rhs), -pi = BTRAN(-c_B));
- * RELP_ENGINE_REVISED: any basis, inverted on the host (basis_inverse_rows.rs:103-129: LU, then m unit solves;
- * slack bases are a signed permutation and take a shortcut); RELP_ENGINE_TABLEAU: RELP_E_UNSUPPORTED. */
+ * RELP_ENGINE_REVISED: any basis (basis_inverse_rows.rs:103-129: LU - factorised on the host like every
+ * refactorisation - then m unit solves, b and -pi on the device; slack bases are a signed permutation and take a
+ * shortcut); RELP_ENGINE_TABLEAU: RELP_E_UNSUPPORTED. */
 relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
 /* Fold every pending deferred update into the stored representation: B0^-1 += W (S' B0^-1) (revised), T0 += W R0
  * (tableau), refactorisation (LU).  No-op when update_block = 0. */

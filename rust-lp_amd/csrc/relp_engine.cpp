@@ -974,7 +974,7 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
 
 relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     // InverseMaintener::from_basis (carry/mod.rs:428-463): any basis on the LU and the revised engine (the
-    // latter inverts on the host; slack bases are a signed permutation and take a shortcut).
+    // latter factorises on the host and runs the m unit solves on the device; slack bases are a signed permutation and take a shortcut).
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
     if (tableau_) return fail(RELP_E_UNSUPPORTED, "from_basis in the tableau engine");
     if (lu_) {
@@ -1011,7 +1011,7 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     std::vector<int32_t> basis(basis_columns, basis_columns + m_);
     std::vector<double> Bn((size_t)m_ * ld_b_, 0.0), b(m_, 0.0), minus_pi(ld_b_, 0.0);
     double objective = 0.0;
-    bool unit_basis = true;
+    bool unit_basis = true, on_device = false;
     for (int32_t i = 0; i < m_; ++i) {
         const int32_t p = basis[i];
         if (p < 0 || p >= n_provider_) return fail(RELP_E_ARG, "from_basis: column out of range");
@@ -1049,31 +1049,39 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
                 if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
             }
         }
-        LUFactors f;
         std::string msg;
-        if (!lu_factor(m_, cols, &f, &msg)) return fail(RELP_E_SINGULAR, "from_basis: " + msg);
-        std::vector<double> unit(m_, 0.0), row;
-        for (int32_t i = 0; i < m_; ++i) {
-            unit[i] = 1.0;
-            lu_btran_host(f, unit, &row);
-            unit[i] = 0.0;
-            double bi = 0.0;
-            const double cost = basis[i] < nr_normal_ ? cost_h_[basis[i]] : 0.0;
-            for (int32_t k = 0; k < m_; ++k) {
-                const double v = row[k];
-                if (v == 0.0) continue;
-                Bn[(size_t)i * ld_b_ + k] = v;
-                bi += v * rhs_h_[k];
-                minus_pi[k] -= cost * v;                 // -pi = -(c_B' B^-1), carry/mod.rs:214-248
-            }
-            b[i] = bi;
-            objective += cost * bi;
-        }
+        if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, "from_basis: " + msg);
+        // the factorisation is host work (like every refactorisation); the m unit solves, b = B^-1 rhs and
+        // -pi = -(c_B' B^-1) run on the device: row i of B^-1 is the BTRAN of e_i, written in place
+        relp_status_t st = lu_upload_factors();
+        if (st) return st;
+        if (!d_lu_scratch_) HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
+        HIP_TRY(hipMemsetAsync(dBinv_, 0, sizeof(double) * (size_t)m_ * ld_b_, stream_));
+        DeferredUpdate none = deferred();
+        none.kmax = 0;
+        for (int32_t i = 0; i < m_; ++i)
+            launch_lu_btran(dlu_, none, nullptr, i, dBinv_ + (int64_t)i * ld_b_, d_lu_scratch_, nullptr, stream_);
+        std::vector<double> w(ld_b_, 0.0);
+        for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = cost_h_[basis[i]];
+        HIP_TRY(hipMemcpyAsync(d_w_, w.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(d_aq_, rhs_h_.data(), sizeof(double) * m_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));                     // w, rhs_h_ are host buffers
+        launch_weighted_column_sums(dBinv_, ld_b_, m_, d_w_, d_minus_pi_, stream_);          // -pi, carry/mod.rs:214-248
+        if ((st = download_rec())) return st;
+        h_rec_->outcome = DEV_RUNNING;
+        if ((st = upload_rec())) return st;
+        launch_ftran(dBinv_, ld_b_, m_, 0, m_, d_aq_, d_b_, 0, d_rec_, stream_);            // b = B^-1 rhs
+        HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int32_t i = 0; i < m_; ++i) objective += w[i] * b[i];
+        on_device = true;
     }
-    HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_b_, b.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
+    if (!on_device) {
+        HIP_TRY(hipMemcpy(dBinv_, Bn.data(), Bn.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_b_, b.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_minus_pi_, minus_pi.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_minus_pi_, minus_pi.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice));
     std::vector<uint8_t> flags(n_alloc_, 0);
     for (int32_t v : basis) flags[v] = 1;
     HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));

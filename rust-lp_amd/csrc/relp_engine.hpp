@@ -156,6 +156,7 @@ class Engine {
     DeviceCSC csc() const { return DeviceCSC{d_cptr_, d_cidx_, d_cval_}; }
     relp_status_t lu_load_matrix(const relp_matrix_data_t& md);
     relp_status_t lu_refactor();
+    relp_status_t lu_upload_factors();
     void enqueue_iteration_lu(int rule);
     DeferredUpdate deferred() const;
     void enqueue_flush();

@@ -83,6 +83,18 @@ relp_status_t Engine::lu_refactor() {
     }
     std::string msg;
     if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
+    relp_status_t st = lu_upload_factors();
+    if (st) return st;
+    launch_flush_reset(deferred(), d_rec_, stream_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    since_flush_ = 0;
+    ++lu_refactors_;
+    return RELP_OK;
+}
+
+// hlu_ (host factors + level schedules) -> one device buffer, dlu_ points into it.  Also used by the revised
+// engine's warm start, which forms the rows of B^-1 with the device BTRAN.
+relp_status_t Engine::lu_upload_factors() {
     // pack everything into one buffer (16-byte aligned pieces): rowperm, colperm, then per schedule the
     // rows in solve order, the entry indices / values and the level offsets
     const TriangularSchedule* sch[4] = {&hlu_.Lf, &hlu_.Uf, &hlu_.Ub, &hlu_.Lb};
@@ -125,10 +137,7 @@ relp_status_t Engine::lu_refactor() {
         ds[k]->n_levels = (int32_t)sch[k]->level_ptr.size() - 1;
         ds[k]->nnz = (int32_t)sch[k]->idx.size();
     }
-    launch_flush_reset(deferred(), d_rec_, stream_);
     HIP_TRY(hipStreamSynchronize(stream_));             // buf is stack-owned
-    since_flush_ = 0;
-    ++lu_refactors_;
     return RELP_OK;
 }
 
