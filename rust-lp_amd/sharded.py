@@ -1,7 +1,14 @@
-"""Multi-GPU pivot loop: structural columns of A and rows of B^-1 sharded over the ranks
-(SURVEY.md section 8e), one process per GPU, collectives through ``torch.distributed``
+"""Multi-GPU pivot loop, one process per GPU, collectives through ``torch.distributed``
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 
+Tableau engine (what bench.py --gpus N runs): the stored tableau columns are split over the ranks; b, the basis and
+the pending-update block W are replicated.  Per pivot ONE all-gather: every rank sends [key, j, d_j, its tableau
+column of j (m), the block minima of the ratio test]; every rank picks the same winner, runs the ratio test on the
+winner's column and updates its own columns.  Both phases of any `MatrixData`: at the end of phase 1 the ranks pivot
+the basic artificial variables out through the same exchange (the library calls back through the collective hooks),
+redundant rows are removed on every rank.
+
+Revised engine (explicit B^-1): structural columns of A and rows of B^-1 sharded; LPs with a full slack basis.
 Per pivot, with G ranks and m rows (all messages are device buffers, no host sync):
   1. local PRICE over the owned columns            -> candidate [key, j, d_j, a_j (m)]
      all-gather of the G candidates                   (8 * (m + 3) B per rank; the tableau engine appends
