@@ -219,13 +219,12 @@ def main():
     events = not args.no_kernel_events
     primary = "tableau" if args.engine in ("default", "tableau") else "revised"
 
-    nums_b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
-    nums_c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
-
     loop_kind = {}
 
-    def measure(kind):
+    def measure(kind, m=m, n=n, seed=seed):
         """Build the engine of `kind` on the synthetic LP (generated in HBM) and time K pivots."""
+        nums_b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
+        nums_c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
         md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=nums_b / 4000.0, cost=nums_c / 1000.0,
                         upper_bound=np.full(n, np.inf))
         cfg = engine.default_config(device=local_rank, poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world,
@@ -338,6 +337,15 @@ def main():
                      "ftran_traffic": load_traffic(args.workload, "ftran"),
                      "objective_after_run": r2["objective"]}
 
+    # BASELINE.json configs[1] (dense 2,000 x 2,000, dense-tableau path) beside the 10k target, same engine
+    c2 = None
+    if args.engine == "default" and not sharded and rank == 0 and args.workload != "c2":
+        m2, n2, seed2 = WORKLOADS["c2"]
+        r3 = measure("tableau", m2, n2, seed2)
+        c2 = {"workload": f"c2: synthetic dense LP {m2}x{n2} f64, dense tableau", "value": K / r3["dt"], "unit": "iterations/s",
+              "ms_per_step": r3["dt"] * 1e3 / K, "update_block": r3["block"], "kernels": r3["kernels"],
+              "objective_after_run": r3["objective"]}
+
     sparse = None
     if args.engine == "default" and not sharded and rank == 0 and not args.no_sparse:
         sparse = sparse_path(events, not args.no_cpu_baseline)
@@ -362,6 +370,8 @@ def main():
             out["config"]["shard_loop"] = loop_kind.get(primary)
         if secondary is not None:
             out["revised_engine"] = secondary
+        if c2 is not None:
+            out["c2"] = c2
         if sparse is not None:
             out["sparse_engine"] = sparse
         if world == 1:
