@@ -17,12 +17,13 @@ ptr = C.c_void_p()
 assert lib.relp_device_alloc(C.byref(ptr), m * n * 8) == 0
 assert lib.relp_synth_fill_dense(ptr, m, m, n, seed, 0, None) == 0
 md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=b, cost=c, upper_bound=np.full(n, np.inf))
-for label, kw in (("K=64", {}), ("K=16", dict(update_block=16)), ("K=8", dict(update_block=8)), ("K=128", dict(update_block=128)),
-                  ("K=64 tol_tie=0", dict(tol_tie=0.0))):
+for label, kw in (("K=64", {}), ("K=16", dict(update_block=16)), ("K=8", dict(update_block=8)), ("K=32", dict(update_block=32)),
+                  ("K=48", dict(update_block=48)), ("K=80", dict(update_block=80)), ("K=96", dict(update_block=96)),
+                  ("K=128", dict(update_block=128)), ("K=64 tol_tie=0", dict(tol_tie=0.0))):
     t = engine.Tableau(md, engine=engine.ENGINE_TABLEAU, device_dense_ptr=ptr.value, device_dense_ld=m, poll_interval=1024, **kw)
     t.run(1)
     t.run(64)
-    K = 512
+    K = 1536
     t0 = time.perf_counter()
     done, oc = t.run(K)
     dt = time.perf_counter() - t0
