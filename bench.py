@@ -258,7 +258,7 @@ def main():
                     loop = NativeShardedLoop(t, dist, dev)
                     loop_kind[kind] = "native (relp_shard_run, RCCL from C++)"
                 except engine.RelpError as e:             # agreed on by all ranks (all-reduce MIN inside)
-                    print(f"[bench] native sharded loop unavailable: {e}", file=sys.stderr)
+                    print(f"[bench] native sharded loop unavailable, using the Python loop: {e}", file=sys.stderr)
             if loop is None:
                 loop = ShardedPivotLoop(t, dist, dev)
                 loop_kind[kind] = "python (torch.distributed collectives)"

@@ -150,6 +150,7 @@ struct Options {
     Options& update_block(int32_t k) { cfg.update_block = k; return *this; }
     Options& trace_capacity(int32_t n) { cfg.trace_capacity = n; return *this; }
     Options& device(int32_t d) { cfg.device = d; return *this; }
+    Options& shard(int32_t rank, int32_t count) { cfg.shard_rank = rank; cfg.shard_count = count; return *this; }
 };
 
 // tableau/mod.rs:24-38.  Starts like `Tableau::<_, Partially<_>>::new(&matrix_data)` (artificial variables on
@@ -256,6 +257,27 @@ class Tableau {
             default: throw Error(RELP_E_STATE, "iteration limit reached");
         }
     }
+    // ---- one LP on several GPUs (no counterpart in the reference, which is single-threaded) ---------------------
+    // Options::shard(rank, count) at construction, the owned structural columns in `MatrixData` (relp_shard_plan);
+    // rank 0 makes the RCCL id, the host program hands it to every rank, every rank attaches, then the loop runs
+    // inside the library with one all-gather per pivot.
+    static std::vector<uint8_t> rccl_unique_id() {
+        std::vector<uint8_t> id(RELP_RCCL_ID_BYTES);
+        const relp_status_t st = relp_rccl_unique_id(id.data());
+        if (st != RELP_OK) throw Error(st, "no RCCL library could be loaded");
+        return id;
+    }
+    void attach_rccl(const std::vector<uint8_t>& id) {
+        if (id.size() != RELP_RCCL_ID_BYTES) throw Error(RELP_E_ARG, "the RCCL unique id has 128 bytes");
+        ck(relp_rccl_attach(h_, id.data()));
+    }
+    relp_outcome_t shard_run(int64_t max_iters = std::numeric_limits<int64_t>::max(), int64_t* done = nullptr) {
+        int32_t oc = 0; int64_t n = 0;
+        ck(relp_shard_run(h_, max_iters, &n, &oc));
+        if (done) *done = n;
+        return (relp_outcome_t)oc;
+    }
+
     // InverseMaintener::from_basis (carry/mod.rs:428-463): provider column per row; the tableau is NonArtificial after
     void from_basis(const std::vector<int32_t>& basis_columns) {
         if ((int32_t)basis_columns.size() != nr_rows()) throw Error(RELP_E_ARG, "one basis column per row");

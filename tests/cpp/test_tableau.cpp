@@ -215,6 +215,14 @@ int main() {
             CHECK_THROWS(t.from_basis({2, 3, 4}), RELP_E_UNSUPPORTED);
         }
         CHECK_THROWS(MatrixData::from_rows({{1, 2}}, 2, {1, 2}, {}, 0, 0, 1, 0, {1, 1}), RELP_E_ARG);
+        {   // the loop inside the library on a communicator of one rank (RCCL): the single-engine result
+            Tableau t(problem_2(), Options().inverse_maintenance(InverseMaintenance::DenseTableau).shard(0, 1));
+            CHECK_THROWS(t.shard_run(), RELP_E_STATE);                       // no collectives attached yet
+            t.attach_rccl(Tableau::rccl_unique_id());
+            CHECK(t.shard_run() == RELP_PHASE_ONE_DONE);
+            CHECK(t.shard_run() == RELP_OPTIMAL);
+            CHECK(near(t.current_bfs(), SparseVector{{1, 0.5}, {3, 2.5}, {4, 1.5}}));
+        }
     } catch (const std::exception& e) {
         std::printf("unexpected exception: %s\n", e.what());
         return 2;
