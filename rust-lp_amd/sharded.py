@@ -288,6 +288,13 @@ class NativeShardedLoop:
         on_device = dist.get_backend() == "nccl"
         buf_dev = device if on_device else "cpu"
         ident = (C.c_uint8 * self.ID_BYTES)()
+        # every rank must be able to load RCCL before anybody enters ncclCommInitRank (a rank that cannot would
+        # leave the others waiting there): probe locally, agree, and only then make the id that is used
+        loadable = 1 if self.lib.relp_rccl_unique_id(ident) == 0 else 0
+        agreed = torch.tensor([loadable], dtype=torch.int32, device=buf_dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            raise _engine.RelpError("no RCCL library could be loaded on at least one rank")
         status = 0
         if dist.get_rank() == 0:
             status = self.lib.relp_rccl_unique_id(ident)
