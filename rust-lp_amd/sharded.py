@@ -33,6 +33,7 @@ from __future__ import annotations
 # finds "No HIP GPUs").  bench.py and the tests do.
 
 import ctypes as C
+import sys
 from typing import Tuple
 
 from . import engine as _engine
@@ -150,6 +151,7 @@ class ShardedPivotLoop:
             return torch.cuda.stream(self.stream) if self.stream is not None else _NullContext()
 
         self.hook_calls = 0
+        self.hook_error = None
 
         def allgather(ctx, send, recv, nbytes, stream):
             try:
@@ -164,7 +166,9 @@ class ShardedPivotLoop:
                         dist.all_gather_into_tensor(host, src.cpu())
                         dst.copy_(host)
                 return 0
-            except Exception:                                       # noqa: BLE001  (reported through the status code)
+            except Exception as e:                                  # noqa: BLE001  (reported through the status code)
+                self.hook_error = repr(e)
+                print(f"[rust_lp_amd.sharded] all-gather hook failed: {e!r}", file=sys.stderr)
                 return 1
 
         def allreduce(ctx, buf, count, stream):
@@ -178,7 +182,9 @@ class ShardedPivotLoop:
                         dist.all_reduce(host, op=dist.ReduceOp.SUM)
                         t.copy_(host)
                 return 0
-            except Exception:                                       # noqa: BLE001
+            except Exception as e:                                  # noqa: BLE001
+                self.hook_error = repr(e)
+                print(f"[rust_lp_amd.sharded] all-reduce hook failed: {e!r}", file=sys.stderr)
                 return 1
 
         self._hook_allgather = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(allgather)
