@@ -227,15 +227,22 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
     ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
 }
 
-// Ratio test of a workgroup of BS threads from the minimum ratio of every block of kThreads rows (`rmin`, nblk
+// Ratio test of a workgroup of BS threads from the minimum ratio of every block of `rpb` rows (`rmin`, nblk
 // entries, written by the kernel that formed alpha): the global minimum is the minimum of the block minima, and
 // a row inside the tie band lives in a block whose own minimum is inside the band, so only those blocks' rows
 // (usually one or two blocks) are read again.  Same result as ratio_body.  `p` = rec->n_eta read by the caller.
+// b_i / alpha_i as the ratio test's first pass forms it (ratio_body), +inf when the row does not qualify
+__device__ __forceinline__ double row_ratio(double a, double bi, const Tolerances& tol) {
+    if (fabs(bi) <= tol.zero) bi = 0.0;
+    return a > tol.pivot ? bi / a : INFINITY;
+}
+
 template <int BS>
 __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alpha, const double* __restrict__ b,
                                                   const int32_t* __restrict__ basis_indices, int m, const Tolerances& tol,
                                                   const DeferredUpdate& du, const double* __restrict__ rmin, int nblk, int p,
-                                                  PivotRecord* rec, double first = INFINITY, bool have_first = false) {
+                                                  PivotRecord* rec, double first = INFINITY, bool have_first = false,
+                                                  int rpb = kThreads) {
     __shared__ double s_min[BS / 64];
     __shared__ double s_bcast;
     constexpr int kListMax = 64;
@@ -270,11 +277,11 @@ __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alp
     __syncthreads();
     const int listed = s_cnt;
     const bool use_list = listed <= kListMax;
-    const int total = (use_list ? listed : nblk) * kThreads;
+    const int total = (use_list ? listed : nblk) * rpb;
     int best_leave = 0x7fffffff, best_row = -1;
     for (int idx = threadIdx.x; idx < total; idx += BS) {
-        const int t = use_list ? s_list[idx / kThreads] : idx / kThreads;
-        const int i = t * kThreads + idx % kThreads;
+        const int t = use_list ? s_list[idx / rpb] : idx / rpb;
+        const int i = t * rpb + idx % rpb;
         if (i >= m) continue;
         const double a = alpha[i];
         double bi = b[i];

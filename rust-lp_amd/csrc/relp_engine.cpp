@@ -289,7 +289,6 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         HIP_TRY(dev_alloc(&dR0_, ld_r_ * (block_ + 1)));        // + one scratch row (d_aq_big)
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
         HIP_TRY(dev_alloc(&d_idcol_, m_));
-        HIP_TRY(dev_alloc(&d_rmin_, m_ / 256 + 2));
     }
     if (block_ > 0) {
         HIP_TRY(dev_alloc(&d_v_, ld_b_));
@@ -300,6 +299,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         HIP_TRY(dev_alloc(&d_pos_of_row_, m_));
         HIP_TRY(hipMemset(d_pos_of_row_, 0xFF, sizeof(int32_t) * m_));      // -1 everywhere
     }
+    HIP_TRY(dev_alloc(&d_rmin_, m_ / 8 + 2));          // block minima of the ratio test (8 or 256 rows per block)
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_rec_), sizeof(PivotRecord), hipHostMallocDefault));
     trace_cap_ = std::max(cfg_.trace_capacity, 0);
     if (trace_cap_ > 0) HIP_TRY(dev_alloc(&d_trace_, 4 * trace_cap_));
@@ -463,11 +463,13 @@ void Engine::enqueue_iteration(int rule) {
     prof_end();
     if (block_ == 0) {
         // explicit inverse, rank-1 update at every pivot (basis_inverse_rows.rs:131-142)
+        // FTRAN leaves the minimum ratio of every 8 rows behind; the ratio test starts from those
         prof_begin(RELP_K_FTRAN);
-        launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_alpha_, 0, d_rec_, stream_);
+        launch_ftran_rmin(Binv, ld_b_, m_, d_aq_, d_alpha_, d_b_, tolerances(), d_rmin_, d_rec_, stream_);
         prof_end();
         prof_begin(RELP_K_RATIO);
-        launch_ratio(d_alpha_, d_b_, d_basis_, m_, tolerances(), d_rec_, stream_);
+        launch_ratio_rows(d_alpha_, d_b_, d_basis_, m_, tolerances(), DeferredUpdate{}, d_rmin_, ftran_rows_per_block(), d_rec_,
+                          stream_);
         prof_end();
         prof_begin(RELP_K_UPDATE_VECTORS);
         launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
@@ -485,10 +487,10 @@ void Engine::enqueue_iteration(int rule) {
     launch_ftran(Binv, ld_b_, m_, row_lo_, row_hi_, d_aq_, d_v_, 0, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_APPLY_W);
-    launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
+    launch_apply_w_rmin(du, m_, d_v_, d_alpha_, d_b_, tolerances(), d_rmin_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_RATIO);
-    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
+    launch_ratio_rows(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rmin_, 256, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_UPDATE_W);
     launch_update_w(du, m_, d_alpha_, d_rec_, stream_);

@@ -172,10 +172,10 @@ void Engine::enqueue_iteration_lu(int rule) {
     launch_lu_ftran(dlu_, d_aq_, d_v_, d_lu_scratch_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_APPLY_W);
-    launch_apply_w(du, m_, d_v_, d_alpha_, d_rec_, stream_);
+    launch_apply_w_rmin(du, m_, d_v_, d_alpha_, d_b_, tolerances(), d_rmin_, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_RATIO);
-    launch_ratio_eta(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rec_, stream_);
+    launch_ratio_rows(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rmin_, 256, d_rec_, stream_);
     prof_end();
     prof_begin(RELP_K_UPDATE_W);
     launch_update_w(du, m_, d_alpha_, d_rec_, stream_);

@@ -167,6 +167,16 @@ void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t see
 // alpha[i] = v[i] + sum_j W[i,j] v[S[j]] for every row
 void launch_apply_w(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const PivotRecord* rec,
                     hipStream_t s);
+// FTRAN / alpha = v + W (S'v) that also leave the minimum ratio b_i / alpha_i of every block of rows (8 rows per
+// k_ftran workgroup, 256 per k_apply_w workgroup), and the ratio test that starts from those minima (same result
+// as launch_ratio / launch_ratio_eta; re-reads only the blocks inside the tie band).  Unsharded engines.
+int32_t ftran_rows_per_block();
+void launch_ftran_rmin(const double* Binv, int64_t ld_b, int32_t m, const double* aq, double* out, const double* b,
+                       Tolerances tol, double* rmin, const PivotRecord* rec, hipStream_t s);
+void launch_apply_w_rmin(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const double* b, Tolerances tol,
+                         double* rmin, const PivotRecord* rec, hipStream_t s);
+void launch_ratio_rows(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
+                       const DeferredUpdate& du, const double* rmin, int32_t rows_per_block, PivotRecord* rec, hipStream_t s);
 // wr = W[r,:], pick the target column (existing column of row r or a new one), book-keeping
 void launch_eta_prepare(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s);
 // W <- W + u W[r,:], then column target += / = u, with u = eta - e_r built from alpha

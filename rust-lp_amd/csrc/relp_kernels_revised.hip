@@ -366,17 +366,38 @@ __global__ void k_build_column(const double* __restrict__ A, int64_t ld_a, Colum
     aq[i] = v;
 }
 
+// `rmin` (may be null; unsharded only): the minimum ratio b_i / alpha_i of this workgroup's kVecPerBlock rows
 __global__ __launch_bounds__(kThreads) void k_ftran(const double* __restrict__ Binv, int64_t ld_b, int m,
                                                     int row_lo, int row_hi, const double* __restrict__ aq,
                                                     double* __restrict__ out, int out_offset,
+                                                    const double* __restrict__ b, Tolerances tol, double* __restrict__ rmin,
                                                     const PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
     __shared__ double s_partial[4 * kVecPerBlock];
     const int v0 = row_lo + blockIdx.x * kVecPerBlock;
+    const int i = v0 + threadIdx.x;
+    const double b_i = (rmin && threadIdx.x < kVecPerBlock && i < row_hi) ? b[i] : 0.0;
     double dot = 0.0;
     block_multi_dot(Binv, ld_b, m, v0, row_hi, aq, s_partial, dot);
-    const int i = v0 + threadIdx.x;
     if (threadIdx.x < kVecPerBlock && i < row_hi) out[i - out_offset] = dot;
+    if (rmin && threadIdx.x < 64) {                               // lanes 0..7 of wavefront 0 hold the rows
+        double ratio = (threadIdx.x < kVecPerBlock && i < row_hi) ? row_ratio(dot, b_i, tol) : INFINITY;
+#pragma unroll
+        for (int off = kVecPerBlock / 2; off > 0; off >>= 1) ratio = fmin(ratio, __shfl_down(ratio, off, 64));
+        if (threadIdx.x == 0) rmin[blockIdx.x] = ratio;
+    }
+}
+
+// Ratio test from the block minima k_ftran / k_apply_w leave (ratio_blocks_body): one workgroup; `rpb` rows per
+// block.  Same result as k_ratio.
+__global__ __launch_bounds__(kSingleBlock) void k_ratio_rows(const double* __restrict__ alpha, const double* __restrict__ b,
+                                                             const int32_t* __restrict__ basis_indices, int m, Tolerances tol,
+                                                             DeferredUpdate du, const double* __restrict__ rmin, int nblk,
+                                                             int rpb, PivotRecord* rec) {
+    const int outcome = rec->outcome, p = rec->n_eta;
+    const double first = (int)threadIdx.x < nblk ? rmin[threadIdx.x] : INFINITY;      // same round trip as the record
+    if (outcome != DEV_RUNNING) return;
+    ratio_blocks_body<kSingleBlock>(alpha, b, basis_indices, m, tol, du, rmin, nblk, p, rec, first, true, rpb);
 }
 
 __global__ __launch_bounds__(kSingleBlock) void k_ratio(const double* __restrict__ alpha,
@@ -483,18 +504,31 @@ __global__ __launch_bounds__(kThreads) void k_update_inverse(double* __restrict_
 // ------------------------------------------------------------------------------------------------
 
 // alpha = M v = v + W (S' v).  One thread per row; the p gathered entries v[S[j]] sit in LDS.
+// `rmin` (may be null): the minimum ratio b_i / alpha_i of this workgroup's 256 rows, for k_ratio_rows
 __global__ __launch_bounds__(kThreads) void k_apply_w(DeferredUpdate du, int m, const double* __restrict__ v,
-                                                      double* __restrict__ alpha, const PivotRecord* rec) {
+                                                      double* __restrict__ alpha, const double* __restrict__ b, Tolerances tol,
+                                                      double* __restrict__ rmin, const PivotRecord* rec) {
     if (rec->outcome != DEV_RUNNING) return;
     __shared__ double s_vs[kMaxEta];
+    __shared__ double s_min[kThreads / 64];
     const int p = rec->n_eta;
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = v[du.S[threadIdx.x]];
-    __syncthreads();
     const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= m) return;
-    double a = v[i];
-    for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
-    alpha[i] = a;
+    const double b_i = (rmin && i < m) ? b[i] : 0.0;
+    __syncthreads();
+    double ratio = INFINITY;
+    if (i < m) {
+        double a = v[i];
+        for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
+        alpha[i] = a;
+        ratio = row_ratio(a, b_i, tol);
+    }
+    if (!rmin) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ratio = fmin(ratio, __shfl_down(ratio, off, 64));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = ratio;
+    __syncthreads();
+    if (threadIdx.x == 0) rmin[blockIdx.x] = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
 }
 
 // One wavefront-sized workgroup: save row r of W, choose the column that will receive u.
@@ -894,7 +928,22 @@ void launch_ftran(const double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, i
     if (row_hi <= row_lo) return;
     const int blocks = cdiv(row_hi - row_lo, kVecPerBlock);
     hipLaunchKernelGGL(k_ftran, dim3(blocks), dim3(kThreads), 0, s, Binv, ld_b, m, row_lo, row_hi, aq, out,
-                       out_offset, rec);
+                       out_offset, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec);
+}
+
+int32_t ftran_rows_per_block() { return kVecPerBlock; }
+
+void launch_ftran_rmin(const double* Binv, int64_t ld_b, int32_t m, const double* aq, double* out, const double* b,
+                       Tolerances tol, double* rmin, const PivotRecord* rec, hipStream_t s) {
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_ftran, dim3(cdiv(m, kVecPerBlock)), dim3(kThreads), 0, s, Binv, ld_b, m, 0, m, aq, out, 0, b, tol,
+                       rmin, rec);
+}
+
+void launch_ratio_rows(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
+                       const DeferredUpdate& du, const double* rmin, int32_t rows_per_block, PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_ratio_rows, dim3(1), dim3(kSingleBlock), 0, s, alpha, b, basis_indices, m, tol, du, rmin,
+                       cdiv(m, rows_per_block), rows_per_block, rec);
 }
 
 void launch_ratio(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m,
@@ -944,7 +993,13 @@ void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t see
 
 void launch_apply_w(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const PivotRecord* rec,
                     hipStream_t s) {
-    hipLaunchKernelGGL(k_apply_w, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, v, alpha, rec);
+    hipLaunchKernelGGL(k_apply_w, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, v, alpha, (const double*)nullptr,
+                       Tolerances{}, (double*)nullptr, rec);
+}
+
+void launch_apply_w_rmin(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const double* b, Tolerances tol,
+                         double* rmin, const PivotRecord* rec, hipStream_t s) {
+    hipLaunchKernelGGL(k_apply_w, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, du, m, v, alpha, b, tol, rmin, rec);
 }
 
 void launch_eta_prepare(const DeferredUpdate& du, PivotRecord* rec, hipStream_t s) {
