@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--update-block", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-path (LU engine, Netlib 25FV47) section")
+    ap.add_argument("--no-c2", action="store_true", help="skip the configs[1] (dense 2,000 x 2,000) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
@@ -339,7 +340,7 @@ def main():
 
     # BASELINE.json configs[1] (dense 2,000 x 2,000, dense-tableau path) beside the 10k target, same engine
     c2 = None
-    if args.engine == "default" and not sharded and rank == 0 and args.workload != "c2":
+    if args.engine == "default" and not sharded and rank == 0 and args.workload != "c2" and not args.no_c2:
         m2, n2, seed2 = WORKLOADS["c2"]
         r3 = measure("tableau", m2, n2, seed2)
         c2 = {"workload": f"c2: synthetic dense LP {m2}x{n2} f64, dense tableau", "value": K / r3["dt"], "unit": "iterations/s",
