@@ -452,11 +452,15 @@ void Engine::enqueue_iteration(int rule) {
     sp.n = n; sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = col_lo_; sp.cols_per_slot = 8;
     const int nb_virt = price_virtual_blocks(ct);
     prof_begin(RELP_K_PRICE);
-    launch_price_structural_sel(A, ld_a_, ct, d_minus_pi_, d_d_, col_lo_, col_hi_, phase_, sp, d_rec_, stream_);
-    if (col_lo_ > 0 || col_hi_ < nr_normal_) launch_price_mask_unowned(ct, d_d_, col_lo_, col_hi_, d_rec_, stream_);
-    SelectPartials spv = sp;
-    spv.offset = nb_struct;
-    launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
+    if (col_lo_ > 0 || col_hi_ < nr_normal_) {
+        launch_price_structural_sel(A, ld_a_, ct, d_minus_pi_, d_d_, col_lo_, col_hi_, phase_, sp, d_rec_, stream_);
+        launch_price_mask_unowned(ct, d_d_, col_lo_, col_hi_, d_rec_, stream_);
+        SelectPartials spv = sp;
+        spv.offset = nb_struct;
+        launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
+    } else {
+        launch_price_all_sel(A, ld_a_, ct, d_minus_pi_, d_d_, col_lo_, col_hi_, phase_, sp, d_rec_, stream_);
+    }
     prof_end();
     prof_begin(RELP_K_SELECT_COLUMN);
     launch_select_partials(sp, nb_struct + nb_virt, d_d_, A, ld_a_, ct, m_, d_aq_, d_rec_, stream_);
@@ -473,11 +477,11 @@ void Engine::enqueue_iteration(int rule) {
         prof_end();
         prof_begin(RELP_K_UPDATE_VECTORS);
         launch_compute_rho(Binv, ld_b_, m_, row_lo_, row_hi_, d_rho_, d_rec_, stream_);
-        launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_,
-                              d_rec_, stream_);
         prof_end();
+        // rank-1 update of B^-1 together with b, -pi, -obj, basis, flags, trace
         prof_begin(RELP_K_UPDATE_INVERSE);
-        launch_update_inverse(Binv, ld_b_, m_, row_lo_, row_hi_, d_alpha_, d_rho_, d_rec_, stream_);
+        launch_update_inverse_vectors(Binv, ld_b_, m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_,
+                                      trace_cap_, d_rec_, stream_);
         prof_end();
         return;
     }

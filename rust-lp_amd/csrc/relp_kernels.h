@@ -122,6 +122,10 @@ void launch_price_structural_sel(const double* A, int64_t ld_a, const ColumnTabl
                                  const PivotRecord* rec, hipStream_t s);
 void launch_price_virtual_sel(const ColumnTable& ct, const double* minus_pi, double* d, int32_t cost_mode,
                               SelectPartials sp, const PivotRecord* rec, hipStream_t s);
+// both of the above in one launch (unsharded loop): structural workgroups first, then the virtual ones
+void launch_price_all_sel(const double* A, int64_t ld_a, const ColumnTable& ct, const double* minus_pi, double* d,
+                          int32_t p_lo, int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec,
+                          hipStream_t s);
 int32_t price_structural_blocks(int32_t p_lo, int32_t p_hi);
 int32_t price_virtual_blocks(const ColumnTable& ct);
 // reduce `count` partials, record q / d_q, and build aq (= k_select_column + k_build_column)
@@ -155,6 +159,10 @@ void launch_update_vectors(int32_t m, const double* alpha, const double* rho, do
 // rank-1 update of rows [row_lo,row_hi) of Binv: row_r = rho; row_i -= alpha_i * rho
 void launch_update_inverse(double* Binv, int64_t ld_b, int32_t m, int32_t row_lo, int32_t row_hi,
                            const double* alpha, const double* rho, const PivotRecord* rec, hipStream_t s);
+// launch_update_vectors + launch_update_inverse in one launch (unsharded explicit path)
+void launch_update_inverse_vectors(double* Binv, int64_t ld_b, int32_t m, const double* alpha, const double* rho, double* b,
+                                   double* minus_pi, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,
+                                   int64_t trace_cap, PivotRecord* rec, hipStream_t s);
 
 // phase switch: minus_pi[j] = -sum_i w[i] * Binv[i,j]  (w = cost of basis column of row i)
 void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, const double* w,

@@ -20,12 +20,11 @@
 namespace relp {
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_price_structural(
-    const double* __restrict__ A, int64_t ld_a, ColumnTable ct, const double* __restrict__ minus_pi,
-    double* __restrict__ d, int p_lo, int p_hi, int cost_mode, SelectPartials sp, const PivotRecord* rec) {
-    if (rec && rec->outcome != DEV_RUNNING) return;
+__device__ __forceinline__ void price_structural_body(
+    const double* __restrict__ A, int64_t ld_a, const ColumnTable& ct, const double* __restrict__ minus_pi,
+    double* __restrict__ d, int p_lo, int p_hi, int cost_mode, const SelectPartials& sp, const PivotRecord* rec, int block) {
     __shared__ double s_partial[4 * kVecPerBlock];
-    const int v0 = p_lo + blockIdx.x * kVecPerBlock;
+    const int v0 = p_lo + block * kVecPerBlock;
     double dot = 0.0;
     block_multi_dot(A, ld_a, ct.nr_constraints, v0, p_hi, minus_pi, s_partial, dot);
     const int p = v0 + threadIdx.x;
@@ -47,8 +46,15 @@ __global__ __launch_bounds__(kThreads) void k_price_structural(
             const int oj = __shfl_down(kj, off, 64);
             if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
         }
-        if (threadIdx.x == 0) { sp.k1[sp.offset + blockIdx.x] = key; sp.j[sp.offset + blockIdx.x] = kj; }
+        if (threadIdx.x == 0) { sp.k1[sp.offset + block] = key; sp.j[sp.offset + block] = kj; }
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_price_structural(
+    const double* __restrict__ A, int64_t ld_a, ColumnTable ct, const double* __restrict__ minus_pi,
+    double* __restrict__ d, int p_lo, int p_hi, int cost_mode, SelectPartials sp, const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    price_structural_body(A, ld_a, ct, minus_pi, d, p_lo, p_hi, cost_mode, sp, rec, blockIdx.x);
 }
 
 __global__ void k_price_mask_unowned(ColumnTable ct, double* __restrict__ d, int p_lo, int p_hi,
@@ -58,11 +64,10 @@ __global__ void k_price_mask_unowned(ColumnTable ct, double* __restrict__ d, int
     if (p < ct.nr_normal && (p < p_lo || p >= p_hi)) d[ct.nr_artificial + p] = INFINITY;
 }
 
-__global__ __launch_bounds__(kThreads) void k_price_virtual(ColumnTable ct, const double* __restrict__ minus_pi,
-                                                            double* __restrict__ d, int cost_mode, SelectPartials sp,
-                                                            const PivotRecord* rec) {
-    if (rec && rec->outcome != DEV_RUNNING) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void price_virtual_body(const ColumnTable& ct, const double* __restrict__ minus_pi,
+                                                   double* __restrict__ d, int cost_mode, const SelectPartials& sp,
+                                                   const PivotRecord* rec, int block) {
+    const int t = block * kThreads + threadIdx.x;
     int j = -1;
     double val = 0.0;
     if (t < ct.nr_artificial) {
@@ -99,8 +104,32 @@ __global__ __launch_bounds__(kThreads) void k_price_virtual(ColumnTable ct, cons
     if (threadIdx.x == 0) {
         for (int w = 1; w < kThreads / 64; ++w)
             if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
-        sp.k1[sp.offset + blockIdx.x] = key;
-        sp.j[sp.offset + blockIdx.x] = kj;
+        sp.k1[sp.offset + block] = key;
+        sp.j[sp.offset + block] = kj;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_price_virtual(ColumnTable ct, const double* __restrict__ minus_pi,
+                                                            double* __restrict__ d, int cost_mode, SelectPartials sp,
+                                                            const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    price_virtual_body(ct, minus_pi, d, cost_mode, sp, rec, blockIdx.x);
+}
+
+// PRICE of the structural and of the virtual (artificial, slack, bound) columns in ONE launch: workgroups
+// [0, nb_struct) take 8 structural columns each, the others 256 virtual columns each; their partial argmins
+// land in consecutive slots.
+__global__ __launch_bounds__(kThreads) void k_price_all(const double* __restrict__ A, int64_t ld_a, ColumnTable ct,
+                                                        const double* __restrict__ minus_pi, double* __restrict__ d, int p_lo,
+                                                        int p_hi, int cost_mode, SelectPartials sp, int nb_struct,
+                                                        const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    if ((int)blockIdx.x < nb_struct) {
+        price_structural_body(A, ld_a, ct, minus_pi, d, p_lo, p_hi, cost_mode, sp, rec, blockIdx.x);
+    } else {
+        SelectPartials spv = sp;
+        spv.offset = sp.offset + nb_struct;
+        price_virtual_body(ct, minus_pi, d, cost_mode, spv, rec, blockIdx.x - nb_struct);
     }
 }
 
@@ -470,12 +499,9 @@ __global__ void k_update_vectors(int m, const double* __restrict__ alpha, const 
 // strip, keeps its rho pair in registers and streams the chunk's rows read-modify-write.  Rows
 // with alpha_i == 0 are skipped (wave-uniform), like the reference skips absent entries.
 static constexpr int kUpdRowsPerBlock = 32;
-__global__ __launch_bounds__(kThreads) void k_update_inverse(double* __restrict__ Binv, int64_t ld_b, int m,
-                                                             int row_lo, int row_hi,
-                                                             const double* __restrict__ alpha,
-                                                             const double* __restrict__ rho,
-                                                             const PivotRecord* rec) {
-    if (rec->outcome != DEV_RUNNING) return;
+__device__ __forceinline__ void update_inverse_body(double* __restrict__ Binv, int64_t ld_b, int m, int row_lo, int row_hi,
+                                                    const double* __restrict__ alpha, const double* __restrict__ rho,
+                                                    const PivotRecord* rec) {
     const int c = (blockIdx.x * kThreads + threadIdx.x) * 2;
     if (c >= (int)ld_b) return;
     const int r = rec->r;
@@ -496,6 +522,55 @@ __global__ __launch_bounds__(kThreads) void k_update_inverse(double* __restrict_
                 *p = v;
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_update_inverse(double* __restrict__ Binv, int64_t ld_b, int m,
+                                                             int row_lo, int row_hi,
+                                                             const double* __restrict__ alpha,
+                                                             const double* __restrict__ rho,
+                                                             const PivotRecord* rec) {
+    if (rec->outcome != DEV_RUNNING) return;
+    update_inverse_body(Binv, ld_b, m, row_lo, row_hi, alpha, rho, rec);
+}
+
+// The rank-1 update of B^-1 and the update of b, -pi, -obj, basis, flags, trace in ONE launch (unsharded explicit
+// path): the workgroups with blockIdx.y < ny update B^-1, the extra slab blockIdx.y == ny walks the m-vectors.  The
+// two parts write disjoint data and both only read alpha, rho and the pivot's record fields.
+__global__ __launch_bounds__(kThreads) void k_update_inverse_vectors(double* __restrict__ Binv, int64_t ld_b, int m,
+                                                                     const double* __restrict__ alpha,
+                                                                     const double* __restrict__ rho, double* __restrict__ b,
+                                                                     double* __restrict__ minus_pi,
+                                                                     int32_t* __restrict__ basis_indices,
+                                                                     uint8_t* __restrict__ in_basis, int32_t* __restrict__ trace,
+                                                                     int64_t trace_cap, int ny, PivotRecord* rec) {
+    const PivotRecord R = *rec;
+    if (R.outcome != DEV_RUNNING) return;
+    if ((int)blockIdx.y < ny) { update_inverse_body(Binv, ld_b, m, 0, m, alpha, rho, &R); return; }
+    const double d_q = R.d_q, br = R.b_r / R.alpha_r;
+    const int r = R.r;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < m; i += gridDim.x * kThreads) {
+        minus_pi[i] = fma(-d_q, rho[i], minus_pi[i]);
+        if (i == r) b[i] = br;
+        else {
+            const double a = alpha[i];
+            if (a != 0.0) b[i] = fma(-a, br, b[i]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int q = R.q, leaving = R.leaving;
+        rec->minus_objective = fma(-d_q, br, R.minus_objective);
+        basis_indices[r] = q;
+        if (leaving < kWrappedArtificialBase) in_basis[leaving] = 0;   // a wrapped artificial has no flag
+        in_basis[q] = 1;
+        const long long it = R.iterations;
+        if (trace && it < trace_cap) {
+            trace[0 * trace_cap + it] = R.phase;
+            trace[1 * trace_cap + it] = q;
+            trace[2 * trace_cap + it] = r;
+            trace[3 * trace_cap + it] = leaving;
+        }
+        rec->iterations = it + 1;
     }
 }
 
@@ -901,6 +976,15 @@ void launch_price_virtual_sel(const ColumnTable& ct, const double* minus_pi, dou
     hipLaunchKernelGGL(k_price_virtual, dim3(blocks), dim3(kThreads), 0, s, ct, minus_pi, d, cost_mode, sp, rec);
 }
 
+void launch_price_all_sel(const double* A, int64_t ld_a, const ColumnTable& ct, const double* minus_pi, double* d,
+                          int32_t p_lo, int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec,
+                          hipStream_t s) {
+    const int nb_struct = price_structural_blocks(p_lo, p_hi), nb_virt = price_virtual_blocks(ct);
+    if (nb_struct + nb_virt == 0) return;
+    hipLaunchKernelGGL(k_price_all, dim3(nb_struct + nb_virt), dim3(kThreads), 0, s, A, ld_a, ct, minus_pi, d, p_lo, p_hi,
+                       cost_mode, sp, nb_struct, rec);
+}
+
 void launch_select_partials(SelectPartials sp, int32_t count, const double* d, const double* A, int64_t ld_a,
                             const ColumnTable& ct, int32_t m, double* aq, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_select_partials, dim3(1), dim3(kSingleBlock), 0, s, sp, count, d, A, ld_a, DeviceCSC{}, ct, m, aq,
@@ -971,6 +1055,16 @@ void launch_update_inverse(double* Binv, int64_t ld_b, int32_t m, int32_t row_lo
     dim3 grid(cdiv(ld_b, 2 * kThreads), cdiv(row_hi - row_lo, kUpdRowsPerBlock));
     hipLaunchKernelGGL(k_update_inverse, grid, dim3(kThreads), 0, s, Binv, ld_b, m, row_lo, row_hi, alpha, rho,
                        rec);
+}
+
+void launch_update_inverse_vectors(double* Binv, int64_t ld_b, int32_t m, const double* alpha, const double* rho, double* b,
+                                   double* minus_pi, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,
+                                   int64_t trace_cap, PivotRecord* rec, hipStream_t s) {
+    if (m <= 0) return;
+    const int ny = cdiv(m, kUpdRowsPerBlock);
+    dim3 grid(cdiv(ld_b, 2 * kThreads), ny + 1);
+    hipLaunchKernelGGL(k_update_inverse_vectors, grid, dim3(kThreads), 0, s, Binv, ld_b, m, alpha, rho, b, minus_pi,
+                       basis_indices, in_basis, trace, trace_cap, ny, rec);
 }
 
 void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, const double* w,
