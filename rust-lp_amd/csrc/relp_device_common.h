@@ -98,6 +98,53 @@ __device__ __forceinline__ void block_partial_min(double key, int kj, SelectPart
     }
 }
 
+// PRICE of 256 virtual columns (artificial, slack, bound slack; no matrix data: d_j = cost + (+-)(-pi)_row) and their
+// partial argmin; `block` = index of the workgroup among the virtual-column workgroups.
+__device__ __forceinline__ void price_virtual_body(const ColumnTable& ct, const double* __restrict__ minus_pi,
+                                                   double* __restrict__ d, int cost_mode, const SelectPartials& sp,
+                                                   const PivotRecord* rec, int block) {
+    const int t = block * kThreads + threadIdx.x;
+    int j = -1;
+    double val = 0.0;
+    if (t < ct.nr_artificial) {
+        j = t;
+        val = (cost_mode == 1 ? 1.0 : 0.0) + minus_pi[ct.column_to_row[t]];   // Cost::One + (-pi)_row
+    } else {
+        const int v = t - ct.nr_artificial;
+        if (v < ct.nr_virtual) {
+            // a slack whose row was removed as redundant (RemoveRows) is an empty column: vrow0 = -1
+            const int r0 = ct.vrow0[v];
+            double s = r0 >= 0 ? (double)ct.vsign[v] * minus_pi[r0] : 0.0;
+            const int r1 = ct.vrow1[v];
+            if (r1 >= 0) s += minus_pi[r1];
+            j = ct.nr_artificial + ct.nr_normal + v;              // slack cost is None (zero)
+            val = s;
+        }
+    }
+    if (j >= 0) d[j] = val;
+    if (!sp.k1) return;
+    __shared__ double s_k[kThreads / 64];
+    __shared__ int s_j[kThreads / 64];
+    double key = INFINITY;
+    int kj = 0x7fffffff;
+    if (j >= 0 && !sp.in_basis[j] && val < -sp.tol_cost) { key = select_key(sp.rule, sp.n, rec, j, val); kj = j; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(key, off, 64);
+        const int oj = __shfl_down(kj, off, 64);
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_k[wave] = key; s_j[wave] = kj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w)
+            if (s_k[w] < key || (s_k[w] == key && s_j[w] < kj)) { key = s_k[w]; kj = s_j[w]; }
+        sp.k1[sp.offset + block] = key;
+        sp.j[sp.offset + block] = kj;
+    }
+}
+
 static constexpr int kMaxEta = 128;
 
 // ------------------------------------------------------------------------------------------------

@@ -160,10 +160,14 @@ void Engine::enqueue_iteration_lu(int rule) {
     sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.cols_per_slot = 256;
     const int nb_virt = price_virtual_blocks(ct);
     prof_begin(RELP_K_PRICE);
-    launch_price_csc(csc(), ct, d_minus_pi_, d_d_, 0, nr_normal_, phase_, sp, d_rec_, stream_);
-    SelectPartials spv = sp;
-    spv.offset = nb_struct;
-    launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
+    if (nb_struct > 0 && nb_virt > 0) {
+        launch_price_csc_all(csc(), ct, d_minus_pi_, d_d_, nr_normal_, phase_, sp, nb_virt, d_rec_, stream_);
+    } else {
+        launch_price_csc(csc(), ct, d_minus_pi_, d_d_, 0, nr_normal_, phase_, sp, d_rec_, stream_);
+        SelectPartials spv = sp;
+        spv.offset = nb_struct;
+        launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
+    }
     prof_end();
     prof_begin(RELP_K_SELECT_COLUMN);
     launch_select_partials_csc(sp, nb_struct + nb_virt, d_d_, csc(), ct, m_, d_aq_, d_rec_, stream_);

@@ -282,6 +282,9 @@ void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row
 // PRICE over CSC columns (thread per column), partial argmin per 256 columns
 void launch_price_csc(const DeviceCSC& csc, const ColumnTable& ct, const double* vec, double* d, int32_t p_lo,
                       int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec, hipStream_t s);
+// the same plus the virtual columns (launch_price_virtual_sel) in one launch
+void launch_price_csc_all(const DeviceCSC& csc, const ColumnTable& ct, const double* vec, double* d, int32_t nr_normal,
+                          int32_t cost_mode, SelectPartials sp, int32_t nb_virtual, const PivotRecord* rec, hipStream_t s);
 int32_t price_csc_blocks(int32_t p_lo, int32_t p_hi);
 // k_select_partials with the entering column scattered from CSC instead of copied from dense A
 void launch_select_partials_csc(SelectPartials sp, int32_t count, const double* d, const DeviceCSC& csc,

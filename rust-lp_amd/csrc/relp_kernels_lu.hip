@@ -13,10 +13,17 @@ namespace relp {
 // ------------------------------------------------------------------------------------------------
 // d_j = c_j + sum_i (-pi)_i a_ij over the stored entries of column j (vector/dense.rs:81-92), thread per
 // column; the workgroup's best (key, j) goes to the PRICE partials.
+// nb_struct > 0: the workgroups from nb_struct on price the virtual columns in the same launch (price_virtual_body)
 __global__ __launch_bounds__(kThreads) void k_price_csc(DeviceCSC csc, ColumnTable ct, const double* __restrict__ vec,
                                                         double* __restrict__ d, int p_lo, int p_hi, int cost_mode,
-                                                        SelectPartials sp, const PivotRecord* rec) {
+                                                        SelectPartials sp, int nb_struct, const PivotRecord* rec) {
     if (rec && rec->outcome != DEV_RUNNING) return;
+    if (nb_struct > 0 && (int)blockIdx.x >= nb_struct) {
+        SelectPartials spv = sp;
+        spv.offset = sp.offset + nb_struct;
+        price_virtual_body(ct, vec, d, cost_mode, spv, rec, blockIdx.x - nb_struct);
+        return;
+    }
     const int p = p_lo + blockIdx.x * kThreads + threadIdx.x;
     double key = INFINITY;
     int kj = 0x7fffffff;
@@ -202,7 +209,19 @@ void launch_price_csc(const DeviceCSC& csc, const ColumnTable& ct, const double*
                       int32_t p_hi, int32_t cost_mode, SelectPartials sp, const PivotRecord* rec, hipStream_t s) {
     const int blocks = price_csc_blocks(p_lo, p_hi);
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_price_csc, dim3(blocks), dim3(kThreads), 0, s, csc, ct, vec, d, p_lo, p_hi, cost_mode, sp, rec);
+    hipLaunchKernelGGL(k_price_csc, dim3(blocks), dim3(kThreads), 0, s, csc, ct, vec, d, p_lo, p_hi, cost_mode, sp, 0, rec);
+}
+
+// structural (CSC) and virtual columns in one launch; `nb_virtual` = price_virtual_blocks(ct)
+void launch_price_csc_all(const DeviceCSC& csc, const ColumnTable& ct, const double* vec, double* d, int32_t nr_normal,
+                          int32_t cost_mode, SelectPartials sp, int32_t nb_virtual, const PivotRecord* rec, hipStream_t s) {
+    const int nb_struct = price_csc_blocks(0, nr_normal);
+    if (nb_struct == 0 || nb_virtual == 0) {            // degenerate shapes: the two-launch path handles them
+        launch_price_csc(csc, ct, vec, d, 0, nr_normal, cost_mode, sp, rec, s);
+        return;
+    }
+    hipLaunchKernelGGL(k_price_csc, dim3(nb_struct + nb_virtual), dim3(kThreads), 0, s, csc, ct, vec, d, 0, nr_normal,
+                       cost_mode, sp, nb_struct, rec);
 }
 
 struct LuLdsPlan { int x_in_lds, stage_first, stage_second; size_t bytes; };
