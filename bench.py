@@ -319,7 +319,7 @@ def main():
         else:
             streaming = [k for k in kernels if k in ("price", "ftran", "update_inverse")]
             dom = max(streaming, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
-            traffic_key = {"price": "price_structural", "ftran": "ftran", "update_inverse": "update_inverse"}[dom]
+            traffic_key = {"price": "price_all", "ftran": "ftran", "update_inverse": "update_inverse_vectors"}[dom]
             roofline = {"kernel": "k_" + traffic_key, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4),
                         "traffic": load_traffic(args.workload, traffic_key),
