@@ -67,6 +67,8 @@ relp_status_t relp_solve_relaxation(relp_engine_t* h, int64_t max_iters, int32_t
 relp_status_t relp_from_basis(relp_engine_t* h, const int32_t* basis) { return (h && basis) ? H(h).from_basis(basis) : RELP_E_ARG; }
 
 relp_status_t relp_flush(relp_engine_t* h) { return h ? H(h).flush() : RELP_E_ARG; }
+relp_status_t relp_set_reinversion_interval(relp_engine_t* h, int64_t pivots) { return h ? H(h).set_reinversion_interval(pivots) : RELP_E_ARG; }
+int64_t relp_reinversions(const relp_engine_t* h) { return h ? H(h).reinversions() : -1; }
 int32_t relp_update_block(const relp_engine_t* h) { return h ? H(h).update_block() : -1; }
 relp_status_t relp_lu_stats(const relp_engine_t* h, int64_t* out8) { return (h && out8) ? H(h).lu_stats(out8) : RELP_E_ARG; }
 relp_status_t relp_shard_flush_begin(relp_engine_t* h, double** snap, int64_t* len) {

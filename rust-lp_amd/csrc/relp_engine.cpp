@@ -340,6 +340,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         HIP_TRY(up(d_w_, w.data(), sizeof(double) * ld_b_));
         launch_tab_price_init(tview(), d_w_, d_cost_store_, stream_);
     }
+    // f64 only: the explicit inverse is updated thousands of times on long solves; below 4,096 rows (where the host
+    // factorisation is cheap) it is rebuilt from the basis columns every 1,000 pivots (relp_set_reinversion_interval)
+    reinvert_interval_ = (!tableau_ && !lu_ && cfg_.shard_count == 1 && m_ <= 4096) ? 1000 : 0;
     std::memset(h_rec_, 0, sizeof(PivotRecord));
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->minus_objective = -objective;
@@ -717,6 +720,11 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
         enqueue_iteration(rule);
         if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
+        if (reinvert_interval_ > 0 && ++since_reinvert_ >= reinvert_interval_) {
+            if ((st = download_rec())) return st;
+            if (h_rec_->outcome != DEV_RUNNING) break;
+            if ((st = reinvert())) return st;
+        }
         if (it + 1 == next_poll) {
             next_poll += phase_ == 1 ? std::min<int64_t>(next_poll, cfg_.poll_interval) : cfg_.poll_interval;
             if ((st = download_rec())) return st;
@@ -883,6 +891,10 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     }
     const int32_t m_new = m_ - (int32_t)rows.size();
     for (int32_t r : rows) if (r >= mc_) return fail(RELP_E_STATE, "only constraint rows can be redundant");
+    // The reference marks the INDEX of a stuck artificial as the redundant row (phase_one.rs:252).  When that index
+    // lands on a <= or >= row, a row that is not redundant is deleted and what remains is no longer the inverse of a
+    // basis of the filtered problem: the literal state is kept from here on, never rebuilt from the columns.
+    for (int32_t r : rows) if (r >= nr_eq_ + nr_range_) reinvert_interval_ = 0;
     const int32_t mc_new = mc_ - (int32_t)rows.size();
     // B^-1 (or the tableau), b, basis
     const bool no_inv = tableau_ || lu_;
@@ -978,6 +990,87 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     return RELP_OK;
 }
 
+relp_status_t Engine::set_reinversion_interval(int64_t pivots) {
+    if (pivots < 0) return fail(RELP_E_ARG, "negative interval");
+    if (pivots > 0 && (tableau_ || lu_ || cfg_.shard_count > 1))
+        return fail(RELP_E_UNSUPPORTED, "re-inversion is the unsharded revised engine's (the LU engine refactorises anyway)");
+    reinvert_interval_ = pivots;
+    since_reinvert_ = 0;
+    return RELP_OK;
+}
+
+// Sparse columns of the current basis in row space, for the host factorisation: artificial columns (phase 1,
+// and the ones that survived it with a wrapped index) are unit columns of their rows, structural columns come
+// from the device-resident A (+ their bound row), virtual columns from the descriptors.
+relp_status_t Engine::build_basis_columns(const std::vector<int32_t>& basis,
+                                          std::vector<std::vector<std::pair<int32_t, double>>>* cols) {
+    cols->assign(m_, {});
+    std::vector<double> colbuf(std::max(mc_, 1));
+    for (int32_t i = 0; i < m_; ++i) {
+        const int32_t j = basis[i];
+        auto& c = (*cols)[i];
+        if (j >= kWrappedArtificialBase) { c.emplace_back(column_to_row_[wrapped_na_ - 1 - (INT32_MAX - j)], 1.0); continue; }
+        if (j < nr_artificial_) { c.emplace_back(column_to_row_[j], 1.0); continue; }
+        const int32_t p = j - nr_artificial_;
+        if (p < 0 || p >= n_provider_) return fail(RELP_E_STATE, "basis column out of range");
+        if (p < nr_normal_) {
+            HIP_TRY(hipMemcpy(colbuf.data(), dA_ + (int64_t)(p - col_lo_) * ld_a_, sizeof(double) * mc_, hipMemcpyDeviceToHost));
+            for (int32_t r = 0; r < mc_; ++r) if (colbuf[r] != 0.0) c.emplace_back(r, colbuf[r]);
+            if (bound_row_h_[p] >= 0) c.emplace_back(bound_row_h_[p], 1.0);
+        } else {
+            const int32_t v = p - nr_normal_;
+            if (vrow0_h_[v] >= 0) c.emplace_back(vrow0_h_[v], (double)vsign_h_[v]);
+            if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
+        }
+    }
+    return RELP_OK;
+}
+
+// B^-1, b, -pi and -obj from scratch for the CURRENT basis (either phase): host LU of the basis columns, then on
+// the device the m unit BTRANs, b = B^-1 rhs and -pi = -(c_B' B^-1) with the costs of the phase.  What
+// `LUDecomposition` does every 11 updates (lower_upper/mod.rs:199-202) the f64 explicit inverse needs every now and
+// then: it is only ever updated, and on ill-conditioned LPs its error reaches the pivot tolerance after a few
+// thousand pivots.
+relp_status_t Engine::reinvert() {
+    if (tableau_ || lu_ || cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "re-inversion is the unsharded revised engine's");
+    since_reinvert_ = 0;
+    enqueue_flush();
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    std::vector<std::vector<std::pair<int32_t, double>>> cols;
+    relp_status_t st = build_basis_columns(basis, &cols);
+    if (st) return st;
+    std::string msg;
+    if (!lu_factor(m_, cols, &hlu_, &msg)) return RELP_OK;        // numerically singular for the LU: keep the updated inverse
+    if ((st = lu_upload_factors())) return st;
+    if (!d_lu_scratch_) HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
+    HIP_TRY(hipMemsetAsync(dBinv_, 0, sizeof(double) * (size_t)m_ * ld_b_, stream_));
+    DeferredUpdate none = deferred();
+    none.kmax = 0;
+    launch_lu_btran_rows(dlu_, none, dBinv_, ld_b_, d_lu_scratch_, stream_);
+    // costs of the phase: Cost::One on artificial columns in phase 1, the variable costs in phase 2
+    std::vector<double> w(ld_b_, 0.0), b(m_);
+    for (int32_t i = 0; i < m_; ++i) {
+        const int32_t j = basis[i];
+        if (j >= kWrappedArtificialBase) continue;
+        if (phase_ == 1) w[i] = j < nr_artificial_ ? 1.0 : 0.0;
+        else if (j < nr_normal_) w[i] = cost_h_[j];
+    }
+    HIP_TRY(hipMemcpyAsync(d_w_, w.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_aq_, rhs_h_.data(), sizeof(double) * m_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    launch_weighted_column_sums(dBinv_, ld_b_, m_, d_w_, d_minus_pi_, stream_);
+    launch_ftran(dBinv_, ld_b_, m_, 0, m_, d_aq_, d_b_, 0, d_rec_, stream_);
+    HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+    if ((st = download_rec())) return st;
+    double objective = 0.0;
+    for (int32_t i = 0; i < m_; ++i) objective += w[i] * b[i];
+    h_rec_->minus_objective = -objective;
+    ++reinversions_;
+    return upload_rec();
+}
+
 relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     // InverseMaintener::from_basis (carry/mod.rs:428-463): any basis on the LU and the revised engine (the
     // latter factorises on the host and runs the m unit solves on the device; slack bases are a signed permutation and take a shortcut).
@@ -1065,8 +1158,7 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
         HIP_TRY(hipMemsetAsync(dBinv_, 0, sizeof(double) * (size_t)m_ * ld_b_, stream_));
         DeferredUpdate none = deferred();
         none.kmax = 0;
-        for (int32_t i = 0; i < m_; ++i)
-            launch_lu_btran(dlu_, none, nullptr, i, dBinv_ + (int64_t)i * ld_b_, d_lu_scratch_, nullptr, stream_);
+        launch_lu_btran_rows(dlu_, none, dBinv_, ld_b_, d_lu_scratch_, stream_);
         std::vector<double> w(ld_b_, 0.0);
         for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = cost_h_[basis[i]];
         HIP_TRY(hipMemcpyAsync(d_w_, w.data(), sizeof(double) * ld_b_, hipMemcpyHostToDevice, stream_));

@@ -43,6 +43,8 @@ class Engine {
     relp_status_t run(int64_t max_iters, int64_t* done, int32_t* outcome);
     relp_status_t solve_relaxation(int64_t max_iters, int32_t* outcome);
     relp_status_t from_basis(const int32_t* basis_columns);
+    relp_status_t set_reinversion_interval(int64_t pivots);
+    int64_t reinversions() const { return reinversions_; }
     relp_status_t flush();
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
@@ -153,10 +155,14 @@ class Engine {
     DeviceLU dlu_{};
     relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop
     int64_t lu_refactors_ = 0;
+    // revised engine: B^-1 is re-inverted from the basis columns every `reinvert_interval_` pivots (0 = never)
+    int64_t reinvert_interval_ = 0, since_reinvert_ = 0, reinversions_ = 0;
     DeviceCSC csc() const { return DeviceCSC{d_cptr_, d_cidx_, d_cval_}; }
     relp_status_t lu_load_matrix(const relp_matrix_data_t& md);
     relp_status_t lu_refactor();
     relp_status_t lu_upload_factors();
+    relp_status_t reinvert();
+    relp_status_t build_basis_columns(const std::vector<int32_t>& basis, std::vector<std::vector<std::pair<int32_t, double>>>* cols);
     void enqueue_iteration_lu(int rule);
     DeferredUpdate deferred() const;
     void enqueue_flush();

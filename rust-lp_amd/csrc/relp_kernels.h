@@ -298,6 +298,9 @@ void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* sc
 //        or z = rhs (dense, indexed by basis position)
 void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double* rhs, int32_t row, double* rho,
                      double* scratch, const PivotRecord* rec, hipStream_t s);
+// every row of B^-1 = (LU)^-1 in one launch (workgroup i: e_i' B^-1 -> out + i * ld); `none`: a DeferredUpdate with kmax = 0
+void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double* out, int64_t ld, double* scratch,
+                          hipStream_t s);
 
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);

@@ -174,10 +174,9 @@ __global__ __launch_bounds__(kLuThreads) void k_lu_ftran(DeviceLU lu, const doub
 
 // BTRAN (lower_upper/mod.rs:204-222): z' B = c'  ->  U' t = Q' c, L' w = t, z = P' w
 template <bool kXLds, bool kStage1, bool kStage2>
-__global__ __launch_bounds__(kLuThreads) void k_lu_btran(DeviceLU lu, DeferredUpdate du, const double* __restrict__ rhs,
-                                                           int row, double* __restrict__ rho, double* __restrict__ scratch,
-                                                           const PivotRecord* rec) {
-    if (rec && rec->outcome != DEV_RUNNING) return;
+__device__ __forceinline__ void lu_btran_body(const DeviceLU& lu, const DeferredUpdate& du, const double* __restrict__ rhs,
+                                              int row, double* __restrict__ rho, double* __restrict__ scratch,
+                                              const PivotRecord* rec) {
     extern __shared__ __align__(16) char lds[];
     double* x = kXLds ? reinterpret_cast<double*>(lds) : scratch;
     char* base = lds + (kXLds ? lu_up16((int64_t)lu.m * 8) : 0);
@@ -197,6 +196,22 @@ __global__ __launch_bounds__(kLuThreads) void k_lu_btran(DeviceLU lu, DeferredUp
     solve_schedule<kStage1>(lu.Ub, lu.m, base, x);
     solve_schedule<kStage2>(lu.Lb, lu.m, base, x);
     for (int k = threadIdx.x; k < lu.m; k += blockDim.x) rho[lu.rowperm[k]] = x[k];
+}
+
+template <bool kXLds, bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_btran(DeviceLU lu, DeferredUpdate du, const double* __restrict__ rhs,
+                                                           int row, double* __restrict__ rho, double* __restrict__ scratch,
+                                                           const PivotRecord* rec) {
+    if (rec && rec->outcome != DEV_RUNNING) return;
+    lu_btran_body<kXLds, kStage1, kStage2>(lu, du, rhs, row, rho, scratch, rec);
+}
+
+// All m rows of B^-1 at once (re-inversion, warm start): workgroup i solves e_i' B^-1 and writes row i of `out`.
+// x lives in each workgroup's LDS (the launcher falls back to one launch per row otherwise).
+template <bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_btran_rows(DeviceLU lu, DeferredUpdate none, double* __restrict__ out,
+                                                                int64_t ld) {
+    lu_btran_body<true, kStage1, kStage2>(lu, none, nullptr, blockIdx.x, out + (int64_t)blockIdx.x * ld, nullptr, nullptr);
 }
 
 
@@ -260,6 +275,19 @@ void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* sc
                               k_lu_ftran<true, true, false>, k_lu_ftran<true, false, true>, k_lu_ftran<true, true, true>);
     allow_big_lds(reinterpret_cast<const void*>(fn));
     hipLaunchKernelGGL(fn, dim3(1), dim3(kLuThreads), p.bytes, s, lu, aq, v, scratch, rec);
+}
+
+void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double* out, int64_t ld, double* scratch,
+                          hipStream_t s) {
+    const LuLdsPlan p = plan_lu_lds(lu.m, lu.Ub, lu.Lb);
+    if (!p.x_in_lds) {                                   // x in global scratch: one solve at a time
+        for (int32_t i = 0; i < lu.m; ++i) launch_lu_btran(lu, none, nullptr, i, out + (int64_t)i * ld, scratch, nullptr, s);
+        return;
+    }
+    auto fn = p.stage_first ? (p.stage_second ? k_lu_btran_rows<true, true> : k_lu_btran_rows<true, false>)
+                            : (p.stage_second ? k_lu_btran_rows<false, true> : k_lu_btran_rows<false, false>);
+    allow_big_lds(reinterpret_cast<const void*>(fn));
+    hipLaunchKernelGGL(fn, dim3(lu.m), dim3(kLuThreads), p.bytes, s, lu, none, out, ld);
 }
 
 void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double* rhs, int32_t row, double* rho,

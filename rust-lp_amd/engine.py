@@ -118,6 +118,8 @@ _SIGNATURES = {
     "relp_shard_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "relp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "relp_shard_pivot": (C.c_int, [C.c_void_p]),
+    "relp_set_reinversion_interval": (C.c_int, [C.c_void_p, C.c_int64]),
+    "relp_reinversions": (C.c_int64, [C.c_void_p]),
     "relp_shard_set_collectives": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "relp_shard_run": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "relp_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
@@ -290,6 +292,13 @@ class Tableau:
         v = C.c_double()
         self._ck(self._lib.relp_generate_element(self._h, i, j, C.byref(v)))
         return v.value
+
+    def set_reinversion_interval(self, pivots: int) -> None:
+        """Revised engine: rebuild B^-1, b, -pi from the basis columns every `pivots` basis changes (0 = never)."""
+        self._ck(self._lib.relp_set_reinversion_interval(self._h, int(pivots)))
+
+    def reinversions(self) -> int:
+        return int(self._lib.relp_reinversions(self._h))
 
     def select_primal_pivot_row(self, column=None) -> Optional[int]:
         """tableau/mod.rs:221-247.  Without an argument: on the last generated column (device resident);

@@ -813,6 +813,54 @@ def test_ratio_test_from_block_minima_on_many_degenerate_rows(degenerate_rows):
         assert traces[0][0][2] == 0 and traces[0][0][3] == n
 
 
+@pytest.mark.parametrize("block", [0, 5, 16, 20])
+def test_25fv47_with_periodic_reinversion_is_block_independent(block):
+    """An explicit inverse that is only ever updated loses accuracy on 25FV47 (max |B^-1 B - I| reaches 1e-6 .. 1e-4
+    after ~2,000 pivots); without re-inversion the blocked update with K = 5, 16, 20 blows up in phase 1.  The
+    revised engine rebuilds B^-1, b, -pi from the basis columns every 1,000 pivots (default below 4,097 rows):
+    every block length reaches the reference's pin, and the inverse stays accurate."""
+    from lp_files import load
+    gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
+    t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=block, **C3_TOLERANCES)
+    assert t.solve_relaxation() == engine.OPTIMAL
+    assert t.reinversions() >= 8
+    got = t.objective_function_value() + float(gf.fixed_cost)
+    assert abs(got - 5.5018459e+03) < 1e-4
+    ident, basic, min_b = t.check_basis()
+    assert ident <= 1e-6 and min_b >= -1e-6
+    t.close()
+
+
+def test_reinversion_every_few_pivots_keeps_the_oracle_path():
+    """Re-inversion only refreshes numbers: with B^-1, b and -pi rebuilt every 4 pivots (both phases, artificial and
+    wrapped columns in the basis, redundant rows removed) well-conditioned LPs still walk the oracle's pivots."""
+    rng = np.random.default_rng(99)
+    checked = 0
+    for case in range(40):
+        m, n = int(rng.integers(5, 70)), int(rng.integers(5, 100))
+        d = synthetic.mixed_lp(m, n, 9300 + case, nnz_per_col=int(rng.integers(2, 6)), frac_negative_cost=0.1,
+                               infeasible=(case % 9 == 8))
+        md = MatrixData.from_sparse_dict(d)
+        ref = relp_f64.OracleF64(md)
+        status = ref.run(200000)
+        # (when the reference deletes a non-redundant row - see test_random_mixed_lps_... - the engine keeps the
+        # literal state and stops re-inverting; those cases pass here because of that)
+        for block in (0, 3):
+            t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=block, trace_capacity=1 << 15)
+            t.set_reinversion_interval(4)
+            assert engine.OUTCOME_NAMES[t.solve_relaxation()] == status, case
+            assert t.trace() == ref.trace, case
+            if len(ref.trace) >= 8:
+                assert t.reinversions() >= 1
+            if status == "optimal":
+                assert abs(t.objective_function_value() - ref.objective) <= OBJ_RTOL * max(1.0, abs(ref.objective)), case
+            t.close()
+            checked += 1
+    assert checked == 80
+    with pytest.raises(engine.RelpError):
+        engine.Tableau(md, engine=engine.ENGINE_LU).set_reinversion_interval(10)
+
+
 # ------------------------------------------------------------------------------------------------
 # Randomised differential test (a fixed slice of tests/tools/fuzz_gpu.py)
 # ------------------------------------------------------------------------------------------------
