@@ -115,12 +115,14 @@ def sparse_path(events, with_cpu):
             out["ftran_GBps"] = round(factor_bytes / (kt["ftran"]["avg_us"] * 1e-6) / 1e9, 3)
             out["ftran_note"] = "12 (nnz L + nnz U) + 40 m bytes of the last factor / average FTRAN time: dependency-bound"
     # the same LP on the explicit-inverse engine (m = 790: B^-1 is 5 MB, the dense kernels are at their latency floor)
+    # (re-inverted every 1,000 pivots, the engine's default at this size)
     t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=0, **tol)
     t0 = time.perf_counter()
     outcome2 = t.solve_relaxation()
     dt2 = time.perf_counter() - t0
     out["explicit_inverse_engine"] = {"outcome": engine.OUTCOME_NAMES.get(outcome2), "pivots": t.iterations(),
                                       "value": t.iterations() / dt2, "unit": "iterations/s", "seconds": dt2,
+                                      "reinversions": t.reinversions(),
                                       "objective": t.objective_function_value() + float(gf.fixed_cost)}
     t.close()
     if with_cpu:
