@@ -165,11 +165,12 @@ relp_status_t relp_solve_relaxation(relp_engine_t *h, int64_t max_iters, int32_t
  * refactorisation - then m unit solves, b and -pi on the device; slack bases are a signed permutation and take a
  * shortcut); RELP_ENGINE_TABLEAU: RELP_E_UNSUPPORTED. */
 relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
-/* RELP_ENGINE_REVISED (unsharded) only, an f64 matter (the exact reference never needs it, `should_refactor() = false`,
- * basis_inverse_rows.rs:175-179): every `pivots` basis changes inside relp_run, B^-1, b, -pi and -obj are rebuilt from the
- * columns of the current basis (host LU, device unit solves), which bounds the error of an inverse that is otherwise only
- * ever updated.  Default: 1,000 when the problem has at most 4,096 rows, else 0 = never.  relp_reinversions: how many
- * have been done. */
+/* RELP_ENGINE_REVISED and RELP_ENGINE_TABLEAU (unsharded), an f64 matter (the exact reference never needs it,
+ * `should_refactor() = false`, basis_inverse_rows.rs:175-179): every `pivots` basis changes inside relp_run the state is
+ * rebuilt from the columns of the current basis -- host LU, then on the device B^-1 row by row (revised) or the tableau
+ * B^-1 [A | I] column by column (tableau), b = B^-1 rhs, -pi / the reduced costs and -obj -- which bounds the error of a
+ * representation that is otherwise only ever updated.  Default: 1,000 when the problem has at most 4,096 rows, else
+ * 0 = never.  relp_reinversions: how many have been done. */
 relp_status_t relp_set_reinversion_interval(relp_engine_t *h, int64_t pivots);
 int64_t       relp_reinversions(const relp_engine_t *h);
 /* Fold every pending deferred update into the stored representation: B0^-1 += W (S' B0^-1) (revised), T0 += W R0

@@ -342,7 +342,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     }
     // f64 only: the explicit inverse is updated thousands of times on long solves; below 4,096 rows (where the host
     // factorisation is cheap) it is rebuilt from the basis columns every 1,000 pivots (relp_set_reinversion_interval)
-    reinvert_interval_ = (!tableau_ && !lu_ && cfg_.shard_count == 1 && m_ <= 4096) ? 1000 : 0;
+    reinvert_interval_ = (!lu_ && cfg_.shard_count == 1 && m_ <= 4096) ? 1000 : 0;
     std::memset(h_rec_, 0, sizeof(PivotRecord));
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->minus_objective = -objective;
@@ -953,7 +953,7 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     HIP_TRY(hipMemcpy(d_b_, bn.data(), sizeof(double) * m_new, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_basis_, basisn.data(), sizeof(int32_t) * m_new, hipMemcpyHostToDevice));
     // A: drop the rows inside every structural column (the tableau engine no longer reads A)
-    if (nr_normal_ > 0 && !no_inv) {
+    if (nr_normal_ > 0 && !lu_ && cfg_.shard_count == 1) {   // (the unsharded tableau engine re-tabulates from A)
         std::vector<double> Ah((size_t)ld_a_ * nr_normal_);
         HIP_TRY(hipMemcpy(Ah.data(), dA_, Ah.size() * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<double> An((size_t)ld_a_ * nr_normal_, 0.0);
@@ -992,8 +992,8 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
 
 relp_status_t Engine::set_reinversion_interval(int64_t pivots) {
     if (pivots < 0) return fail(RELP_E_ARG, "negative interval");
-    if (pivots > 0 && (tableau_ || lu_ || cfg_.shard_count > 1))
-        return fail(RELP_E_UNSUPPORTED, "re-inversion is the unsharded revised engine's (the LU engine refactorises anyway)");
+    if (pivots > 0 && (lu_ || cfg_.shard_count > 1))
+        return fail(RELP_E_UNSUPPORTED, "re-inversion is for the unsharded revised and tableau engines (the LU engine refactorises anyway)");
     reinvert_interval_ = pivots;
     since_reinvert_ = 0;
     return RELP_OK;
@@ -1031,8 +1031,57 @@ relp_status_t Engine::build_basis_columns(const std::vector<int32_t>& basis,
 // `LUDecomposition` does every 11 updates (lower_upper/mod.rs:199-202) the f64 explicit inverse needs every now and
 // then: it is only ever updated, and on ill-conditioned LPs its error reaches the pivot tolerance after a few
 // thousand pivots.
+// The dense tableau's counterpart: T0 = B^-1 [artificial | A + bound rows | virtual] recomputed column by column from
+// a fresh factorisation of the basis (one launch: workgroup c solves stored column c), b = B^-1 rhs, d re-priced
+// from the new T0, -obj from b.  T0 is otherwise only ever updated (every flush adds W R0 to it).
+relp_status_t Engine::retabulate() {
+    since_reinvert_ = 0;
+    enqueue_flush();
+    HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<int32_t> basis(m_);
+    HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    std::vector<std::vector<std::pair<int32_t, double>>> cols;
+    relp_status_t st = build_basis_columns(basis, &cols);
+    if (st) return st;
+    std::string msg;
+    if (!lu_factor(m_, cols, &hlu_, &msg)) return RELP_OK;        // keep the updated tableau
+    if ((st = lu_upload_factors())) return st;
+    if (!d_lu_scratch_) HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
+    const TableauView tv = tview();
+    const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
+    // phase 2 keeps the artificial block in storage but never reads it: only the live columns are rebuilt
+    const int32_t c_first = std::max(sc_lo_, tv.col_off);
+    ColumnTable storage = table();
+    storage.nr_artificial = tab_na_;                    // storage columns keep the artificial block in front
+    if (!launch_lu_ftran_cols(dlu_, tv, A, ld_a_, storage, c_first, sc_hi_ - c_first, stream_)) return RELP_OK;
+    HIP_TRY(hipMemcpyAsync(d_aq_, rhs_h_.data(), sizeof(double) * m_, hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    launch_lu_ftran(dlu_, d_aq_, d_b_, d_lu_scratch_, nullptr, stream_);                 // b = B^-1 rhs
+    // d = c - c_B' T0 and the PRICE partials, as after every few flushes
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    launch_tab_basis_costs(tv, d_basis_, d_cost_store_, d_w_, stream_);
+    launch_tab_price_init(tv, d_w_, d_cost_store_, stream_);
+    launch_tab_scan(tv, tab_partials(rule), d_rec_, stream_);
+    tab_partials_valid_ = true;
+    flushes_since_reprice_ = 0;
+    std::vector<double> b(m_);
+    HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
+    if ((st = download_rec())) return st;
+    double objective = 0.0;
+    for (int32_t i = 0; i < m_; ++i) {
+        const int32_t j = basis[i];
+        if (j >= kWrappedArtificialBase) continue;
+        if (phase_ == 1) { if (j < nr_artificial_) objective += b[i]; }
+        else if (j < nr_normal_) objective += cost_h_[j] * b[i];
+    }
+    h_rec_->minus_objective = -objective;
+    ++reinversions_;
+    return upload_rec();
+}
+
 relp_status_t Engine::reinvert() {
-    if (tableau_ || lu_ || cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "re-inversion is the unsharded revised engine's");
+    if (lu_ || cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "re-inversion is for the unsharded revised and tableau engines");
+    if (tableau_) return retabulate();
     since_reinvert_ = 0;
     enqueue_flush();
     HIP_TRY(hipStreamSynchronize(stream_));

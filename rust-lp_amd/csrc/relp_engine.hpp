@@ -162,6 +162,7 @@ class Engine {
     relp_status_t lu_refactor();
     relp_status_t lu_upload_factors();
     relp_status_t reinvert();
+    relp_status_t retabulate();
     relp_status_t build_basis_columns(const std::vector<int32_t>& basis, std::vector<std::vector<std::pair<int32_t, double>>>* cols);
     void enqueue_iteration_lu(int rule);
     DeferredUpdate deferred() const;

@@ -224,6 +224,10 @@ void launch_tab_basis_costs(const TableauView& tv, const int32_t* basis_indices,
                             hipStream_t s);
 void launch_tab_scan(const TableauView& tv, SelectPartials sp, const PivotRecord* rec, hipStream_t s);
 int32_t tab_scan_blocks(int32_t n_owned_columns);
+// re-tabulation: T0[:, c] = (LU)^-1 a_c for the stored columns [c_first, c_first + c_count) in one launch (a_c as in
+// launch_tab_build); false when the solve vector does not fit into LDS
+bool launch_lu_ftran_cols(const DeviceLU& lu, const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct,
+                          int32_t c_first, int32_t c_count, hipStream_t s);
 // entering column from the partials (no column build: the tableau column is read directly)
 void launch_tab_select(const TableauView& tv, SelectPartials sp, int32_t count, PivotRecord* rec, hipStream_t s);
 // alpha = T[:,q] = T0[:,q] + W R0[:,q]

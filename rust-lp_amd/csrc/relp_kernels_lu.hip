@@ -277,6 +277,54 @@ void launch_lu_ftran(const DeviceLU& lu, const double* aq, double* v, double* sc
     hipLaunchKernelGGL(fn, dim3(1), dim3(kLuThreads), p.bytes, s, lu, aq, v, scratch, rec);
 }
 
+// Re-tabulation of the dense tableau: workgroup c solves B^-1 a_c for stored column c (artificial unit column,
+// structural column of A + its bound row, virtual unit column -- the same definition as k_tab_build) and writes
+// column c of T0.  x lives in LDS.
+template <bool kStage1, bool kStage2>
+__global__ __launch_bounds__(kLuThreads) void k_lu_ftran_cols(DeviceLU lu, TableauView tv, const double* __restrict__ A,
+                                                                int64_t ld_a, ColumnTable ct, int c_first) {
+    extern __shared__ __align__(16) char lds[];
+    double* x = reinterpret_cast<double*>(lds);
+    char* base = lds + lu_up16((int64_t)lu.m * 8);
+    const int c = c_first + blockIdx.x;
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) {
+        const int i = lu.rowperm[k];
+        double v = 0.0;
+        if (c < ct.nr_artificial) {
+            v = (i == ct.column_to_row[c]) ? 1.0 : 0.0;
+        } else {
+            const int p = c - ct.nr_artificial;
+            if (p < ct.nr_normal) {
+                if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
+                else v = (i == ct.bound_row[p]) ? 1.0 : 0.0;
+            } else {
+                const int vv = p - ct.nr_normal;
+                if (i == ct.vrow0[vv]) v = (double)ct.vsign[vv];
+                else if (i == ct.vrow1[vv]) v = 1.0;
+            }
+        }
+        x[k] = v;
+    }
+    __syncthreads();
+    solve_schedule<kStage1>(lu.Lf, lu.m, base, x);
+    solve_schedule<kStage2>(lu.Uf, lu.m, base, x);
+    double* out = tv.T0 + (int64_t)c * tv.ld_t;
+    for (int k = threadIdx.x; k < lu.m; k += blockDim.x) out[lu.colperm[k]] = x[k];
+}
+
+// returns false when x does not fit into LDS (the caller then leaves the tableau as it is)
+bool launch_lu_ftran_cols(const DeviceLU& lu, const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct,
+                          int32_t c_first, int32_t c_count, hipStream_t s) {
+    const LuLdsPlan p = plan_lu_lds(lu.m, lu.Lf, lu.Uf);
+    if (!p.x_in_lds) return false;
+    if (c_count <= 0) return true;
+    auto fn = p.stage_first ? (p.stage_second ? k_lu_ftran_cols<true, true> : k_lu_ftran_cols<true, false>)
+                            : (p.stage_second ? k_lu_ftran_cols<false, true> : k_lu_ftran_cols<false, false>);
+    allow_big_lds(reinterpret_cast<const void*>(fn));
+    hipLaunchKernelGGL(fn, dim3(c_count), dim3(kLuThreads), p.bytes, s, lu, tv, A, ld_a, ct, c_first);
+    return true;
+}
+
 void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double* out, int64_t ld, double* scratch,
                           hipStream_t s) {
     const LuLdsPlan p = plan_lu_lds(lu.m, lu.Ub, lu.Lb);
