@@ -125,6 +125,16 @@ def sparse_path(events, with_cpu):
                                       "reinversions": t.reinversions(),
                                       "objective": t.objective_function_value() + float(gf.fixed_cost)}
     t.close()
+    # ... and on the dense tableau engine (T0 = 790 x 2,300 doubles; re-tabulated every 1,000 pivots)
+    t = engine.Tableau(md, engine=engine.ENGINE_TABLEAU, update_block=32, **tol)
+    t0 = time.perf_counter()
+    outcome3 = t.solve_relaxation()
+    dt3 = time.perf_counter() - t0
+    out["tableau_engine"] = {"outcome": engine.OUTCOME_NAMES.get(outcome3), "pivots": t.iterations(),
+                             "value": t.iterations() / dt3, "unit": "iterations/s", "seconds": dt3,
+                             "retabulations": t.reinversions(),
+                             "objective": t.objective_function_value() + float(gf.fixed_cost)}
+    t.close()
     if with_cpu:
         from oracle import relp_f64
         ref = relp_f64.OracleF64(md, **tol)
