@@ -236,7 +236,7 @@ class Tableau {
     }
     int64_t iterations() { int64_t it = 0; ck(relp_get_iterations(h_, &it)); return it; }
     // f64 only (the exact reference never refactors `BasisInverseRows`): rebuild B^-1, b, -pi from the basis columns
-    // every `pivots` basis changes; revised engine, default 1,000 below 4,097 rows, 0 = never
+    // every `pivots` basis changes; revised and tableau engines, default 1,000 for sparse input below 4,097 rows, 0 = never
     void set_reinversion_interval(int64_t pivots) { ck(relp_set_reinversion_interval(h_, pivots)); }
     int64_t reinversions() const { return relp_reinversions(h_); }
 

@@ -169,8 +169,9 @@ relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
  * `should_refactor() = false`, basis_inverse_rows.rs:175-179): every `pivots` basis changes inside relp_run the state is
  * rebuilt from the columns of the current basis -- host LU, then on the device B^-1 row by row (revised) or the tableau
  * B^-1 [A | I] column by column (tableau), b = B^-1 rhs, -pi / the reduced costs and -obj -- which bounds the error of a
- * representation that is otherwise only ever updated.  Default: 1,000 when the problem has at most 4,096 rows, else
- * 0 = never.  relp_reinversions: how many have been done. */
+ * representation that is otherwise only ever updated.  Default: 1,000 for sparse input (CSC, at most 10 % nonzeros)
+ * with at most 4,096 rows -- where the host factorisation of a basis is cheap -- else 0 = never.
+ * relp_reinversions: how many have been done. */
 relp_status_t relp_set_reinversion_interval(relp_engine_t *h, int64_t pivots);
 int64_t       relp_reinversions(const relp_engine_t *h);
 /* Fold every pending deferred update into the stored representation: B0^-1 += W (S' B0^-1) (revised), T0 += W R0

@@ -340,9 +340,15 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         HIP_TRY(up(d_w_, w.data(), sizeof(double) * ld_b_));
         launch_tab_price_init(tview(), d_w_, d_cost_store_, stream_);
     }
-    // f64 only: the explicit inverse is updated thousands of times on long solves; below 4,096 rows (where the host
-    // factorisation is cheap) it is rebuilt from the basis columns every 1,000 pivots (relp_set_reinversion_interval)
-    reinvert_interval_ = (!lu_ && cfg_.shard_count == 1 && m_ <= 4096) ? 1000 : 0;
+    // f64 only: the explicit inverse / the tableau is updated thousands of times on long solves; for sparse problems
+    // below 4,097 rows (where the host factorisation of a basis is cheap: CSC input with at most 10 % nonzeros) it is
+    // rebuilt from the basis columns every 1,000 pivots (relp_set_reinversion_interval changes or enables it)
+    {
+        bool sparse_input = false;
+        if (md.format == RELP_FORMAT_CSC && md.col_ptr && nr_normal_ > 0 && mc_ > 0)
+            sparse_input = (double)md.col_ptr[nr_normal_] <= 0.10 * (double)nr_normal_ * (double)mc_;
+        reinvert_interval_ = (!lu_ && cfg_.shard_count == 1 && m_ <= 4096 && sparse_input) ? 1000 : 0;
+    }
     std::memset(h_rec_, 0, sizeof(PivotRecord));
     h_rec_->outcome = DEV_RUNNING;
     h_rec_->minus_objective = -objective;

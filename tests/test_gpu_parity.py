@@ -816,7 +816,7 @@ def test_ratio_test_from_block_minima_on_many_degenerate_rows(degenerate_rows):
 @pytest.mark.parametrize("block", [8, 32, 64])
 def test_25fv47_on_the_tableau_engine_with_periodic_retabulation(block):
     """The dense tableau is only ever updated (T0 += W R0 at every flush); on 25FV47 it drifts until phase 1 ends in
-    `no_row_phase_one` (K = 32, 64 without re-tabulation).  Every 1,000 pivots (default below 4,097 rows) T0 is
+    `no_row_phase_one` (K = 32, 64 without re-tabulation).  Every 1,000 pivots (default for sparse input below 4,097 rows) T0 is
     recomputed column by column from a fresh factorisation of the basis (k_lu_ftran_cols: one workgroup per stored
     column), b and d with it: the reference's pin, and a tableau that still is B^-1 [A | I]."""
     from lp_files import load
@@ -835,7 +835,7 @@ def test_25fv47_on_the_tableau_engine_with_periodic_retabulation(block):
 def test_25fv47_with_periodic_reinversion_is_block_independent(block):
     """An explicit inverse that is only ever updated loses accuracy on 25FV47 (max |B^-1 B - I| reaches 1e-6 .. 1e-4
     after ~2,000 pivots); without re-inversion the blocked update with K = 5, 16, 20 blows up in phase 1.  The
-    revised engine rebuilds B^-1, b, -pi from the basis columns every 1,000 pivots (default below 4,097 rows):
+    revised engine rebuilds B^-1, b, -pi from the basis columns every 1,000 pivots (default for sparse input below 4,097 rows):
     every block length reaches the reference's pin, and the inverse stays accurate."""
     from lp_files import load
     gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
