@@ -197,6 +197,8 @@ relp_status_t relp_get_basis_inverse(relp_engine_t *h, double *out_mm); /* dense
 /* current_bfs (carry/mod.rs:616-625): (column, value) pairs sorted by column, zeros dropped. */
 relp_status_t relp_current_bfs(relp_engine_t *h, int32_t *cols, double *vals, int32_t cap, int32_t *count);
 relp_status_t relp_get_iterations(relp_engine_t *h, int64_t *out);
+/* how many of those pivots were degenerate: ratio b_r / alpha_r exactly 0, the basis changed but b did not */
+relp_status_t relp_get_degenerate_pivots(relp_engine_t *h, int64_t *out);
 /* recorded pivots: phase, entering, row, leaving (each `cap` long); count = pivots so far */
 relp_status_t relp_get_trace(relp_engine_t *h, int32_t *phase, int32_t *entering, int32_t *row,
                              int32_t *leaving, int64_t cap, int64_t *count);

@@ -96,6 +96,7 @@ relp_status_t relp_current_bfs(relp_engine_t* h, int32_t* cols, double* vals, in
     return h ? H(h).current_bfs(cols, vals, cap, count) : RELP_E_ARG;
 }
 relp_status_t relp_get_iterations(relp_engine_t* h, int64_t* out) { return (h && out) ? H(h).get_iterations(out) : RELP_E_ARG; }
+relp_status_t relp_get_degenerate_pivots(relp_engine_t* h, int64_t* out) { return (h && out) ? H(h).get_degenerate_pivots(out) : RELP_E_ARG; }
 relp_status_t relp_get_trace(relp_engine_t* h, int32_t* phase, int32_t* entering, int32_t* row, int32_t* leaving,
                              int64_t cap, int64_t* count) {
     return h ? H(h).get_trace(phase, entering, row, leaving, cap, count) : RELP_E_ARG;

@@ -1327,6 +1327,13 @@ relp_status_t Engine::get_iterations(int64_t* out) {
     return RELP_OK;
 }
 
+relp_status_t Engine::get_degenerate_pivots(int64_t* out) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    *out = h_rec_->degenerate;
+    return RELP_OK;
+}
+
 relp_status_t Engine::get_trace(int32_t* phase, int32_t* entering, int32_t* row, int32_t* leaving, int64_t cap,
                                 int64_t* count) {
     relp_status_t st = download_rec();

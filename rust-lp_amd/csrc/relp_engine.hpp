@@ -62,6 +62,7 @@ class Engine {
     relp_status_t get_basis_inverse(double* out);
     relp_status_t current_bfs(int32_t* cols, double* vals, int32_t cap, int32_t* count);
     relp_status_t get_iterations(int64_t* out);
+    relp_status_t get_degenerate_pivots(int64_t* out);
     relp_status_t get_trace(int32_t* phase, int32_t* entering, int32_t* row, int32_t* leaving, int64_t cap,
                             int64_t* count);
     relp_status_t check_basis(double* max_identity_error, double* max_basic_cost, double* min_b);

@@ -33,7 +33,7 @@ struct PivotRecord {
     int32_t n_eta;          // deferred update: columns of W in use (distinct pivot rows since the last flush)
     int32_t eta_target;     // deferred update: column of W that receives this pivot's u
     int32_t n_eta_old;      // deferred update: n_eta before this pivot
-    int32_t pad2_;
+    int32_t degenerate;     // pivots so far whose ratio b_r / alpha_r was exactly 0 (reported for config C5)
 };
 
 // Deferred (blocked) update of the explicit inverse:  B^-1 = (I + W S') B0inv, where B0inv is the

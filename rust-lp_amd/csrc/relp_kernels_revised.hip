@@ -445,6 +445,7 @@ __global__ void k_update_vectors(int m, const double* __restrict__ alpha, const 
             trace[2 * trace_cap + it] = r;
             trace[3 * trace_cap + it] = leaving;
         }
+        if (br == 0.0) rec->degenerate += 1;            // ratio 0: the basis changes, the vertex does not
         rec->iterations = it + 1;
     }
 }
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(kThreads) void k_update_inverse_vectors(double* __r
             trace[2 * trace_cap + it] = r;
             trace[3 * trace_cap + it] = leaving;
         }
+        if (br == 0.0) rec->degenerate += 1;            // ratio 0: the basis changes, the vertex does not
         rec->iterations = it + 1;
     }
 }

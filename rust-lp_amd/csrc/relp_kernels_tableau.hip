@@ -242,6 +242,7 @@ __device__ __forceinline__ void tab_update_w_vectors_body(const DeferredUpdate& 
             trace[2 * trace_cap + it] = r;
             trace[3 * trace_cap + it] = leaving;
         }
+        if (br == 0.0) rec->degenerate += 1;            // ratio 0: the basis changes, the vertex does not
         rec->iterations = it + 1;
     }
 }
@@ -501,6 +502,7 @@ __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, do
             trace[2 * trace_cap + it] = r;
             trace[3 * trace_cap + it] = leaving;
         }
+        if (br == 0.0) rec->degenerate += 1;            // ratio 0: the basis changes, the vertex does not
         rec->iterations = it + 1;
     }
 }

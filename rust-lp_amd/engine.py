@@ -99,6 +99,7 @@ _SIGNATURES = {
     "relp_get_basis_inverse": (C.c_int, [C.c_void_p, C.c_void_p]),
     "relp_current_bfs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "relp_get_iterations": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_get_degenerate_pivots": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_get_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64)]),
     "relp_check_basis": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -381,6 +382,12 @@ class Tableau:
         cols, vals, cnt = np.zeros(m, dtype=np.int32), np.zeros(m), C.c_int32()
         self._ck(self._lib.relp_current_bfs(self._h, cols.ctypes.data, vals.ctypes.data, m, C.byref(cnt)))
         return list(zip(cols[:cnt.value].tolist(), vals[:cnt.value].tolist()))
+
+    def degenerate_pivots(self) -> int:
+        """Pivots so far with ratio exactly 0 (the basis changed, b did not)."""
+        out = C.c_int64()
+        self._ck(self._lib.relp_get_degenerate_pivots(self._h, C.byref(out)))
+        return out.value
 
     def iterations(self) -> int:
         v = C.c_int64()

@@ -708,24 +708,29 @@ def test_lu_engine_degenerate_sparse_reaches_the_oracle_optimum():
 def test_acc_tight4_degenerate_stress_prefix_matches_the_oracle():
     """BASELINE config C5's degenerate stress: MIPLIB acc-tight4 (3,285 constraints + 1,620 bound rows, all columns
     bounded; tests/miplib/test.rs:14-18, `#[ignore = "Too computationally expensive"]` in the reference: phase 1 alone
-    needs far more than 400,000 pivots, nearly all of them degenerate).  No optimum to pin, so the check is the path:
-    the first 1,500 pivots of every engine equal the f64 oracle's, ties and all, and the phase-1 objective never
-    increases over 6,000 pivots."""
+    needs far more than 400,000 pivots).  No optimum to pin, so the check is the path: the first 1,500 pivots of every
+    engine equal the f64 oracle's, ties and all (more than half of them have ratio exactly 0), and the phase-1
+    objective never increases over 6,000 pivots."""
     from lp_files import load
     gf, ex, md, emd = load("miplib/acc-tight4.mps", fixed=False)
     assert (md.nr_eq, md.nr_le, md.nr_ge, md.nr_normal) == (297, 756, 2232, 1620)
     ref = relp_f64.OracleF64(md)
     assert ref.run(1500) == "iteration_limit"
+    degenerate = []
     for kind, block in ((engine.ENGINE_TABLEAU, 64), (engine.ENGINE_REVISED, -1), (engine.ENGINE_LU, -1)):
         t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 13)
         objs = []
-        for _ in range(12):
+        for k in range(12):
             done, oc = t.run(500)
             assert done == 500 and oc == engine.RUNNING
             objs.append(t.objective_function_value())
+            if k == 2:
+                degenerate.append(t.degenerate_pivots())     # after the 1,500 pivots every engine shares
         assert t.trace()[:1500] == ref.trace
         assert all(b <= a + 1e-7 for a, b in zip(objs, objs[1:])) and objs[-1] < objs[0]
         t.close()
+    # the count SURVEY 8d asks for: pivots with ratio exactly 0 -- the same on every engine, and most of them
+    assert degenerate[0] == degenerate[1] == degenerate[2] and degenerate[0] > 750, degenerate
 
 
 # ------------------------------------------------------------------------------------------------

@@ -182,7 +182,7 @@ def test_25fv47_f64_oracle_with_looser_pivot_tolerance():
 def test_acc_tight4_standardises_and_the_oracle_walks_phase_one():
     """MIPLIB acc-tight4 (tests/miplib/test.rs:14-18, ignored by the reference as too expensive): the file goes through
     the reader, presolve and standardisation (3,285 constraint rows, every one of the 1,620 columns bounded), and the
-    f64 oracle starts phase 1 on it -- a few hundred of the > 400,000 heavily degenerate pivots it would need."""
+    f64 oracle starts phase 1 on it -- a few hundred of the > 400,000 pivots it would need."""
     gf, ex, md, emd = load("miplib/acc-tight4.mps", fixed=False)
     assert (md.nr_eq, md.nr_range, md.nr_le, md.nr_ge, md.nr_normal) == (297, 0, 756, 2232, 1620)
     assert int(np.isfinite(md.upper_bound).sum()) == 1620 and float(gf.fixed_cost) == 0.0
