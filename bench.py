@@ -97,6 +97,7 @@ def sparse_path(events, with_cpu):
     outcome = t.solve_relaxation()
     dt = time.perf_counter() - t0
     its = t.iterations()
+    degenerate = t.degenerate_pivots()
     stats = t.lu_stats()
     prof = t.profile_read() if events else {}
     obj = t.objective_function_value() + float(gf.fixed_cost)
@@ -104,7 +105,8 @@ def sparse_path(events, with_cpu):
     out = {"workload": f"Netlib 25FV47 after presolve: {stats['m']} rows, {md.nr_normal} structural columns, "
                        f"{len(md.values)} nonzeros; FirstProfitableWithMemory / SteepestDescent, whole two-phase solve",
            "engine": "lu", "outcome": engine.OUTCOME_NAMES.get(outcome), "objective": obj, "reference_objective": 5.5018459e+03,
-           "pivots": its, "value": its / dt, "unit": "iterations/s", "seconds": dt, "tolerances": tol,
+           "pivots": its, "degenerate_pivots": degenerate, "value": its / dt, "unit": "iterations/s", "seconds": dt,
+           "tolerances": tol,
            "refactorisations": stats["refactorisations"],
            "last_factor": {k: stats[k] for k in ("nnz_l", "nnz_u", "levels_l", "levels_u")}}
     if prof:

@@ -235,6 +235,8 @@ class Tableau {
         return out;
     }
     int64_t iterations() { int64_t it = 0; ck(relp_get_iterations(h_, &it)); return it; }
+    // pivots so far with ratio exactly 0 (the basis changed, the vertex did not)
+    int64_t degenerate_pivots() { int64_t n = 0; ck(relp_get_degenerate_pivots(h_, &n)); return n; }
     // f64 only (the exact reference never refactors `BasisInverseRows`): rebuild B^-1, b, -pi from the basis columns
     // every `pivots` basis changes; revised and tableau engines, default 1,000 for sparse input below 4,097 rows, 0 = never
     void set_reinversion_interval(int64_t pivots) { ck(relp_set_reinversion_interval(h_, pivots)); }
