@@ -317,7 +317,7 @@ def test_shard_entry_points_on_one_gpu(world, m, n, seed, kind, block):
         np.testing.assert_allclose(t.b(), single.b(), rtol=1e-9, atol=1e-9)
 
 
-def _native_ranks(world, make_md, kind, block, poll_interval=16, return_calls=False):
+def _native_ranks(world, make_md, kind, block, poll_interval=16, return_calls=False, limit=None):
     """G engines on one GPU, each driven by `relp_shard_run` on its own thread with the in-process collectives
     of tests/shard_threads.py; returns [(outcome of phase 1, pivots, outcome, trace, objective, b)] per rank."""
     import ctypes as C
@@ -339,6 +339,9 @@ def _native_ranks(world, make_md, kind, block, poll_interval=16, return_calls=Fa
     def body(r):
         t = tabs[r]
         done, oc = C.c_int64(), C.c_int32()
+        if limit is not None:                              # a bounded number of pivots of the current phase
+            assert lib.relp_shard_run(t.handle, limit, C.byref(done), C.byref(oc)) == 0, (lib.relp_last_error(t.handle).decode(), shared.errors)
+            return oc.value, done.value, oc.value, t.trace(), t.objective_function_value(), t.b()
         assert lib.relp_shard_run(t.handle, 1 << 20, C.byref(done), C.byref(oc)) == 0, (lib.relp_last_error(t.handle).decode(), shared.errors)
         first = oc.value
         total = done.value
@@ -731,6 +734,27 @@ def test_acc_tight4_degenerate_stress_prefix_matches_the_oracle():
         t.close()
     # the count SURVEY 8d asks for: pivots with ratio exactly 0 -- the same on every engine, and most of them
     assert degenerate[0] == degenerate[1] == degenerate[2] and degenerate[0] > 750, degenerate
+
+
+def test_acc_tight4_on_the_sharded_tableau_engine():
+    """Config C5 as BASELINE.json words it -- MIPLIB relaxation, degenerate pivoting stress, sharded pricing: the
+    first 1,000 phase-1 pivots of acc-tight4 on 4 ranks (native loop) are the f64 oracle's on every rank."""
+    import torch  # noqa: F401
+    from lp_files import load
+    gf, ex, md, emd = load("miplib/acc-tight4.mps", fixed=False)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run(1000) == "iteration_limit"
+    dense = np.array(md.ensure_dense().dense)
+
+    def make_md(cfg):
+        part = MatrixData(nr_normal=md.nr_normal, nr_eq=md.nr_eq, nr_range=md.nr_range, nr_le=md.nr_le, nr_ge=md.nr_ge, b=md.b,
+                          cost=md.cost, upper_bound=md.upper_bound, ranges=md.ranges)
+        lo, hi = engine.shard_plan(part, cfg)
+        part.dense = np.asfortranarray(dense[:, lo:hi]) if hi > lo else np.zeros((dense.shape[0], 1), order="F")
+        return part
+    for first, total, oc, trace, obj, b in _native_ranks(4, make_md, engine.ENGINE_TABLEAU, 64, poll_interval=100, limit=1000):
+        assert oc == engine.RUNNING and total == 1000
+        assert trace[:1000] == ref.trace
 
 
 # ------------------------------------------------------------------------------------------------
