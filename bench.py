@@ -8,6 +8,14 @@ resident in HBM before the timed region.  One JSON line on stdout (rank 0).
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N            (no WORLD_SIZE in the environment: starts the line above as a child)
+
+Timed region (warm-up, then the median of 5 runs).  The engines fold their pivots
+into the stored representation once per `update_block` pivots (the "flush"), so a window that is not a
+whole number of blocks would leave amortised work outside the clock.  The timed region is therefore
+5 windows of `steps_per_window` = max(K, 4 * update_block) rounded UP to whole blocks, the first one
+starting right after a flush; `steps` in the JSON is that actual pivot count per window, `value` =
+steps / median window time.
 
 Workloads (config.workload):
   dense10k  (default) m = 10,000 rows, n = 10,000 structural columns (+10,000 slacks), f64,
@@ -20,14 +28,17 @@ Engines (--engine):
   revised   explicit dense inverse `Carry<_, BasisInverseRows<_>>`: PRICE streams A (8 m n bytes) and
             FTRAN streams B^-1 (8 m^2 bytes) at every pivot -- the FTRAN/PRICE HBM-roofline numbers.
   At N = 1 the default run measures the tableau engine as `value` and adds the revised engine's
-  numbers under "revised_engine" (its own K timed pivots).
+  numbers under "revised_engine" and inside "roofline".
 N > 1: the same LP (strong scaling); the stored tableau columns are split contiguously over the
 ranks, ONE all-gather of [key, j, d_j, alpha(m)] candidates per pivot over RCCL, everything else local.
+Every N also reports "c4" (10,000 x 50,000, the shape whose flush is large enough for sharding to pay).
 """
 import argparse
 import json
 import os
 import shutil
+import statistics
+import subprocess
 import sys
 import time
 
@@ -38,122 +49,58 @@ if ROOT not in sys.path:
 WORKLOADS = {"dense10k": (10000, 10000, 20250002), "c2": (2000, 2000, 20250001), "c4": (10000, 50000, 20250003)}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F64_MFMA_PEAK_TF = 78.6    # FP64 matrix 78.6 TFLOP/s
+WINDOWS = 5                # median of 5 runs
+CPU_BUDGET_S = 20.0        # cpu_baseline: bounded sample (10-30 s of CPU work)
 
 
-def cpu_baseline(m, n, seed, warmup, steps, budget_s=20.0):
-    """The C (f64) restatement of the reference path (oracle/relp_f64.c, kind "port"), one core,
-    timed on the same LP over the same iteration window [warmup, warmup + k) until ~budget_s."""
-    from rust_lp_amd import MatrixData, synthetic
-    from oracle import relp_f64
-    lp = synthetic.dense_lp(m, n, seed)
-    md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]).ensure_csc()
-    md.dense = None
-    del lp
-    ref = relp_f64.OracleF64(md)
-    ref.run(max_iters=1 << 40, through_phases=False, record=False)      # empty phase 1 -> phase 2
-    ref.run(max_iters=warmup, record=False)
-    done, t0 = 0, time.perf_counter()
-    chunk = max(1, min(5, steps))
-    while done < steps and time.perf_counter() - t0 < budget_s:
-        ref.run(max_iters=min(chunk, steps - done), record=False)
-        done += ref.last_n_done
-        if ref.last_n_done == 0:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt if dt > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{done} pivots (iterations {warmup}..{warmup + done}) of the same {m}x{n} LP, "
-                      f"oracle/relp_f64.c (f64 restatement of Carry<_, BasisInverseRows>), {dt:.1f} s",
-            "nproc": os.cpu_count(), "cpu_model": cpu_model(),
-            "reference_toolchain": "cargo " + ("present (not used: the crate needs a 2021 nightly and crates.io)"
-                                               if shutil.which("cargo") else "absent on this host")}
+# ------------------------------------------------------------------------------------------------------------
+# Pure helpers (no GPU, no torch): window plan, algorithmic bytes, JSON assembly.  tests/test_bench_json.py
+# feeds these with profile dictionaries for K in {1, 20, 64, 200}.
+# ------------------------------------------------------------------------------------------------------------
+def window_steps(requested, block):
+    """Pivots per timed window: at least `requested`, at least 4 update blocks, a whole number of blocks."""
+    requested = max(int(requested), 1)
+    if block <= 0:
+        return requested
+    want = max(requested, 4 * block)
+    return (want + block - 1) // block * block
 
 
-def cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def sparse_path(events, with_cpu):
-    """The sparse path (BASELINE.json configs[2]): Netlib 25FV47 through the build's MPS reader, presolve and
-    standardisation, solved to optimality by the LU engine (host Markowitz refactorisation every 128 pivots,
-    level-scheduled FTRAN / BTRAN in LDS, CSC PRICE).  The whole solve is timed; it is latency-bound (the
-    factors are a few hundred KB), so the HBM figure is reported for what it is."""
-    from rust_lp_amd import engine, general_form, mps
-    path = os.path.join(ROOT, "tests", "golden", "mps", "netlib", "25FV47.SIF")
-    if not os.path.exists(path):
-        return None
-    gf = general_form.GeneralForm.from_mps(mps.import_file(path, True))
-    md = gf.to_matrix_data(gf.derive_matrix_data_exact())
-    tol = dict(tol_pivot=1e-5, tol_cost=1e-7)            # see tests/test_gpu_parity.py, config C3
-    t = engine.Tableau(md, engine=engine.ENGINE_LU, **tol)
-    if events:
-        t.profile_enable(True, 40000, 8)
-    t0 = time.perf_counter()
-    outcome = t.solve_relaxation()
-    dt = time.perf_counter() - t0
-    its = t.iterations()
-    degenerate = t.degenerate_pivots()
-    stats = t.lu_stats()
-    prof = t.profile_read() if events else {}
-    obj = t.objective_function_value() + float(gf.fixed_cost)
-    t.close()
-    out = {"workload": f"Netlib 25FV47 after presolve: {stats['m']} rows, {md.nr_normal} structural columns, "
-                       f"{len(md.values)} nonzeros; FirstProfitableWithMemory / SteepestDescent, whole two-phase solve",
-           "engine": "lu", "outcome": engine.OUTCOME_NAMES.get(outcome), "objective": obj, "reference_objective": 5.5018459e+03,
-           "pivots": its, "degenerate_pivots": degenerate, "value": its / dt, "unit": "iterations/s", "seconds": dt,
-           "tolerances": tol,
-           "refactorisations": stats["refactorisations"],
-           "last_factor": {k: stats[k] for k in ("nnz_l", "nnz_u", "levels_l", "levels_u")}}
-    if prof:
-        kt = {name: {"launches": cnt, "avg_us": round(ms * 1e3 / cnt, 3)} for name, (cnt, ms) in prof.items() if cnt}
-        out["kernels"] = kt
-        if "ftran" in kt:
-            factor_bytes = 12.0 * (stats["nnz_l"] + stats["nnz_u"]) + 40.0 * stats["m"]
-            out["ftran_GBps"] = round(factor_bytes / (kt["ftran"]["avg_us"] * 1e-6) / 1e9, 3)
-            out["ftran_note"] = "12 (nnz L + nnz U) + 40 m bytes of the last factor / average FTRAN time: dependency-bound"
-    # the same LP on the explicit-inverse engine (m = 790: B^-1 is 5 MB, the dense kernels are at their latency floor)
-    # (re-inverted every 1,000 pivots, the engine's default at this size)
-    t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=0, **tol)
-    t0 = time.perf_counter()
-    outcome2 = t.solve_relaxation()
-    dt2 = time.perf_counter() - t0
-    out["explicit_inverse_engine"] = {"outcome": engine.OUTCOME_NAMES.get(outcome2), "pivots": t.iterations(),
-                                      "value": t.iterations() / dt2, "unit": "iterations/s", "seconds": dt2,
-                                      "reinversions": t.reinversions(),
-                                      "objective": t.objective_function_value() + float(gf.fixed_cost)}
-    t.close()
-    # ... and on the dense tableau engine (T0 = 790 x 2,300 doubles; re-tabulated every 1,000 pivots)
-    t = engine.Tableau(md, engine=engine.ENGINE_TABLEAU, update_block=32, **tol)
-    t0 = time.perf_counter()
-    outcome3 = t.solve_relaxation()
-    dt3 = time.perf_counter() - t0
-    out["tableau_engine"] = {"outcome": engine.OUTCOME_NAMES.get(outcome3), "pivots": t.iterations(),
-                             "value": t.iterations() / dt3, "unit": "iterations/s", "seconds": dt3,
-                             "retabulations": t.reinversions(),
-                             "objective": t.objective_function_value() + float(gf.fixed_cost)}
-    t.close()
-    if with_cpu:
-        from oracle import relp_f64
-        ref = relp_f64.OracleF64(md, **tol)
-        c0 = time.perf_counter()
-        ref.run(max_iters=3000, record=False)
-        cdt = time.perf_counter() - c0
-        out["cpu_baseline"] = {"value": 3000 / cdt, "unit": "iterations/s", "cores": 1, "kind": "port",
-                               "sample": f"first 3000 pivots of the same LP, oracle/relp_f64.c, {cdt:.1f} s"}
-    return out
+def algorithmic_bytes(kind, m, n, world, block):
+    """Algorithmic HBM bytes (and flops) per launch of the streaming kernels, and per pivot, for the local shard.
+    DESIGN.md section 5 derives them; n = structural columns, the stored tableau has n + m columns."""
+    if kind == "tableau":
+        n_owned = (n + m + world - 1) // world
+        p_avg = max(block - 1, 0) / 2.0                              # average number of pending pivots in a block
+        per_pivot = 8.0 * n_owned * (p_avg + 1) + 8.0 * m * (p_avg + 1) + 16.0 * m * p_avg + 24.0 * m
+        flush = 16.0 * m * n_owned
+        return {"launch": {"flush": flush}, "flops": {"flush": 2.0 * m * n_owned * max(block, 1)},
+                "pivot": per_pivot + (flush / block if block > 0 else 0.0),
+                "pivot_formula": "8 n_s (p+1) [tableau row] + 8 m (p+1) [tableau column] + 16 m p [W update] + 24 m "
+                                 "[b, alpha, basis] with p = (K-1)/2 pending pivots on average, + 16 m n_s / K [flush]; "
+                                 "n_s = stored columns of this rank"}
+    rows_local = (m + world - 1) // world
+    n_local = (n + world - 1) // world
+    launch = {"price": 8.0 * m * n_local, "ftran": 8.0 * rows_local * m + 16.0 * m,
+              "update_inverse": 16.0 * rows_local * m, "flush": 16.0 * rows_local * m}
+    if block > 0:
+        p_avg = max(block - 1, 0) / 2.0
+        per_pivot = launch["price"] + launch["ftran"] + 24.0 * m * p_avg + 8.0 * m * (p_avg + 1) + launch["flush"] / block
+        formula = "8 m n_local [PRICE] + 8 m_local m [FTRAN] + 24 m p [W] + 8 m (p+1) [pivot row] + 16 m_local m / K [flush]"
+    else:
+        per_pivot = launch["price"] + launch["ftran"] + launch["update_inverse"] + 40.0 * m
+        formula = "8 m n_local [PRICE] + 8 m_local m [FTRAN] + 16 m_local m [rank-1 update] + 40 m (SURVEY.md section 8d)"
+    return {"launch": launch, "flops": {"flush": 2.0 * rows_local * m * max(block, 1)}, "pivot": per_pivot,
+            "pivot_formula": formula}
 
 
 def kernel_table(prof, alg_bytes, alg_flops):
+    """prof: {kernel class: (bracketed launches, total ms)} -> per-class averages (+ GB/s, TFLOP/s where defined)."""
     kernels = {}
-    for name, (cnt, ms) in prof.items():
-        if cnt > 0:
+    for name, (cnt, ms) in (prof or {}).items():
+        if cnt and cnt > 0 and ms > 0:
             avg_us = ms * 1e3 / cnt
-            entry = {"launches": cnt, "avg_us": round(avg_us, 3)}
+            entry = {"launches": int(cnt), "avg_us": round(avg_us, 3)}
             if name in alg_bytes:
                 entry["GBps"] = round(alg_bytes[name] / (avg_us * 1e-6) / 1e9, 1)
             if name in alg_flops:
@@ -172,6 +119,223 @@ def load_traffic(workload, kernel):
     return None
 
 
+TRAFFIC_KEY = {"price": "price_all", "ftran": "ftran", "update_inverse": "update_inverse_vectors", "flush": "flush_apply"}
+
+
+def kernel_roofline(kind, workload, kernels, alg):
+    """The streaming kernel that dominates the pivot, priced against HBM.  None when no bracketed launch of a
+    streaming kernel exists (events switched off)."""
+    if kind == "tableau":
+        fl = kernels.get("flush")
+        if not fl or "GBps" not in fl:
+            return None
+        return {"kernel": "k_tab_flush_lds", "bound": "hbm", "achieved": fl["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(fl["GBps"] / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload, "tab_flush_lds"),
+                "avg_us": fl["avg_us"], "launches_timed": fl["launches"],
+                "algorithmic_bytes_per_launch": alg["launch"]["flush"],
+                "mfma": {"achieved": fl.get("TFLOPs"), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s (f64 matrix)",
+                         "frac": round((fl.get("TFLOPs") or 0.0) / F64_MFMA_PEAK_TF, 4)}}
+    streaming = [k for k in ("price", "ftran", "update_inverse", "flush") if "GBps" in kernels.get(k, {})]
+    if not streaming:
+        return None
+    dom = max(streaming, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+    return {"kernel": "k_" + TRAFFIC_KEY[dom], "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4),
+            "traffic": load_traffic(workload, TRAFFIC_KEY[dom]), "avg_us": kernels[dom]["avg_us"],
+            "launches_timed": kernels[dom]["launches"], "algorithmic_bytes_per_launch": alg["launch"][dom]}
+
+
+def pivot_roofline(alg, ms_per_step):
+    """Whole pivot against HBM: algorithmic bytes of one pivot (flush share included) / measured time per pivot."""
+    gbps = alg["pivot"] / (ms_per_step * 1e-3) / 1e9 if ms_per_step > 0 else None
+    return {"algorithmic_bytes": round(alg["pivot"]), "formula": alg["pivot_formula"],
+            "achieved": round(gbps, 1) if gbps is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbps / HBM_PEAK_GBS, 4) if gbps is not None else None}
+
+
+def section(res, workload, m, n, world, kind):
+    """One measured engine -> its JSON section (value, window statistics, kernels, rooflines)."""
+    steps = res["steps"]
+    med = statistics.median(res["window_s"])
+    ms_per_step = med * 1e3 / steps
+    alg = algorithmic_bytes(kind, m, n, world, res["block"])
+    kernels = kernel_table(res.get("prof"), alg["launch"], alg["flops"])
+    roof = kernel_roofline(kind, workload, kernels, alg)
+    out = {"value": steps / med, "unit": "iterations/s", "steps": steps, "windows": len(res["window_s"]),
+           "ms_per_step": ms_per_step, "window_ms": [round(w * 1e3, 4) for w in res["window_s"]],
+           "update_block": res["block"], "kernels": kernels, "roofline": roof,
+           "pivot_roofline": pivot_roofline(alg, ms_per_step), "objective_after_run": res.get("objective")}
+    return out
+
+
+def assemble(args_ns, world, primary_kind, primary, secondary=None, c2=None, c4=None, sparse=None, cpu=None,
+             loop_kind=None):
+    """The ONE JSON line.  `primary` etc. are outputs of section(); any of the optional parts may be None, and no
+    kernel class is assumed to be present."""
+    m, n, seed = WORKLOADS[args_ns.workload]
+    roofline = dict(primary["roofline"]) if primary.get("roofline") else \
+        {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "note": "no bracketed launch of a streaming kernel in the timed windows (kernel events off)"}
+    roofline["pivot"] = primary["pivot_roofline"]
+    if secondary is not None:
+        k2 = secondary.get("kernels", {})
+        roofline["revised_engine"] = {
+            name: {"kernel": "k_" + TRAFFIC_KEY[name], "achieved": k2[name]["GBps"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                   "frac": round(k2[name]["GBps"] / HBM_PEAK_GBS, 4), "avg_us": k2[name]["avg_us"],
+                   "traffic": load_traffic(args_ns.workload, TRAFFIC_KEY[name])}
+            for name in ("ftran", "price", "update_inverse", "flush") if "GBps" in k2.get(name, {})}
+        roofline["revised_engine"]["pivot"] = secondary["pivot_roofline"]
+    out = {
+        "metric": "simplex iterations/sec", "value": primary["value"], "unit": "iterations/s", "n_gpus": world,
+        "steps": primary["steps"], "warmup": args_ns.warmup, "ms_per_step": primary["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args_ns.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), SteepestDescent, "
+                               + ("dense tableau with blocked f64-MFMA updates" if primary_kind == "tableau"
+                                  else "explicit dense basis inverse"),
+                   "m": m, "n": n, "seed": seed, "engine": primary_kind, "update_block": primary["update_block"],
+                   "parallelism": "single GPU" if world == 1 else
+                   (f"stored tableau columns sharded x{world}, one all-gather per pivot" if primary_kind == "tableau"
+                    else f"columns of A and rows of B^-1 sharded x{world}")},
+        "timing": {"steps_requested": args_ns.steps, "windows": primary["windows"], "window_ms": primary["window_ms"],
+                   "statistic": "median window; every window is a whole number of update blocks and starts right after a flush"},
+        "roofline": roofline, "kernels": primary["kernels"],
+        "kernel_event_stride": None if args_ns.no_kernel_events else args_ns.event_stride,
+        "objective_after_run": primary.get("objective_after_run"),
+        "reference_iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
+    }
+    if loop_kind:
+        out["config"]["shard_loop"] = loop_kind
+    if secondary is not None:
+        out["revised_engine"] = dict(secondary, note="explicit dense inverse (Carry<_, BasisInverseRows<_>>): PRICE streams A, "
+                                     "FTRAN streams B^-1 every pivot; GB/s = algorithmic bytes / HIP-event duration")
+    if c2 is not None:
+        out["c2"] = c2
+    if c4 is not None:
+        out["c4"] = c4
+    if sparse is not None:
+        out["sparse_engine"] = sparse
+    if world == 1:
+        out["cpu_baseline"] = cpu
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline and the sparse path
+# ------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(m, n, seed, warmup, budget_s=CPU_BUDGET_S, max_pivots=2000):
+    """The C (f64) restatement of the reference path (oracle/relp_f64.c, kind "port"), one core, timed on the same
+    LP from iteration `warmup` on until ~budget_s of CPU time (independent of --steps)."""
+    from rust_lp_amd import MatrixData, synthetic
+    from oracle import relp_f64
+    lp = synthetic.dense_lp(m, n, seed)
+    md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]).ensure_csc()
+    md.dense = None
+    del lp
+    ref = relp_f64.OracleF64(md)
+    ref.run(max_iters=1 << 40, through_phases=False, record=False)      # empty phase 1 -> phase 2
+    ref.run(max_iters=warmup, record=False)
+    done, t0 = 0, time.perf_counter()
+    while done < max_pivots and time.perf_counter() - t0 < budget_s:
+        ref.run(max_iters=5, record=False)
+        done += ref.last_n_done
+        if ref.last_n_done == 0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt if dt > 0 and done else None, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} pivots (iterations {warmup}..{warmup + done}) of the same {m}x{n} LP, "
+                      f"oracle/relp_f64.c (f64 restatement of Carry<_, BasisInverseRows>), {dt:.1f} s",
+            "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+            "reference_toolchain": "cargo " + ("present (not used: the crate needs a 2021 nightly and crates.io)"
+                                               if shutil.which("cargo") else "absent on this host")}
+
+
+def sparse_path(events, with_cpu):
+    """The sparse path (BASELINE.json configs[2]): Netlib 25FV47 through the build's MPS reader, presolve and
+    standardisation, solved to optimality by the LU engine.  The whole solve is timed; it is latency-bound (the
+    factors are a few hundred KB), so the HBM figure is reported for what it is."""
+    from rust_lp_amd import engine, general_form, mps
+    path = os.path.join(ROOT, "tests", "golden", "mps", "netlib", "25FV47.SIF")
+    if not os.path.exists(path):
+        return None
+    gf = general_form.GeneralForm.from_mps(mps.import_file(path, True))
+    md = gf.to_matrix_data(gf.derive_matrix_data_exact())
+    out = {"reference_objective": 5.5018459e+03, "tolerances": "relp_default_config"}
+
+    def solve(kind, **cfg):
+        t = engine.Tableau(md, engine=kind, **cfg)
+        if events and kind == engine.ENGINE_LU:
+            t.profile_enable(True, 40000, 8)
+        t0 = time.perf_counter()
+        outcome = t.solve_relaxation()
+        dt = time.perf_counter() - t0
+        its = t.iterations()
+        res = {"outcome": engine.OUTCOME_NAMES.get(outcome), "pivots": its, "value": its / dt if dt > 0 else None,
+               "unit": "iterations/s", "seconds": dt, "objective": t.objective_function_value() + float(gf.fixed_cost),
+               "degenerate_pivots": t.degenerate_pivots()}
+        return t, res
+
+    t, res = solve(engine.ENGINE_LU)
+    stats = t.lu_stats()
+    prof = t.profile_read() if events else {}
+    t.close()
+    out.update(res)
+    out.update({"workload": f"Netlib 25FV47 after presolve: {stats['m']} rows, {md.nr_normal} structural columns, "
+                            f"{len(md.values)} nonzeros; FirstProfitableWithMemory / SteepestDescent, whole two-phase solve",
+                "engine": "lu", "refactorisations": stats["refactorisations"],
+                "last_factor": {k: stats[k] for k in ("nnz_l", "nnz_u", "levels_l", "levels_u")}})
+    kt = {name: {"launches": cnt, "avg_us": round(ms * 1e3 / cnt, 3)} for name, (cnt, ms) in prof.items() if cnt}
+    if kt:
+        out["kernels"] = kt
+    if "ftran" in kt:
+        factor_bytes = 12.0 * (stats["nnz_l"] + stats["nnz_u"]) + 40.0 * stats["m"]
+        out["ftran_GBps"] = round(factor_bytes / (kt["ftran"]["avg_us"] * 1e-6) / 1e9, 3)
+        out["ftran_note"] = "12 (nnz L + nnz U) + 40 m bytes of the last factor / average FTRAN time: dependency-bound"
+    # the same LP on the explicit-inverse engine (m = 790: B^-1 is 5 MB) and on the dense tableau engine
+    t, res = solve(engine.ENGINE_REVISED, update_block=0)
+    res["reinversions"] = t.reinversions()
+    t.close()
+    out["explicit_inverse_engine"] = res
+    t, res = solve(engine.ENGINE_TABLEAU, update_block=32)
+    res["retabulations"] = t.reinversions()
+    t.close()
+    out["tableau_engine"] = res
+    if with_cpu:
+        from oracle import relp_f64
+        ref = relp_f64.OracleF64(md)
+        c0 = time.perf_counter()
+        ref.run(max_iters=3000, record=False)
+        cdt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": 3000 / cdt, "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"first 3000 pivots of the same LP, oracle/relp_f64.c, {cdt:.1f} s"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as a fresh child process (nothing in
+    this process has touched the GPU yet) and relay its single JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE)
+    sys.stdout.buffer.write(proc.stdout)
+    sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +348,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-path (LU engine, Netlib 25FV47) section")
     ap.add_argument("--no-c2", action="store_true", help="skip the configs[1] (dense 2,000 x 2,000) section")
+    ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] (dense 10,000 x 50,000) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
@@ -192,6 +357,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE JSON line: anything a library prints there on the way (RCCL writes its
     # version banner to stdout at communicator creation) is sent to stderr instead
@@ -212,10 +380,7 @@ def main():
     rehearse = os.environ.get("RELP_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
@@ -228,21 +393,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    m, n, seed = WORKLOADS[args.workload]
-    K, W = args.steps, args.warmup
+    K, W = max(args.steps, 1), max(args.warmup, 0)
     lib = engine.load_library()
     events = not args.no_kernel_events
-    primary = "tableau" if args.engine in ("default", "tableau") else "revised"
-
+    primary_kind = "tableau" if args.engine in ("default", "tableau") else "revised"
     loop_kind = {}
 
-    def measure(kind, m=m, n=n, seed=seed):
-        """Build the engine of `kind` on the synthetic LP (generated in HBM) and time K pivots."""
+    def measure(kind, workload):
+        """Build the engine of `kind` on the synthetic LP (generated in HBM), warm up, flush, and time WINDOWS
+        windows of whole update blocks."""
+        m, n, seed = WORKLOADS[workload]
         nums_b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
         nums_c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64))
         md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=nums_b / 4000.0, cost=nums_c / 1000.0,
                         upper_bound=np.full(n, np.inf))
-        cfg = engine.default_config(device=local_rank, poll_interval=max(K, W, 1), shard_rank=rank, shard_count=world,
+        cfg = engine.default_config(device=local_rank, poll_interval=1 << 20, shard_rank=rank, shard_count=world,
                                     engine=engine.ENGINE_TABLEAU if kind == "tableau" else engine.ENGINE_REVISED,
                                     update_block=args.update_block)
         col_lo, col_hi = engine.shard_plan(md, cfg)
@@ -252,18 +417,12 @@ def main():
         assert st == 0, "synthetic fill failed"
         t = engine.Tableau(md, config=cfg, device_dense_ptr=A.data_ptr(), device_dense_ld=m)
         torch.cuda.synchronize()
+        block = t.update_block()
+        steps = window_steps(K, block)
         if not sharded:
+            run, flush = t.run, t.flush
             done, oc = t.run(1)                        # phase 1 is empty (slack basis): one PRICE proves it
             assert oc == engine.PHASE_ONE_DONE, engine.OUTCOME_NAMES.get(oc)
-            done, oc = t.run(W)
-            assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
-            if events:
-                t.profile_enable(True, 12 * K + 16, args.event_stride)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            done, oc = t.run(K)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
         else:
             from rust_lp_amd.sharded import NativeShardedLoop, ShardedPivotLoop
             loop = None
@@ -275,122 +434,64 @@ def main():
                 except engine.RelpError as e:             # agreed on by all ranks (all-reduce MIN inside)
                     print(f"[bench] native sharded loop unavailable, using the Python loop: {e}", file=sys.stderr)
             if loop is None:
-                loop = ShardedPivotLoop(t, dist, dev)
+                loop = ShardedPivotLoop(t, dist, dev, poll_interval=1 << 20)
                 loop_kind[kind] = "python (torch.distributed collectives)"
-            oc = loop.finish_phase_one()
-            assert oc == engine.PHASE_ONE_DONE
-            done, oc = loop.run(W)
-            assert done == W and oc == engine.RUNNING
-            if events:
-                t.profile_enable(True, 12 * K + 16, args.event_stride)
-            dist.barrier()
+            run, flush = loop.run, loop.flush
+            assert loop.finish_phase_one() == engine.PHASE_ONE_DONE
+        if W > 0:
+            done, oc = run(W)
+            assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
+        flush()                                        # the first window starts with an empty update block
+        if events:
+            per_pivot = 12 * (WINDOWS * steps // max(args.event_stride, 1) + 1)
+            t.profile_enable(True, per_pivot + 4 * WINDOWS * (steps // max(block, 1) + 1) + 64, args.event_stride)
+        windows = []
+        for _ in range(WINDOWS):
+            if sharded:
+                dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            done, oc = loop.run(K)
+            done, oc = run(steps)
             torch.cuda.synchronize()
-            dist.barrier()
+            if sharded:
+                dist.barrier()
             dt = time.perf_counter() - t0
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        assert done == K, f"only {done} of {K} pivots were possible"
+            if sharded:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev if not rehearse else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            assert done == steps and oc == engine.RUNNING, f"only {done} of {steps} pivots were possible ({engine.OUTCOME_NAMES.get(oc)})"
+            windows.append(dt)
         prof = t.profile_read() if events else {}
-        block = t.update_block()
         obj = t.objective_function_value()
         t.close()
         del A
         torch.cuda.empty_cache()
-        # algorithmic bytes / flops per launch, local shard
-        if kind == "tableau":
-            n_store = n + m
-            n_owned = (n_store + world - 1) // world
-            alg_bytes = {"flush": 16.0 * m * n_owned}
-            alg_flops = {"flush": 2.0 * m * n_owned * block}
-        else:
-            rows_local = (m + world - 1) // world
-            alg_bytes = {"price": 8.0 * m * n_local, "ftran": 8.0 * rows_local * m + 16.0 * m,
-                         "update_inverse": 16.0 * rows_local * m, "flush": 16.0 * rows_local * m}
-            alg_flops = {"flush": 2.0 * rows_local * m * max(block, 1)}
-        return {"dt": dt, "kernels": kernel_table(prof, alg_bytes, alg_flops), "alg_bytes": alg_bytes, "block": block,
-                "objective": obj}
+        res = {"steps": steps, "window_s": windows, "prof": prof, "block": block, "objective": obj}
+        return section(res, workload, m, n, world, kind)
 
-    res = measure(primary)
-    dt, kernels = res["dt"], res["kernels"]
-
-    roofline = None
-    if kernels:
-        if primary == "tableau" and "flush" in kernels:
-            # the flush T0 += W R0 is the one kernel that streams the m x (n + m) tableau; at K = 64 its HBM time
-            # (16 m n bytes) exceeds its MFMA time (2 m n K flops at 78.6 TFLOP/s), so it is priced against HBM
-            fl = kernels["flush"]
-            roofline = {"kernel": "k_tab_flush_lds", "bound": "hbm", "achieved": fl["GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(fl["GBps"] / HBM_PEAK_GBS, 4),
-                        "traffic": load_traffic(args.workload, "tab_flush_lds"),
-                        "algorithmic_bytes_per_launch": res["alg_bytes"]["flush"],
-                        "launches_per_pivot": 1.0 / max(res["block"], 1),
-                        "mfma": {"achieved": fl.get("TFLOPs"), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s (f64 matrix)",
-                                 "frac": round(fl.get("TFLOPs", 0.0) / F64_MFMA_PEAK_TF, 4)}}
-        else:
-            streaming = [k for k in kernels if k in ("price", "ftran", "update_inverse")]
-            dom = max(streaming, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
-            traffic_key = {"price": "price_all", "ftran": "ftran", "update_inverse": "update_inverse_vectors"}[dom]
-            roofline = {"kernel": "k_" + traffic_key, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4),
-                        "traffic": load_traffic(args.workload, traffic_key),
-                        "algorithmic_bytes_per_launch": res["alg_bytes"][dom]}
-
-    secondary = None
-    if args.engine == "default" and not sharded and rank == 0:
-        r2 = measure("revised")
-        k2 = r2["kernels"]
-        secondary = {"value": K / r2["dt"], "unit": "iterations/s", "ms_per_step": r2["dt"] * 1e3 / K,
-                     "update_block": r2["block"], "kernels": k2,
-                     "note": "explicit dense inverse (Carry<_, BasisInverseRows<_>>): PRICE streams A, FTRAN streams B^-1 "
-                             "every pivot; GB/s = algorithmic bytes / HIP-event duration",
-                     "ftran_hbm_frac": round(k2["ftran"]["GBps"] / HBM_PEAK_GBS, 4) if "ftran" in k2 else None,
-                     "price_hbm_frac": round(k2["price"]["GBps"] / HBM_PEAK_GBS, 4) if "price" in k2 else None,
-                     "ftran_traffic": load_traffic(args.workload, "ftran"),
-                     "objective_after_run": r2["objective"]}
-
+    primary = measure(primary_kind, args.workload)
+    solo = args.engine == "default" and not sharded and rank == 0
+    secondary = measure("revised", args.workload) if solo else None
     # BASELINE.json configs[1] (dense 2,000 x 2,000, dense-tableau path) beside the 10k target, same engine
     c2 = None
-    if args.engine == "default" and not sharded and rank == 0 and args.workload != "c2" and not args.no_c2:
-        m2, n2, seed2 = WORKLOADS["c2"]
-        r3 = measure("tableau", m2, n2, seed2)
-        c2 = {"workload": f"c2: synthetic dense LP {m2}x{n2} f64, dense tableau", "value": K / r3["dt"], "unit": "iterations/s",
-              "ms_per_step": r3["dt"] * 1e3 / K, "update_block": r3["block"], "kernels": r3["kernels"],
-              "objective_after_run": r3["objective"]}
-
-    sparse = None
-    if args.engine == "default" and not sharded and rank == 0 and not args.no_sparse:
-        sparse = sparse_path(events, not args.no_cpu_baseline)
+    if solo and args.workload != "c2" and not args.no_c2:
+        m2, n2, _ = WORKLOADS["c2"]
+        c2 = dict(measure("tableau", "c2"), workload=f"c2: synthetic dense LP {m2}x{n2} f64, dense tableau")
+    # BASELINE.json configs[3] (10,000 x 50,000): at every N, the stored columns sharded like the primary workload
+    c4 = None
+    if args.engine == "default" and args.workload != "c4" and not args.no_c4:
+        m4, n4, _ = WORKLOADS["c4"]
+        c4 = dict(measure("tableau", "c4"), workload=f"c4: synthetic dense LP {m4}x{n4} f64, dense tableau, "
+                                                      + ("single GPU" if world == 1 else f"stored columns sharded x{world}"))
+    sparse = sparse_path(events, not args.no_cpu_baseline) if solo and not args.no_sparse else None
 
     if rank == 0:
-        out = {
-            "metric": "simplex iterations/sec", "value": K / dt, "unit": "iterations/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), SteepestDescent, "
-                                   + ("dense tableau with blocked f64-MFMA updates" if primary == "tableau"
-                                      else "explicit dense basis inverse"),
-                       "m": m, "n": n, "seed": seed, "engine": primary, "update_block": res["block"],
-                       "parallelism": "single GPU" if world == 1 else
-                       (f"stored tableau columns sharded x{world}, one all-gather per pivot" if primary == "tableau"
-                        else f"columns of A and rows of B^-1 sharded x{world}")},
-            "roofline": roofline, "kernels": kernels, "kernel_event_stride": args.event_stride if events else None,
-            "objective_after_run": res["objective"],
-            "reference_iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
-        }
-        if sharded:
-            out["config"]["shard_loop"] = loop_kind.get(primary)
-        if secondary is not None:
-            out["revised_engine"] = secondary
-        if c2 is not None:
-            out["c2"] = c2
-        if sparse is not None:
-            out["sparse_engine"] = sparse
-        if world == 1:
-            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(m, n, seed, W, K)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            m, n, seed = WORKLOADS[args.workload]
+            cpu = cpu_baseline(m, n, seed, W)
+        out = assemble(args, world, primary_kind, primary, secondary, c2, c4, sparse, cpu, loop_kind.get(primary_kind))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if sharded:

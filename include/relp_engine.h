@@ -86,7 +86,11 @@ typedef struct {
     int32_t phase_two_rule;
     double  tol_cost;             /* candidate iff d_j < -tol_cost          (pivot_rule.rs:56,81,117) */
     double  tol_pivot;            /* ratio test iff alpha_i > tol_pivot      (tableau/mod.rs:227).  Defaults:
-                                   * tol_cost = tol_pivot = tol_feas = 1e-7, tol_tie = 1e-9, tol_zero = 1e-11 */
+                                   * tol_cost = tol_feas = 1e-7, tol_pivot = 1e-5, tol_tie = 1e-9, tol_zero = 1e-11.
+                                   * tol_pivot is larger than the others because an alpha_i that is exactly 0 in the
+                                   * reference's rational field carries the rounding noise of B^-1 in f64 (1e-7 .. 1e-6 on
+                                   * unscaled Netlib data such as 25FV47, whose entries span 1e-3 .. 1e4): a pivot on
+                                   * such an element destroys the basis inverse */
     double  tol_zero;             /* |b_i| <= tol_zero reads as 0 in the ratio */
     double  tol_tie;              /* ratio ties: <= min + tol_tie*max(1,|min|), smallest leaving column wins
                                      (tableau/mod.rs:229-239) */

@@ -193,7 +193,7 @@ static int32_t select_primal_pivot_row(const oracle_engine_t *e, const svec *alp
         double x = alpha->d[k].val;
         if (x > c->tol_pivot) {
             double bi = e->b[alpha->d[k].idx];
-            if (fabs(bi) <= c->tol_zero) bi = 0.0;
+            if (bi <= c->tol_zero) bi = 0.0;      /* also clamps a b_i that rounding pushed below 0 */
             double ratio = bi / x;
             if (!any || ratio < min_ratio) { min_ratio = ratio; any = 1; }
         }
@@ -206,7 +206,7 @@ static int32_t select_primal_pivot_row(const oracle_engine_t *e, const svec *alp
         if (x > c->tol_pivot) {
             int32_t row = (int32_t)alpha->d[k].idx;
             double bi = e->b[row];
-            if (fabs(bi) <= c->tol_zero) bi = 0.0;
+            if (bi <= c->tol_zero) bi = 0.0;      /* also clamps a b_i that rounding pushed below 0 */
             double ratio = bi / x;
             if (ratio <= bound) {
                 int32_t leaving = e->basis_indices[row];

@@ -69,7 +69,7 @@ def lib():
     return _lib
 
 
-DEFAULT_TOLERANCES = dict(tol_cost=1e-7, tol_pivot=1e-7, tol_zero=1e-11, tol_tie=1e-9, tol_feas=1e-7)
+DEFAULT_TOLERANCES = dict(tol_cost=1e-7, tol_pivot=1e-5, tol_zero=1e-11, tol_tie=1e-9, tol_feas=1e-7)
 
 
 class OracleF64:

@@ -17,7 +17,7 @@ void relp_default_config(relp_config_t* cfg) {
     cfg->device = -1;
     cfg->phase_one_rule = RELP_RULE_FIRST_PROFITABLE_WITH_MEMORY;   // phase_one.rs:55,97
     cfg->phase_two_rule = RELP_RULE_STEEPEST_DESCENT;               // two_phase/mod.rs:44,101
-    cfg->tol_cost = 1e-7; cfg->tol_pivot = 1e-7; cfg->tol_zero = 1e-11; cfg->tol_tie = 1e-9; cfg->tol_feas = 1e-7;
+    cfg->tol_cost = 1e-7; cfg->tol_pivot = 1e-5; cfg->tol_zero = 1e-11; cfg->tol_tie = 1e-9; cfg->tol_feas = 1e-7;
     cfg->poll_interval = 64;
     cfg->trace_capacity = 0;
     cfg->shard_rank = 0; cfg->shard_count = 1;
@@ -26,7 +26,7 @@ void relp_default_config(relp_config_t* cfg) {
 }
 
 const char* relp_last_error(const relp_engine_t* h) { return h ? H(h).last_error() : "null handle"; }
-const char* relp_version(void) { return "relp-mi355x 0.1 (gfx950, explicit-inverse engine)"; }
+const char* relp_version(void) { return "relp-mi355x 0.2 (gfx950; engines: explicit inverse, dense tableau, sparse LU + Forrest-Tomlin)"; }
 
 relp_status_t relp_engine_create(const relp_matrix_data_t* md, const relp_config_t* cfg, relp_engine_t** out) {
     if (!md || !cfg || !out) return RELP_E_ARG;

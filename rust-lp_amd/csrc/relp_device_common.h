@@ -224,7 +224,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
             const double a = in ? alpha[i] : 0.0;
             double bi = in ? b[i] : 0.0;
             leave_r[k] = in ? basis_indices[i] : 0x7fffffff;
-            if (fabs(bi) <= tol.zero) bi = 0.0;
+            if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
             ratio_r[k] = (in && a > tol.pivot) ? bi / a : INFINITY;
             mn = fmin(mn, ratio_r[k]);
         }
@@ -233,7 +233,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
         for (int i = threadIdx.x; i < m; i += BS) {
             const double a = alpha[i];
             double bi = b[i];
-            if (fabs(bi) <= tol.zero) bi = 0.0;
+            if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
             const double ratio = (a > tol.pivot) ? bi / a : INFINITY;
             mn = fmin(mn, ratio);
         }
@@ -267,7 +267,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
             const double a = alpha[i];
             double bi = b[i];
             const int lv = basis_indices[i];
-            if (fabs(bi) <= tol.zero) bi = 0.0;
+            if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
             if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
         }
     }
@@ -280,7 +280,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
 // (usually one or two blocks) are read again.  Same result as ratio_body.  `p` = rec->n_eta read by the caller.
 // b_i / alpha_i as the ratio test's first pass forms it (ratio_body), +inf when the row does not qualify
 __device__ __forceinline__ double row_ratio(double a, double bi, const Tolerances& tol) {
-    if (fabs(bi) <= tol.zero) bi = 0.0;
+    if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
     return a > tol.pivot ? bi / a : INFINITY;
 }
 
@@ -332,7 +332,7 @@ __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alp
         if (i >= m) continue;
         const double a = alpha[i];
         double bi = b[i];
-        if (fabs(bi) <= tol.zero) bi = 0.0;
+        if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
         if (a > tol.pivot && bi / a <= bound) {
             const int lv = basis_indices[i];
             if (lv < best_leave) { best_leave = lv; best_row = i; }

@@ -560,8 +560,22 @@ void Engine::enqueue_flush() {
 }
 
 relp_status_t Engine::flush() {
-    if (cfg_.shard_count > 1 && block_ > 0) return fail(RELP_E_STATE, "sharded flush needs relp_shard_flush_begin/end");
-    enqueue_flush();
+    if (cfg_.shard_count > 1 && block_ > 0 && !tableau_) {
+        // the rows S' B0inv live on different ranks: with the collective hooks attached the library completes the
+        // snapshot itself (every rank must call), otherwise the caller drives relp_shard_flush_begin / _end
+        if (!coll_allreduce_) return fail(RELP_E_STATE, "sharded flush needs relp_shard_flush_begin/end (or the collective hooks)");
+        if (since_flush_ == 0) return RELP_OK;
+        double* snap = nullptr; int64_t len = 0;
+        relp_status_t st = shard_flush_begin(&snap, &len);
+        if (st) return st;
+        if (len > 0) {
+            if (coll_allreduce_(coll_ctx_, snap, len, stream_)) return fail(RELP_E_HIP, "all-reduce of the flush snapshot failed");
+            if ((st = shard_flush_end())) return st;
+        }
+        since_flush_ = 0;
+        return RELP_OK;
+    }
+    enqueue_flush();                                   // sharded tableau: the flush is local to the owned columns
     return RELP_OK;
 }
 

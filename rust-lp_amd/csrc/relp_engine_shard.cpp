@@ -71,8 +71,8 @@ relp_status_t Engine::shard_select_column(const double* dev_candidates, int32_t 
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     if (tableau_) {
         // the winner's payload is the entering tableau column (alpha) itself: pick it and run the ratio test
-        prof_begin(RELP_K_RATIO);
         if (count > 64) return fail(RELP_E_UNSUPPORTED, "at most 64 shards");
+        prof_begin(RELP_K_RATIO);
         launch_tab_select_candidate_ratio(dev_candidates, count, cand_len_, m_, d_alpha_, d_b_, d_basis_, rule, tolerances(),
                                           deferred(), -1, d_rec_, stream_);
         prof_end();

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
         alpha[i] = a;
         // the same expression as the ratio test's first pass (ratio_body), so min over the block minima is
         // bit for bit the minimum over all rows
-        const double bz = fabs(b_i) <= tol.zero ? 0.0 : b_i;
+        const double bz = b_i <= tol.zero ? 0.0 : b_i;
         if (a > tol.pivot) ratio = bz / a;
     }
     if (!rmin) return;

@@ -234,6 +234,19 @@ class ShardedPivotLoop:
             self.ops.flush_end()
         self._since_flush = 0
 
+    def flush(self):
+        """Fold the pending pivots into the stored representation now (every rank must call): the tableau engine's
+        flush is local to the owned columns, the revised engine's needs the all-reduce of `_flush`."""
+        if getattr(self.ops, "tableau", False):
+            if hasattr(self.ops, "lib"):                       # (the numpy stand-ins of the CPU tests keep no block)
+                self.ops._ck(self.ops.lib.relp_flush(self.ops.h))
+        elif self._block > 0 and self._since_flush > 0:
+            if self.stream is not None:
+                with self.torch.cuda.stream(self.stream):
+                    self._flush()
+            else:
+                self._flush()
+
     def _enqueue(self, count: int):
         if self.stream is not None:
             with self.torch.cuda.stream(self.stream):
@@ -327,3 +340,10 @@ class NativeShardedLoop:
 
     def finish_phase_one(self) -> int:
         return self.run(1)[1]
+
+    def flush(self):
+        """relp_flush on every rank: local for the tableau engine, completed by the library's own all-reduce
+        (the RCCL hooks are attached) for the revised engine."""
+        st = self.lib.relp_flush(self.h)
+        if st != 0:
+            raise _engine.RelpError(f"relp_flush failed ({st}): {self.lib.relp_last_error(self.h).decode()}")

@@ -35,8 +35,6 @@ def main():
                           ("lu16", dict(engine=engine.ENGINE_LU, update_block=16)),
                           ("revised", dict(engine=engine.ENGINE_REVISED, update_block=0)),
                           ("tableau", dict(engine=engine.ENGINE_TABLEAU, update_block=32))):
-            if "25FV47" in name:
-                kw = dict(kw, tol_pivot=1e-5, tol_cost=1e-7)     # config C3, see tests/test_gpu_parity.py
             t = engine.Tableau(md, **kw)
             t0 = time.perf_counter()
             try:

@@ -13,6 +13,6 @@ else:
     from rust_lp_amd import general_form, mps
     gf = general_form.GeneralForm.from_mps(mps.import_file(os.path.join("tests", "golden", "mps", "netlib", "25FV47.SIF"), True))
     md = gf.to_matrix_data(gf.derive_matrix_data_exact())
-    kw = dict(tol_pivot=1e-5, tol_cost=1e-7)
+    kw = {}
 t = engine.Tableau(md, engine=engine.ENGINE_LU, **kw)
 print(engine.OUTCOME_NAMES[t.solve_relaxation()], t.iterations(), t.lu_stats())

@@ -7,7 +7,7 @@ RUNNING, OPTIMAL, UNBOUNDED, PHASE_ONE_DONE = 0, 1, 2, 4
 
 
 class NumpyShardOps:
-    def __init__(self, rank, world, m, n, A_local, col_lo, b, c, tol_cost=1e-7, tol_pivot=1e-7, tol_zero=1e-11,
+    def __init__(self, rank, world, m, n, A_local, col_lo, b, c, tol_cost=1e-7, tol_pivot=1e-5, tol_zero=1e-11,
                  tol_tie=1e-9):
         self.rank, self.world, self.m, self.n = rank, world, m, n
         self.A, self.col_lo, self.col_hi = A_local, col_lo, col_lo + A_local.shape[1]
@@ -96,7 +96,7 @@ class NumpyShardOps:
         if not pos.any():
             self.outcome = 2
             return
-        bb = np.where(np.abs(self.b) <= tz, 0.0, self.b)
+        bb = np.where(self.b <= tz, 0.0, self.b)
         ratios = np.where(pos, bb / np.where(pos, self.alpha, 1.0), np.inf)
         mn = ratios.min()
         tie = pos & (ratios <= mn + tt * max(1.0, abs(mn)))
@@ -147,7 +147,7 @@ class NumpyTableauShardOps:
     tableau = True
     update_block = 0
 
-    def __init__(self, rank, world, m, n, A_full, b, c, tol_cost=1e-7, tol_pivot=1e-7, tol_zero=1e-11, tol_tie=1e-9):
+    def __init__(self, rank, world, m, n, A_full, b, c, tol_cost=1e-7, tol_pivot=1e-5, tol_zero=1e-11, tol_tie=1e-9):
         self.m, self.n = m, n
         n_store = n + m
         per = -(-n_store // world)
@@ -212,7 +212,7 @@ class NumpyTableauShardOps:
         if not pos.any():
             self.outcome = 2
             return
-        bb = np.where(np.abs(self.b) <= tz, 0.0, self.b)
+        bb = np.where(self.b <= tz, 0.0, self.b)
         ratios = np.where(pos, bb / np.where(pos, self.alpha, 1.0), np.inf)
         mn = ratios.min()
         rows = np.nonzero(pos & (ratios <= mn + tt * max(1.0, abs(mn))))[0]

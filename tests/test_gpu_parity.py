@@ -332,7 +332,9 @@ def _native_ranks(world, make_md, kind, block, poll_interval=16, return_calls=Fa
     for r in range(world):
         cfg = engine.default_config(shard_rank=r, shard_count=world, engine=kind, update_block=block, trace_capacity=1 << 14,
                                     poll_interval=poll_interval)
-        t = engine.Tableau(make_md(cfg), config=cfg)
+        made = make_md(cfg)                              # MatrixData, or (MatrixData, Tableau keyword arguments)
+        md_r, kw_r = made if isinstance(made, tuple) else (made, {})
+        t = engine.Tableau(md_r, config=cfg, **kw_r)
         tabs.append(t)
         ranks.append(ThreadRank(shared, r, lib, t.handle, torch, dev))
 
@@ -760,30 +762,47 @@ def test_acc_tight4_on_the_sharded_tableau_engine():
 # ------------------------------------------------------------------------------------------------
 # Config C3: Netlib 25FV47 (BASELINE.json configs[2])
 # ------------------------------------------------------------------------------------------------
-C3_TOLERANCES = dict(tol_pivot=1e-5, tol_cost=1e-7)
-
-
-@pytest.mark.parametrize("kind,block", [(engine.ENGINE_LU, 64), (engine.ENGINE_REVISED, 0)])
-def test_25fv47_reaches_the_netlib_optimum(kind, block):
-    """25FV47 after presolve: m = 790 rows, 1,539 structural columns, ~12,000 pivots over two phases.  With
-    the default 1e-9 pivot tolerance f64 loses feasibility in phase 1 (pivots on 1e-9-sized elements; CPU
-    oracle and GPU alike - the reference is exact and `#[ignore]`s this file as too expensive); with
-    tol_pivot = 1e-5, tol_cost = 1e-7 the LU engine (the configuration BASELINE.json names: eta-file basis
-    maintenance) and the explicit-inverse engine reach the optimum the reference pins (the dense tableau
-    engine: test_25fv47_on_the_tableau_engine_with_periodic_retabulation)
-    (tests/netlib/test.rs:152-158: 5.5018459e+03, given to 8 digits).  The first 300 pivots equal the CPU
-    oracle's with the same tolerances."""
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_LU, -1), (engine.ENGINE_REVISED, 0), (engine.ENGINE_TABLEAU, 32)])
+def test_25fv47_reaches_the_netlib_optimum_under_the_default_config(kind, block):
+    """25FV47 after presolve: m = 790 rows, 1,539 structural columns, ~12,000 pivots over two phases, solved with
+    `relp_default_config` (no hand-set tolerances) by all three engines: the LU engine (the configuration
+    BASELINE.json names: eta-file basis maintenance), the explicit-inverse engine and the dense tableau reach the
+    optimum the reference pins (tests/netlib/test.rs:152-158: 5.5018459e+03, given to 8 digits; the reference is
+    exact and `#[ignore]`s this file as too expensive)."""
     from lp_files import load
     gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
-    t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 15, **C3_TOLERANCES)
+    t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 15)
+    assert t.config.tol_pivot == 1e-5 and t.config.tol_cost == 1e-7            # relp_default_config
     assert t.solve_relaxation() == engine.OPTIMAL
     got = t.objective_function_value() + float(gf.fixed_cost)
     assert abs(got - 5.5018459e+03) < 1e-4
-    ref = relp_f64.OracleF64(md, **C3_TOLERANCES)
-    ref.run(300, through_phases=True)
-    assert t.trace()[:300] == ref.trace
     ident, basic, min_b = t.check_basis()
     assert ident <= 1e-6 and min_b >= -1e-6
+    t.close()
+
+
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_REVISED, 0), (engine.ENGINE_LU, -1)])
+def test_25fv47_whole_phase_one_equals_the_f64_oracle(kind, block):
+    """The whole of phase 1 (5,602 pivots, FirstProfitableWithMemory, 446 artificial variables driven out) pivot by
+    pivot against oracle/relp_f64.c under the default tolerances, then the phase switch: same basis, b and -pi.
+    The explicit-inverse engine runs without its periodic re-inversion here (the oracle is
+    `Carry<_, BasisInverseRows>` literally: an inverse that is only ever updated)."""
+    from lp_files import load
+    gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run(through_phases=False) == "phase_one_done"
+    t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 14)
+    if kind == engine.ENGINE_REVISED:
+        t.set_reinversion_interval(0)
+    done, oc = t.run(1 << 20)
+    assert oc == engine.PHASE_ONE_DONE
+    tr = t.trace()
+    first_diff = next((k for k, (a, b) in enumerate(zip(tr, ref.trace)) if a != b), None)
+    assert first_diff is None and len(tr) == len(ref.trace), f"traces differ at pivot {first_diff} of {len(ref.trace)}"
+    assert t.basis_indices().tolist() == ref.basis().tolist()
+    bref = ref.b()
+    assert np.max(np.abs(t.b() - bref)) <= 1e-6 * max(1.0, np.max(np.abs(bref)))
+    t.close()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -833,6 +852,126 @@ def test_dense10k_full_size_engines_agree_and_match_the_cpu_oracle_prefix():
     assert lib.relp_device_free(ptr) == 0
 
 
+# ------------------------------------------------------------------------------------------------
+# Config C4: synthetic dense 10,000 x 50,000 (BASELINE.json configs[3]), one GPU and 8 shards on one GPU
+# ------------------------------------------------------------------------------------------------
+def _c4_fixture():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_prefix.json")
+    fx = json.load(open(path))
+    assert (fx["m"], fx["n"], fx["seed"]) == (10000, 50000, 20250003) and fx["pivots"] >= 40
+    return fx, [tuple(t) for t in fx["trace"]]
+
+
+def _c4_counts():
+    m, n, seed = 10000, 50000, 20250003
+    b = n * (1000 + (synthetic.splitmix64(seed, 1, np.arange(m, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64)) / 4000.0
+    c = -(1000 + (synthetic.splitmix64(seed, 2, np.arange(n, dtype=np.uint64)) % np.uint64(1000)).astype(np.int64)) / 1000.0
+    return m, n, seed, b, c
+
+
+def test_c4_full_size_on_one_gpu_matches_the_oracle_prefix_and_both_engines_agree():
+    """10,000 x 50,000 generated in HBM (4 GB; the tableau is 4.8 GB).  The first 40 pivots equal the f64 CPU
+    oracle's (tests/golden/c4_prefix.json, scripts/gen_c4_prefix.py: too large to re-run here), the tableau and the
+    revised engine walk the same 192 pivots (three flush blocks of 64), and the size-independent invariants hold."""
+    import ctypes as C
+    lib = engine.load_library()
+    fx, prefix = _c4_fixture()
+    m, n, seed, b, c = _c4_counts()
+    ptr = C.c_void_p()
+    assert lib.relp_device_alloc(C.byref(ptr), m * n * 8) == 0
+    assert lib.relp_synth_fill_dense(ptr, m, m, n, seed, 0, None) == 0
+    counts = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=b, cost=c, upper_bound=np.full(n, np.inf))
+    traces = []
+    for kind in (engine.ENGINE_TABLEAU, engine.ENGINE_REVISED):
+        t = engine.Tableau(counts, engine=kind, device_dense_ptr=ptr.value, device_dense_ld=m, trace_capacity=1024)
+        assert t.update_block() == 64
+        assert t.run(1)[1] == engine.PHASE_ONE_DONE
+        objs = []
+        for _ in range(3):
+            done, outcome = t.run(64)
+            assert done == 64 and outcome == engine.RUNNING
+            objs.append(t.objective_function_value())
+        assert all(y <= x + 1e-9 for x, y in zip(objs, objs[1:]))           # monotone objective
+        tr = t.trace()
+        assert tr[:40] == prefix[:40]
+        bb, basis = t.b(), t.basis_indices()
+        assert bb.min() >= -1e-8 and len(set(basis.tolist())) == m
+        d = t.relative_costs()
+        assert np.max(np.abs(d[basis])) <= 1e-7                              # basic reduced costs vanish
+        cc = np.concatenate([c, np.zeros(m)])
+        assert abs(cc[basis] @ bb - objs[-1]) <= 1e-9 * abs(objs[-1])       # objective = c_B . x_B
+        traces.append(tr)
+        t.close()
+    assert traces[0] == traces[1] and len(traces[0]) == 192
+    assert lib.relp_device_free(ptr) == 0
+
+
+def test_c4_full_size_column_sharded_over_eight_ranks_on_one_gpu():
+    """BASELINE.json configs[3] as it is meant to run: the 60,000 stored tableau columns split over 8 ranks (7,500
+    each), every rank's structural columns generated in HBM, one all-gather of the PRICE candidates per pivot, the
+    native loop (`relp_shard_run`) on one thread per rank with tests/shard_threads.py standing in for RCCL (which
+    refuses two ranks on one device).  Every rank walks the oracle's 40-pivot prefix and the same 192 pivots
+    (three local flushes) with the same objective and b."""
+    import ctypes as C
+    import torch  # noqa: F401
+    lib = engine.load_library()
+    fx, prefix = _c4_fixture()
+    m, n, seed, b, c = _c4_counts()
+    owned = []
+
+    def make_md(cfg):
+        md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=b, cost=c, upper_bound=np.full(n, np.inf))
+        lo, hi = engine.shard_plan(md, cfg)
+        ptr = C.c_void_p()
+        assert lib.relp_device_alloc(C.byref(ptr), max(hi - lo, 1) * m * 8) == 0
+        assert lib.relp_synth_fill_dense(ptr, m, m, hi - lo, seed, lo, None) == 0
+        owned.append(ptr)
+        return md, dict(device_dense_ptr=ptr.value, device_dense_ld=m)
+    results = _c4_sharded_run(lib, make_md, 192)
+    for p in owned:
+        assert lib.relp_device_free(p) == 0
+    first = results[0]
+    assert first[0][:40] == prefix[:40] and len(first[0]) == 192
+    for tr, obj, bb in results[1:]:
+        assert tr == first[0] and obj == first[1]
+        np.testing.assert_array_equal(bb, first[2])
+    assert first[2].min() >= -1e-8
+
+
+def _c4_sharded_run(lib, make_md, pivots, world=8):
+    import ctypes as C
+    import torch
+    from shard_threads import ThreadRank, ThreadWorld, run_ranks
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+    shared = ThreadWorld(world)
+    tabs, ranks = [], []
+    for r in range(world):
+        cfg = engine.default_config(shard_rank=r, shard_count=world, engine=engine.ENGINE_TABLEAU, update_block=64,
+                                    trace_capacity=1024, poll_interval=64)
+        md, kw = make_md(cfg)
+        t = engine.Tableau(md, config=cfg, **kw)
+        tabs.append(t)
+        ranks.append(ThreadRank(shared, r, lib, t.handle, torch, dev))
+
+    def body(r):
+        t = tabs[r]
+        done, oc = C.c_int64(), C.c_int32()
+        assert lib.relp_shard_run(t.handle, 1, C.byref(done), C.byref(oc)) == 0, lib.relp_last_error(t.handle).decode()
+        assert oc.value == engine.PHASE_ONE_DONE
+        assert lib.relp_shard_run(t.handle, pivots, C.byref(done), C.byref(oc)) == 0, lib.relp_last_error(t.handle).decode()
+        assert done.value == pivots and oc.value == engine.RUNNING
+        return t.trace(), t.objective_function_value(), t.b()
+    out = run_ranks(world, body)
+    assert not shared.errors, shared.errors
+    assert all(rk.calls["allgather"] >= pivots for rk in ranks)
+    for t in tabs:
+        t.close()
+    return out
+
+
 @pytest.mark.parametrize("degenerate_rows", ["all", "most", "few"])
 def test_ratio_test_from_block_minima_on_many_degenerate_rows(degenerate_rows):
     """17,000 rows = 67 blocks of 256: the tableau engine's ratio test starts from the per-block minimum ratios
@@ -873,7 +1012,7 @@ def test_25fv47_on_the_tableau_engine_with_periodic_retabulation(block):
     column), b and d with it: the reference's pin, and a tableau that still is B^-1 [A | I]."""
     from lp_files import load
     gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
-    t = engine.Tableau(md, engine=engine.ENGINE_TABLEAU, update_block=block, **C3_TOLERANCES)
+    t = engine.Tableau(md, engine=engine.ENGINE_TABLEAU, update_block=block)
     assert t.solve_relaxation() == engine.OPTIMAL
     assert t.reinversions() >= 8
     got = t.objective_function_value() + float(gf.fixed_cost)
@@ -891,7 +1030,7 @@ def test_25fv47_with_periodic_reinversion_is_block_independent(block):
     every block length reaches the reference's pin, and the inverse stays accurate."""
     from lp_files import load
     gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
-    t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=block, **C3_TOLERANCES)
+    t = engine.Tableau(md, engine=engine.ENGINE_REVISED, update_block=block)
     assert t.solve_relaxation() == engine.OPTIMAL
     assert t.reinversions() >= 8
     got = t.objective_function_value() + float(gf.fixed_cost)

@@ -170,11 +170,14 @@ def test_free_and_fixed_parsers_agree_on_adlittle():
     assert a.rows == b.rows and a.columns == b.columns and a.rhss == b.rhss and a.cost_values == b.cost_values
 
 
-def test_25fv47_f64_oracle_with_looser_pivot_tolerance():
+def test_25fv47_f64_oracle_under_the_default_tolerances():
     """Config C3.  tests/netlib/test.rs:152-158 pins 5.5018459e+03 (8 digits; the reference ignores the test
-    as too expensive for exact arithmetic).  f64 needs a pivot tolerance above the 1e-9 default here."""
+    as too expensive for exact arithmetic).  The default tolerances (the engine's relp_default_config: tol_pivot
+    1e-5, the others 1e-7 .. 1e-11) reach it; a pivot tolerance of 1e-6 or below accepts rounding noise of B^-1
+    as a pivot element on this unscaled file and loses feasibility in phase 1."""
     gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
-    ref = relp_f64.OracleF64(md, tol_pivot=1e-5, tol_cost=1e-7)
+    assert relp_f64.DEFAULT_TOLERANCES["tol_pivot"] == 1e-5
+    ref = relp_f64.OracleF64(md)
     assert ref.run(max_iters=100000) == "optimal"
     assert abs(ref.objective + float(gf.fixed_cost) - 5.5018459e+03) < 1e-4
 
