@@ -188,6 +188,39 @@ int32_t       relp_update_block(const relp_engine_t *h);
  * U', L' (BTRAN) }.  Levels bound the length of the dependent chain of a triangular solve. */
 relp_status_t relp_lu_stats(const relp_engine_t *h, int64_t *out8);
 
+/* ---- the `BasisInverse` surface (carry/mod.rs:68-157) beside the tableau-level calls above ------------------------
+ * BasisInverse::basis_inverse_row(row) (carry/mod.rs:145-150): row `row` of B^-1, dense, m entries.  LU engine: one BTRAN
+ * of e_row (lower_upper/mod.rs:204-222); revised engine: a copy of the stored row (basis_inverse_rows.rs:181-183);
+ * tableau engine: row `row` of the tableau over the columns that were the identity. */
+relp_status_t relp_basis_inverse_row(relp_engine_t *h, int32_t row, double *out_m);
+/* BasisInverse::should_refactor (carry/mod.rs:138-143).  LU engine: 1 when as many updates are pending as
+ * relp_config_t.update_block allows (lower_upper/mod.rs:199-202 refactors when updates.len() > 10: update_block = 11) or the
+ * eta pool is exhausted; relp_run / relp_bring_into_basis refactor by themselves (Carry::after_basis_change,
+ * carry/mod.rs:602-614).  Revised and tableau engine: always 0 (basis_inverse_rows.rs:175-179). */
+relp_status_t relp_should_refactor(relp_engine_t *h, int32_t *out);
+/* BasisInverse::generate_column(original_column) (carry/mod.rs:108-118) for a column the caller supplies as sorted
+ * (row, value) pairs over the m tableau rows -- the reference's signature, where relp_generate_column takes a column
+ * index of the provider.  The result also becomes the "last generated column" (relp_select_primal_pivot_row,
+ * relp_lu_change_basis).  Tableau engine: computed on the host from B^-1 read off the tableau. */
+relp_status_t relp_generate_column_of(relp_engine_t *h, const int32_t *row_idx, const double *values, int32_t nnz, double *out_m);
+/* InverseMaintener::cost_difference(column) (carry/mod.rs:572-577): (-pi) . column */
+relp_status_t relp_cost_difference_of(relp_engine_t *h, const int32_t *row_idx, const double *values, int32_t nnz, double *out);
+/* BasisInverse::change_basis(pivot_row_index, column) on the inverse alone (lower_upper/mod.rs:92-155): the Forrest-Tomlin
+ * update with the column (and spike, mod.rs:378-381) of the last relp_generate_column / relp_generate_column_of.  b, -pi and
+ * the basis indices are NOT touched (that is Carry::change_basis = relp_bring_into_basis).  LU engine only. */
+relp_status_t relp_lu_change_basis(relp_engine_t *h, int32_t pivot_row_index);
+/* `LUDecomposition { row_permutation: identity, column_permutation: identity, lower_triangular, upper_triangular, updates: [] }`
+ * given literally (lower_upper/mod.rs:33-57), the way the reference's tests construct their starting points: L column-major
+ * with the unit diagonal implied, U column-major with its diagonal; CSC arrays of m columns each. */
+relp_status_t relp_lu_set_factors(relp_engine_t *h, const int64_t *l_col_ptr, const int32_t *l_row_idx, const double *l_values,
+                                  const int64_t *u_col_ptr, const int32_t *u_row_idx, const double *u_values);
+/* The update file in the reference's coordinates: `updates.len()`; `updates[k]` = (EtaFile { values, pivot, len },
+ * RotateToBack { index: pivot }) with positions as they were before that rotation (eta_file.rs:14-18, mod.rs:56);
+ * `upper_triangular` after every update so far: column-major, rows sorted, diagonal last in its column (mod.rs:48-52). */
+relp_status_t relp_lu_updates(relp_engine_t *h, int32_t *count);
+relp_status_t relp_lu_get_update(relp_engine_t *h, int32_t k, int32_t *pivot, int32_t *idx, double *values, int32_t cap, int32_t *nnz);
+relp_status_t relp_lu_get_upper(relp_engine_t *h, int64_t *col_ptr_m1, int32_t *row_idx, double *values, int64_t cap, int64_t *nnz);
+
 /* ---- state getters (InverseMaintener accessors, inverse_maintenance/mod.rs:200-266) ----------- */
 int32_t relp_nr_rows(const relp_engine_t *h);
 int32_t relp_nr_columns(const relp_engine_t *h);
@@ -216,8 +249,9 @@ typedef enum {
     RELP_K_RATIO = 4, RELP_K_UPDATE_VECTORS = 5, RELP_K_UPDATE_INVERSE = 6,
     RELP_K_APPLY_W = 7,          /* deferred update: alpha = v + W (S'v) */
     RELP_K_UPDATE_W = 8,         /* deferred update: W <- E W, pivot row rho */
-    RELP_K_FLUSH = 9,            /* deferred update: B0inv += W (S' B0inv) */
-    RELP_K_COUNT = 10
+    RELP_K_FLUSH = 9,            /* deferred update: B0inv += W (S' B0inv); LU engine: refactorisation */
+    RELP_K_FT_RUN = 10,          /* LU engine: the persistent pivot kernel (many pivots per launch) */
+    RELP_K_COUNT = 11
 } relp_kernel_id_t;
 /* When enabled, the kernel classes of every `sample_every`-th pivot inside relp_run are bracketed by
  * HIP events on the engine's stream (an event pair costs ~4 us of stream time, so bracketing every

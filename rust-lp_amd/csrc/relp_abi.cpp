@@ -71,6 +71,26 @@ relp_status_t relp_set_reinversion_interval(relp_engine_t* h, int64_t pivots) { 
 int64_t relp_reinversions(const relp_engine_t* h) { return h ? H(h).reinversions() : -1; }
 int32_t relp_update_block(const relp_engine_t* h) { return h ? H(h).update_block() : -1; }
 relp_status_t relp_lu_stats(const relp_engine_t* h, int64_t* out8) { return (h && out8) ? H(h).lu_stats(out8) : RELP_E_ARG; }
+relp_status_t relp_basis_inverse_row(relp_engine_t* h, int32_t row, double* out_m) { return (h && out_m) ? H(h).basis_inverse_row(row, out_m) : RELP_E_ARG; }
+relp_status_t relp_should_refactor(relp_engine_t* h, int32_t* out) { return (h && out) ? H(h).should_refactor(out) : RELP_E_ARG; }
+relp_status_t relp_generate_column_of(relp_engine_t* h, const int32_t* idx, const double* val, int32_t nnz, double* out_m) {
+    return h ? H(h).generate_column_of(idx, val, nnz, out_m) : RELP_E_ARG;
+}
+relp_status_t relp_cost_difference_of(relp_engine_t* h, const int32_t* idx, const double* val, int32_t nnz, double* out) {
+    return h ? H(h).cost_difference_of(idx, val, nnz, out) : RELP_E_ARG;
+}
+relp_status_t relp_lu_change_basis(relp_engine_t* h, int32_t row) { return h ? H(h).lu_change_basis(row) : RELP_E_ARG; }
+relp_status_t relp_lu_set_factors(relp_engine_t* h, const int64_t* l_ptr, const int32_t* l_idx, const double* l_val,
+                                  const int64_t* u_ptr, const int32_t* u_idx, const double* u_val) {
+    return h ? H(h).lu_set_factors(l_ptr, l_idx, l_val, u_ptr, u_idx, u_val) : RELP_E_ARG;
+}
+relp_status_t relp_lu_updates(relp_engine_t* h, int32_t* count) { return (h && count) ? H(h).lu_updates(count) : RELP_E_ARG; }
+relp_status_t relp_lu_get_update(relp_engine_t* h, int32_t k, int32_t* pivot, int32_t* idx, double* val, int32_t cap, int32_t* nnz) {
+    return h ? H(h).lu_get_update(k, pivot, idx, val, cap, nnz) : RELP_E_ARG;
+}
+relp_status_t relp_lu_get_upper(relp_engine_t* h, int64_t* col_ptr, int32_t* row_idx, double* values, int64_t cap, int64_t* nnz) {
+    return h ? H(h).lu_get_upper(col_ptr, row_idx, values, cap, nnz) : RELP_E_ARG;
+}
 relp_status_t relp_shard_flush_begin(relp_engine_t* h, double** snap, int64_t* len) {
     return h ? H(h).shard_flush_begin(snap, len) : RELP_E_ARG;
 }

@@ -25,7 +25,8 @@ void Engine::free_all() {
     fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
     fr(d_msg_cand_); fr(d_msg_cands_); fr(d_msg_slice_); fr(d_msg_slices_); fr(d_msg_rho_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
-    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_);
+    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_); fr(d_ft_buf_);
+    if (h_ft_hdr_) { (void)hipHostFree(h_ft_hdr_); h_ft_hdr_ = nullptr; }
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
     prof_ev_.clear();
@@ -277,6 +278,8 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         // here an update is one column of W, so longer blocks are cheap)
         block_ = cfg_.update_block < 0 ? 128 : std::max(1, std::min(cfg_.update_block, 128));
         HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
+        relp_status_t fst = ft_plan_and_alloc();           // Forrest-Tomlin on the device when the LDS budget allows
+        if (fst) return fst;
     }
     if (tableau_) {
         if (block_ == 0) block_ = 64;                  // the tableau is always maintained in blocks
@@ -290,7 +293,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
         HIP_TRY(dev_alloc(&d_idcol_, m_));
     }
-    if (block_ > 0) {
+    if (block_ > 0 && ft_) {
+        HIP_TRY(dev_alloc(&d_v_, ld_b_));                  // (no W: the update file lives in FtState)
+    } else if (block_ > 0) {
         HIP_TRY(dev_alloc(&d_v_, ld_b_));
         HIP_TRY(dev_alloc(&d_W_, ld_b_ * block_));
         if (!tableau_) HIP_TRY(dev_alloc(&d_R_, ld_b_ * block_));
@@ -521,7 +526,7 @@ void Engine::enqueue_iteration(int rule) {
 void Engine::enqueue_flush() {
     if (block_ == 0) return;
     if (lu_) {
-        if (since_flush_ == 0) return;                 // the factors already describe the current basis
+        if (since_flush_ == 0 && !ft_need_refactor_) return;   // the factors already describe the current basis
         prof_begin(RELP_K_FLUSH);
         const relp_status_t st = lu_refactor();
         prof_end();
@@ -620,6 +625,8 @@ relp_status_t Engine::generate_column(int32_t column, double* out_m) {
     if ((st = upload_rec())) return st;
     if (tableau_) {
         launch_tab_column(tview(), deferred(), d_alpha_, d_rec_, stream_);
+    } else if (lu_ && ft_) {
+        launch_ft_ftran(dlu_, fts_, ft_problem(0), column, nullptr, d_alpha_, stream_);     // leaves the spike for change_basis
     } else if (lu_) {
         launch_build_column_csc(csc(), table(), m_, d_aq_, d_rec_, stream_);
         launch_lu_ftran(dlu_, d_aq_, d_v_, d_lu_scratch_, d_rec_, stream_);
@@ -698,6 +705,19 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
         if (leaving) *leaving = lv;
         return RELP_OK;
     }
+    if (lu_ && ft_) {
+        // Carry::change_basis (carry/mod.rs:549-570): b, then the basis inverse (Forrest-Tomlin update with the spike
+        // of the last generate_column), then -pi from row r of the NEW inverse
+        const FtProblem pb = ft_problem(0);
+        launch_ft_update(dlu_, fts_, pb, stream_);
+        launch_ft_btran(dlu_, fts_, pb, -2, nullptr, d_rho_, stream_);
+        launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_,
+                              d_rec_, stream_);
+        if ((st = ft_read_hdr())) return st;
+        if (leaving) *leaving = lv;
+        if (ft_need_refactor_) return lu_refactor();       // Carry::after_basis_change (carry/mod.rs:602-614)
+        return RELP_OK;
+    }
     if (lu_) {
         const DeferredUpdate du = deferred();
         launch_eta_prepare(du, d_rec_, stream_);
@@ -725,6 +745,7 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
 // Loops (phase_one.rs:125-170, phase_two.rs:22-51)
 // ------------------------------------------------------------------------------------------------
 relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
+    if (ft_) return run_ft(max_iters, done, outcome);
     relp_status_t st = download_rec();
     if (st) return st;
     const long long start = h_rec_->iterations;
@@ -813,7 +834,8 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
             launch_tab_row(tview(), deferred(), pivot_row, d_aq_big(), d_rec_, stream_);        // single GPU: all columns
             HIP_TRY(hipMemcpyAsync(tau.data(), d_aq_big(), sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
         } else if (lu_) {
-            launch_lu_btran(dlu_, deferred(), nullptr, pivot_row, d_rho_, d_lu_scratch_, nullptr, stream_);
+            if (ft_) launch_ft_btran(dlu_, fts_, ft_problem(0), pivot_row, nullptr, d_rho_, stream_);
+            else launch_lu_btran(dlu_, deferred(), nullptr, pivot_row, d_rho_, d_lu_scratch_, nullptr, stream_);
             enqueue_price(0, d_rho_, nullptr, 0, nr_normal_);
             HIP_TRY(hipMemcpyAsync(tau.data(), d_d_, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
         } else {
@@ -874,7 +896,8 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
     if (lu_) {
         if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
-        launch_lu_btran(dlu_, deferred(), d_w_, -1, d_minus_pi_, d_lu_scratch_, nullptr, stream_);
+        if (ft_) launch_ft_btran(dlu_, fts_, ft_problem(0), -1, d_w_, d_minus_pi_, stream_);
+        else launch_lu_btran(dlu_, deferred(), d_w_, -1, d_minus_pi_, d_lu_scratch_, nullptr, stream_);
     } else if (tableau_) {
         // phase-2 reduced costs of every stored column: d = c - c_B' T (the artificial block keeps cost 0)
         cost_store_h_.assign(n_store_, 0.0);
@@ -1056,6 +1079,7 @@ relp_status_t Engine::build_basis_columns(const std::vector<int32_t>& basis,
 // from the new T0, -obj from b.  T0 is otherwise only ever updated (every flush adds W R0 to it).
 relp_status_t Engine::retabulate() {
     since_reinvert_ = 0;
+    retab_done_ = false;
     enqueue_flush();
     HIP_TRY(hipStreamSynchronize(stream_));
     std::vector<int32_t> basis(m_);
@@ -1096,6 +1120,7 @@ relp_status_t Engine::retabulate() {
     }
     h_rec_->minus_objective = -objective;
     ++reinversions_;
+    retab_done_ = true;
     return upload_rec();
 }
 
@@ -1144,7 +1169,36 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
     // InverseMaintener::from_basis (carry/mod.rs:428-463): any basis on the LU and the revised engine (the
     // latter factorises on the host and runs the m unit solves on the device; slack bases are a signed permutation and take a shortcut).
     if (cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "from_basis in sharded mode");
-    if (tableau_) return fail(RELP_E_UNSUPPORTED, "from_basis in the tableau engine");
+    if (tableau_) {
+        // T = B^-1 [A | I] for the given basis: factorise it (host, like every refactorisation), then every stored column
+        // by one FTRAN each in a single launch (re-tabulation), b = B^-1 rhs, d = c - c_B' T
+        enqueue_flush();
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::vector<int32_t> basis(basis_columns, basis_columns + m_);
+        std::vector<uint8_t> flags(n_alloc_, 0);
+        for (int32_t v : basis) {
+            if (v < 0 || v >= n_provider_) return fail(RELP_E_ARG, "from_basis: column out of range");
+            if (flags[v]) return fail(RELP_E_SINGULAR, "from_basis: duplicate column");
+            flags[v] = 1;
+        }
+        const int32_t keep_na = nr_artificial_, keep_phase = phase_;
+        nr_artificial_ = 0; phase_ = 2;
+        HIP_TRY(hipMemcpy(d_basis_, basis.data(), sizeof(int32_t) * m_, hipMemcpyHostToDevice));
+        cost_store_h_.assign(n_store_, 0.0);
+        for (int32_t p = 0; p < nr_normal_; ++p) cost_store_h_[tab_na_ + p] = cost_h_[p];
+        HIP_TRY(hipMemcpy(d_cost_store_, cost_store_h_.data(), sizeof(double) * n_store_, hipMemcpyHostToDevice));
+        relp_status_t st = retabulate();
+        if (st || !retab_done_) {
+            nr_artificial_ = keep_na; phase_ = keep_phase;
+            return st ? st : fail(RELP_E_SINGULAR, "from_basis: the basis could not be factorised (or m is too large for the "
+                                                    "LDS-resident solves of the re-tabulation)");
+        }
+        HIP_TRY(hipMemcpy(d_in_basis_, flags.data(), flags.size(), hipMemcpyHostToDevice));
+        if ((st = download_rec())) return st;
+        h_rec_->outcome = DEV_RUNNING; h_rec_->last_selected = -1; h_rec_->phase = 2;
+        tab_partials_valid_ = false;
+        return upload_rec();
+    }
     if (lu_) {
         // any basis: factorise it, b = B^-1 rhs (FTRAN), -pi = -c_B' B^-1 (BTRAN), carry/mod.rs:428-463
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -1165,8 +1219,13 @@ relp_status_t Engine::from_basis(const int32_t* basis_columns) {
         for (int32_t i = 0; i < m_; ++i) if (basis[i] < nr_normal_) w[i] = -cost_h_[basis[i]];
         HIP_TRY(hipMemcpy(d_w_, w.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_aq_, rhs_h_.data(), sizeof(double) * m_, hipMemcpyHostToDevice));
-        launch_lu_ftran(dlu_, d_aq_, d_b_, d_lu_scratch_, nullptr, stream_);
-        launch_lu_btran(dlu_, deferred(), d_w_, -1, d_minus_pi_, d_lu_scratch_, nullptr, stream_);
+        if (ft_) {
+            launch_ft_ftran(dlu_, fts_, ft_problem(0), -1, d_aq_, d_b_, stream_);
+            launch_ft_btran(dlu_, fts_, ft_problem(0), -1, d_w_, d_minus_pi_, stream_);
+        } else {
+            launch_lu_ftran(dlu_, d_aq_, d_b_, d_lu_scratch_, nullptr, stream_);
+            launch_lu_btran(dlu_, deferred(), d_w_, -1, d_minus_pi_, d_lu_scratch_, nullptr, stream_);
+        }
         HIP_TRY(hipMemcpyAsync(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost, stream_));
         if ((st = download_rec())) return st;
         double objective = 0.0;
@@ -1297,8 +1356,10 @@ relp_status_t Engine::get_basis_inverse(double* out) {
         // row i of B^-1 = BTRAN of e_i (with the pending W); test / debugging path
         double* tmp = nullptr;
         HIP_TRY(dev_alloc(&tmp, (int64_t)m_ * m_));
-        for (int32_t i = 0; i < m_; ++i)
-            launch_lu_btran(dlu_, deferred(), nullptr, i, tmp + (int64_t)i * m_, d_lu_scratch_, nullptr, stream_);
+        for (int32_t i = 0; i < m_; ++i) {
+            if (ft_) launch_ft_btran(dlu_, fts_, ft_problem(0), i, nullptr, tmp + (int64_t)i * m_, stream_);
+            else launch_lu_btran(dlu_, deferred(), nullptr, i, tmp + (int64_t)i * m_, d_lu_scratch_, nullptr, stream_);
+        }
         HIP_TRY(hipMemcpyAsync(out, tmp, sizeof(double) * m_ * m_, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         HIP_TRY(hipFree(tmp));

@@ -48,6 +48,17 @@ class Engine {
     relp_status_t flush();
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
+    // BasisInverse surface of the LU engine (carry/mod.rs:68-157, lower_upper/mod.rs:199-222)
+    relp_status_t basis_inverse_row(int32_t row, double* out_m);
+    relp_status_t should_refactor(int32_t* out);
+    relp_status_t generate_column_of(const int32_t* idx, const double* val, int32_t nnz, double* out_m);
+    relp_status_t cost_difference_of(const int32_t* idx, const double* val, int32_t nnz, double* out);
+    relp_status_t lu_change_basis(int32_t row);
+    relp_status_t lu_updates(int32_t* count);
+    relp_status_t lu_get_update(int32_t k, int32_t* pivot, int32_t* idx, double* val, int32_t cap, int32_t* nnz);
+    relp_status_t lu_get_upper(int64_t* col_ptr, int32_t* row_idx, double* values, int64_t cap, int64_t* nnz);
+    relp_status_t lu_set_factors(const int64_t* l_ptr, const int32_t* l_idx, const double* l_val, const int64_t* u_ptr,
+                                 const int32_t* u_idx, const double* u_val);
     relp_status_t shard_flush_begin(double** dev_snapshot, int64_t* len);
     relp_status_t shard_flush_end();
 
@@ -164,8 +175,22 @@ class Engine {
     relp_status_t lu_upload_factors();
     relp_status_t reinvert();
     relp_status_t retabulate();
+    bool retab_done_ = false;                             // the last retabulate() rebuilt the tableau (it keeps the old one otherwise)
     relp_status_t build_basis_columns(const std::vector<int32_t>& basis, std::vector<std::vector<std::pair<int32_t, double>>>* cols);
     void enqueue_iteration_lu(int rule);
+    // Forrest-Tomlin mode of the LU engine (relp_kernels_ft.hip): whole pivots in one persistent workgroup; chosen at
+    // create when the work vectors, the eta pool and the dense tail of U fit one CU's LDS (m <= kFtMaxRows)
+    bool ft_ = false;
+    FtState fts_{};
+    char* d_ft_buf_ = nullptr;
+    int32_t* h_ft_hdr_ = nullptr;                         // pinned copy of fts_.hdr
+    int32_t ft_tcap_ = 0, ft_eta_cap_ = 0;
+    bool ft_need_refactor_ = false;
+    relp_status_t ft_plan_and_alloc();
+    relp_status_t ft_reset();
+    relp_status_t ft_read_hdr();
+    FtProblem ft_problem(int rule) const;
+    relp_status_t run_ft(int64_t max_iters, int64_t* done, int32_t* outcome);
     DeferredUpdate deferred() const;
     void enqueue_flush();
     int32_t n_alloc_ = 0;     // allocated tableau columns (artificial + provider)

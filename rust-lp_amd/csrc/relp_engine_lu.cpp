@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <initializer_list>
 
 namespace relp {
 
@@ -85,7 +86,8 @@ relp_status_t Engine::lu_refactor() {
     if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
     relp_status_t st = lu_upload_factors();
     if (st) return st;
-    launch_flush_reset(deferred(), d_rec_, stream_);
+    if (ft_) { if ((st = ft_reset())) return st; }
+    else launch_flush_reset(deferred(), d_rec_, stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
     since_flush_ = 0;
     ++lu_refactors_;
@@ -106,6 +108,14 @@ relp_status_t Engine::lu_upload_factors() {
         return o;
     };
     const size_t o_rp = put(hlu_.rowperm.data(), sizeof(int32_t) * m_), o_cp = put(hlu_.colperm.data(), sizeof(int32_t) * m_);
+    // Forrest-Tomlin kernels: original row -> pivot, basis position -> pivot, pivot -> its row in the U / U' schedules
+    std::vector<int32_t> inv_rp(m_), inv_cp(m_), task_uf(m_), task_ub(m_);
+    for (int32_t k = 0; k < m_; ++k) {
+        inv_rp[hlu_.rowperm[k]] = k; inv_cp[hlu_.colperm[k]] = k;
+        task_uf[hlu_.Uf.level_rows[k]] = k; task_ub[hlu_.Ub.level_rows[k]] = k;
+    }
+    const size_t o_irp = put(inv_rp.data(), sizeof(int32_t) * m_), o_icp = put(inv_cp.data(), sizeof(int32_t) * m_);
+    const size_t o_tuf = put(task_uf.data(), sizeof(int32_t) * m_), o_tub = put(task_ub.data(), sizeof(int32_t) * m_);
     size_t o_rows[4], o_idx[4], o_val[4], o_lp[4];
     std::vector<LuRow> rows(m_);
     for (int k = 0; k < 4; ++k) {
@@ -138,6 +148,146 @@ relp_status_t Engine::lu_upload_factors() {
         ds[k]->nnz = (int32_t)sch[k]->idx.size();
     }
     HIP_TRY(hipStreamSynchronize(stream_));             // buf is stack-owned
+    if (ft_) {
+        fts_.m = m_;
+        fts_.inv_rowperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_irp);
+        fts_.inv_colperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_icp);
+        fts_.task_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tuf);
+        fts_.task_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tub);
+        // what is left of the CU's LDS after the work vectors stages one schedule at a time
+        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_);
+        fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
+        int64_t need = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int64_t b = ft_schedule_stage_bytes(m_, (int64_t)sch[k]->idx.size(), (int32_t)sch[k]->level_ptr.size() - 1);
+            fts_.stage[k] = b <= fts_.stage_bytes ? 1 : 0;
+            if (fts_.stage[k]) need = std::max(need, b);
+        }
+        fts_.lds_bytes = (int32_t)(base + need);
+    }
+    return RELP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forrest-Tomlin mode (relp_kernels_ft.hip)
+// ------------------------------------------------------------------------------------------------
+relp_status_t Engine::ft_plan_and_alloc() {
+    ft_ = false;
+    if (m_ > kFtMaxRows) return RELP_OK;
+    // the largest tail that leaves room for an eta pool of at least 2 m entries (one eta never exceeds m)
+    for (int32_t tcap : {64, 48, 32, 16}) {
+        for (int64_t eta_cap : {(int64_t)4 * m_, (int64_t)2 * m_ + 64}) {
+            eta_cap = std::max<int64_t>(eta_cap, 1024);
+            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap) + 4096 <= kFtLdsBudget) {
+                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_ = true;
+                break;
+            }
+        }
+        if (ft_) break;
+    }
+    if (!ft_) return RELP_OK;
+    const int64_t tc = ft_tcap_, ldt = tc + 1, m = m_, nwp = kFtWaves + 1;
+    std::vector<char> dummy;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += round_up(bytes, 16); return at; };
+    const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_pv = take(4 * tc), o_lv = take(4 * tc), o_ts = take(4 * m),
+                  o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp), o_so = take(4 * tc * nwp), o_ei = take(4 * (int64_t)ft_eta_cap_),
+                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
+    HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_ft_hdr_), 4 * sizeof(int32_t), hipHostMallocDefault));
+    std::memset(h_ft_hdr_, 0, 4 * sizeof(int32_t));
+    fts_ = FtState{};
+    fts_.m = m_; fts_.tcap = ft_tcap_; fts_.ldt = (int32_t)ldt; fts_.eta_cap = ft_eta_cap_;
+    fts_.hdr = reinterpret_cast<int32_t*>(d_ft_buf_ + o_hdr);
+    fts_.slot_pivot = reinterpret_cast<int32_t*>(d_ft_buf_ + o_sp);
+    fts_.slot_prev = reinterpret_cast<int32_t*>(d_ft_buf_ + o_pv);
+    fts_.slot_live = reinterpret_cast<int32_t*>(d_ft_buf_ + o_lv);
+    fts_.tslot = reinterpret_cast<int32_t*>(d_ft_buf_ + o_ts);
+    fts_.TC = reinterpret_cast<double*>(d_ft_buf_ + o_tc);
+    fts_.eta_off = reinterpret_cast<int32_t*>(d_ft_buf_ + o_eo);
+    fts_.spk_off = reinterpret_cast<int32_t*>(d_ft_buf_ + o_so);
+    fts_.eta_idx = reinterpret_cast<int32_t*>(d_ft_buf_ + o_ei);
+    fts_.eta_val = reinterpret_cast<double*>(d_ft_buf_ + o_ev);
+    fts_.spk_idx = reinterpret_cast<int32_t*>(d_ft_buf_ + o_si);
+    fts_.spk_val = reinterpret_cast<double*>(d_ft_buf_ + o_sv);
+    fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
+    // refactor when this many updates are pending (lower_upper/mod.rs:199-202 refactors when updates.len() > 10, i.e.
+    // relp_config_t.update_block = 11 reproduces the reference's cadence)
+    fts_.max_updates = cfg_.update_block < 0 ? ft_tcap_ : std::max(1, std::min(cfg_.update_block, ft_tcap_));
+    block_ = fts_.max_updates;
+    return RELP_OK;
+}
+
+// empty update file: t = 0, every pivot "never updated", TC = 0 (after a refactorisation)
+relp_status_t Engine::ft_reset() {
+    const int64_t tc = ft_tcap_;
+    HIP_TRY(hipMemsetAsync(fts_.hdr, 0, 16, stream_));
+    HIP_TRY(hipMemsetAsync(fts_.slot_pivot, 0, 4 * tc, stream_));
+    HIP_TRY(hipMemsetAsync(fts_.slot_prev, 0xFF, 4 * tc, stream_));
+    HIP_TRY(hipMemsetAsync(fts_.slot_live, 0, 4 * tc, stream_));
+    HIP_TRY(hipMemsetAsync(fts_.tslot, 0xFF, 4 * (int64_t)m_, stream_));
+    HIP_TRY(hipMemsetAsync(fts_.TC, 0, 8 * tc * (tc + 1), stream_));
+    HIP_TRY(hipMemsetAsync(fts_.eta_off, 0, 4 * tc * (kFtWaves + 1), stream_));
+    HIP_TRY(hipMemsetAsync(fts_.spk_off, 0, 4 * tc * (kFtWaves + 1), stream_));
+    ft_need_refactor_ = false;
+    return RELP_OK;
+}
+
+relp_status_t Engine::ft_read_hdr() {
+    HIP_TRY(hipMemcpyAsync(h_ft_hdr_, fts_.hdr, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    since_flush_ = h_ft_hdr_[0];
+    ft_need_refactor_ = h_ft_hdr_[2] != 0;
+    return RELP_OK;
+}
+
+FtProblem Engine::ft_problem(int rule) const {
+    FtProblem pb{};
+    pb.csc = csc(); pb.ct = table();
+    pb.minus_pi = d_minus_pi_; pb.b = d_b_; pb.alpha = d_alpha_; pb.rho = d_rho_; pb.d = d_d_;
+    pb.basis = d_basis_; pb.in_basis = d_in_basis_; pb.trace = d_trace_; pb.trace_cap = trace_cap_;
+    pb.rec = d_rec_;
+    pb.tol = tolerances();
+    pb.rule = rule; pb.n = nr_columns(); pb.phase = phase_;
+    return pb;
+}
+
+// phase_one::primal / phase_two::primal with the pivots themselves on the device: one launch runs until the outcome is
+// decided, the iteration budget is spent or the update file is full (then: refactorise on the host, launch again)
+relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome) {
+    relp_status_t st = download_rec();
+    if (st) return st;
+    const long long start = h_rec_->iterations;
+    const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+    struct Tick { int64_t& t; ~Tick() { ++t; } };
+    while (h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters) {
+        if (ft_need_refactor_) {
+            prof_tick_ = 0;                                // refactorisations are always bracketed (like the flush)
+            prof_begin(RELP_K_FLUSH);
+            st = lu_refactor();
+            prof_end();
+            if (st) return st;
+        }
+        prof_tick_ = 0;
+        prof_begin(RELP_K_FT_RUN);
+        launch_ft_run(dlu_, fts_, ft_problem(rule), max_iters - (h_rec_->iterations - start), stream_);
+        prof_end();
+        HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
+        if ((st = ft_read_hdr())) return st;
+        if (!ft_need_refactor_ && h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters)
+            return fail(RELP_E_STATE, "the pivot kernel stopped without a reason");
+    }
+    if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
+    int32_t oc = RELP_RUNNING;
+    if (h_rec_->outcome == DEV_NO_CANDIDATE) {
+        if (phase_ == 2) oc = RELP_OPTIMAL;
+        else if ((st = finish_phase_one(&oc))) return st;
+    } else if (h_rec_->outcome == DEV_NO_ROW) {
+        oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
+    }
+    if (done) *done = h_rec_->iterations - start;
+    if (outcome) *outcome = oc;
     return RELP_OK;
 }
 

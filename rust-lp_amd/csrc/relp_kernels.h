@@ -107,6 +107,55 @@ static constexpr int32_t kWrappedArtificialBase = 0x40000000;
 
 struct DeviceCSC { const int64_t* col_ptr; const int32_t* row_idx; const double* values; };
 
+// ---- sparse LU engine with the Forrest-Tomlin update on the device (relp_kernels_ft.hip) -------------------------
+// lower_upper/mod.rs:92-155 keeps `updates: Vec<(EtaFile, RotateToBack)>` and rewrites U at every basis change.  Here L and
+// U0 of the last refactorisation are never modified (their level schedules stay valid).  A "pivot" is a step k of the
+// factorisation P B Q = L U0; the reference's position of a pivot in U is its rank in the order
+// [pivots never updated, ascending k | updated pivots, by the time of their last update], so its rotate-to-back needs no
+// data movement.  Update number s ("slot" s, pivot p):
+//   * row p and column p of U0 are masked (the pull rows of p get 1/diag = 0, x[p] reads as 0 in the U0 sweeps),
+//   * the row eta r = u_bar U^-1 (R = I - e_p r', eta_file.rs:10-18): sparse part over never-updated pivots in the eta
+//     pool, part over updated pivots in row s of TC (below the diagonal),
+//   * the spike L^-1 a_q (after the earlier etas) becomes the last column of U: sparse part over never-updated pivots in
+//     the spike pool, part over updated pivots in column s of TC (on and above the diagonal; TC[s][s] = new diagonal).
+// A pivot updated again gets a new slot; its old slot is dead (row / column of TC zeroed, diagonal 1).
+static constexpr int kFtThreads = 512;                 // the persistent pivot workgroup: 8 wavefronts
+static constexpr int kFtWaves = kFtThreads / 64;       // sparse lists are bucketed by (pivot % kFtWaves): one wavefront per bucket
+static constexpr int kFtMaxSlots = 64;                 // one lane of a wavefront per slot in the chains over TC
+static constexpr int kFtMaxRows = 4096;                // work vectors (x, spike, -pi) live in LDS
+static constexpr int kFtLdsBudget = 156 * 1024;        // of the CU's 160 KB
+struct FtState {
+    int32_t  m, tcap, ldt, eta_cap;
+    int32_t* hdr;            // [0] updates since the refactorisation (t), [1] eta pool entries in use, [2] refactor requested
+    int32_t* slot_pivot;     // tcap
+    int32_t* slot_prev;      // tcap: earlier slot of the same pivot or -1
+    int32_t* slot_live;      // tcap
+    int32_t* tslot;          // m: live slot of a pivot, -1 = never updated
+    double*  TC;             // tcap x ldt
+    int32_t* eta_off;        // tcap x (kFtWaves + 1): bucket offsets into the eta pool (absolute)
+    int32_t* eta_idx; double* eta_val;     // eta_cap
+    int32_t* spk_off;        // tcap x (kFtWaves + 1): bucket offsets relative to the slot's region s * m
+    int32_t* spk_idx; double* spk_val;     // tcap * m
+    const int32_t* inv_rowperm;            // original row -> pivot
+    const int32_t* inv_colperm;            // basis position -> pivot
+    const int32_t* task_uf;                // pivot -> index of its row in the U (FTRAN) schedule
+    const int32_t* task_ub;                // pivot -> index of its row in the U' (BTRAN) schedule
+    double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
+    int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
+    int32_t  stage_bytes;
+    int32_t  lds_bytes;      // dynamic LDS of every FT kernel
+    int32_t  max_updates;    // refactor when this many updates are pending (<= tcap)
+    int32_t  pad_;
+};
+struct FtProblem {           // what the persistent kernel needs besides the factors
+    DeviceCSC csc; ColumnTable ct;
+    double *minus_pi, *b, *alpha, *rho, *d;
+    int32_t* basis; uint8_t* in_basis; int32_t* trace; int64_t trace_cap;
+    PivotRecord* rec;
+    Tolerances tol;
+    int32_t rule, n, phase, pad_;
+};
+
 // ---- launchers (all asynchronous on `s`) -------------------------------------------------------
 // cost_mode: 0 = no cost term (tableau row), 1 = phase-1 costs (artificial: 1), 2 = phase-2 costs
 // PRICE, structural part: d[na + p] = c_p + (-pi[0:mc]) . A[:,p] (+ -pi[bound_row]) for p in [p_lo, p_hi)
@@ -305,6 +354,24 @@ void launch_lu_btran(const DeviceLU& lu, const DeferredUpdate& du, const double*
 // every row of B^-1 = (LU)^-1 in one launch (workgroup i: e_i' B^-1 -> out + i * ld); `none`: a DeferredUpdate with kmax = 0
 void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double* out, int64_t ld, double* scratch,
                           hipStream_t s);
+
+// ---- Forrest-Tomlin engine (relp_kernels_ft.hip) ---------------------------------------------------------------
+// bytes of dynamic LDS the FT kernels need besides the staging area
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap);
+// LDS bytes a schedule needs to be staged (relp_lu_device.h: schedule_lds_bytes)
+int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels);
+// up to `max_pivots` whole pivots (PRICE -> FTRAN -> RATIO -> FT update -> BTRAN -> b, -pi, basis) in ONE launch of one
+// workgroup; stops early when the outcome is decided or a refactorisation is due (hdr[2] = 1)
+void launch_ft_run(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int64_t max_pivots, hipStream_t s);
+// alpha = B^-1 a for tableau column `column` (>= 0; -2: rec->q) or the dense right-hand side `rhs` (indexed by original
+// row); leaves the spike in st.spike
+void launch_ft_ftran(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t column, const double* rhs, double* alpha,
+                     hipStream_t s);
+// rho' = c' B^-1 with c = e_row (row >= 0; -2: rec->r) or the dense `rhs` (indexed by basis position)
+void launch_ft_btran(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t row, const double* rhs, double* rho,
+                     hipStream_t s);
+// the Forrest-Tomlin update for the basis change in position rec->r with the spike in st.spike
+void launch_ft_update(const DeviceLU& lu, const FtState& st, const FtProblem& pb, hipStream_t s);
 
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);

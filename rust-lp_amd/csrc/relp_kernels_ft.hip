@@ -1,0 +1,708 @@
+// relp_kernels_ft.hip -- the sparse LU engine's persistent pivot kernel: PRICE (CSC) -> FTRAN -> RATIO -> Forrest-Tomlin
+// update -> BTRAN -> b, -pi, basis for MANY pivots in one launch of one workgroup, all work vectors, the eta file and the
+// dense tail of U in LDS.  Reference rows a4 (LU), a8: carry/lower_upper/mod.rs:92-222, eta_file.rs:49-133,
+// permutation/rotate_to_back.rs:15-110; see the layout notes at `FtState` in relp_kernels.h and the numpy design
+// check scripts/ft_prototype.py.
+//
+// Why one workgroup: at Netlib sizes (m ~ 10^3, factors ~ 10^5 bytes) a pivot is a chain of ~150 dependent sparse
+// steps over data that fits one CU's LDS; kernel boundaries (~6.5 us each, 8 per pivot before) and grid barriers
+// (4.8 us at 64 workgroups) cost more than the arithmetic.  Everything between two refactorisations therefore runs
+// behind __syncthreads only.
+#include "relp_lu_device.h"
+
+#include <vector>
+
+namespace relp {
+
+namespace {
+
+constexpr int NT = kFtThreads;
+constexpr int NW = kFtWaves;
+
+__host__ __device__ inline int64_t up16(int64_t b) { return (b + 15) / 16 * 16; }
+
+// byte offsets of the dynamic LDS arrays
+struct FtLayout {
+    int64_t x, sp, pi, tc, dots, zt, uv, ct, slot_pivot, slot_prev, slot_live, slot_next, eta_off, spk_off, tslot, eta_idx,
+        eta_val, red_d, red_i, stage, total;
+};
+__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
+    FtLayout L;
+    int64_t o = 0;
+    const int ldt = tcap + 1;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
+    L.x = take(8LL * m); L.sp = take(8LL * m); L.pi = take(8LL * m);
+    L.tc = take(8LL * tcap * ldt);
+    L.dots = take(8LL * tcap); L.zt = take(8LL * tcap); L.uv = take(8LL * tcap); L.ct = take(8LL * tcap);
+    L.slot_pivot = take(4LL * tcap); L.slot_prev = take(4LL * tcap); L.slot_live = take(4LL * tcap); L.slot_next = take(4LL * tcap);
+    L.eta_off = take(4LL * tcap * (NW + 1)); L.spk_off = take(4LL * tcap * (NW + 1));
+    L.tslot = take(m);
+    L.eta_idx = take(4LL * eta_cap); L.eta_val = take(8LL * eta_cap);
+    L.red_d = take(8LL * 2 * NW); L.red_i = take(4LL * 4 * NW + 64);
+    L.stage = o; L.total = o;
+    return L;
+}
+
+struct FtCtx {
+    double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;
+    int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
+    signed char* tslot;
+    char* stage;
+    int m, tcap, ldt, t, eta_used, eta_cap;
+};
+
+__device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) {
+    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap);
+    c.x = (double*)(lds + L.x); c.sp = (double*)(lds + L.sp); c.pi = (double*)(lds + L.pi); c.TC = (double*)(lds + L.tc);
+    c.dots = (double*)(lds + L.dots); c.zt = (double*)(lds + L.zt); c.uv = (double*)(lds + L.uv); c.ct = (double*)(lds + L.ct);
+    c.slot_pivot = (int*)(lds + L.slot_pivot); c.slot_prev = (int*)(lds + L.slot_prev); c.slot_live = (int*)(lds + L.slot_live);
+    c.slot_next = (int*)(lds + L.slot_next); c.eta_off = (int*)(lds + L.eta_off); c.spk_off = (int*)(lds + L.spk_off);
+    c.tslot = (signed char*)(lds + L.tslot); c.eta_idx = (int*)(lds + L.eta_idx); c.eta_val = (double*)(lds + L.eta_val);
+    c.red_d = (double*)(lds + L.red_d); c.red_i = (int*)(lds + L.red_i); c.stage = lds + L.stage;
+    c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap;
+}
+
+// global state -> LDS (ends with a barrier)
+__device__ __forceinline__ void ft_load(FtCtx& c, const FtState& st, const double* minus_pi) {
+    const int tid = threadIdx.x;
+    c.t = st.hdr[0]; c.eta_used = st.hdr[1];
+    for (int i = tid; i < c.tcap * c.ldt; i += NT) c.TC[i] = st.TC[i];
+    for (int s = tid; s < c.tcap; s += NT) {
+        c.slot_pivot[s] = st.slot_pivot[s]; c.slot_prev[s] = st.slot_prev[s]; c.slot_live[s] = st.slot_live[s];
+        c.slot_next[s] = -1;
+    }
+    for (int i = tid; i < c.tcap * (NW + 1); i += NT) { c.eta_off[i] = st.eta_off[i]; c.spk_off[i] = st.spk_off[i]; }
+    for (int k = tid; k < c.m; k += NT) c.tslot[k] = (signed char)st.tslot[k];
+    for (int e = tid; e < c.eta_used; e += NT) { c.eta_idx[e] = st.eta_idx[e]; c.eta_val[e] = st.eta_val[e]; }
+    if (minus_pi) for (int i = tid; i < c.m; i += NT) c.pi[i] = minus_pi[i];
+    __syncthreads();
+    for (int s = tid; s < c.t; s += NT) { const int pv = c.slot_prev[s]; if (pv >= 0) c.slot_next[pv] = s; }
+    __syncthreads();
+}
+
+// LDS -> global state (what an update may have changed)
+__device__ __forceinline__ void ft_store(const FtCtx& c, const FtState& st, double* minus_pi, int need_refactor) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int i = tid; i < c.tcap * c.ldt; i += NT) st.TC[i] = c.TC[i];
+    for (int s = tid; s < c.tcap; s += NT) {
+        st.slot_pivot[s] = c.slot_pivot[s]; st.slot_prev[s] = c.slot_prev[s]; st.slot_live[s] = c.slot_live[s];
+    }
+    for (int i = tid; i < c.tcap * (NW + 1); i += NT) { st.eta_off[i] = c.eta_off[i]; st.spk_off[i] = c.spk_off[i]; }
+    for (int k = tid; k < c.m; k += NT) st.tslot[k] = c.tslot[k];
+    for (int e = tid; e < c.eta_used; e += NT) { st.eta_idx[e] = c.eta_idx[e]; st.eta_val[e] = c.eta_val[e]; }
+    if (minus_pi) for (int i = tid; i < c.m; i += NT) minus_pi[i] = c.pi[i];
+    if (tid == 0) { st.hdr[0] = c.t; st.hdr[1] = c.eta_used; st.hdr[2] = need_refactor; }
+}
+
+// value of lane `src` (wave-uniform) in every lane
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    src = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+__device__ __forceinline__ void sweep(const DeviceSchedule& s, const FtState& st, int which, FtCtx& c) {
+    if (st.stage[which]) solve_schedule<true, NT>(s, c.m, c.stage, c.x);
+    else solve_schedule<false, NT>(s, c.m, c.stage, c.x);
+}
+
+// ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
+// lower_upper/mod.rs:157-190
+__device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, FtCtx& c) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = c.t;
+    sweep(lu.Lf, st, 0, c);
+    if (t > 0) {
+        // eta.apply_right for every update (eta_file.rs:72-109): w[p_s] -= r_s . w.  The sparse parts read entries no
+        // eta modifies (pivots never updated at the time), so all of them are formed first, a slot per wavefront ...
+        for (int s = wave; s < t; s += NW) {
+            const int e0 = c.eta_off[s * (NW + 1)], e1 = c.eta_off[s * (NW + 1) + NW];
+            double sum = 0.0;
+            for (int e = e0 + lane; e < e1; e += 64) sum = fma(c.eta_val[e], c.x[c.eta_idx[e]], sum);
+            sum = wave_sum(sum);
+            if (lane == 0) c.dots[s] = sum;
+        }
+        __syncthreads();
+        // ... then the chain over the updated pivots (lane = slot), followed by the solve with the dense tail of U
+        if (wave == 0) {
+            const int s = lane;
+            const bool in = s < t;
+            const int prev = in ? c.slot_prev[s] : -1, piv = in ? c.slot_pivot[s] : 0;
+            const bool live = in && c.slot_live[s];
+            double base = (in && prev < 0) ? c.x[piv] : 0.0;
+            const double dot = in ? c.dots[s] : 0.0;
+            double acc = 0.0, val = 0.0;
+            for (int s2 = 0; s2 < t; ++s2) {
+                const double v = lane_bcast(base - dot - acc, s2);
+                if (s == s2) val = v;
+                if (in && s > s2) {
+                    acc = fma(c.TC[s * c.ldt + s2], v, acc);
+                    if (prev == s2) base = v;
+                }
+            }
+            if (live) c.x[piv] = val;
+            // U z = w on the updated pivots: they are last in the order, so they are solved first (from the back)
+            const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
+            const double rhs = live ? val : 0.0;
+            acc = 0.0;
+            double z = 0.0;
+            for (int s2 = t - 1; s2 >= 0; --s2) {
+                const double v = lane_bcast((rhs - acc) * rdiag, s2);
+                if (s == s2) z = v;
+                if (in && s < s2) acc = fma(c.TC[s * c.ldt + s2], v, acc);
+            }
+            if (in) c.zt[s] = live ? z : 0.0;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < c.m; k += NT) c.sp[k] = c.x[k];          // the spike (mod.rs:176)
+    if (t > 0) {
+        __syncthreads();
+        // the spike columns of the updated pivots act on the never-updated rows: x[k] -= U[k, p_s] z_s.  One wavefront per
+        // bucket of rows (k % NW), slots in order: no two lanes ever touch one row, the summation order is fixed
+        for (int s = 0; s < t; ++s) {
+            if (!c.slot_live[s]) continue;
+            const double z = c.zt[s];
+            if (z == 0.0) continue;
+            const int base = s * c.m;
+            const int e0 = c.spk_off[s * (NW + 1) + wave], e1 = c.spk_off[s * (NW + 1) + wave + 1];
+            for (int e = e0 + lane; e < e1; e += 64) {
+                const int k = st.spk_idx[base + e];
+                if (c.tslot[k] < 0) c.x[k] = fma(-st.spk_val[base + e], z, c.x[k]);
+            }
+            wave_fence();
+        }
+        __syncthreads();
+        if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = 0.0;      // masked in the U0 sweep
+        __syncthreads();
+    }
+    sweep(lu.Uf, st, 1, c);
+    if (t > 0) {
+        if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.zt[tid];
+        __syncthreads();
+    }
+}
+
+// ---- y' U = c' for the current U: c in x (pivot-indexed) on entry; y over the never-updated pivots in x, over the
+// slots in zt on exit (invert_upper_left, mod.rs:332-356, on the unrotated representation) ------------------------------
+__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = c.t;
+    if (t > 0) {
+        if (tid < t) {
+            const bool live = c.slot_live[tid];
+            const int piv = c.slot_pivot[tid];
+            c.ct[tid] = live ? c.x[piv] : 0.0;
+            if (live) c.x[piv] = 0.0;
+        }
+        __syncthreads();
+    }
+    if (do_sweep) sweep(lu.Ub, st, 2, c);
+    if (t > 0) {
+        for (int s = wave; s < t; s += NW) {
+            double sum = 0.0;
+            if (c.slot_live[s] && do_sweep) {
+                const int base = s * c.m;
+                const int e0 = c.spk_off[s * (NW + 1)], e1 = c.spk_off[s * (NW + 1) + NW];
+                for (int e = e0 + lane; e < e1; e += 64) {
+                    const int k = st.spk_idx[base + e];
+                    if (c.tslot[k] < 0) sum = fma(st.spk_val[base + e], c.x[k], sum);
+                }
+                sum = wave_sum(sum);
+            }
+            if (lane == 0) c.dots[s] = sum;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int s = lane;
+            const bool in = s < t;
+            const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
+            const double rhs = in ? c.ct[s] - c.dots[s] : 0.0;
+            double acc = 0.0, y = 0.0;
+            for (int s2 = 0; s2 < t; ++s2) {
+                const double v = lane_bcast((rhs - acc) * rdiag, s2);
+                if (s == s2) y = v;
+                if (in && s > s2) acc = fma(c.TC[s2 * c.ldt + s], v, acc);
+            }
+            if (in) c.zt[s] = c.slot_live[s] ? y : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- BTRAN: c (pivot-indexed, i.e. Q' c) in x on entry; w = P z with z' B = c' on exit (mod.rs:204-222) ------------------
+__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = c.t;
+    ft_ut_solve(lu, st, c, do_sweep);
+    if (t > 0) {
+        // eta.apply_left in reverse order (eta_file.rs:49-65): v[j] -= r_s[j] v[p_s]; first the chain over the slots ...
+        if (wave == 0) {
+            const int s = lane;
+            const bool in = s < t;
+            const int nxt = in ? c.slot_next[s] : -1, prev = in ? c.slot_prev[s] : -1;
+            double base = (in && nxt < 0) ? c.zt[s] : 0.0;       // a slot without successor is live
+            double acc = 0.0, u = 0.0;
+            for (int s2 = t - 1; s2 >= 0; --s2) {
+                const double v = lane_bcast(base - acc, s2);
+                if (s == s2) u = v;
+                if (in && s < s2) {
+                    acc = fma(c.TC[s2 * c.ldt + s], v, acc);
+                    if (nxt == s2) base = v;
+                }
+            }
+            if (in) {
+                c.uv[s] = u;
+                if (prev < 0) c.x[c.slot_pivot[s]] = u;          // the value every earlier eta (sparse part) and L' see
+            }
+        }
+        __syncthreads();
+        // ... then the sparse parts, one wavefront per bucket of pivots (j % NW), slots in reverse order
+        for (int s = t - 1; s >= 0; --s) {
+            const double u = c.uv[s];
+            if (u == 0.0) continue;
+            const int e0 = c.eta_off[s * (NW + 1) + wave], e1 = c.eta_off[s * (NW + 1) + wave + 1];
+            for (int e = e0 + lane; e < e1; e += 64) {
+                const int j = c.eta_idx[e];
+                c.x[j] = fma(-c.eta_val[e], u, c.x[j]);
+            }
+            wave_fence();
+        }
+        __syncthreads();
+    }
+    sweep(lu.Lb, st, 3, c);
+}
+
+// Bucketed, order-preserving compaction of the non-zeros of vec over the never-updated pivots (pivot `skip` excluded):
+// bucket w = pivots with k % NW == w, written by wavefront w at [base + off[w], base + off[w + 1]).  off (NW + 1 ints) is
+// left in `off_out` relative to off_base.  Returns the total (all threads).  Ends with a barrier.
+template <class IdxPtr, class ValPtr>
+__device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip, IdxPtr out_idx, ValPtr out_val, int out_base,
+                                          int* off_out, int off_base) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_wave = (c.m - wave + NW - 1) / NW;           // pivots k = wave + NW * i, i < per_wave
+    int cnt = 0;
+    for (int i0 = 0; i0 < per_wave; i0 += 64) {
+        const int i = i0 + lane, k = wave + NW * i;
+        const bool on = i < per_wave && k != skip && c.tslot[k] < 0 && vec[k] != 0.0;
+        cnt += __popcll(__ballot(on));
+    }
+    if (lane == 0) c.red_i[wave] = cnt;
+    __syncthreads();
+    int mine = 0, total = 0;
+    for (int w = 0; w < NW; ++w) { const int v = c.red_i[w]; if (w < wave) mine += v; total += v; }
+    if (tid <= NW) {
+        int o = 0;
+        for (int w = 0; w < tid; ++w) o += c.red_i[w];
+        off_out[tid] = off_base + o;
+    }
+    int pos = out_base + mine;
+    for (int i0 = 0; i0 < per_wave; i0 += 64) {
+        const int i = i0 + lane, k = wave + NW * i;
+        const bool on = i < per_wave && k != skip && c.tslot[k] < 0 && vec[k] != 0.0;
+        const unsigned long long mask = __ballot(on);
+        if (on) {
+            const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
+            out_idx[at] = k;
+            out_val[at] = vec[k];
+        }
+        pos += __popcll(mask);
+    }
+    __syncthreads();
+    return total;
+}
+
+// ---- the Forrest-Tomlin update (mod.rs:92-155) for the basis change in basis position `r`; the spike is in sp -------------
+__device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st, FtCtx& c, int r) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = c.t;
+    const int p = st.inv_colperm[r];                   // the pivot whose column leaves (mod.rs:99-107)
+    const int s_old = c.tslot[p];
+    // u_bar = row p of U right of the diagonal (mod.rs:110-121), scattered into x
+    for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
+    __syncthreads();
+    int any = 0;
+    if (s_old < 0) {
+        const LuRow row = lu.Uf.rows[st.task_uf[p]];
+        for (int e = row.e0 + tid; e < row.e1; e += NT) {
+            const int l = lu.Uf.idx[e];
+            if (c.tslot[l] < 0) { c.x[l] = lu.Uf.val[e]; any = 1; }
+        }
+        // entries of row p in the spike columns of the live slots: only the bucket p % NW of each list can hold them
+        const int bucket = p % NW;
+        for (int s = wave; s < t; s += NW) {
+            if (!c.slot_live[s]) continue;
+            const int base = s * c.m;
+            const int e0 = c.spk_off[s * (NW + 1) + bucket], e1 = c.spk_off[s * (NW + 1) + bucket + 1];
+            for (int e = e0 + lane; e < e1; e += 64)
+                if (st.spk_idx[base + e] == p) c.x[c.slot_pivot[s]] = st.spk_val[base + e];
+        }
+    } else {
+        if (tid < t && tid > s_old && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.TC[s_old * c.ldt + tid];
+    }
+    const bool do_sweep = __syncthreads_or(any) != 0;
+    // r' = u_bar' U^-1 (mod.rs:122)
+    ft_ut_solve(lu, st, c, do_sweep);
+    // R = I - e_p r' (eta_file.rs:10-18): sparse part over the never-updated pivots into the eta pool, bucketed ...
+    const int tn = t;                                  // the new slot
+    int eta_n = 0;
+    if (do_sweep) eta_n = ft_compact(c, c.x, p, c.eta_idx, c.eta_val, c.eta_used, c.eta_off + tn * (NW + 1), c.eta_used);
+    else {
+        if (tid <= NW) c.eta_off[tn * (NW + 1) + tid] = c.eta_used;
+        __syncthreads();
+    }
+    // ... part over the updated pivots into row tn of TC; the diagonal of the spike (update_spike_pivot_value,
+    // eta_file.rs:111-133): sp[p] - r . sp
+    double part = 0.0;
+    for (int e = c.eta_used + tid; e < c.eta_used + eta_n; e += NT) part = fma(c.eta_val[e], c.sp[c.eta_idx[e]], part);
+    if (tid < t) {
+        const double y = c.slot_live[tid] ? c.zt[tid] : 0.0;
+        c.TC[tn * c.ldt + tid] = y;
+        if (y != 0.0) part = fma(y, c.sp[c.slot_pivot[tid]], part);
+    }
+    part = wave_sum(part);
+    if (lane == 0) c.red_d[wave] = part;
+    __syncthreads();
+    double rdot = 0.0;
+    for (int w = 0; w < NW; ++w) rdot += c.red_d[w];
+    const double diag = c.sp[p] - rdot;
+    // delete row p and column p from U (mod.rs:127-129): mask the pivot in U0, or kill its slot
+    if (s_old < 0) {
+        if (tid == 0) {
+            const_cast<LuRow*>(lu.Uf.rows)[st.task_uf[p]].diag = 0.0;
+            const_cast<LuRow*>(lu.Ub.rows)[st.task_ub[p]].diag = 0.0;
+        }
+    } else {
+        if (tid >= s_old && tid < c.tcap) c.TC[s_old * c.ldt + tid] = 0.0;    // (left of the diagonal: eta coefficients, kept)
+        __syncthreads();
+        if (tid <= s_old) c.TC[tid * c.ldt + s_old] = tid == s_old ? 1.0 : 0.0;
+        if (tid == 0) { c.slot_live[s_old] = 0; c.slot_next[s_old] = tn; }
+    }
+    __syncthreads();
+    // the spike becomes the last column (mod.rs:139-148): entries in the rows of the live slots into column tn of TC ...
+    if (tid < t && c.slot_live[tid]) c.TC[tid * c.ldt + tn] = c.sp[c.slot_pivot[tid]];
+    if (tid == 0) {
+        c.TC[tn * c.ldt + tn] = diag;
+        c.slot_pivot[tn] = p; c.slot_prev[tn] = s_old; c.slot_live[tn] = 1; c.slot_next[tn] = -1;
+    }
+    // ... entries in the never-updated rows into the spike pool, bucketed
+    ft_compact(c, c.sp, p, st.spk_idx + (int64_t)tn * c.m, st.spk_val + (int64_t)tn * c.m, 0, c.spk_off + tn * (NW + 1), 0);
+    if (tid == 0) c.tslot[p] = (signed char)tn;
+    c.eta_used += eta_n;
+    c.t = tn + 1;
+    __syncthreads();
+}
+
+// x := P a for tableau column q (partially.rs:72-80, matrix_data.rs:308-348), pivot-indexed.  Ends with a barrier.
+__device__ __forceinline__ void ft_scatter_column(const FtState& st, const FtProblem& pb, FtCtx& c, int q) {
+    const int tid = threadIdx.x;
+    const ColumnTable& ct = pb.ct;
+    for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
+    __syncthreads();
+    if (q < ct.nr_artificial) {
+        if (tid == 0) c.x[st.inv_rowperm[ct.column_to_row[q]]] = 1.0;
+    } else {
+        const int p = q - ct.nr_artificial;
+        if (p < ct.nr_normal) {
+            const int64_t s0 = pb.csc.col_ptr[p], s1 = pb.csc.col_ptr[p + 1];
+            for (int64_t e = s0 + tid; e < s1; e += NT) c.x[st.inv_rowperm[pb.csc.row_idx[e]]] = pb.csc.values[e];
+            const int br = ct.bound_row[p];
+            if (tid == 0 && br >= 0) c.x[st.inv_rowperm[br]] = 1.0;
+        } else if (tid == 0) {
+            const int v = p - ct.nr_normal;
+            const int r0 = ct.vrow0[v], r1 = ct.vrow1[v];
+            if (r0 >= 0) c.x[st.inv_rowperm[r0]] = (double)ct.vsign[v];
+            if (r1 >= 0) c.x[st.inv_rowperm[r1]] = 1.0;
+        }
+    }
+    __syncthreads();
+}
+
+// workgroup minimum of (key, j), lexicographic; result in every thread
+__device__ __forceinline__ void block_min_key(FtCtx& c, double& key, int& kj) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok = __shfl_down(key, off, 64);
+        const int oj = __shfl_down(kj, off, 64);
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+    __syncthreads();
+    if (lane == 0) { c.red_d[wave] = key; c.red_i[wave] = kj; }
+    __syncthreads();
+    key = c.red_d[0]; kj = c.red_i[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        const double ok = c.red_d[w];
+        const int oj = c.red_i[w];
+        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
+    }
+}
+
+__device__ __forceinline__ int block_min_int(FtCtx& c, int v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if (lane == 0) c.red_i[wave] = v;
+    __syncthreads();
+    v = c.red_i[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v = min(v, c.red_i[w]);
+    return v;
+}
+
+__device__ __forceinline__ double block_min_double(FtCtx& c, double v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if (lane == 0) c.red_d[wave] = v;
+    __syncthreads();
+    v = c.red_d[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v = fmin(v, c.red_d[w]);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The persistent pivot kernel
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProblem pb, long long max_pivots) {
+    extern __shared__ __align__(16) char lds[];
+    PivotRecord* rec = pb.rec;
+    if (rec->outcome != DEV_RUNNING) return;
+    FtCtx c;
+    ft_bind(c, lds, st);
+    ft_load(c, st, pb.minus_pi);
+    const int tid = threadIdx.x;
+    const ColumnTable& ct = pb.ct;
+    const int m = c.m, n = pb.n, rule = pb.rule, cost_mode = pb.phase;
+    int last_selected = rec->last_selected;
+    double minus_objective = rec->minus_objective;
+    long long iterations = rec->iterations;
+    int degenerate = rec->degenerate;
+    int outcome = DEV_RUNNING, need_refactor = 0;
+    int q = rec->q, r = rec->r, leaving = rec->leaving;
+    double d_q = rec->d_q, alpha_r = rec->alpha_r, b_r = rec->b_r, key1 = rec->key1;
+    PivotRecord fake;                                  // select_key reads rule memory through a record
+    fake.last_selected = last_selected;
+
+    for (long long it = 0; it < max_pivots; ++it) {
+        if (c.t >= st.max_updates || c.t >= c.tcap || c.eta_cap - c.eta_used < m) { need_refactor = 1; break; }
+        // ---- PRICE (pivot_rule.rs:38-126 over tableau/mod.rs:102-108): d_j = c_j + (-pi) . a_j, thread per column ----------
+        fake.last_selected = last_selected;
+        double key = INFINITY;
+        int kj = 0x7fffffff;
+        for (int j = tid; j < n; j += NT) {
+            double v;
+            if (j < ct.nr_artificial) {
+                v = (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]];
+            } else {
+                const int p = j - ct.nr_artificial;
+                if (p < ct.nr_normal) {
+                    v = 0.0;
+                    const int64_t s0 = pb.csc.col_ptr[p], s1 = pb.csc.col_ptr[p + 1];
+                    for (int64_t e = s0; e < s1; ++e) v = fma(c.pi[pb.csc.row_idx[e]], pb.csc.values[e], v);
+                    const int br = ct.bound_row[p];
+                    if (br >= 0) v += c.pi[br];
+                    if (cost_mode == 2) v += ct.cost[p];
+                } else {
+                    const int vv = p - ct.nr_normal;
+                    const int r0 = ct.vrow0[vv], r1 = ct.vrow1[vv];
+                    v = r0 >= 0 ? (double)ct.vsign[vv] * c.pi[r0] : 0.0;
+                    if (r1 >= 0) v += c.pi[r1];
+                }
+            }
+            pb.d[j] = v;
+            if (!pb.in_basis[j] && v < -pb.tol.cost) {
+                const double k = select_key(rule, n, &fake, j, v);
+                if (k < key || (k == key && j < kj)) { key = k; kj = j; }
+            }
+        }
+        block_min_key(c, key, kj);
+        if (kj != 0x7fffffff && rule == 2 && pb.tol.tie > 0.0) {
+            // Dantzig ties: lowest index within the tie band of the minimum (every thread re-reads its own columns)
+            const double bound = key + pb.tol.tie * fmax(1.0, fabs(key));
+            int lowest = 0x7fffffff;
+            for (int j = tid; j < n; j += NT) {
+                const double v = pb.d[j];
+                if (!pb.in_basis[j] && v < -pb.tol.cost && v <= bound && j < lowest) lowest = j;
+            }
+            kj = block_min_int(c, lowest);
+        }
+        if (kj == 0x7fffffff) {
+            outcome = DEV_NO_CANDIDATE;
+            if (rule == 1) last_selected = -1;
+            break;
+        }
+        q = kj; key1 = key; d_q = pb.d[q];
+        if (rule == 1) last_selected = q;
+
+        // ---- FTRAN (mod.rs:157-190) ------------------------------------------------------------------------------------
+        ft_scatter_column(st, pb, c, q);
+        ft_ftran(lu, st, c);
+
+        // ---- RATIO TEST (tableau/mod.rs:221-247; two passes as relp_device_common.h ratio_body) ------------------------
+        double mn = INFINITY;
+        for (int i = tid; i < m; i += NT) {
+            const double a = c.x[st.inv_colperm[i]];
+            pb.alpha[i] = a;
+            mn = fmin(mn, row_ratio(a, pb.b[i], pb.tol));
+        }
+        const double gmin = block_min_double(c, mn);
+        if (gmin == INFINITY) { outcome = DEV_NO_ROW; break; }
+        const double bound = gmin + pb.tol.tie * fmax(1.0, fabs(gmin));
+        int best_leave = 0x7fffffff;
+        for (int i = tid; i < m; i += NT) {
+            const double a = c.x[st.inv_colperm[i]];
+            if (row_ratio(a, pb.b[i], pb.tol) <= bound) best_leave = min(best_leave, pb.basis[i]);
+        }
+        leaving = block_min_int(c, best_leave);
+        // the row of the leaving column
+        int rr = 0x7fffffff;
+        for (int i = tid; i < m; i += NT)
+            if (pb.basis[i] == leaving && row_ratio(c.x[st.inv_colperm[i]], pb.b[i], pb.tol) <= bound) rr = i;
+        r = block_min_int(c, rr);
+        alpha_r = c.x[st.inv_colperm[r]];
+        b_r = pb.b[r];
+
+        // ---- b (carry/mod.rs:283-313) while alpha is still in x -----------------------------------------------------
+        const double br = b_r / alpha_r;
+        __syncthreads();
+        for (int i = tid; i < m; i += NT) {
+            if (i == r) pb.b[i] = br;
+            else {
+                const double a = c.x[st.inv_colperm[i]];
+                if (a != 0.0) pb.b[i] = fma(-a, br, pb.b[i]);
+            }
+        }
+        __syncthreads();
+
+        // ---- basis inverse: the Forrest-Tomlin update, then row r of the new inverse (mod.rs:92-155, 204-222) --------------
+        ft_update(lu, st, c, r);
+        for (int k = tid; k < m; k += NT) c.x[k] = 0.0;
+        __syncthreads();
+        if (tid == 0) c.x[st.inv_colperm[r]] = 1.0;
+        __syncthreads();
+        ft_btran(lu, st, c, false);                    // the leaving pivot is last in U now: no sweep over U0'
+        // ---- -pi, -obj, basis (carry/mod.rs:326-333, 549-570) ----------------------------------------------------------
+        for (int k = tid; k < m; k += NT) {
+            const int i = lu.rowperm[k];
+            const double rho = c.x[k];
+            pb.rho[i] = rho;
+            c.pi[i] = fma(-d_q, rho, c.pi[i]);
+        }
+        if (tid == 0) {
+            pb.basis[r] = q;
+            if (leaving < kWrappedArtificialBase) pb.in_basis[leaving] = 0;
+            pb.in_basis[q] = 1;
+            if (pb.trace && iterations < pb.trace_cap) {
+                pb.trace[0 * pb.trace_cap + iterations] = pb.phase;
+                pb.trace[1 * pb.trace_cap + iterations] = q;
+                pb.trace[2 * pb.trace_cap + iterations] = r;
+                pb.trace[3 * pb.trace_cap + iterations] = leaving;
+            }
+        }
+        minus_objective = fma(-d_q, br, minus_objective);
+        if (br == 0.0) degenerate += 1;
+        iterations += 1;
+        __syncthreads();
+    }
+    ft_store(c, st, pb.minus_pi, need_refactor);
+    if (tid == 0) {
+        rec->outcome = outcome; rec->q = q; rec->d_q = d_q; rec->r = r; rec->leaving = leaving; rec->alpha_r = alpha_r;
+        rec->b_r = b_r; rec->minus_objective = minus_objective; rec->iterations = iterations;
+        rec->last_selected = last_selected; rec->key1 = key1; rec->degenerate = degenerate;
+    }
+}
+
+// ---- single steps (step-wise API, phase boundaries) ------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProblem pb, int column, const double* rhs,
+                                                  double* alpha) {
+    extern __shared__ __align__(16) char lds[];
+    FtCtx c;
+    ft_bind(c, lds, st);
+    ft_load(c, st, nullptr);
+    const int tid = threadIdx.x;
+    if (rhs) {
+        for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.rowperm[k]];
+        __syncthreads();
+    } else {
+        ft_scatter_column(st, pb, c, column == -2 ? pb.rec->q : column);
+    }
+    ft_ftran(lu, st, c);
+    for (int k = tid; k < c.m; k += NT) { alpha[lu.colperm[k]] = c.x[k]; st.spike[k] = c.sp[k]; }
+}
+
+__global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProblem pb, int row, const double* rhs, double* rho) {
+    extern __shared__ __align__(16) char lds[];
+    FtCtx c;
+    ft_bind(c, lds, st);
+    ft_load(c, st, nullptr);
+    const int tid = threadIdx.x;
+    bool sweep_u = true;
+    if (rhs) {
+        for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.colperm[k]];
+    } else {
+        const int r = row == -2 ? pb.rec->r : row;
+        const int p = st.inv_colperm[r];
+        for (int k = tid; k < c.m; k += NT) c.x[k] = k == p ? 1.0 : 0.0;
+        sweep_u = c.tslot[p] < 0;                      // an updated pivot has no entry in U0 any more
+    }
+    __syncthreads();
+    ft_btran(lu, st, c, sweep_u);
+    for (int k = tid; k < c.m; k += NT) rho[lu.rowperm[k]] = c.x[k];
+}
+
+__global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtProblem pb) {
+    extern __shared__ __align__(16) char lds[];
+    FtCtx c;
+    ft_bind(c, lds, st);
+    ft_load(c, st, nullptr);
+    for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
+    __syncthreads();
+    ft_update(lu, st, c, pb.rec->r);
+    ft_store(c, st, nullptr, (c.t >= st.max_updates || c.t >= c.tcap || c.eta_cap - c.eta_used < c.m) ? 1 : 0);
+}
+
+void ft_allow_lds(const void* fn, int bytes) {
+    static std::vector<const void*> done;
+    for (auto f : done) if (f == fn) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)bytes;
+    done.push_back(fn);
+}
+
+}  // namespace
+
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap) { return (size_t)ft_layout(m, tcap, eta_cap).total; }
+int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels) { return schedule_lds_bytes(m, nnz, n_levels); }
+
+void launch_ft_run(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int64_t max_pivots, hipStream_t s) {
+    ft_allow_lds(reinterpret_cast<const void*>(k_ft_run), st.lds_bytes);
+    hipLaunchKernelGGL(k_ft_run, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, (long long)max_pivots);
+}
+
+void launch_ft_ftran(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t column, const double* rhs, double* alpha,
+                     hipStream_t s) {
+    ft_allow_lds(reinterpret_cast<const void*>(k_ft_ftran), st.lds_bytes);
+    hipLaunchKernelGGL(k_ft_ftran, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, column, rhs, alpha);
+}
+
+void launch_ft_btran(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t row, const double* rhs, double* rho,
+                     hipStream_t s) {
+    ft_allow_lds(reinterpret_cast<const void*>(k_ft_btran), st.lds_bytes);
+    hipLaunchKernelGGL(k_ft_btran, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, row, rhs, rho);
+}
+
+void launch_ft_update(const DeviceLU& lu, const FtState& st, const FtProblem& pb, hipStream_t s) {
+    ft_allow_lds(reinterpret_cast<const void*>(k_ft_update), st.lds_bytes);
+    hipLaunchKernelGGL(k_ft_update, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb);
+}
+
+}  // namespace relp

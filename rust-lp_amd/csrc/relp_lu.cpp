@@ -261,6 +261,36 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     return true;
 }
 
+bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& lcols_in,
+                       const std::vector<std::vector<std::pair<int32_t, double>>>& ucols_in, LUFactors* out, std::string* err) {
+    std::vector<std::vector<std::pair<int32_t, double>>> lrows(m), lcols(m), urows(m), ucols(m);
+    std::vector<double> udiag(m, 0.0), ones(m, 1.0);
+    out->nnz_l = 0; out->nnz_u = 0;
+    for (int32_t j = 0; j < (int32_t)lcols_in.size() && j < m; ++j)
+        for (auto& e : lcols_in[j]) {
+            if (e.first <= j || e.first >= m) { if (err) *err = "L entry outside the strict lower triangle"; return false; }
+            lrows[e.first].emplace_back(j, e.second); lcols[j].emplace_back(e.first, e.second); ++out->nnz_l;
+        }
+    for (int32_t j = 0; j < m; ++j)
+        for (auto& e : ucols_in[j]) {
+            if (e.first > j || e.first < 0) { if (err) *err = "U entry below the diagonal"; return false; }
+            ++out->nnz_u;
+            if (e.first == j) { udiag[j] = e.second; continue; }
+            urows[e.first].emplace_back(j, e.second); ucols[j].emplace_back(e.first, e.second);
+        }
+    for (int32_t j = 0; j < m; ++j) if (udiag[j] == 0.0) { if (err) *err = "zero on the diagonal of U"; return false; }
+    for (auto& v : lrows) std::sort(v.begin(), v.end());
+    for (auto& v : urows) std::sort(v.begin(), v.end());
+    out->m = m;
+    out->rowperm.resize(m); out->colperm.resize(m);
+    for (int32_t k = 0; k < m; ++k) { out->rowperm[k] = k; out->colperm[k] = k; }
+    build_schedule(m, lrows, ones, true, &out->Lf);
+    build_schedule(m, urows, udiag, false, &out->Uf);
+    build_schedule(m, ucols, udiag, true, &out->Ub);
+    build_schedule(m, lcols, ones, false, &out->Lb);
+    return true;
+}
+
 namespace {
 void solve_schedule_host(const TriangularSchedule& s, std::vector<double>& x) {
     const int32_t nl = (int32_t)s.level_ptr.size() - 1;

@@ -44,6 +44,12 @@ struct LUFactors {
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err);
 
+// Factors given literally (P = Q = I), the way the reference's tests build a `LUDecomposition { lower_triangular,
+// upper_triangular, .. }` (lower_upper/mod.rs:44-52): L column-major, unit diagonal implied, entries (row > column);
+// U column-major, entries (row <= column) with the diagonal among them.
+bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& lcols,
+                       const std::vector<std::vector<std::pair<int32_t, double>>>& ucols, LUFactors* out, std::string* err);
+
 // Host-side solves with the factors (warm starts, tests): x <- B^-1 a (x indexed by basis position on
 // return, a by original row) and z' <- c' B^-1 (c indexed by basis position, z by original row).
 void lu_ftran_host(const LUFactors& f, const std::vector<double>& a, std::vector<double>* x);

@@ -32,9 +32,9 @@ OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded",
                  PHASE_ONE_DONE: "phase_one_done", NO_ROW_PHASE_ONE: "no_row_phase_one"}
 # relp_kernel_id_t
 (K_PRICE, K_SELECT_COLUMN, K_BUILD_COLUMN, K_FTRAN, K_RATIO, K_UPDATE_VECTORS, K_UPDATE_INVERSE, K_APPLY_W,
- K_UPDATE_W, K_FLUSH) = range(10)
+ K_UPDATE_W, K_FLUSH, K_FT_RUN) = range(11)
 KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
-                "apply_w", "update_w", "flush"]
+                "apply_w", "update_w", "flush", "ft_run"]
 ENGINE_REVISED, ENGINE_TABLEAU, ENGINE_LU = 0, 1, 2   # relp_engine_kind_t
 # relp_status_t
 E_ARG, E_HIP, E_ZERO_PIVOT, E_SINGULAR, E_STATE, E_UNSUPPORTED, E_ALLOC = -1, -2, -3, -4, -5, -6, -7
@@ -86,6 +86,15 @@ _SIGNATURES = {
     "relp_flush": (C.c_int, [C.c_void_p]),
     "relp_update_block": (C.c_int32, [C.c_void_p]),
     "relp_lu_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_basis_inverse_row": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "relp_should_refactor": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "relp_generate_column_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "relp_cost_difference_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
+    "relp_lu_change_basis": (C.c_int, [C.c_void_p, C.c_int32]),
+    "relp_lu_set_factors": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "relp_lu_updates": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "relp_lu_get_update": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "relp_lu_get_upper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "relp_shard_flush_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "relp_shard_flush_end": (C.c_int, [C.c_void_p]),
     "relp_nr_rows": (C.c_int32, [C.c_void_p]),
@@ -345,6 +354,78 @@ class Tableau:
         self._ck(self._lib.relp_lu_stats(self._h, out))
         keys = ("refactorisations", "m", "nnz_l", "nnz_u", "levels_l", "levels_u", "levels_ut", "levels_lt")
         return dict(zip(keys, (int(v) for v in out)))
+
+    # -- BasisInverse surface (carry/mod.rs:68-157) ---------------------------------------------
+    def basis_inverse_row(self, row: int) -> np.ndarray:
+        out = np.zeros(self.nr_rows())
+        self._ck(self._lib.relp_basis_inverse_row(self._h, row, out.ctypes.data))
+        return out
+
+    def should_refactor(self) -> bool:
+        v = C.c_int32()
+        self._ck(self._lib.relp_should_refactor(self._h, C.byref(v)))
+        return bool(v.value)
+
+    @staticmethod
+    def _sparse(column):
+        idx = np.ascontiguousarray([i for i, _ in column], dtype=np.int32)
+        val = np.ascontiguousarray([v for _, v in column], dtype=np.float64)
+        return idx, val
+
+    def generate_column_of(self, column) -> np.ndarray:
+        """`BasisInverse::generate_column(original_column)` for sorted (row, value) pairs."""
+        idx, val = self._sparse(column)
+        out = np.zeros(self.nr_rows())
+        self._ck(self._lib.relp_generate_column_of(self._h, idx.ctypes.data, val.ctypes.data, len(idx), out.ctypes.data))
+        return out
+
+    def cost_difference_of(self, column) -> float:
+        idx, val = self._sparse(column)
+        v = C.c_double()
+        self._ck(self._lib.relp_cost_difference_of(self._h, idx.ctypes.data, val.ctypes.data, len(idx), C.byref(v)))
+        return v.value
+
+    def lu_change_basis(self, pivot_row_index: int) -> None:
+        self._ck(self._lib.relp_lu_change_basis(self._h, pivot_row_index))
+
+    def lu_set_factors(self, lower_columns, upper_columns) -> None:
+        """`LUDecomposition { lower_triangular, upper_triangular, .. }` literally (P = Q = I): lists of columns of
+        (row, value) pairs; L without its unit diagonal (m - 1 or m columns), U with its diagonal."""
+        m = self.nr_rows()
+
+        def csc(cols):
+            cols = list(cols) + [[] for _ in range(m - len(cols))]
+            ptr = np.zeros(m + 1, dtype=np.int64)
+            for j, c in enumerate(cols):
+                ptr[j + 1] = ptr[j] + len(c)
+            idx = np.ascontiguousarray([i for c in cols for i, _ in c] or [0], dtype=np.int32)
+            val = np.ascontiguousarray([v for c in cols for _, v in c] or [0.0], dtype=np.float64)
+            return ptr, idx, val
+        lp, li, lv = csc(lower_columns)
+        up, ui, uv = csc(upper_columns)
+        self._ck(self._lib.relp_lu_set_factors(self._h, lp.ctypes.data, li.ctypes.data, lv.ctypes.data, up.ctypes.data,
+                                               ui.ctypes.data, uv.ctypes.data))
+
+    def lu_updates(self):
+        """[(pivot, [(position, value), ...]), ...]: the reference's `updates` (EtaFile values + RotateToBack index)."""
+        n = C.c_int32()
+        self._ck(self._lib.relp_lu_updates(self._h, C.byref(n)))
+        m = self.nr_rows()
+        out = []
+        for k in range(n.value):
+            pivot, nnz = C.c_int32(), C.c_int32()
+            idx, val = np.zeros(m, dtype=np.int32), np.zeros(m)
+            self._ck(self._lib.relp_lu_get_update(self._h, k, C.byref(pivot), idx.ctypes.data, val.ctypes.data, m, C.byref(nnz)))
+            out.append((pivot.value, list(zip(idx[:nnz.value].tolist(), val[:nnz.value].tolist()))))
+        return out
+
+    def lu_upper(self):
+        """The reference's `upper_triangular`: list of columns of (row, value), diagonal last."""
+        m = self.nr_rows()
+        cap = m * (m + 1) // 2 + m
+        ptr, idx, val, nnz = np.zeros(m + 1, dtype=np.int64), np.zeros(cap, dtype=np.int32), np.zeros(cap), C.c_int64()
+        self._ck(self._lib.relp_lu_get_upper(self._h, ptr.ctypes.data, idx.ctypes.data, val.ctypes.data, cap, C.byref(nnz)))
+        return [list(zip(idx[ptr[j]:ptr[j + 1]].tolist(), val[ptr[j]:ptr[j + 1]].tolist())) for j in range(m)]
 
     def from_basis(self, basis_columns) -> None:
         arr = np.ascontiguousarray(basis_columns, dtype=np.int32)
