@@ -673,8 +673,8 @@ __global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtPro
 void ft_allow_lds(const void* fn, int bytes) {
     static std::vector<const void*> done;
     for (auto f : done) if (f == fn) return;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)bytes;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kFtLdsBudget) != hipSuccess) (void)hipGetLastError();
     done.push_back(fn);
 }
 
