@@ -188,6 +188,12 @@ int32_t       relp_update_block(const relp_engine_t *h);
  * U', L' (BTRAN) }.  Levels bound the length of the dependent chain of a triangular solve. */
 relp_status_t relp_lu_stats(const relp_engine_t *h, int64_t *out8);
 
+/* RELP_ENGINE_LU in Forrest-Tomlin mode: shader clocks spent per phase of the pivot inside the persistent kernel since create
+ * (thread 0): out[16] = { PRICE, entering-column scatter, L solve, eta file forward, spike push, U solve, ratio test, b update,
+ * u_bar extraction, U' solve for r, compaction of r and the spike, eta file backward, L' solve, -pi / basis, state load + store,
+ * 0 }.  Measurement aid for profiles/ and DESIGN.md. */
+relp_status_t relp_lu_phase_cycles(relp_engine_t *h, int64_t *out16);
+
 /* ---- the `BasisInverse` surface (carry/mod.rs:68-157) beside the tableau-level calls above ------------------------
  * BasisInverse::basis_inverse_row(row) (carry/mod.rs:145-150): row `row` of B^-1, dense, m entries.  LU engine: one BTRAN
  * of e_row (lower_upper/mod.rs:204-222); revised engine: a copy of the stored row (basis_inverse_rows.rs:181-183);

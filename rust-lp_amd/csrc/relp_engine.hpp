@@ -48,6 +48,7 @@ class Engine {
     relp_status_t flush();
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
+    relp_status_t lu_phase_cycles(int64_t* out16);
     // BasisInverse surface of the LU engine (carry/mod.rs:68-157, lower_upper/mod.rs:199-222)
     relp_status_t basis_inverse_row(int32_t row, double* out_m);
     relp_status_t should_refactor(int32_t* out);

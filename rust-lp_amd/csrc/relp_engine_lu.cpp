@@ -116,7 +116,12 @@ relp_status_t Engine::lu_upload_factors() {
     }
     const size_t o_irp = put(inv_rp.data(), sizeof(int32_t) * m_), o_icp = put(inv_cp.data(), sizeof(int32_t) * m_);
     const size_t o_tuf = put(task_uf.data(), sizeof(int32_t) * m_), o_tub = put(task_ub.data(), sizeof(int32_t) * m_);
-    size_t o_rows[4], o_idx[4], o_val[4], o_lp[4];
+    std::vector<int32_t> lev_ub(m_, 0);
+    for (int32_t l = 0; l + 1 < (int32_t)hlu_.Ub.level_ptr.size(); ++l)
+        for (int32_t t = hlu_.Ub.level_ptr[l]; t < hlu_.Ub.level_ptr[l + 1]; ++t) lev_ub[hlu_.Ub.level_rows[t]] = l;
+    const size_t o_lub = put(lev_ub.data(), sizeof(int32_t) * m_);
+    size_t o_rows[4], o_idx[4], o_val[4], o_lp[4], o_seg[4];
+    int32_t n_seg[4];
     std::vector<LuRow> rows(m_);
     for (int k = 0; k < 4; ++k) {
         const TriangularSchedule& t = *sch[k];
@@ -128,6 +133,22 @@ relp_status_t Engine::lu_upload_factors() {
         o_idx[k] = put(t.idx.data(), sizeof(int32_t) * t.idx.size());
         o_val[k] = put(t.val.data(), sizeof(double) * t.val.size());
         o_lp[k] = put(t.level_ptr.data(), sizeof(int32_t) * t.level_ptr.size());
+        // runs of levels for the pipelined solve: "solo" runs (every level <= 8 rows, at least 2 levels) are walked by one
+        // wavefront without workgroup barriers.  Directly behind level_ptr: the kernel stages all five arrays in one copy.
+        std::vector<int32_t> segs;
+        constexpr int32_t kSoloRows = 8;                   // one pass of eight 8-lane groups
+        const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
+        for (int32_t l = 1; l < nlev;) {
+            const bool narrow = t.level_ptr[l + 1] - t.level_ptr[l] <= kSoloRows;
+            int32_t e = l + 1;
+            while (e < nlev && ((t.level_ptr[e + 1] - t.level_ptr[e] <= kSoloRows) == narrow)) ++e;
+            const bool solo = narrow && e - l >= 2;
+            if (!segs.empty() && !solo && !segs[segs.size() - 1]) segs[segs.size() - 2] = e;      // merge wide runs
+            else { segs.push_back(l); segs.push_back(e); segs.push_back(solo ? 1 : 0); }
+            l = e;
+        }
+        n_seg[k] = (int32_t)segs.size() / 3;
+        o_seg[k] = put(segs.data(), sizeof(int32_t) * segs.size());
     }
     if ((int64_t)buf.size() > lu_cap_) {
         if (d_lu_buf_) HIP_TRY(hipFree(d_lu_buf_));
@@ -146,6 +167,8 @@ relp_status_t Engine::lu_upload_factors() {
         ds[k]->level_ptr = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lp[k]);
         ds[k]->n_levels = (int32_t)sch[k]->level_ptr.size() - 1;
         ds[k]->nnz = (int32_t)sch[k]->idx.size();
+        ds[k]->seg = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_seg[k]);
+        ds[k]->n_seg = n_seg[k]; ds[k]->pad_ = 0;
     }
     HIP_TRY(hipStreamSynchronize(stream_));             // buf is stack-owned
     if (ft_) {
@@ -154,12 +177,13 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.inv_colperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_icp);
         fts_.task_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tuf);
         fts_.task_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tub);
+        fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
         // what is left of the CU's LDS after the work vectors stages one schedule at a time
         const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_);
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
         int64_t need = 0;
         for (int k = 0; k < 4; ++k) {
-            const int64_t b = ft_schedule_stage_bytes(m_, (int64_t)sch[k]->idx.size(), (int32_t)sch[k]->level_ptr.size() - 1);
+            const int64_t b = ft_schedule_stage_bytes(m_, (int64_t)sch[k]->idx.size(), (int32_t)sch[k]->level_ptr.size() - 1, n_seg[k]);
             fts_.stage[k] = b <= fts_.stage_bytes ? 1 : 0;
             if (fts_.stage[k]) need = std::max(need, b);
         }
@@ -192,7 +216,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     auto take = [&](int64_t bytes) { const int64_t at = o; o += round_up(bytes, 16); return at; };
     const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_pv = take(4 * tc), o_lv = take(4 * tc), o_ts = take(4 * m),
                   o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp), o_so = take(4 * tc * nwp), o_ei = take(4 * (int64_t)ft_eta_cap_),
-                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m);
+                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 16);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_ft_hdr_), 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -212,6 +236,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spk_idx = reinterpret_cast<int32_t*>(d_ft_buf_ + o_si);
     fts_.spk_val = reinterpret_cast<double*>(d_ft_buf_ + o_sv);
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
+    fts_.prof = reinterpret_cast<long long*>(d_ft_buf_ + o_prof);
     // refactor when this many updates are pending (lower_upper/mod.rs:199-202 refactors when updates.len() > 10, i.e.
     // relp_config_t.update_block = 11 reproduces the reference's cadence)
     fts_.max_updates = cfg_.update_block < 0 ? ft_tcap_ : std::max(1, std::min(cfg_.update_block, ft_tcap_));
@@ -288,6 +313,14 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     }
     if (done) *done = h_rec_->iterations - start;
     if (outcome) *outcome = oc;
+    return RELP_OK;
+}
+
+// shader clocks (thread 0 of the persistent kernel) per phase of the pivot, accumulated since create
+relp_status_t Engine::lu_phase_cycles(int64_t* out16) {
+    if (!lu_ || !ft_) return fail(RELP_E_UNSUPPORTED, "phase clocks are the persistent pivot kernel's");
+    HIP_TRY(hipStreamSynchronize(stream_));
+    HIP_TRY(hipMemcpy(out16, fts_.prof, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return RELP_OK;
 }
 

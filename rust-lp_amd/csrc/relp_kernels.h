@@ -94,6 +94,9 @@ struct DeviceSchedule {
     const int32_t* idx; const double* val;
     const int32_t* level_ptr;   // n_levels + 1 offsets into rows
     int32_t n_levels; int32_t nnz;
+    // runs of levels (begin, end, solo) from level 1 on: solo = 1 when every level of the run has at most 8 rows, so that
+    // ONE wavefront walks the run without workgroup barriers (relp_lu_device.h: levels_pipelined)
+    const int32_t* seg; int32_t n_seg; int32_t pad_;
 };
 struct DeviceLU {
     int32_t m; int32_t pad_;
@@ -140,12 +143,14 @@ struct FtState {
     const int32_t* inv_colperm;            // basis position -> pivot
     const int32_t* task_uf;                // pivot -> index of its row in the U (FTRAN) schedule
     const int32_t* task_ub;                // pivot -> index of its row in the U' (BTRAN) schedule
+    const int32_t* lev_ub;                 // pivot -> level of its row in the U' schedule (a solve with e_p or u_bar starts there)
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
     int32_t  stage_bytes;
     int32_t  lds_bytes;      // dynamic LDS of every FT kernel
     int32_t  max_updates;    // refactor when this many updates are pending (<= tcap)
     int32_t  pad_;
+    long long* prof;         // 16 phase accumulators of the persistent kernel (shader clocks, thread 0) or nullptr
 };
 struct FtProblem {           // what the persistent kernel needs besides the factors
     DeviceCSC csc; ColumnTable ct;
@@ -359,7 +364,7 @@ void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double
 // bytes of dynamic LDS the FT kernels need besides the staging area
 size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap);
 // LDS bytes a schedule needs to be staged (relp_lu_device.h: schedule_lds_bytes)
-int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels);
+int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg);
 // up to `max_pivots` whole pivots (PRICE -> FTRAN -> RATIO -> FT update -> BTRAN -> b, -pi, basis) in ONE launch of one
 // workgroup; stops early when the outcome is decided or a refactorisation is due (hdr[2] = 1)
 void launch_ft_run(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int64_t max_pivots, hipStream_t s);

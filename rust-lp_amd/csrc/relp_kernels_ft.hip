@@ -18,6 +18,7 @@ namespace {
 
 constexpr int NT = kFtThreads;
 constexpr int NW = kFtWaves;
+static_assert(kFtMaxSlots * 8 <= kFtThreads && kFtMaxSlots <= 64, "eight lanes per slot; one lane per slot in the chains");
 
 __host__ __device__ inline int64_t up16(int64_t b) { return (b + 15) / 16 * 16; }
 
@@ -43,12 +44,31 @@ __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
     return L;
 }
 
+// Phase clock of the persistent kernel (thread 0, s_memtime): where a pivot's time goes (relp_lu_phase_cycles)
+enum FtPhase { FT_PRICE = 0, FT_SCATTER, FT_L, FT_ETA_FWD, FT_PUSH, FT_U, FT_RATIO, FT_B, FT_UBAR, FT_UT, FT_COMPACT, FT_BT_CHAIN,
+               FT_LT, FT_VECTORS, FT_LOAD_STORE, FT_STAGE, FT_PHASES };
+struct FtClock {
+    long long acc[FT_PHASES]; long long last; bool on;
+    __device__ __forceinline__ void start(const long long* out) {
+        on = out != nullptr && threadIdx.x == 0;
+        for (int k = 0; k < FT_PHASES; ++k) acc[k] = 0;
+        last = on ? clock64() : 0;
+    }
+    __device__ __forceinline__ void lap(int phase) {            // phase is a constant at every call site: acc stays in registers
+        if (on) { const long long now = clock64(); acc[phase] += now - last; last = now; }
+    }
+    __device__ __forceinline__ void flush(long long* out) {
+        if (on) for (int k = 0; k < FT_PHASES; ++k) out[k] += acc[k];
+    }
+};
+
 struct FtCtx {
     double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;
     int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
     signed char* tslot;
     char* stage;
     int m, tcap, ldt, t, eta_used, eta_cap;
+    FtClock clk;
 };
 
 __device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) {
@@ -60,6 +80,7 @@ __device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) 
     c.tslot = (signed char*)(lds + L.tslot); c.eta_idx = (int*)(lds + L.eta_idx); c.eta_val = (double*)(lds + L.eta_val);
     c.red_d = (double*)(lds + L.red_d); c.red_i = (int*)(lds + L.red_i); c.stage = lds + L.stage;
     c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap;
+    c.clk.start(nullptr);
 }
 
 // global state -> LDS (ends with a barrier)
@@ -105,9 +126,60 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-__device__ __forceinline__ void sweep(const DeviceSchedule& s, const FtState& st, int which, FtCtx& c) {
-    if (st.stage[which]) solve_schedule<true, NT>(s, c.m, c.stage, c.x);
-    else solve_schedule<false, NT>(s, c.m, c.stage, c.x);
+// Triangular chain over the update slots by ONE wavefront (lane = slot), the sequential core of the eta file and of the
+// dense tail of U: for s2 in order, lane s2 publishes (base - sub - acc) * scale, and every lane "after" s2 accumulates its
+// coefficient times that value.  kRow: the coefficient of (lane, s2) is TC[lane][s2], else TC[s2][lane].  `link`: when the
+// published slot is this lane's predecessor (the same pivot updated earlier / later), its value replaces `base`.
+// Coefficients are fetched eight steps ahead, so a step costs two v_readlane and one v_fma, not an LDS round trip.
+template <bool kAsc, bool kRow>
+__device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int lane, double base, double sub, double scale,
+                                           int link) {
+    constexpr int CH = 8;
+    const bool in = lane < t;
+    double acc = 0.0, mine = 0.0;
+    double cur[CH], nxt[CH];
+    auto load = [&](int ch, double* buf) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
+            buf[j] = (in && o < t) ? (kRow ? TC[lane * ldt + s2] : TC[s2 * ldt + lane]) : 0.0;
+        }
+    };
+    const int nch = (t + CH - 1) / CH;
+    load(0, cur);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) load(ch + 1, nxt);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
+            if (o < t) {                                           // wave-uniform
+                const double v = lane_bcast((base - sub - acc) * scale, s2);
+                if (lane == s2) mine = v;
+                if (in && (kAsc ? lane > s2 : lane < s2)) {
+                    acc = fma(cur[j], v, acc);
+                    if (link == s2) base = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+    }
+    return mine;
+}
+
+// sum over the 8 lanes of a group (valid in the group's lane 0), register to register
+__device__ __forceinline__ double sum8(double v) {
+    v += dpp_row_shl<0x104>(v);
+    v += dpp_row_shl<0x102>(v);
+    v += dpp_row_shl<0x101>(v);
+    return v;
+}
+
+constexpr int NTS = 256;                               // threads that walk the levels of a solve (one wavefront per SIMD)
+__device__ __forceinline__ void sweep(const DeviceSchedule& s, const FtState& st, int which, FtCtx& c, int first_level = 1) {
+    auto lap = [&]() { c.clk.lap(FT_STAGE); };
+    if (st.stage[which]) solve_schedule_pipelined<true, NT, NTS>(s, c.m, c.stage, c.x, first_level, lap);
+    else solve_schedule_pipelined<false, NT, NTS>(s, c.m, c.stage, c.x, first_level, lap);
 }
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
@@ -116,15 +188,19 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     sweep(lu.Lf, st, 0, c);
+    c.clk.lap(FT_L);
     if (t > 0) {
         // eta.apply_right for every update (eta_file.rs:72-109): w[p_s] -= r_s . w.  The sparse parts read entries no
         // eta modifies (pivots never updated at the time), so all of them are formed first, a slot per wavefront ...
-        for (int s = wave; s < t; s += NW) {
-            const int e0 = c.eta_off[s * (NW + 1)], e1 = c.eta_off[s * (NW + 1) + NW];
+        {   // eight lanes per slot: all slots at once
+            const int s = tid >> 3, l8 = tid & 7;
             double sum = 0.0;
-            for (int e = e0 + lane; e < e1; e += 64) sum = fma(c.eta_val[e], c.x[c.eta_idx[e]], sum);
-            sum = wave_sum(sum);
-            if (lane == 0) c.dots[s] = sum;
+            if (s < t) {
+                const int e0 = c.eta_off[s * (NW + 1)], e1 = c.eta_off[s * (NW + 1) + NW];
+                for (int e = e0 + l8; e < e1; e += 8) sum = fma(c.eta_val[e], c.x[c.eta_idx[e]], sum);
+            }
+            sum = sum8(sum);
+            if (s < t && l8 == 0) c.dots[s] = sum;
         }
         __syncthreads();
         // ... then the chain over the updated pivots (lane = slot), followed by the solve with the dense tail of U
@@ -133,63 +209,70 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
             const bool in = s < t;
             const int prev = in ? c.slot_prev[s] : -1, piv = in ? c.slot_pivot[s] : 0;
             const bool live = in && c.slot_live[s];
-            double base = (in && prev < 0) ? c.x[piv] : 0.0;
-            const double dot = in ? c.dots[s] : 0.0;
-            double acc = 0.0, val = 0.0;
-            for (int s2 = 0; s2 < t; ++s2) {
-                const double v = lane_bcast(base - dot - acc, s2);
-                if (s == s2) val = v;
-                if (in && s > s2) {
-                    acc = fma(c.TC[s * c.ldt + s2], v, acc);
-                    if (prev == s2) base = v;
-                }
-            }
+            const double val = tc_chain<true, true>(c.TC, c.ldt, t, s, (in && prev < 0) ? c.x[piv] : 0.0, in ? c.dots[s] : 0.0, 1.0, prev);
             if (live) c.x[piv] = val;
             // U z = w on the updated pivots: they are last in the order, so they are solved first (from the back)
             const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
-            const double rhs = live ? val : 0.0;
-            acc = 0.0;
-            double z = 0.0;
-            for (int s2 = t - 1; s2 >= 0; --s2) {
-                const double v = lane_bcast((rhs - acc) * rdiag, s2);
-                if (s == s2) z = v;
-                if (in && s < s2) acc = fma(c.TC[s * c.ldt + s2], v, acc);
-            }
+            const double z = tc_chain<false, true>(c.TC, c.ldt, t, s, live ? val : 0.0, 0.0, rdiag, -1);
             if (in) c.zt[s] = live ? z : 0.0;
         }
         __syncthreads();
     }
+    c.clk.lap(FT_ETA_FWD);
     for (int k = tid; k < c.m; k += NT) c.sp[k] = c.x[k];          // the spike (mod.rs:176)
     if (t > 0) {
         __syncthreads();
         // the spike columns of the updated pivots act on the never-updated rows: x[k] -= U[k, p_s] z_s.  One wavefront per
         // bucket of rows (k % NW), slots in order: no two lanes ever touch one row, the summation order is fixed
-        for (int s = 0; s < t; ++s) {
-            if (!c.slot_live[s]) continue;
-            const double z = c.zt[s];
-            if (z == 0.0) continue;
-            const int base = s * c.m;
-            const int e0 = c.spk_off[s * (NW + 1) + wave], e1 = c.spk_off[s * (NW + 1) + wave + 1];
-            for (int e = e0 + lane; e < e1; e += 64) {
-                const int k = st.spk_idx[base + e];
-                if (c.tslot[k] < 0) c.x[k] = fma(-st.spk_val[base + e], z, c.x[k]);
+        // (lane s keeps slot s's z and bucket bounds in registers; the pairs of the next slot are in flight while this
+        // one is applied: the loop touches LDS only for the read-modify-write of x)
+        {
+            const bool on = lane < t && c.slot_live[lane] && c.zt[lane] != 0.0;
+            const double zreg = lane < t ? c.zt[lane] : 0.0;
+            const int o0 = lane < t ? c.spk_off[lane * (NW + 1) + wave] : 0, o1 = lane < t ? c.spk_off[lane * (NW + 1) + wave + 1] : 0;
+            unsigned long long mask = __ballot(on);
+            int pk = -1, pe0 = 0, pe1 = 0, ps = 0;
+            double pv = 0.0;
+            auto fetch = [&]() {
+                ps = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+                mask &= mask - 1;
+                pe0 = __builtin_amdgcn_readlane(o0, ps); pe1 = __builtin_amdgcn_readlane(o1, ps);
+                pk = -1;
+                if (pe0 + lane < pe1) { pk = st.spk_idx[ps * c.m + pe0 + lane]; pv = st.spk_val[ps * c.m + pe0 + lane]; }
+            };
+            bool more = mask != 0;
+            if (more) fetch();
+            while (more) {
+                const int cs = ps, ck = pk, ce0 = pe0, ce1 = pe1;
+                const double cv = pv;
+                more = mask != 0;
+                if (more) fetch();
+                const double z = lane_bcast(zreg, cs);
+                if (ck >= 0 && c.tslot[ck] < 0) c.x[ck] = fma(-cv, z, c.x[ck]);
+                for (int e = ce0 + lane + 64; e < ce1; e += 64) {
+                    const int k = st.spk_idx[cs * c.m + e];
+                    if (c.tslot[k] < 0) c.x[k] = fma(-st.spk_val[cs * c.m + e], z, c.x[k]);
+                }
+                wave_fence();
             }
-            wave_fence();
         }
         __syncthreads();
         if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = 0.0;      // masked in the U0 sweep
         __syncthreads();
     }
+    c.clk.lap(FT_PUSH);
     sweep(lu.Uf, st, 1, c);
     if (t > 0) {
         if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.zt[tid];
         __syncthreads();
     }
+    c.clk.lap(FT_U);
 }
 
 // ---- y' U = c' for the current U: c in x (pivot-indexed) on entry; y over the never-updated pivots in x, over the
 // slots in zt on exit (invert_upper_left, mod.rs:332-356, on the unrotated representation) ------------------------------
-__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep) {
+// first_level: the sweep over U0' may start at this level (everything below is known to be zero)
+__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 1) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     if (t > 0) {
@@ -201,80 +284,92 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
         }
         __syncthreads();
     }
-    if (do_sweep) sweep(lu.Ub, st, 2, c);
+    if (do_sweep) sweep(lu.Ub, st, 2, c, first_level);
     if (t > 0) {
-        for (int s = wave; s < t; s += NW) {
+        {   // spike column of slot s against y over the never-updated pivots: eight lanes per slot, all slots at once
+            const int s = tid >> 3, l8 = tid & 7;
             double sum = 0.0;
-            if (c.slot_live[s] && do_sweep) {
+            if (s < t && do_sweep && c.slot_live[s]) {
                 const int base = s * c.m;
                 const int e0 = c.spk_off[s * (NW + 1)], e1 = c.spk_off[s * (NW + 1) + NW];
-                for (int e = e0 + lane; e < e1; e += 64) {
+#pragma unroll 4
+                for (int e = e0 + l8; e < e1; e += 8) {
                     const int k = st.spk_idx[base + e];
-                    if (c.tslot[k] < 0) sum = fma(st.spk_val[base + e], c.x[k], sum);
+                    const double v = st.spk_val[base + e];
+                    if (c.tslot[k] < 0) sum = fma(v, c.x[k], sum);
                 }
-                sum = wave_sum(sum);
             }
-            if (lane == 0) c.dots[s] = sum;
+            sum = sum8(sum);
+            if (s < t && l8 == 0) c.dots[s] = sum;
         }
         __syncthreads();
         if (wave == 0) {
             const int s = lane;
             const bool in = s < t;
             const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
-            const double rhs = in ? c.ct[s] - c.dots[s] : 0.0;
-            double acc = 0.0, y = 0.0;
-            for (int s2 = 0; s2 < t; ++s2) {
-                const double v = lane_bcast((rhs - acc) * rdiag, s2);
-                if (s == s2) y = v;
-                if (in && s > s2) acc = fma(c.TC[s2 * c.ldt + s], v, acc);
-            }
+            const double y = tc_chain<true, false>(c.TC, c.ldt, t, s, in ? c.ct[s] - c.dots[s] : 0.0, 0.0, rdiag, -1);
             if (in) c.zt[s] = c.slot_live[s] ? y : 0.0;
         }
         __syncthreads();
     }
+    c.clk.lap(FT_UT);
 }
 
 // ---- BTRAN: c (pivot-indexed, i.e. Q' c) in x on entry; w = P z with z' B = c' on exit (mod.rs:204-222) ------------------
-__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep) {
+__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 1) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
-    ft_ut_solve(lu, st, c, do_sweep);
+    ft_ut_solve(lu, st, c, do_sweep, first_level);
     if (t > 0) {
         // eta.apply_left in reverse order (eta_file.rs:49-65): v[j] -= r_s[j] v[p_s]; first the chain over the slots ...
         if (wave == 0) {
             const int s = lane;
             const bool in = s < t;
             const int nxt = in ? c.slot_next[s] : -1, prev = in ? c.slot_prev[s] : -1;
-            double base = (in && nxt < 0) ? c.zt[s] : 0.0;       // a slot without successor is live
-            double acc = 0.0, u = 0.0;
-            for (int s2 = t - 1; s2 >= 0; --s2) {
-                const double v = lane_bcast(base - acc, s2);
-                if (s == s2) u = v;
-                if (in && s < s2) {
-                    acc = fma(c.TC[s2 * c.ldt + s], v, acc);
-                    if (nxt == s2) base = v;
-                }
-            }
+            // (a slot without successor is live: its value starts from y)
+            const double u = tc_chain<false, false>(c.TC, c.ldt, t, s, (in && nxt < 0) ? c.zt[s] : 0.0, 0.0, 1.0, nxt);
             if (in) {
                 c.uv[s] = u;
                 if (prev < 0) c.x[c.slot_pivot[s]] = u;          // the value every earlier eta (sparse part) and L' see
             }
         }
         __syncthreads();
-        // ... then the sparse parts, one wavefront per bucket of pivots (j % NW), slots in reverse order
-        for (int s = t - 1; s >= 0; --s) {
-            const double u = c.uv[s];
-            if (u == 0.0) continue;
-            const int e0 = c.eta_off[s * (NW + 1) + wave], e1 = c.eta_off[s * (NW + 1) + wave + 1];
-            for (int e = e0 + lane; e < e1; e += 64) {
-                const int j = c.eta_idx[e];
-                c.x[j] = fma(-c.eta_val[e], u, c.x[j]);
+        // ... then the sparse parts, one wavefront per bucket of pivots (j % NW), slots in reverse order; the pairs of the
+        // next slot are fetched while this one is applied
+        {
+            const double ureg = lane < t ? c.uv[lane] : 0.0;
+            const int o0 = lane < t ? c.eta_off[lane * (NW + 1) + wave] : 0, o1 = lane < t ? c.eta_off[lane * (NW + 1) + wave + 1] : 0;
+            unsigned long long mask = __ballot(lane < t && ureg != 0.0 && o1 > o0);
+            int pj = -1, pe0 = 0, pe1 = 0, ps = 0;
+            double pv = 0.0;
+            auto fetch = [&]() {
+                ps = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)mask));
+                mask &= ~(1ull << ps);
+                pe0 = __builtin_amdgcn_readlane(o0, ps); pe1 = __builtin_amdgcn_readlane(o1, ps);
+                pj = -1;
+                if (pe0 + lane < pe1) { pj = c.eta_idx[pe0 + lane]; pv = c.eta_val[pe0 + lane]; }
+            };
+            bool more = mask != 0;
+            if (more) fetch();
+            while (more) {
+                const int cs = ps, cj = pj, ce0 = pe0, ce1 = pe1;
+                const double cv = pv;
+                more = mask != 0;
+                if (more) fetch();
+                const double u = lane_bcast(ureg, cs);
+                if (cj >= 0) c.x[cj] = fma(-cv, u, c.x[cj]);
+                for (int e = ce0 + lane + 64; e < ce1; e += 64) {
+                    const int j = c.eta_idx[e];
+                    c.x[j] = fma(-c.eta_val[e], u, c.x[j]);
+                }
+                wave_fence();
             }
-            wave_fence();
         }
         __syncthreads();
     }
+    c.clk.lap(FT_BT_CHAIN);
     sweep(lu.Lb, st, 3, c);
+    c.clk.lap(FT_LT);
 }
 
 // Bucketed, order-preserving compaction of the non-zeros of vec over the never-updated pivots (pivot `skip` excluded):
@@ -345,8 +440,9 @@ __device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st,
         if (tid < t && tid > s_old && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.TC[s_old * c.ldt + tid];
     }
     const bool do_sweep = __syncthreads_or(any) != 0;
-    // r' = u_bar' U^-1 (mod.rs:122)
-    ft_ut_solve(lu, st, c, do_sweep);
+    c.clk.lap(FT_UBAR);
+    // r' = u_bar' U^-1 (mod.rs:122); u_bar lives on pivots after p, i.e. in levels above p's own
+    ft_ut_solve(lu, st, c, do_sweep, st.lev_ub[p] + 1);
     // R = I - e_p r' (eta_file.rs:10-18): sparse part over the never-updated pivots into the eta pool, bucketed ...
     const int tn = t;                                  // the new slot
     int eta_n = 0;
@@ -395,6 +491,7 @@ __device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st,
     c.eta_used += eta_n;
     c.t = tn + 1;
     __syncthreads();
+    c.clk.lap(FT_COMPACT);
 }
 
 // x := P a for tableau column q (partially.rs:72-80, matrix_data.rs:308-348), pivot-indexed.  Ends with a barrier.
@@ -478,7 +575,9 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     if (rec->outcome != DEV_RUNNING) return;
     FtCtx c;
     ft_bind(c, lds, st);
+    c.clk.start(st.prof);
     ft_load(c, st, pb.minus_pi);
+    c.clk.lap(FT_LOAD_STORE);
     const int tid = threadIdx.x;
     const ColumnTable& ct = pb.ct;
     const int m = c.m, n = pb.n, rule = pb.rule, cost_mode = pb.phase;
@@ -498,28 +597,52 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         fake.last_selected = last_selected;
         double key = INFINITY;
         int kj = 0x7fffffff;
+        // (column offsets and the basis flag of the thread's NEXT column are fetched while this one is priced, and the
+        // entries of a column are fetched eight at a time: one memory round trip per column instead of one per entry)
+        const int na = ct.nr_artificial, nstr = ct.nr_normal;
+        long long ns0 = 0, ns1 = 0;
+        int nflag = 0;
+        auto prefetch = [&](int j) {
+            if (j < n) {
+                nflag = pb.in_basis[j];
+                const int p = j - na;
+                if (p >= 0 && p < nstr) { ns0 = pb.csc.col_ptr[p]; ns1 = pb.csc.col_ptr[p + 1]; }
+            }
+        };
+        prefetch(tid);
         for (int j = tid; j < n; j += NT) {
+            const long long s0 = ns0, s1 = ns1;
+            const int flag = nflag;
+            prefetch(j + NT);
             double v;
-            if (j < ct.nr_artificial) {
+            if (j < na) {
                 v = (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]];
             } else {
-                const int p = j - ct.nr_artificial;
-                if (p < ct.nr_normal) {
+                const int p = j - na;
+                if (p < nstr) {
                     v = 0.0;
-                    const int64_t s0 = pb.csc.col_ptr[p], s1 = pb.csc.col_ptr[p + 1];
-                    for (int64_t e = s0; e < s1; ++e) v = fma(c.pi[pb.csc.row_idx[e]], pb.csc.values[e], v);
+                    for (long long e = s0; e < s1; e += 8) {
+                        int ri[8];
+                        double va[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (e + u < s1) { ri[u] = pb.csc.row_idx[e + u]; va[u] = pb.csc.values[e + u]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (e + u < s1) v = fma(c.pi[ri[u]], va[u], v);
+                    }
                     const int br = ct.bound_row[p];
                     if (br >= 0) v += c.pi[br];
                     if (cost_mode == 2) v += ct.cost[p];
                 } else {
-                    const int vv = p - ct.nr_normal;
+                    const int vv = p - nstr;
                     const int r0 = ct.vrow0[vv], r1 = ct.vrow1[vv];
                     v = r0 >= 0 ? (double)ct.vsign[vv] * c.pi[r0] : 0.0;
                     if (r1 >= 0) v += c.pi[r1];
                 }
             }
             pb.d[j] = v;
-            if (!pb.in_basis[j] && v < -pb.tol.cost) {
+            if (!flag && v < -pb.tol.cost) {
                 const double k = select_key(rule, n, &fake, j, v);
                 if (k < key || (k == key && j < kj)) { key = k; kj = j; }
             }
@@ -542,9 +665,11 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         }
         q = kj; key1 = key; d_q = pb.d[q];
         if (rule == 1) last_selected = q;
+        c.clk.lap(FT_PRICE);
 
         // ---- FTRAN (mod.rs:157-190) ------------------------------------------------------------------------------------
         ft_scatter_column(st, pb, c, q);
+        c.clk.lap(FT_SCATTER);
         ft_ftran(lu, st, c);
 
         // ---- RATIO TEST (tableau/mod.rs:221-247; two passes as relp_device_common.h ratio_body) ------------------------
@@ -570,6 +695,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         r = block_min_int(c, rr);
         alpha_r = c.x[st.inv_colperm[r]];
         b_r = pb.b[r];
+        c.clk.lap(FT_RATIO);
 
         // ---- b (carry/mod.rs:283-313) while alpha is still in x -----------------------------------------------------
         const double br = b_r / alpha_r;
@@ -583,6 +709,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         }
         __syncthreads();
 
+        c.clk.lap(FT_B);
         // ---- basis inverse: the Forrest-Tomlin update, then row r of the new inverse (mod.rs:92-155, 204-222) --------------
         ft_update(lu, st, c, r);
         for (int k = tid; k < m; k += NT) c.x[k] = 0.0;
@@ -612,8 +739,11 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (br == 0.0) degenerate += 1;
         iterations += 1;
         __syncthreads();
+        c.clk.lap(FT_VECTORS);
     }
     ft_store(c, st, pb.minus_pi, need_refactor);
+    c.clk.lap(FT_LOAD_STORE);
+    c.clk.flush(st.prof);
     if (tid == 0) {
         rec->outcome = outcome; rec->q = q; rec->d_q = d_q; rec->r = r; rec->leaving = leaving; rec->alpha_r = alpha_r;
         rec->b_r = b_r; rec->minus_objective = minus_objective; rec->iterations = iterations;
@@ -646,6 +776,7 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
     ft_load(c, st, nullptr);
     const int tid = threadIdx.x;
     bool sweep_u = true;
+    int first = 1;
     if (rhs) {
         for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.colperm[k]];
     } else {
@@ -653,9 +784,10 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
         const int p = st.inv_colperm[r];
         for (int k = tid; k < c.m; k += NT) c.x[k] = k == p ? 1.0 : 0.0;
         sweep_u = c.tslot[p] < 0;                      // an updated pivot has no entry in U0 any more
+        first = st.lev_ub[p];                          // e_p: nothing below the level of p's own row
     }
     __syncthreads();
-    ft_btran(lu, st, c, sweep_u);
+    ft_btran(lu, st, c, sweep_u, first);
     for (int k = tid; k < c.m; k += NT) rho[lu.rowperm[k]] = c.x[k];
 }
 
@@ -681,7 +813,7 @@ void ft_allow_lds(const void* fn, int bytes) {
 }  // namespace
 
 size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap) { return (size_t)ft_layout(m, tcap, eta_cap).total; }
-int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels) { return schedule_lds_bytes(m, nnz, n_levels); }
+int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg) { return schedule_lds_bytes(m, nnz, n_levels, n_seg); }
 
 void launch_ft_run(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int64_t max_pivots, hipStream_t s) {
     ft_allow_lds(reinterpret_cast<const void*>(k_ft_run), st.lds_bytes);

@@ -18,8 +18,9 @@ static constexpr int kLuLdsBytes = 156 * 1024;        // of the CU's 160 KB
 
 __host__ __device__ inline int64_t lu_up16(int64_t b) { return (b + 15) / 16 * 16; }
 // bytes needed to hold a schedule (m rows, nnz entries) in LDS
-__host__ __device__ inline int64_t schedule_lds_bytes(int m, int64_t nnz, int n_levels) {
-    return lu_up16((int64_t)sizeof(LuRow) * m) + lu_up16(8 * nnz) + lu_up16(4 * nnz) + lu_up16(4 * ((int64_t)n_levels + 1));
+__host__ __device__ inline int64_t schedule_lds_bytes(int m, int64_t nnz, int n_levels, int n_seg = 0) {
+    return lu_up16((int64_t)sizeof(LuRow) * m) + lu_up16(8 * nnz) + lu_up16(4 * nnz) + lu_up16(4 * ((int64_t)n_levels + 1)) +
+           lu_up16(12 * (int64_t)n_seg);
 }
 
 // Sum over the 8 lanes of a group, result valid in the group's lane 0.  DPP row shifts (lane i reads lane
@@ -62,6 +63,12 @@ template <int NT>
 __device__ __forceinline__ int group_lanes(int rows) {
     return rows <= NT / 64 ? 64 : rows <= NT / 32 ? 32 : rows <= NT / 16 ? 16 : 8;
 }
+// the same as a shift count: the group width is a power of two, and an integer division by a run-time value costs
+// ~40 instructions on this hardware (five of them per level were most of a level's 1,200 clocks)
+template <int NT>
+__device__ __forceinline__ int group_shift(int rows) {
+    return rows <= NT / 64 ? 6 : rows <= NT / 32 ? 5 : rows <= NT / 16 ? 4 : 3;
+}
 
 // kStage: copy the schedule into LDS at `base` and solve from there; otherwise solve from global memory.
 // NT = threads of the workgroup.
@@ -83,25 +90,27 @@ __device__ __forceinline__ void solve_schedule(const DeviceSchedule& s, int m, c
     const int tid = threadIdx.x;
     // prefetched first row of the level about to be solved
     int t0 = level_ptr[0], t1 = level_ptr[1];
-    int G = group_lanes<NT>(t1 - t0);
+    int lg = group_shift<NT>(t1 - t0);
     LuRow pr{0, 0, 0, 0, 1.0};
     int pidx = 0; double pval = 0.0;
-    bool have = t0 + tid / G < t1;
+    bool have = t0 + (tid >> lg) < t1;
     if (have) {
-        pr = rows[t0 + tid / G];
-        if (pr.e0 + tid % G < pr.e1) { pidx = idx[pr.e0 + tid % G]; pval = val[pr.e0 + tid % G]; }
+        pr = rows[t0 + (tid >> lg)];
+        const int l0 = tid & ((1 << lg) - 1);
+        if (pr.e0 + l0 < pr.e1) { pidx = idx[pr.e0 + l0]; pval = val[pr.e0 + l0]; }
     }
     for (int lev = 0; lev < n_levels; ++lev) {
         const LuRow cr = pr; const int cidx = pidx; const double cval = pval; const bool chave = have;
-        const int ct0 = t0, ct1 = t1, cG = G;
-        const int g = tid / cG, lane = tid % cG, ngroups = NT / cG;
+        const int ct0 = t0, ct1 = t1, cG = 1 << lg;
+        const int g = tid >> lg, lane = tid & (cG - 1), ngroups = NT >> lg;
         if (lev + 1 < n_levels) {
             t0 = t1; t1 = level_ptr[lev + 2];
-            G = group_lanes<NT>(t1 - t0);
-            have = t0 + tid / G < t1; pval = 0.0; pidx = 0;
+            lg = group_shift<NT>(t1 - t0);
+            have = t0 + (tid >> lg) < t1; pval = 0.0; pidx = 0;
             if (have) {
-                pr = rows[t0 + tid / G];
-                if (pr.e0 + tid % G < pr.e1) { pidx = idx[pr.e0 + tid % G]; pval = val[pr.e0 + tid % G]; }
+                pr = rows[t0 + (tid >> lg)];
+                const int l0 = tid & ((1 << lg) - 1);
+                if (pr.e0 + l0 < pr.e1) { pidx = idx[pr.e0 + l0]; pval = val[pr.e0 + l0]; }
             }
         }
         if (chave) {
@@ -118,6 +127,130 @@ __device__ __forceinline__ void solve_schedule(const DeviceSchedule& s, int m, c
             if (lane == 0) x[r.k] = (x[r.k] + sum) * r.diag;
         }
         __syncthreads();
+    }
+}
+
+// ---- the solve as a software pipeline over segments of levels (the persistent pivot kernel) -----------------------------
+// Every load whose address does not depend on x is issued one (entries) or two (row headers, level offsets) levels ahead,
+// so that inside a level a wavefront waits for one LDS round trip - the gather x[idx] of its own row - then reduces
+// over the lane group and writes x[k].  Levels [lo, hi) on the first W threads of the workgroup:
+//   kBarrier = true   every level ends with a workgroup barrier (wide levels: rows spread over W / 64 wavefronts);
+//   kBarrier = false  W = 64: ONE wavefront walks a run of narrow levels (<= 8 rows each) with no barrier at all - LDS
+//                     operations of a wavefront execute in order, so the write of x[k] in one level is seen by the
+//                     gather of the next.  A barrier costs more than the arithmetic of a level with three rows, and the
+//                     tail of a basis factor is dozens of such levels.
+template <int W, bool kBarrier>
+__device__ __forceinline__ void levels_pipelined(const LuRow* rows, const int32_t* idx, const double* val, const int32_t* level_ptr,
+                                                 int nl, int lo, int hi, double* x) {
+    const int tid = threadIdx.x;
+    auto lp = [&](int i) { return level_ptr[i < nl ? i : nl]; };
+    // c = the level being solved, n = the next one (header loaded), f = the one after (offsets known)
+    int c_t0 = lp(lo), c_t1 = lp(lo + 1), n_t1 = lp(lo + 2), f_t1 = lp(lo + 3);
+    int c_lg = group_shift<W>(c_t1 - c_t0), n_lg = group_shift<W>(n_t1 - c_t1), f_lg = group_shift<W>(f_t1 - n_t1);
+    const LuRow none{0, 0, 0, 0, 0.0};
+    LuRow c_h = none, n_h = none;
+    bool c_on = c_t0 + (tid >> c_lg) < c_t1, n_on = c_t1 + (tid >> n_lg) < n_t1;
+    if (c_on) c_h = rows[c_t0 + (tid >> c_lg)];
+    if (n_on) n_h = rows[c_t1 + (tid >> n_lg)];
+    int c_idx = 0; double c_val = 0.0;
+    {
+        const int l0 = tid & ((1 << c_lg) - 1);
+        if (c_on && c_h.e0 + l0 < c_h.e1) { c_idx = idx[c_h.e0 + l0]; c_val = val[c_h.e0 + l0]; }
+    }
+    for (int lev = lo; lev < hi; ++lev) {
+        const int c_G = 1 << c_lg, lane = tid & (c_G - 1), g = tid >> c_lg, ngroups = W >> c_lg;
+        // the loads the critical path waits for: the operand of this lane's first entry and the row's own unknown
+        const double xv = (c_on && c_h.e0 + lane < c_h.e1) ? x[c_idx] : 0.0;
+        const double xk = (c_on && lane == 0) ? x[c_h.k] : 0.0;
+        // first entry of the next level's row, header of the level after that, one more level offset
+        int n_idx = 0; double n_val = 0.0;
+        {
+            const int ln = tid & ((1 << n_lg) - 1);
+            if (n_on && n_h.e0 + ln < n_h.e1) { n_idx = idx[n_h.e0 + ln]; n_val = val[n_h.e0 + ln]; }
+        }
+        const int f_t0 = n_t1;
+        const bool f_on = f_t0 + (tid >> f_lg) < f_t1;
+        LuRow f_h = none;
+        if (f_on) f_h = rows[f_t0 + (tid >> f_lg)];
+        const int ff_t1 = lp(lev + 4);
+        if (c_on) {
+            double sum = (c_h.e0 + lane < c_h.e1) ? -c_val * xv : 0.0;
+            for (int e = c_h.e0 + lane + c_G; e < c_h.e1; e += c_G) sum = fma(-val[e], x[idx[e]], sum);
+            sum = group_sum(sum, c_G);
+            if (lane == 0) x[c_h.k] = (xk + sum) * c_h.diag;
+        }
+        for (int t = c_t0 + g + ngroups; t < c_t1; t += ngroups) {        // levels wider than one pass
+            const LuRow r = rows[t];
+            double sum = 0.0;
+            for (int e = r.e0 + lane; e < r.e1; e += c_G) sum = fma(-val[e], x[idx[e]], sum);
+            sum = group_sum(sum, c_G);
+            if (lane == 0) x[r.k] = (x[r.k] + sum) * r.diag;
+        }
+        if (kBarrier) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        c_t0 = c_t1; c_t1 = n_t1; n_t1 = f_t1; f_t1 = ff_t1;
+        c_lg = n_lg; n_lg = f_lg; f_lg = group_shift<W>(f_t1 - n_t1);
+        c_h = n_h; c_on = n_on; c_idx = n_idx; c_val = n_val;
+        n_h = f_h; n_on = f_on;
+    }
+}
+
+// NT threads stage the schedule (one contiguous copy) and solve level 0; the segments of levels run on NTW threads with
+// barriers (wide) or on one wavefront without (solo), as the host marked them (Engine::lu_upload_factors).  `first_level`
+// >= 1: levels below it are known to hold zeros only.  Same arithmetic and order as solve_schedule.
+struct NoLap { __device__ void operator()() const {} };
+template <bool kStage, int NT, int NTW = NT, class Lap = NoLap>
+__device__ __forceinline__ void solve_schedule_pipelined(const DeviceSchedule& s, int m, char* base, double* x,
+                                                         int first_level = 1, Lap lap = Lap()) {
+    const LuRow* rows = s.rows; const int32_t* idx = s.idx; const double* val = s.val; const int32_t* level_ptr = s.level_ptr;
+    const int32_t* seg = s.seg;
+    if (kStage) {
+        // The engine packs a schedule's arrays back to back, each padded to 16 bytes (rows, idx, val, level_ptr,
+        // segments), and the LDS image keeps that layout.  16-byte loads, eight in flight per thread.
+        const int64_t b_rows = lu_up16((int64_t)sizeof(LuRow) * m), b_idx = lu_up16(4 * (int64_t)s.nnz),
+                      b_val = lu_up16(8 * (int64_t)s.nnz), b_lp = lu_up16(4 * ((int64_t)s.n_levels + 1)),
+                      b_seg = lu_up16(12 * (int64_t)s.n_seg);
+        const int n16 = (int)((b_rows + b_idx + b_val + b_lp + b_seg) / 16);
+        const int4* src = reinterpret_cast<const int4*>(s.rows);
+        int4* dst = reinterpret_cast<int4*>(base);
+        for (int i0 = threadIdx.x; i0 < n16; i0 += 8 * NT) {
+            int4 buf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) buf[u] = src[i0 + u * NT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) dst[i0 + u * NT] = buf[u];
+        }
+        __syncthreads();
+        rows = reinterpret_cast<const LuRow*>(base);
+        idx = reinterpret_cast<const int32_t*>(base + b_rows);
+        val = reinterpret_cast<const double*>(base + b_rows + b_idx);
+        level_ptr = reinterpret_cast<const int32_t*>(base + b_rows + b_idx + b_val);
+        seg = reinterpret_cast<const int32_t*>(base + b_rows + b_idx + b_val + b_lp);
+    }
+    const int nl = s.n_levels;
+    const int tid = threadIdx.x;
+    // level 0 = the rows without entries (often most of the factor: slack and singleton columns): one thread per row
+    if (first_level <= 1) {
+        const int z0 = level_ptr[0], z1 = level_ptr[nl < 1 ? nl : 1];
+        for (int t = z0 + tid; t < z1; t += NT) {
+            const LuRow r = rows[t];
+            if (r.diag != 1.0) x[r.k] *= r.diag;
+        }
+        __syncthreads();
+    }
+    lap();                                             // (phase clock of the caller: staging + level 0 end here)
+    const int l0v = first_level < 1 ? 1 : first_level;
+    for (int sg = 0; sg < s.n_seg; ++sg) {
+        const int lo = max(seg[3 * sg], l0v), hi = seg[3 * sg + 1], solo = seg[3 * sg + 2];
+        if (lo >= hi) continue;
+        if (solo) {
+            if (tid < 64) levels_pipelined<64, false>(rows, idx, val, level_ptr, nl, lo, hi, x);
+            __syncthreads();
+        } else if (tid < NTW) {
+            levels_pipelined<NTW, true>(rows, idx, val, level_ptr, nl, lo, hi, x);
+        } else {
+            for (int lev = lo; lev < hi; ++lev) __syncthreads();      // wavefronts that only keep the barrier count
+        }
     }
 }
 

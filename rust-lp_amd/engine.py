@@ -86,6 +86,7 @@ _SIGNATURES = {
     "relp_flush": (C.c_int, [C.c_void_p]),
     "relp_update_block": (C.c_int32, [C.c_void_p]),
     "relp_lu_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_lu_phase_cycles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_basis_inverse_row": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "relp_should_refactor": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "relp_generate_column_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -426,6 +427,14 @@ class Tableau:
         ptr, idx, val, nnz = np.zeros(m + 1, dtype=np.int64), np.zeros(cap, dtype=np.int32), np.zeros(cap), C.c_int64()
         self._ck(self._lib.relp_lu_get_upper(self._h, ptr.ctypes.data, idx.ctypes.data, val.ctypes.data, cap, C.byref(nnz)))
         return [list(zip(idx[ptr[j]:ptr[j + 1]].tolist(), val[ptr[j]:ptr[j + 1]].tolist())) for j in range(m)]
+
+    PHASE_NAMES = ("price", "scatter", "l_solve", "eta_forward", "spike_push", "u_solve", "ratio", "b_update", "u_bar",
+                   "ut_solve", "compact", "eta_backward", "lt_solve", "vectors", "load_store", "stage_and_level0")
+
+    def lu_phase_cycles(self) -> dict:
+        out = (C.c_int64 * 16)()
+        self._ck(self._lib.relp_lu_phase_cycles(self._h, out))
+        return dict(zip(self.PHASE_NAMES, (int(v) for v in out)))
 
     def from_basis(self, basis_columns) -> None:
         arr = np.ascontiguousarray(basis_columns, dtype=np.int32)

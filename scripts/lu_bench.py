@@ -31,11 +31,13 @@ def problems(argv):
 def main():
     argv = sys.argv[1:] or ["synth", "400", "800", "77"]
     for name, md in problems(argv):
-        for label, kw in (("lu128", dict(engine=engine.ENGINE_LU)), ("lu64", dict(engine=engine.ENGINE_LU, update_block=64)),
-                          ("lu16", dict(engine=engine.ENGINE_LU, update_block=16)),
+        for label, kw in (("lu", dict(engine=engine.ENGINE_LU)), ("lu32", dict(engine=engine.ENGINE_LU, update_block=32)),
+                          ("lu11", dict(engine=engine.ENGINE_LU, update_block=11)),
                           ("revised", dict(engine=engine.ENGINE_REVISED, update_block=0)),
                           ("tableau", dict(engine=engine.ENGINE_TABLEAU, update_block=32))):
             t = engine.Tableau(md, **kw)
+            if label.startswith("lu"):
+                t.profile_enable(True, 100000, 1)
             t0 = time.perf_counter()
             try:
                 oc = t.solve_relaxation()
@@ -45,6 +47,12 @@ def main():
             dt = time.perf_counter() - t0
             it = t.iterations()
             extra = t.lu_stats() if label.startswith("lu") else ""
+            if label.startswith("lu"):
+                prof = {k: (c, round(ms, 2)) for k, (c, ms) in t.profile_read().items() if c}
+                extra = f"{extra} events {prof}"
+                ph = t.lu_phase_cycles()
+                tot = sum(ph.values()) or 1
+                extra += " phases% " + " ".join(f"{k}={100.0 * v / tot:.1f}" for k, v in ph.items()) + f" cycles/pivot={tot / max(it, 1):.0f}"
             print(f"{name:28s} {label:8s} {engine.OUTCOME_NAMES[oc]:10s} pivots {it:7d}  {dt:8.3f} s  {it / dt:9.0f} it/s  "
                   f"obj {t.objective_function_value():.9g} {extra}", flush=True)
 
