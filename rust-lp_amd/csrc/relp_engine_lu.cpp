@@ -4,10 +4,13 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
 #include <cstring>
 #include <initializer_list>
 
 namespace relp {
+
+static_assert(sizeof(EllPassHost) == 16 && sizeof(EllPass) == 16, "the packed pass header is one 16-byte load");
 
 // ------------------------------------------------------------------------------------------------
 // Sparse LU engine: matrix in CSC, factors from the host (relp_lu.cpp), solves on the device
@@ -120,6 +123,28 @@ relp_status_t Engine::lu_upload_factors() {
     for (int32_t l = 0; l + 1 < (int32_t)hlu_.Ub.level_ptr.size(); ++l)
         for (int32_t t = hlu_.Ub.level_ptr[l]; t < hlu_.Ub.level_ptr[l + 1]; ++t) lev_ub[hlu_.Ub.level_rows[t]] = l;
     const size_t o_lub = put(lev_ub.data(), sizeof(int32_t) * m_);
+    // the four schedules once more, packed "ELL by group" for the persistent pivot kernel: one contiguous image each
+    // (groups | lvl_grp | rdiag | sval | sidx | rk); rows of U and U' without entries are kept, an update may mask them
+    EllPacked ell[4];
+    size_t o_ell[4] = {0, 0, 0, 0}, o_ruf = 0, o_rub = 0;
+    if (ft_) {
+        for (int k = 0; k < 4; ++k) {
+            ell_pack(*sch[k], k == 1 || k == 2, &ell[k]);
+            const EllPacked& e = ell[k];
+            o_ell[k] = put(e.passes.data(), sizeof(EllPassHost) * e.passes.size());
+            put(e.lvl_pass.data(), sizeof(int32_t) * e.lvl_pass.size());
+            put(e.rdiag.data(), sizeof(double) * e.rdiag.size());
+            put(e.sval.data(), sizeof(double) * e.sval.size());
+            put(e.oval.data(), sizeof(double) * e.oval.size());
+            put(e.rovf.data(), sizeof(int32_t) * e.rovf.size());
+            put(e.sidx.data(), sizeof(uint16_t) * e.sidx.size());
+            put(e.srow.data(), sizeof(uint16_t) * e.srow.size());
+            put(e.rk.data(), sizeof(uint16_t) * e.rk.size());
+            put(e.oidx.data(), sizeof(uint16_t) * e.oidx.size());
+        }
+        o_ruf = put(ell[1].row_of_pivot.data(), sizeof(int32_t) * m_);
+        o_rub = put(ell[2].row_of_pivot.data(), sizeof(int32_t) * m_);
+    }
     size_t o_rows[4], o_idx[4], o_val[4], o_lp[4], o_seg[4];
     int32_t n_seg[4];
     std::vector<LuRow> rows(m_);
@@ -178,14 +203,35 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.task_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tuf);
         fts_.task_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tub);
         fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
-        // what is left of the CU's LDS after the work vectors stages one schedule at a time
+        fts_.row_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_ruf);
+        fts_.row_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rub);
+        // what is left of the CU's LDS after the work vectors stages one schedule image at a time
         const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_);
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
         int64_t need = 0;
+        auto up16 = [](int64_t b) { return (b + 15) / 16 * 16; };
         for (int k = 0; k < 4; ++k) {
-            const int64_t b = ft_schedule_stage_bytes(m_, (int64_t)sch[k]->idx.size(), (int32_t)sch[k]->level_ptr.size() - 1, n_seg[k]);
-            fts_.stage[k] = b <= fts_.stage_bytes ? 1 : 0;
-            if (fts_.stage[k]) need = std::max(need, b);
+            const EllPacked& e = ell[k];
+            EllSchedule& d = fts_.ell[k];
+            const int64_t np = (int64_t)e.passes.size(), nlv = (int64_t)e.lvl_pass.size(), nr = (int64_t)e.rk.size(),
+                          nln = (int64_t)e.sidx.size(), nov = (int64_t)e.oidx.size();
+            char* q = d_lu_buf_ + o_ell[k];
+            char* const q0 = q;
+            d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * np);
+            d.lvl_pass = reinterpret_cast<const int32_t*>(q); q += up16(4 * nlv);
+            d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * nr);
+            d.sval = reinterpret_cast<const double*>(q); q += up16(8 * nln);
+            d.oval = reinterpret_cast<const double*>(q); q += up16(8 * nov);
+            d.rovf = reinterpret_cast<const int32_t*>(q); q += up16(8 * nr);
+            d.sidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
+            d.srow = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
+            d.rk = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nr);
+            d.oidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nov);
+            const int64_t total = q - q0;
+            d.n_passes = (int32_t)np; d.n_levels = (int32_t)nlv - 1; d.n_rows = (int32_t)nr; d.n_lanes = (int32_t)nln; d.n_ovf = (int32_t)nov;
+            d.bytes = (int32_t)total;
+            fts_.stage[k] = total <= fts_.stage_bytes ? 1 : 0;
+            if (fts_.stage[k]) need = std::max(need, total);
         }
         fts_.lds_bytes = (int32_t)(base + need);
     }
@@ -216,7 +262,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     auto take = [&](int64_t bytes) { const int64_t at = o; o += round_up(bytes, 16); return at; };
     const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_pv = take(4 * tc), o_lv = take(4 * tc), o_ts = take(4 * m),
                   o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp), o_so = take(4 * tc * nwp), o_ei = take(4 * (int64_t)ft_eta_cap_),
-                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 16);
+                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_ft_hdr_), 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -321,6 +367,11 @@ relp_status_t Engine::lu_phase_cycles(int64_t* out16) {
     if (!lu_ || !ft_) return fail(RELP_E_UNSUPPORTED, "phase clocks are the persistent pivot kernel's");
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemcpy(out16, fts_.prof, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    int64_t probe[4];
+    HIP_TRY(hipMemcpy(probe, fts_.prof + 16, sizeof(probe), hipMemcpyDeviceToHost));
+    if (probe[3] > 0)
+        std::fprintf(stderr, "[relp probe] passes %lld: loads %.0f, reduce+write %.0f, barrier %.0f clocks per pass\n", (long long)probe[3],
+                     (double)probe[0] / probe[3], (double)probe[1] / probe[3], (double)probe[2] / probe[3]);
     return RELP_OK;
 }
 

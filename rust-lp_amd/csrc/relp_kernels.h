@@ -104,6 +104,23 @@ struct DeviceLU {
     const int32_t* colperm;   // pivot step -> basis position
     DeviceSchedule Lf, Uf, Ub, Lb;
 };
+// The same solve packed "ELL by pass" for the persistent pivot kernel (relp_lu.hpp: ell_pack; relp_lu_device.h: ell_solve):
+// one image per schedule, contiguous in device memory in the order of the members below, every array padded to 16 bytes.
+struct EllPass { int32_t lane0, lanes, info, level; };     // info: max lg | last-of-level << 8 | overflow << 9
+struct EllSchedule {
+    const EllPass*  passes;      // n_passes
+    const int32_t*  lvl_pass;    // n_levels + 1: first pass of a level
+    double*         rdiag;       // n_rows: 1 / diagonal; 0 = row masked by a Forrest-Tomlin update (the only mutable part)
+    const double*   sval;        // n_lanes
+    const double*   oval;        // n_ovf: entries beyond the 64th of a row
+    const int32_t*  rovf;        // 2 n_rows: overflow range of a row
+    const uint16_t* sidx;        // n_lanes
+    const uint16_t* srow;        // n_lanes: row descriptor | lg << 13
+    const uint16_t* rk;          // n_rows: the row's own pivot
+    const uint16_t* oidx;        // n_ovf
+    int32_t n_passes, n_levels, n_rows, n_lanes, n_ovf;
+    int32_t bytes;               // size of the image
+};
 // Column indices at or above this value are artificial variables that survived phase 1 (see
 // Engine::switch_to_phase_two): INT32_MAX - (na - 1 - a).  They have no flag, no cost and no column.
 static constexpr int32_t kWrappedArtificialBase = 0x40000000;
@@ -143,6 +160,9 @@ struct FtState {
     const int32_t* inv_colperm;            // basis position -> pivot
     const int32_t* task_uf;                // pivot -> index of its row in the U (FTRAN) schedule
     const int32_t* task_ub;                // pivot -> index of its row in the U' (BTRAN) schedule
+    const int32_t* row_uf;                 // pivot -> row descriptor in the packed U schedule  (masked by rdiag = 0)
+    const int32_t* row_ub;                 // pivot -> row descriptor in the packed U' schedule
+    EllSchedule ell[4];                    // L, U, U', L' packed for the persistent kernel
     const int32_t* lev_ub;                 // pivot -> level of its row in the U' schedule (a solve with e_p or u_bar starts there)
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area

@@ -176,10 +176,11 @@ __device__ __forceinline__ double sum8(double v) {
 }
 
 constexpr int NTS = 256;                               // threads that walk the levels of a solve (one wavefront per SIMD)
-__device__ __forceinline__ void sweep(const DeviceSchedule& s, const FtState& st, int which, FtCtx& c, int first_level = 1) {
+// `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
+__device__ __forceinline__ void sweep(const FtState& st, int which, FtCtx& c, int first_level = 0) {
     auto lap = [&]() { c.clk.lap(FT_STAGE); };
-    if (st.stage[which]) solve_schedule_pipelined<true, NT, NTS>(s, c.m, c.stage, c.x, first_level, lap);
-    else solve_schedule_pipelined<false, NT, NTS>(s, c.m, c.stage, c.x, first_level, lap);
+    if (st.stage[which]) ell_solve<true, NT, NTS>(st.ell[which], c.stage, c.x, first_level, lap, st.prof ? st.prof + 16 : nullptr);
+    else ell_solve<false, NT, NTS>(st.ell[which], c.stage, c.x, first_level, lap, st.prof ? st.prof + 16 : nullptr);
 }
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
@@ -187,7 +188,7 @@ __device__ __forceinline__ void sweep(const DeviceSchedule& s, const FtState& st
 __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, FtCtx& c) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
-    sweep(lu.Lf, st, 0, c);
+    sweep(st, 0, c);
     c.clk.lap(FT_L);
     if (t > 0) {
         // eta.apply_right for every update (eta_file.rs:72-109): w[p_s] -= r_s . w.  The sparse parts read entries no
@@ -261,7 +262,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
         __syncthreads();
     }
     c.clk.lap(FT_PUSH);
-    sweep(lu.Uf, st, 1, c);
+    sweep(st, 1, c);
     if (t > 0) {
         if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.zt[tid];
         __syncthreads();
@@ -272,7 +273,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
 // ---- y' U = c' for the current U: c in x (pivot-indexed) on entry; y over the never-updated pivots in x, over the
 // slots in zt on exit (invert_upper_left, mod.rs:332-356, on the unrotated representation) ------------------------------
 // first_level: the sweep over U0' may start at this level (everything below is known to be zero)
-__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 1) {
+__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     if (t > 0) {
@@ -284,7 +285,7 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
         }
         __syncthreads();
     }
-    if (do_sweep) sweep(lu.Ub, st, 2, c, first_level);
+    if (do_sweep) sweep(st, 2, c, first_level);
     if (t > 0) {
         {   // spike column of slot s against y over the never-updated pivots: eight lanes per slot, all slots at once
             const int s = tid >> 3, l8 = tid & 7;
@@ -316,7 +317,7 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
 }
 
 // ---- BTRAN: c (pivot-indexed, i.e. Q' c) in x on entry; w = P z with z' B = c' on exit (mod.rs:204-222) ------------------
-__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 1) {
+__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     ft_ut_solve(lu, st, c, do_sweep, first_level);
@@ -368,7 +369,7 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
         __syncthreads();
     }
     c.clk.lap(FT_BT_CHAIN);
-    sweep(lu.Lb, st, 3, c);
+    sweep(st, 3, c);
     c.clk.lap(FT_LT);
 }
 
@@ -469,8 +470,8 @@ __device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st,
     // delete row p and column p from U (mod.rs:127-129): mask the pivot in U0, or kill its slot
     if (s_old < 0) {
         if (tid == 0) {
-            const_cast<LuRow*>(lu.Uf.rows)[st.task_uf[p]].diag = 0.0;
-            const_cast<LuRow*>(lu.Ub.rows)[st.task_ub[p]].diag = 0.0;
+            st.ell[1].rdiag[st.row_uf[p]] = 0.0;
+            st.ell[2].rdiag[st.row_ub[p]] = 0.0;
         }
     } else {
         if (tid >= s_old && tid < c.tcap) c.TC[s_old * c.ldt + tid] = 0.0;    // (left of the diagonal: eta coefficients, kept)
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
     ft_load(c, st, nullptr);
     const int tid = threadIdx.x;
     bool sweep_u = true;
-    int first = 1;
+    int first = 0;
     if (rhs) {
         for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.colperm[k]];
     } else {

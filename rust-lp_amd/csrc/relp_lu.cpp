@@ -261,6 +261,57 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     return true;
 }
 
+void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
+    const int32_t m = (int32_t)t.diag.size();
+    const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
+    *out = EllPacked{};
+    out->row_of_pivot.assign(m, -1);
+    out->lvl_pass.assign(nlev + 1, 0);
+    constexpr int32_t kLanes = 256;                      // threads that walk the passes (relp_lu_device.h: ell_solve)
+    struct Row { int32_t lg, k; };
+    for (int32_t l = 0; l < nlev; ++l) {
+        out->lvl_pass[l] = (int32_t)out->passes.size();
+        std::vector<Row> rows;
+        for (int32_t i = t.level_ptr[l]; i < t.level_ptr[l + 1]; ++i) {
+            const int32_t k = t.level_rows[i], n = t.ptr[k + 1] - t.ptr[k];
+            if (n == 0 && !keep_trivial && t.diag[k] == 1.0) continue;
+            int32_t lg = 0;
+            while ((1 << lg) < n && lg < 6) ++lg;
+            rows.push_back(Row{lg, k});
+        }
+        std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.lg > b.lg; });
+        const size_t first_pass = out->passes.size();
+        for (size_t i = 0; i < rows.size();) {
+            EllPassHost ps{(int32_t)out->sidx.size(), 0, 0, l};
+            int32_t pos = 0, max_lg = 0, ovf = 0;
+            while (i < rows.size() && pos + (1 << rows[i].lg) <= kLanes) {
+                const int32_t k = rows[i].k, lg = rows[i].lg, w = 1 << lg, n = t.ptr[k + 1] - t.ptr[k];
+                const int32_t row = (int32_t)out->rk.size();
+                out->row_of_pivot[k] = row;
+                out->rk.push_back((uint16_t)k);
+                out->rdiag.push_back(1.0 / t.diag[k]);
+                out->rovf.push_back((int32_t)out->oidx.size());
+                for (int32_t j = 0; j < w; ++j) {
+                    const bool has = j < n;
+                    out->sidx.push_back(has ? (uint16_t)t.idx[t.ptr[k] + j] : 0);
+                    out->sval.push_back(has ? t.val[t.ptr[k] + j] : 0.0);
+                    out->srow.push_back((uint16_t)(row | (lg << 13)));
+                }
+                for (int32_t e = t.ptr[k] + w; e < t.ptr[k + 1]; ++e) { out->oidx.push_back((uint16_t)t.idx[e]); out->oval.push_back(t.val[e]); ovf = 1; }
+                out->rovf.push_back((int32_t)out->oidx.size());
+                max_lg = std::max(max_lg, lg);
+                pos += w;
+                ++i;
+            }
+            ps.lanes = pos;
+            ps.info = max_lg | (ovf << 9);
+            out->passes.push_back(ps);
+        }
+        if (out->passes.size() > first_pass) out->passes.back().info |= 1 << 8;
+    }
+    out->lvl_pass[nlev] = (int32_t)out->passes.size();
+}
+
 bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& lcols_in,
                        const std::vector<std::vector<std::pair<int32_t, double>>>& ucols_in, LUFactors* out, std::string* err) {
     std::vector<std::vector<std::pair<int32_t, double>>> lrows(m), lcols(m), urows(m), ucols(m);

@@ -44,6 +44,24 @@ struct LUFactors {
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err);
 
+// A triangular schedule packed for the persistent pivot kernel ("ELL by pass"): a level is executed in passes of up to
+// 256 lanes; inside a pass every row owns 2^lg consecutive lanes (lg = ceil(log2(entries)), at most 64 lanes; widths
+// sorted descending so that every row starts at a multiple of its width), lane j of a row holds entry j of the row as an
+// (index, value) slot plus the row's descriptor index.  Thread t of the workgroup finds everything it needs at
+// lane0 + t: no ranges, no searches.  Entries beyond the 64th of a row live in an overflow list (rare).  Padding slots
+// are (0, 0.0).
+struct EllPassHost { int32_t lane0, lanes, info, level; };     // info: max lg | (last pass of its level) << 8 | (has overflow rows) << 9
+struct EllPacked {
+    std::vector<EllPassHost> passes;
+    std::vector<int32_t> lvl_pass;       // level -> first pass (n_levels + 1)
+    std::vector<double> rdiag, sval, oval;
+    std::vector<int32_t> rovf;           // 2 per row: overflow entries [begin, end)
+    std::vector<uint16_t> sidx, srow, rk, oidx;   // srow: row descriptor | lg << 13
+    std::vector<int32_t> row_of_pivot;   // pivot -> row descriptor or -1 (rows without entries of a unit-diagonal factor are left out)
+};
+// keep_trivial: also pack the rows without entries whose diagonal is 1 (needed when rows can be masked later: U, U')
+void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out);
+
 // Factors given literally (P = Q = I), the way the reference's tests build a `LUDecomposition { lower_triangular,
 // upper_triangular, .. }` (lower_upper/mod.rs:44-52): L column-major, unit diagonal implied, entries (row > column);
 // U column-major, entries (row <= column) with the diagonal among them.

@@ -254,4 +254,118 @@ __device__ __forceinline__ void solve_schedule_pipelined(const DeviceSchedule& s
     }
 }
 
+// ---- the solve on the "ELL by pass" image (relp_lu.hpp: ell_pack) -----------------------------------------------------
+// levels_pipelined above spends ~120 instructions per level on row headers, entry ranges and lane-group arithmetic, and a
+// wavefront of this kernel retires roughly one instruction per 9 clocks (dependent address arithmetic), so a level costs
+// ~1,100 clocks whatever its three rows hold.  Here thread t finds its (index, value) slot and its row at lane0 + t; the
+// slots of the pass after next, the row descriptors of the next pass and the operands of this pass are fetched in the
+// same iteration, none of these loads depending on another.
+__host__ __device__ inline int64_t ell_image_bytes(int n_passes, int n_levels, int n_rows, int n_lanes, int n_ovf) {
+    return lu_up16(16LL * n_passes) + lu_up16(4LL * (n_levels + 1)) + lu_up16(8LL * n_rows) + lu_up16(8LL * n_lanes) +
+           lu_up16(8LL * n_ovf) + lu_up16(8LL * n_rows) + lu_up16(2LL * n_lanes) + lu_up16(2LL * n_lanes) + lu_up16(2LL * n_rows) +
+           lu_up16(2LL * n_ovf);
+}
+
+struct EllHeader { int lane0, lanes, max_lg, last, ovf; };
+__device__ __forceinline__ EllHeader ell_header(const EllPass* passes, int p, int p1) {
+    EllHeader h{0, 0, 0, 0, 0};
+    if (p < p1) {
+        const int4 raw = *reinterpret_cast<const int4*>(passes + p);
+        h.lane0 = __builtin_amdgcn_readfirstlane(raw.x);
+        h.lanes = __builtin_amdgcn_readfirstlane(raw.y);
+        const int info = __builtin_amdgcn_readfirstlane(raw.z);
+        h.max_lg = info & 0xff; h.last = (info >> 8) & 1; h.ovf = (info >> 9) & 1;
+    }
+    return h;
+}
+
+// NT threads stage the image and keep the barrier count; the first NTW threads walk the passes from level `first_level`
+// on (levels below it are known to hold zeros only; 0 = everything, incl. the rows without entries).
+template <bool kStage, int NT, int NTW, class Lap = NoLap>
+__device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int first_level = 0, Lap lap = Lap(),
+                                          long long* probe = nullptr) {
+    const EllPass* passes = s.passes; const int32_t* lvl_pass = s.lvl_pass; const double* rdiag = s.rdiag;
+    const double* sval = s.sval; const double* oval = s.oval; const int32_t* rovf = s.rovf;
+    const uint16_t* sidx = s.sidx; const uint16_t* srow = s.srow; const uint16_t* rk = s.rk; const uint16_t* oidx = s.oidx;
+    const int tid = threadIdx.x;
+    if (kStage) {
+        const int n16 = s.bytes / 16;
+        const int4* src = reinterpret_cast<const int4*>(s.passes);
+        int4* dst = reinterpret_cast<int4*>(base);
+        for (int i0 = tid; i0 < n16; i0 += 8 * NT) {
+            int4 buf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) buf[u] = src[i0 + u * NT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) dst[i0 + u * NT] = buf[u];
+        }
+        __syncthreads();
+        char* q = base;
+        passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * s.n_passes);
+        lvl_pass = reinterpret_cast<const int32_t*>(q); q += lu_up16(4LL * (s.n_levels + 1));
+        rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_rows);
+        sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
+        oval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_ovf);
+        rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(8LL * s.n_rows);
+        sidx = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
+        srow = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
+        rk = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_rows);
+        oidx = reinterpret_cast<const uint16_t*>(q);
+    }
+    lap();
+    const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
+    const int p0 = __builtin_amdgcn_readfirstlane(lvl_pass[fl]), p1 = s.n_passes;
+    if (tid >= NTW) {                                  // wavefronts that only keep the barrier count
+        for (int p = p0; p < p1; ++p)
+            if ((reinterpret_cast<const int4*>(passes + p)->z >> 8) & 1) __syncthreads();
+        return;
+    }
+    // c = the pass being solved (slots and row descriptors loaded), n = the next one (slots loaded), f = the one after
+    EllHeader hc = ell_header(passes, p0, p1), hn = ell_header(passes, p0 + 1, p1), hf = ell_header(passes, p0 + 2, p1);
+    int c_idx = 0, c_rowlg = 0, c_k = 0, n_idx = 0, n_rowlg = 0;
+    double c_val = 0.0, c_diag = 0.0, n_val = 0.0;
+    if (tid < hc.lanes) {
+        c_idx = sidx[hc.lane0 + tid]; c_val = sval[hc.lane0 + tid]; c_rowlg = srow[hc.lane0 + tid];
+        c_k = rk[c_rowlg & 0x1fff]; c_diag = rdiag[c_rowlg & 0x1fff];
+    }
+    if (tid < hn.lanes) { n_idx = sidx[hn.lane0 + tid]; n_val = sval[hn.lane0 + tid]; n_rowlg = srow[hn.lane0 + tid]; }
+    long long pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, prn = 0;
+    for (int p = p0; p < p1; ++p) {
+        const bool act = tid < hc.lanes;
+        long long tA = 0, tB = 0, tC = 0, tD = 0;
+        if (probe) tA = clock64();
+        // what the critical path waits for: the operand of this lane's slot and the row's own unknown
+        const double xv = act ? x[c_idx] : 0.0;
+        const double xk = act ? x[c_k] : 0.0;
+        // row descriptors of the next pass, slots of the one after, header of the one after that
+        int n_k = 0, f_idx = 0, f_rowlg = 0;
+        double n_diag = 0.0, f_val = 0.0;
+        if (tid < hn.lanes) { n_k = rk[n_rowlg & 0x1fff]; n_diag = rdiag[n_rowlg & 0x1fff]; }
+        if (tid < hf.lanes) { f_idx = sidx[hf.lane0 + tid]; f_val = sval[hf.lane0 + tid]; f_rowlg = srow[hf.lane0 + tid]; }
+        const EllHeader hff = ell_header(passes, p + 3, p1);
+        if (probe) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tB = clock64(); }
+        const int lg = c_rowlg >> 13;
+        double sum = -c_val * xv;
+        if (hc.ovf && act) {                           // rows with more than 64 entries
+            const int row = c_rowlg & 0x1fff;
+            for (int e = rovf[2 * row] + (tid & 63); e < rovf[2 * row + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
+        }
+        // sum over the 2^lg lanes of every row (rows are aligned to their width; a lane outside the step's reach adds 0)
+        if (hc.max_lg >= 6) sum = fma(lane_plus_32(sum), lg >= 6 ? 1.0 : 0.0, sum);
+        if (hc.max_lg >= 5) sum = fma(lane_plus_16(sum), lg >= 5 ? 1.0 : 0.0, sum);
+        if (hc.max_lg >= 4) sum = fma(dpp_row_shl<0x108>(sum), lg >= 4 ? 1.0 : 0.0, sum);
+        if (hc.max_lg >= 3) sum = fma(dpp_row_shl<0x104>(sum), lg >= 3 ? 1.0 : 0.0, sum);
+        if (hc.max_lg >= 2) sum = fma(dpp_row_shl<0x102>(sum), lg >= 2 ? 1.0 : 0.0, sum);
+        if (hc.max_lg >= 1) sum = fma(dpp_row_shl<0x101>(sum), lg >= 1 ? 1.0 : 0.0, sum);
+        if (act && (tid & ((1 << lg) - 1)) == 0) x[c_k] = (xk + sum) * c_diag;
+        if (probe) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tC = clock64(); }
+        if (hc.last) __syncthreads();
+        if (probe) { tD = clock64(); pr0 += tB - tA; pr1 += tC - tB; pr2 += tD - tC; prn += 1; }
+        hc = hn; hn = hf; hf = hff;
+        c_idx = n_idx; c_val = n_val; c_rowlg = n_rowlg; c_k = n_k; c_diag = n_diag;
+        n_idx = f_idx; n_val = f_val; n_rowlg = f_rowlg;
+    }
+    if (probe && tid == 0) { probe[0] += pr0; probe[1] += pr1; probe[2] += pr2; probe[3] += prn; (void)pr3; }
+}
+
 }  // namespace relp
