@@ -168,6 +168,7 @@ class Engine {
     DeviceLU dlu_{};
     relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop
     int64_t lu_refactors_ = 0;
+    double refactor_us_[3] = {0.0, 0.0, 0.0};            // host time: basis + columns, factorisation, schedules + upload
     // revised engine: B^-1 is re-inverted from the basis columns every `reinvert_interval_` pivots (0 = never)
     int64_t reinvert_interval_ = 0, since_reinvert_ = 0, reinversions_ = 0;
     DeviceCSC csc() const { return DeviceCSC{d_cptr_, d_cidx_, d_cval_}; }

@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <climits>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 
@@ -62,6 +64,7 @@ relp_status_t Engine::lu_load_matrix(const relp_matrix_data_t& md) {
 // Refactorisation (lower_upper/mod.rs:199-202 + carry/mod.rs:602-614): B from the current basis
 // columns, P B Q = L U on the host, schedules to the device, W := empty.  Synchronises the stream.
 relp_status_t Engine::lu_refactor() {
+    const auto tb = std::chrono::steady_clock::now();
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpyAsync(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -86,12 +89,22 @@ relp_status_t Engine::lu_refactor() {
         }
     }
     std::string msg;
+    const auto t0 = std::chrono::steady_clock::now();
     if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
+    const auto t1 = std::chrono::steady_clock::now();
     relp_status_t st = lu_upload_factors();
     if (st) return st;
     if (ft_) { if ((st = ft_reset())) return st; }
     else launch_flush_reset(deferred(), d_rec_, stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
+    const auto t2 = std::chrono::steady_clock::now();
+    refactor_us_[0] += std::chrono::duration<double, std::micro>(t0 - tb).count();
+    refactor_us_[1] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    refactor_us_[2] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+    if (std::getenv("RELP_DEBUG") && lu_refactors_ % 60 == 59)
+        std::fprintf(stderr, "[relp] refactorisations so far %lld: basis download + columns %.0f us, lu_factor %.0f us, schedules + upload %.0f us (averages)\n",
+                     (long long)lu_refactors_ + 1, refactor_us_[0] / (lu_refactors_ + 1), refactor_us_[1] / (lu_refactors_ + 1),
+                     refactor_us_[2] / (lu_refactors_ + 1));
     since_flush_ = 0;
     ++lu_refactors_;
     return RELP_OK;
@@ -222,7 +235,7 @@ relp_status_t Engine::lu_upload_factors() {
             d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * nr);
             d.sval = reinterpret_cast<const double*>(q); q += up16(8 * nln);
             d.oval = reinterpret_cast<const double*>(q); q += up16(8 * nov);
-            d.rovf = reinterpret_cast<const int32_t*>(q); q += up16(8 * nr);
+            d.rovf = reinterpret_cast<const int32_t*>(q); q += up16(4 * (int64_t)e.rovf.size());
             d.sidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
             d.srow = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
             d.rk = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nr);
@@ -234,6 +247,11 @@ relp_status_t Engine::lu_upload_factors() {
             if (fts_.stage[k]) need = std::max(need, total);
         }
         fts_.lds_bytes = (int32_t)(base + need);
+        if (std::getenv("RELP_DEBUG") && lu_refactors_ % 60 == 59)
+            for (int k = 0; k < 4; ++k)
+                std::fprintf(stderr, "[relp] schedule %d: %d levels, %d passes, %d rows, %d lanes (%d entries), image %d bytes, staged %d (stage area %d, base %lld)\n",
+                             k, fts_.ell[k].n_levels, fts_.ell[k].n_passes, fts_.ell[k].n_rows, fts_.ell[k].n_lanes, (int)sch[k]->idx.size(),
+                             fts_.ell[k].bytes, fts_.stage[k], fts_.stage_bytes, (long long)base);
     }
     return RELP_OK;
 }
@@ -246,7 +264,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     if (m_ > kFtMaxRows) return RELP_OK;
     // the largest tail that leaves room for an eta pool of at least 2 m entries (one eta never exceeds m)
     for (int32_t tcap : {64, 48, 32, 16}) {
-        for (int64_t eta_cap : {(int64_t)4 * m_, (int64_t)2 * m_ + 64}) {
+        for (int64_t eta_cap : {(int64_t)2 * m_ + 64}) {     // (one eta never exceeds m entries; the rest of the LDS stages the schedules)
             eta_cap = std::max<int64_t>(eta_cap, 1024);
             if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap) + 4096 <= kFtLdsBudget) {
                 ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_ = true;
@@ -367,11 +385,6 @@ relp_status_t Engine::lu_phase_cycles(int64_t* out16) {
     if (!lu_ || !ft_) return fail(RELP_E_UNSUPPORTED, "phase clocks are the persistent pivot kernel's");
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemcpy(out16, fts_.prof, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
-    int64_t probe[4];
-    HIP_TRY(hipMemcpy(probe, fts_.prof + 16, sizeof(probe), hipMemcpyDeviceToHost));
-    if (probe[3] > 0)
-        std::fprintf(stderr, "[relp probe] passes %lld: loads %.0f, reduce+write %.0f, barrier %.0f clocks per pass\n", (long long)probe[3],
-                     (double)probe[0] / probe[3], (double)probe[1] / probe[3], (double)probe[2] / probe[3]);
     return RELP_OK;
 }
 

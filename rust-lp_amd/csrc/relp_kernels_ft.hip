@@ -32,7 +32,7 @@ __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
     int64_t o = 0;
     const int ldt = tcap + 1;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
-    L.x = take(8LL * m); L.sp = take(8LL * m); L.pi = take(8LL * m);
+    L.x = take(8LL * (m + 1)); L.sp = take(8LL * m); L.pi = take(8LL * m);      // x[m]: scratch word of ell_solve
     L.tc = take(8LL * tcap * ldt);
     L.dots = take(8LL * tcap); L.zt = take(8LL * tcap); L.uv = take(8LL * tcap); L.ct = take(8LL * tcap);
     L.slot_pivot = take(4LL * tcap); L.slot_prev = take(4LL * tcap); L.slot_live = take(4LL * tcap); L.slot_next = take(4LL * tcap);
@@ -179,8 +179,8 @@ constexpr int NTS = 256;                               // threads that walk the 
 // `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
 __device__ __forceinline__ void sweep(const FtState& st, int which, FtCtx& c, int first_level = 0) {
     auto lap = [&]() { c.clk.lap(FT_STAGE); };
-    if (st.stage[which]) ell_solve<true, NT, NTS>(st.ell[which], c.stage, c.x, first_level, lap, st.prof ? st.prof + 16 : nullptr);
-    else ell_solve<false, NT, NTS>(st.ell[which], c.stage, c.x, first_level, lap, st.prof ? st.prof + 16 : nullptr);
+    if (st.stage[which]) ell_solve<true, NT, NTS>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    else ell_solve<false, NT, NTS>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
 }
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------

@@ -310,6 +310,7 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
         if (out->passes.size() > first_pass) out->passes.back().info |= 1 << 8;
     }
     out->lvl_pass[nlev] = (int32_t)out->passes.size();
+    if (out->oidx.empty()) out->rovf.clear();            // no row has more than 64 entries: the ranges are never read
 }
 
 bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& lcols_in,

@@ -266,24 +266,42 @@ __host__ __device__ inline int64_t ell_image_bytes(int n_passes, int n_levels, i
            lu_up16(2LL * n_ovf);
 }
 
-struct EllHeader { int lane0, lanes, max_lg, last, ovf; };
-__device__ __forceinline__ EllHeader ell_header(const EllPass* passes, int p, int p1) {
-    EllHeader h{0, 0, 0, 0, 0};
-    if (p < p1) {
-        const int4 raw = *reinterpret_cast<const int4*>(passes + p);
-        h.lane0 = __builtin_amdgcn_readfirstlane(raw.x);
-        h.lanes = __builtin_amdgcn_readfirstlane(raw.y);
-        const int info = __builtin_amdgcn_readfirstlane(raw.z);
-        h.max_lg = info & 0xff; h.last = (info >> 8) & 1; h.ovf = (info >> 9) & 1;
-    }
+// sel: the reduction variant of the pass = max lg of its rows (0..6), or 7 when a row has more than 64 entries
+struct EllHeader { int lane0, lanes, sel, last; };
+__device__ __forceinline__ EllHeader ell_decode(const int4& raw, bool valid) {
+    EllHeader h;
+    h.lane0 = valid ? __builtin_amdgcn_readfirstlane(raw.x) : 0;
+    h.lanes = valid ? __builtin_amdgcn_readfirstlane(raw.y) : 0;
+    const int info = valid ? __builtin_amdgcn_readfirstlane(raw.z) : 0;
+    h.sel = (info >> 9) & 1 ? 7 : (info & 0xff);
+    h.last = (info >> 8) & 1;
     return h;
+}
+__device__ __forceinline__ EllHeader ell_header(const EllPass* passes, int p, int p1) {
+    const int4 raw = *reinterpret_cast<const int4*>(passes + (p < p1 ? p : p1 - 1));
+    return ell_decode(raw, p < p1);
+}
+
+// sum over the 2^lg lanes of every row of a pass whose widest row has 2^MAXLG lanes (rows are aligned to their width; a lane
+// whose row is narrower than a step's reach adds 0).  Straight-line: on this machine a branch costs ~20 clocks, an
+// instruction ~5 (scripts/microbench/issue_rate.hip), so the variant is chosen once per pass, not once per step.
+template <int MAXLG>
+__device__ __forceinline__ double ell_reduce(double sum, int lg) {
+    if (MAXLG >= 6) sum = fma(lane_plus_32(sum), lg >= 6 ? 1.0 : 0.0, sum);
+    if (MAXLG >= 5) sum = fma(lane_plus_16(sum), lg >= 5 ? 1.0 : 0.0, sum);
+    if (MAXLG >= 4) sum = fma(dpp_row_shl<0x108>(sum), lg >= 4 ? 1.0 : 0.0, sum);
+    if (MAXLG >= 3) sum = fma(dpp_row_shl<0x104>(sum), lg >= 3 ? 1.0 : 0.0, sum);
+    if (MAXLG >= 2) sum = fma(dpp_row_shl<0x102>(sum), lg >= 2 ? 1.0 : 0.0, sum);
+    if (MAXLG >= 1) sum = fma(dpp_row_shl<0x101>(sum), lg >= 1 ? 1.0 : 0.0, sum);
+    return sum;
 }
 
 // NT threads stage the image and keep the barrier count; the first NTW threads walk the passes from level `first_level`
-// on (levels below it are known to hold zeros only; 0 = everything, incl. the rows without entries).
+// on (levels below it are known to hold zeros only; 0 = everything, incl. the rows without entries).  x[dummy] is a
+// scratch word behind the vector: lanes that are not the first of their row store there, so the loop body has no
+// divergent branch (its loads are unconditional too: lanes beyond a pass re-read its last slot and contribute 0).
 template <bool kStage, int NT, int NTW, class Lap = NoLap>
-__device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int first_level = 0, Lap lap = Lap(),
-                                          long long* probe = nullptr) {
+__device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
     const EllPass* passes = s.passes; const int32_t* lvl_pass = s.lvl_pass; const double* rdiag = s.rdiag;
     const double* sval = s.sval; const double* oval = s.oval; const int32_t* rovf = s.rovf;
     const uint16_t* sidx = s.sidx; const uint16_t* srow = s.srow; const uint16_t* rk = s.rk; const uint16_t* oidx = s.oidx;
@@ -295,9 +313,9 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         for (int i0 = tid; i0 < n16; i0 += 8 * NT) {
             int4 buf[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) buf[u] = src[i0 + u * NT];
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; buf[u] = src[i < n16 ? i : n16 - 1]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) dst[i0 + u * NT] = buf[u];
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; if (i < n16) dst[i] = buf[u]; }
         }
         __syncthreads();
         char* q = base;
@@ -306,7 +324,7 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_rows);
         sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
         oval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_ovf);
-        rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(8LL * s.n_rows);
+        rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(s.n_ovf > 0 ? 8LL * s.n_rows : 0);
         sidx = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
         srow = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
         rk = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_rows);
@@ -315,6 +333,7 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
     lap();
     const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
     const int p0 = __builtin_amdgcn_readfirstlane(lvl_pass[fl]), p1 = s.n_passes;
+    if (p0 >= p1) return;                              // (uniform)
     if (tid >= NTW) {                                  // wavefronts that only keep the barrier count
         for (int p = p0; p < p1; ++p)
             if ((reinterpret_cast<const int4*>(passes + p)->z >> 8) & 1) __syncthreads();
@@ -322,50 +341,53 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
     }
     // c = the pass being solved (slots and row descriptors loaded), n = the next one (slots loaded), f = the one after
     EllHeader hc = ell_header(passes, p0, p1), hn = ell_header(passes, p0 + 1, p1), hf = ell_header(passes, p0 + 2, p1);
-    int c_idx = 0, c_rowlg = 0, c_k = 0, n_idx = 0, n_rowlg = 0;
-    double c_val = 0.0, c_diag = 0.0, n_val = 0.0;
-    if (tid < hc.lanes) {
-        c_idx = sidx[hc.lane0 + tid]; c_val = sval[hc.lane0 + tid]; c_rowlg = srow[hc.lane0 + tid];
+    auto slot_of = [&](const EllHeader& h) { const int top = h.lanes > 0 ? h.lanes - 1 : 0; return h.lane0 + (tid < top ? tid : top); };
+    int c_idx, c_rowlg, c_k, n_idx, n_rowlg;
+    double c_val, c_diag, n_val;
+    {
+        const int sc = slot_of(hc), sn = slot_of(hn);
+        c_idx = sidx[sc]; c_val = sval[sc]; c_rowlg = srow[sc];
+        n_idx = sidx[sn]; n_val = sval[sn]; n_rowlg = srow[sn];
         c_k = rk[c_rowlg & 0x1fff]; c_diag = rdiag[c_rowlg & 0x1fff];
     }
-    if (tid < hn.lanes) { n_idx = sidx[hn.lane0 + tid]; n_val = sval[hn.lane0 + tid]; n_rowlg = srow[hn.lane0 + tid]; }
-    long long pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, prn = 0;
     for (int p = p0; p < p1; ++p) {
         const bool act = tid < hc.lanes;
-        long long tA = 0, tB = 0, tC = 0, tD = 0;
-        if (probe) tA = clock64();
         // what the critical path waits for: the operand of this lane's slot and the row's own unknown
-        const double xv = act ? x[c_idx] : 0.0;
-        const double xk = act ? x[c_k] : 0.0;
-        // row descriptors of the next pass, slots of the one after, header of the one after that
-        int n_k = 0, f_idx = 0, f_rowlg = 0;
-        double n_diag = 0.0, f_val = 0.0;
-        if (tid < hn.lanes) { n_k = rk[n_rowlg & 0x1fff]; n_diag = rdiag[n_rowlg & 0x1fff]; }
-        if (tid < hf.lanes) { f_idx = sidx[hf.lane0 + tid]; f_val = sval[hf.lane0 + tid]; f_rowlg = srow[hf.lane0 + tid]; }
-        const EllHeader hff = ell_header(passes, p + 3, p1);
-        if (probe) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tB = clock64(); }
+        const double xv = x[c_idx];
+        const double xk = x[c_k];
+        // row descriptors of the next pass, slots of the one after, raw header of the one after that
+        const int nrow = n_rowlg & 0x1fff;
+        const int n_k = rk[nrow];
+        const double n_diag = rdiag[nrow];
+        const int sf = slot_of(hf);
+        const int f_idx = sidx[sf], f_rowlg = srow[sf];
+        const double f_val = sval[sf];
+        const int4 raw = *reinterpret_cast<const int4*>(passes + (p + 3 < p1 ? p + 3 : p1 - 1));
         const int lg = c_rowlg >> 13;
-        double sum = -c_val * xv;
-        if (hc.ovf && act) {                           // rows with more than 64 entries
-            const int row = c_rowlg & 0x1fff;
-            for (int e = rovf[2 * row] + (tid & 63); e < rovf[2 * row + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
+        double sum = act ? -c_val * xv : 0.0;
+        switch (hc.sel) {
+            case 0: break;
+            case 1: sum = ell_reduce<1>(sum, lg); break;
+            case 2: sum = ell_reduce<2>(sum, lg); break;
+            case 3: sum = ell_reduce<3>(sum, lg); break;
+            case 4: sum = ell_reduce<4>(sum, lg); break;
+            case 5: sum = ell_reduce<5>(sum, lg); break;
+            case 6: sum = ell_reduce<6>(sum, lg); break;
+            default: {                                 // a row with more than 64 entries in this pass
+                if (act) {
+                    const int row = c_rowlg & 0x1fff;
+                    for (int e = rovf[2 * row] + (tid & 63); e < rovf[2 * row + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
+                }
+                sum = ell_reduce<6>(sum, lg);
+            }
         }
-        // sum over the 2^lg lanes of every row (rows are aligned to their width; a lane outside the step's reach adds 0)
-        if (hc.max_lg >= 6) sum = fma(lane_plus_32(sum), lg >= 6 ? 1.0 : 0.0, sum);
-        if (hc.max_lg >= 5) sum = fma(lane_plus_16(sum), lg >= 5 ? 1.0 : 0.0, sum);
-        if (hc.max_lg >= 4) sum = fma(dpp_row_shl<0x108>(sum), lg >= 4 ? 1.0 : 0.0, sum);
-        if (hc.max_lg >= 3) sum = fma(dpp_row_shl<0x104>(sum), lg >= 3 ? 1.0 : 0.0, sum);
-        if (hc.max_lg >= 2) sum = fma(dpp_row_shl<0x102>(sum), lg >= 2 ? 1.0 : 0.0, sum);
-        if (hc.max_lg >= 1) sum = fma(dpp_row_shl<0x101>(sum), lg >= 1 ? 1.0 : 0.0, sum);
-        if (act && (tid & ((1 << lg) - 1)) == 0) x[c_k] = (xk + sum) * c_diag;
-        if (probe) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tC = clock64(); }
+        const bool lead = act && (tid & ((1 << lg) - 1)) == 0;
+        x[lead ? c_k : dummy] = (xk + sum) * c_diag;
         if (hc.last) __syncthreads();
-        if (probe) { tD = clock64(); pr0 += tB - tA; pr1 += tC - tB; pr2 += tD - tC; prn += 1; }
-        hc = hn; hn = hf; hf = hff;
+        hc = hn; hn = hf; hf = ell_decode(raw, p + 3 < p1);
         c_idx = n_idx; c_val = n_val; c_rowlg = n_rowlg; c_k = n_k; c_diag = n_diag;
         n_idx = f_idx; n_val = f_val; n_rowlg = f_rowlg;
     }
-    if (probe && tid == 0) { probe[0] += pr0; probe[1] += pr1; probe[2] += pr2; probe[3] += prn; (void)pr3; }
 }
 
 }  // namespace relp
