@@ -290,6 +290,35 @@ class Tableau {
         ck(relp_from_basis(h_, basis_columns.data()));
     }
 
+    // ---- the `BasisInverse` surface (carry/mod.rs:68-157) ----------------------------------------------------
+    // basis_inverse_row (carry/mod.rs:145-150; lower_upper/mod.rs:204-222; basis_inverse_rows.rs:181-183)
+    std::vector<double> basis_inverse_row(int32_t row) {
+        std::vector<double> out(nr_rows());
+        ck(relp_basis_inverse_row(h_, row, out.data()));
+        return out;
+    }
+    // should_refactor (lower_upper/mod.rs:199-202; basis_inverse_rows.rs:175-179)
+    bool should_refactor() { int32_t v = 0; ck(relp_should_refactor(h_, &v)); return v != 0; }
+    // generate_column(original_column) (carry/mod.rs:108-118) for sorted (row, value) pairs
+    std::vector<double> generate_column(const SparseVector& original_column) {
+        std::vector<int32_t> idx; std::vector<double> val;
+        for (auto& e : original_column) { idx.push_back(e.first); val.push_back(e.second); }
+        std::vector<double> out(nr_rows());
+        ck(relp_generate_column_of(h_, idx.data(), val.data(), (int32_t)idx.size(), out.data()));
+        return out;
+    }
+    // InverseMaintener::cost_difference (carry/mod.rs:572-577)
+    double cost_difference(const SparseVector& original_column) {
+        std::vector<int32_t> idx; std::vector<double> val;
+        for (auto& e : original_column) { idx.push_back(e.first); val.push_back(e.second); }
+        double out = 0.0;
+        ck(relp_cost_difference_of(h_, idx.data(), val.data(), (int32_t)idx.size(), &out));
+        return out;
+    }
+    // LUDecomposition: change_basis on the inverse alone (lower_upper/mod.rs:92-155) and `updates.len()`
+    void lu_change_basis(int32_t pivot_row_index) { ck(relp_lu_change_basis(h_, pivot_row_index)); }
+    int32_t lu_updates() { int32_t n = 0; ck(relp_lu_updates(h_, &n)); return n; }
+
   private:
     void ck(relp_status_t st) {
         if (st != RELP_OK) throw Error(st, relp_last_error(h_));

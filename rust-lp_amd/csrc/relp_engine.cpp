@@ -710,6 +710,18 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
         // of the last generate_column), then -pi from row r of the NEW inverse
         const FtProblem pb = ft_problem(0);
         launch_ft_update(dlu_, fts_, pb, stream_);
+        if ((st = ft_read_hdr())) return st;
+        if (h_ft_hdr_[2] == 2) {
+            // r did not fit the eta pool: refactorise the CURRENT basis, form the spike of the entering column again on
+            // the fresh factors (alpha itself is unchanged) and update those
+            std::vector<double> keep_alpha(m_);
+            HIP_TRY(hipMemcpy(keep_alpha.data(), d_alpha_, sizeof(double) * m_, hipMemcpyDeviceToHost));
+            if ((st = lu_refactor())) return st;
+            launch_ft_ftran(dlu_, fts_, pb, column, nullptr, d_alpha_, stream_);
+            HIP_TRY(hipMemcpyAsync(d_alpha_, keep_alpha.data(), sizeof(double) * m_, hipMemcpyHostToDevice, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            launch_ft_update(dlu_, fts_, pb, stream_);
+        }
         launch_ft_btran(dlu_, fts_, pb, -2, nullptr, d_rho_, stream_);
         launch_update_vectors(m_, d_alpha_, d_rho_, d_b_, d_minus_pi_, d_basis_, d_in_basis_, d_trace_, trace_cap_,
                               d_rec_, stream_);
@@ -1093,8 +1105,9 @@ relp_status_t Engine::retabulate() {
     if (!d_lu_scratch_) HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
     const TableauView tv = tview();
     const double* A = dA_ - (int64_t)col_lo_ * ld_a_;
-    // phase 2 keeps the artificial block in storage but never reads it: only the live columns are rebuilt
-    const int32_t c_first = std::max(sc_lo_, tv.col_off);
+    // every stored column, the artificial block included: phase 2 never prices it, but B^-1 and -pi are read off the
+    // columns that were the identity originally (relp_get_basis_inverse, relp_basis_inverse_row, relp_get_minus_pi)
+    const int32_t c_first = sc_lo_;
     ColumnTable storage = table();
     storage.nr_artificial = tab_na_;                    // storage columns keep the artificial block in front
     if (!launch_lu_ftran_cols(dlu_, tv, A, ld_a_, storage, c_first, sc_hi_ - c_first, stream_)) return RELP_OK;

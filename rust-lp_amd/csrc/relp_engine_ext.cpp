@@ -128,7 +128,9 @@ relp_status_t Engine::lu_change_basis(int32_t row) {
     h_rec_->r = row;
     if ((st = upload_rec())) return st;
     launch_ft_update(dlu_, fts_, ft_problem(0), stream_);
-    return ft_read_hdr();
+    if ((st = ft_read_hdr())) return st;
+    if (h_ft_hdr_[2] == 2) return fail(RELP_E_STATE, "the eta pool is full: refactor first (relp_flush), then generate the column again");
+    return RELP_OK;
 }
 
 // LUDecomposition { lower_triangular, upper_triangular, .. } given literally, P = Q = I (lower_upper/mod.rs:33-57)

@@ -139,7 +139,7 @@ relp_status_t Engine::lu_upload_factors() {
     // the four schedules once more, packed "ELL by group" for the persistent pivot kernel: one contiguous image each
     // (groups | lvl_grp | rdiag | sval | sidx | rk); rows of U and U' without entries are kept, an update may mask them
     EllPacked ell[4];
-    size_t o_ell[4] = {0, 0, 0, 0}, o_ruf = 0, o_rub = 0;
+    size_t o_ell[4] = {0, 0, 0, 0};
     if (ft_) {
         for (int k = 0; k < 4; ++k) {
             ell_pack(*sch[k], k == 1 || k == 2, &ell[k]);
@@ -151,12 +151,8 @@ relp_status_t Engine::lu_upload_factors() {
             put(e.oval.data(), sizeof(double) * e.oval.size());
             put(e.rovf.data(), sizeof(int32_t) * e.rovf.size());
             put(e.sidx.data(), sizeof(uint16_t) * e.sidx.size());
-            put(e.srow.data(), sizeof(uint16_t) * e.srow.size());
-            put(e.rk.data(), sizeof(uint16_t) * e.rk.size());
             put(e.oidx.data(), sizeof(uint16_t) * e.oidx.size());
         }
-        o_ruf = put(ell[1].row_of_pivot.data(), sizeof(int32_t) * m_);
-        o_rub = put(ell[2].row_of_pivot.data(), sizeof(int32_t) * m_);
     }
     size_t o_rows[4], o_idx[4], o_val[4], o_lp[4], o_seg[4];
     int32_t n_seg[4];
@@ -216,8 +212,6 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.task_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tuf);
         fts_.task_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tub);
         fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
-        fts_.row_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_ruf);
-        fts_.row_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rub);
         // what is left of the CU's LDS after the work vectors stages one schedule image at a time
         const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_);
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
@@ -226,22 +220,20 @@ relp_status_t Engine::lu_upload_factors() {
         for (int k = 0; k < 4; ++k) {
             const EllPacked& e = ell[k];
             EllSchedule& d = fts_.ell[k];
-            const int64_t np = (int64_t)e.passes.size(), nlv = (int64_t)e.lvl_pass.size(), nr = (int64_t)e.rk.size(),
-                          nln = (int64_t)e.sidx.size(), nov = (int64_t)e.oidx.size();
+            const int64_t np = (int64_t)e.passes.size(), nlv = (int64_t)e.lvl_pass.size(), nln = (int64_t)e.sidx.size(),
+                          nov = (int64_t)e.oidx.size();
             char* q = d_lu_buf_ + o_ell[k];
             char* const q0 = q;
             d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * np);
             d.lvl_pass = reinterpret_cast<const int32_t*>(q); q += up16(4 * nlv);
-            d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * nr);
+            d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * (int64_t)m_);
             d.sval = reinterpret_cast<const double*>(q); q += up16(8 * nln);
             d.oval = reinterpret_cast<const double*>(q); q += up16(8 * nov);
             d.rovf = reinterpret_cast<const int32_t*>(q); q += up16(4 * (int64_t)e.rovf.size());
             d.sidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
-            d.srow = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
-            d.rk = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nr);
             d.oidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nov);
             const int64_t total = q - q0;
-            d.n_passes = (int32_t)np; d.n_levels = (int32_t)nlv - 1; d.n_rows = (int32_t)nr; d.n_lanes = (int32_t)nln; d.n_ovf = (int32_t)nov;
+            d.n_passes = (int32_t)np; d.n_levels = (int32_t)nlv - 1; d.m = m_; d.n_lanes = (int32_t)nln; d.n_ovf = (int32_t)nov;
             d.bytes = (int32_t)total;
             fts_.stage[k] = total <= fts_.stage_bytes ? 1 : 0;
             if (fts_.stage[k]) need = std::max(need, total);
@@ -249,8 +241,8 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.lds_bytes = (int32_t)(base + need);
         if (std::getenv("RELP_DEBUG") && lu_refactors_ % 60 == 59)
             for (int k = 0; k < 4; ++k)
-                std::fprintf(stderr, "[relp] schedule %d: %d levels, %d passes, %d rows, %d lanes (%d entries), image %d bytes, staged %d (stage area %d, base %lld)\n",
-                             k, fts_.ell[k].n_levels, fts_.ell[k].n_passes, fts_.ell[k].n_rows, fts_.ell[k].n_lanes, (int)sch[k]->idx.size(),
+                std::fprintf(stderr, "[relp] schedule %d: %d levels, %d passes, %d lanes (%d entries), image %d bytes, staged %d (stage area %d, base %lld)\n",
+                             k, fts_.ell[k].n_levels, fts_.ell[k].n_passes, fts_.ell[k].n_lanes, (int)sch[k]->idx.size(),
                              fts_.ell[k].bytes, fts_.stage[k], fts_.stage_bytes, (long long)base);
     }
     return RELP_OK;

@@ -110,15 +110,13 @@ struct EllPass { int32_t lane0, lanes, info, level; };     // info: max lg | las
 struct EllSchedule {
     const EllPass*  passes;      // n_passes
     const int32_t*  lvl_pass;    // n_levels + 1: first pass of a level
-    double*         rdiag;       // n_rows: 1 / diagonal; 0 = row masked by a Forrest-Tomlin update (the only mutable part)
+    double*         rdiag;       // m: 1 / diagonal by pivot; 0 = row masked by a Forrest-Tomlin update (the only mutable part)
     const double*   sval;        // n_lanes
-    const double*   oval;        // n_ovf: entries beyond the 64th of a row
-    const int32_t*  rovf;        // 2 n_rows: overflow range of a row
-    const uint16_t* sidx;        // n_lanes
-    const uint16_t* srow;        // n_lanes: row descriptor | lg << 13
-    const uint16_t* rk;          // n_rows: the row's own pivot
+    const double*   oval;        // n_ovf: entries beyond the 63rd of a row
+    const int32_t*  rovf;        // 2 m (or nothing when n_ovf = 0): overflow range by pivot
+    const uint16_t* sidx;        // n_lanes: index | lg << 12
     const uint16_t* oidx;        // n_ovf
-    int32_t n_passes, n_levels, n_rows, n_lanes, n_ovf;
+    int32_t n_passes, n_levels, m, n_lanes, n_ovf;
     int32_t bytes;               // size of the image
 };
 // Column indices at or above this value are artificial variables that survived phase 1 (see
@@ -160,8 +158,6 @@ struct FtState {
     const int32_t* inv_colperm;            // basis position -> pivot
     const int32_t* task_uf;                // pivot -> index of its row in the U (FTRAN) schedule
     const int32_t* task_ub;                // pivot -> index of its row in the U' (BTRAN) schedule
-    const int32_t* row_uf;                 // pivot -> row descriptor in the packed U schedule  (masked by rdiag = 0)
-    const int32_t* row_ub;                 // pivot -> row descriptor in the packed U' schedule
     EllSchedule ell[4];                    // L, U, U', L' packed for the persistent kernel
     const int32_t* lev_ub;                 // pivot -> level of its row in the U' schedule (a solve with e_p or u_bar starts there)
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)

@@ -376,9 +376,10 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
 // Bucketed, order-preserving compaction of the non-zeros of vec over the never-updated pivots (pivot `skip` excluded):
 // bucket w = pivots with k % NW == w, written by wavefront w at [base + off[w], base + off[w + 1]).  off (NW + 1 ints) is
 // left in `off_out` relative to off_base.  Returns the total (all threads).  Ends with a barrier.
+// `room`: entries the destination can still take; when the non-zeros do not fit nothing is written and -1 is returned.
 template <class IdxPtr, class ValPtr>
 __device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip, IdxPtr out_idx, ValPtr out_val, int out_base,
-                                          int* off_out, int off_base) {
+                                          int* off_out, int off_base, int room) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_wave = (c.m - wave + NW - 1) / NW;           // pivots k = wave + NW * i, i < per_wave
     int cnt = 0;
@@ -391,6 +392,7 @@ __device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip,
     __syncthreads();
     int mine = 0, total = 0;
     for (int w = 0; w < NW; ++w) { const int v = c.red_i[w]; if (w < wave) mine += v; total += v; }
+    if (total > room) { __syncthreads(); return -1; }
     if (tid <= NW) {
         int o = 0;
         for (int w = 0; w < tid; ++w) o += c.red_i[w];
@@ -413,7 +415,8 @@ __device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip,
 }
 
 // ---- the Forrest-Tomlin update (mod.rs:92-155) for the basis change in basis position `r`; the spike is in sp -------------
-__device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st, FtCtx& c, int r) {
+// Returns false, with the update file untouched, when r does not fit the eta pool any more (refactorisation due).
+__device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st, FtCtx& c, int r) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     const int p = st.inv_colperm[r];                   // the pivot whose column leaves (mod.rs:99-107)
@@ -447,8 +450,10 @@ __device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st,
     // R = I - e_p r' (eta_file.rs:10-18): sparse part over the never-updated pivots into the eta pool, bucketed ...
     const int tn = t;                                  // the new slot
     int eta_n = 0;
-    if (do_sweep) eta_n = ft_compact(c, c.x, p, c.eta_idx, c.eta_val, c.eta_used, c.eta_off + tn * (NW + 1), c.eta_used);
-    else {
+    if (do_sweep) {
+        eta_n = ft_compact(c, c.x, p, c.eta_idx, c.eta_val, c.eta_used, c.eta_off + tn * (NW + 1), c.eta_used, c.eta_cap - c.eta_used);
+        if (eta_n < 0) return false;
+    } else {
         if (tid <= NW) c.eta_off[tn * (NW + 1) + tid] = c.eta_used;
         __syncthreads();
     }
@@ -470,8 +475,8 @@ __device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st,
     // delete row p and column p from U (mod.rs:127-129): mask the pivot in U0, or kill its slot
     if (s_old < 0) {
         if (tid == 0) {
-            st.ell[1].rdiag[st.row_uf[p]] = 0.0;
-            st.ell[2].rdiag[st.row_ub[p]] = 0.0;
+            st.ell[1].rdiag[p] = 0.0;
+            st.ell[2].rdiag[p] = 0.0;
         }
     } else {
         if (tid >= s_old && tid < c.tcap) c.TC[s_old * c.ldt + tid] = 0.0;    // (left of the diagonal: eta coefficients, kept)
@@ -487,12 +492,13 @@ __device__ __forceinline__ void ft_update(const DeviceLU& lu, const FtState& st,
         c.slot_pivot[tn] = p; c.slot_prev[tn] = s_old; c.slot_live[tn] = 1; c.slot_next[tn] = -1;
     }
     // ... entries in the never-updated rows into the spike pool, bucketed
-    ft_compact(c, c.sp, p, st.spk_idx + (int64_t)tn * c.m, st.spk_val + (int64_t)tn * c.m, 0, c.spk_off + tn * (NW + 1), 0);
+    ft_compact(c, c.sp, p, st.spk_idx + (int64_t)tn * c.m, st.spk_val + (int64_t)tn * c.m, 0, c.spk_off + tn * (NW + 1), 0, c.m);
     if (tid == 0) c.tslot[p] = (signed char)tn;
     c.eta_used += eta_n;
     c.t = tn + 1;
     __syncthreads();
     c.clk.lap(FT_COMPACT);
+    return true;
 }
 
 // x := P a for tableau column q (partially.rs:72-80, matrix_data.rs:308-348), pivot-indexed.  Ends with a barrier.
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     fake.last_selected = last_selected;
 
     for (long long it = 0; it < max_pivots; ++it) {
-        if (c.t >= st.max_updates || c.t >= c.tcap || c.eta_cap - c.eta_used < m) { need_refactor = 1; break; }
+        if (need_refactor || c.t >= st.max_updates || c.t >= c.tcap) { need_refactor = 1; break; }
         // ---- PRICE (pivot_rule.rs:38-126 over tableau/mod.rs:102-108): d_j = c_j + (-pi) . a_j, thread per column ----------
         fake.last_selected = last_selected;
         double key = INFINITY;
@@ -712,16 +718,26 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
 
         c.clk.lap(FT_B);
         // ---- basis inverse: the Forrest-Tomlin update, then row r of the new inverse (mod.rs:92-155, 204-222) --------------
-        ft_update(lu, st, c, r);
+        const bool updated = ft_update(lu, st, c, r);
+        const int pl = st.inv_colperm[r];
         for (int k = tid; k < m; k += NT) c.x[k] = 0.0;
         __syncthreads();
-        if (tid == 0) c.x[st.inv_colperm[r]] = 1.0;
+        if (tid == 0) c.x[pl] = 1.0;
         __syncthreads();
-        ft_btran(lu, st, c, false);                    // the leaving pivot is last in U now: no sweep over U0'
+        double rho_scale = 1.0;
+        if (updated) {
+            ft_btran(lu, st, c, false);                // the leaving pivot is last in U now: no sweep over U0'
+        } else {
+            // the eta pool is full: row r of the new inverse = row r of the old one / alpha_r (basis_inverse_rows.rs:42-51
+            // states the same division); the factors are rebuilt before the next pivot
+            ft_btran(lu, st, c, c.tslot[pl] < 0, st.lev_ub[pl]);
+            rho_scale = 1.0 / alpha_r;
+            need_refactor = 1;
+        }
         // ---- -pi, -obj, basis (carry/mod.rs:326-333, 549-570) ----------------------------------------------------------
         for (int k = tid; k < m; k += NT) {
             const int i = lu.rowperm[k];
-            const double rho = c.x[k];
+            const double rho = c.x[k] * rho_scale;
             pb.rho[i] = rho;
             c.pi[i] = fma(-d_q, rho, c.pi[i]);
         }
@@ -799,8 +815,8 @@ __global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtPro
     ft_load(c, st, nullptr);
     for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
     __syncthreads();
-    ft_update(lu, st, c, pb.rec->r);
-    ft_store(c, st, nullptr, (c.t >= st.max_updates || c.t >= c.tcap || c.eta_cap - c.eta_used < c.m) ? 1 : 0);
+    const bool updated = ft_update(lu, st, c, pb.rec->r);
+    ft_store(c, st, nullptr, !updated ? 2 : (c.t >= st.max_updates || c.t >= c.tcap) ? 1 : 0);
 }
 
 void ft_allow_lds(const void* fn, int bytes) {

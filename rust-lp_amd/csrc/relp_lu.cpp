@@ -265,8 +265,9 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
     const int32_t m = (int32_t)t.diag.size();
     const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
     *out = EllPacked{};
-    out->row_of_pivot.assign(m, -1);
     out->lvl_pass.assign(nlev + 1, 0);
+    out->rdiag.assign(m, 1.0);
+    out->rovf.assign(2 * (size_t)m, 0);
     constexpr int32_t kLanes = 256;                      // threads that walk the passes (relp_lu_device.h: ell_solve)
     struct Row { int32_t lg, k; };
     for (int32_t l = 0; l < nlev; ++l) {
@@ -276,7 +277,7 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
             const int32_t k = t.level_rows[i], n = t.ptr[k + 1] - t.ptr[k];
             if (n == 0 && !keep_trivial && t.diag[k] == 1.0) continue;
             int32_t lg = 0;
-            while ((1 << lg) < n && lg < 6) ++lg;
+            while ((1 << lg) < n + 1 && lg < 6) ++lg;
             rows.push_back(Row{lg, k});
         }
         std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.lg > b.lg; });
@@ -286,19 +287,17 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
             int32_t pos = 0, max_lg = 0, ovf = 0;
             while (i < rows.size() && pos + (1 << rows[i].lg) <= kLanes) {
                 const int32_t k = rows[i].k, lg = rows[i].lg, w = 1 << lg, n = t.ptr[k + 1] - t.ptr[k];
-                const int32_t row = (int32_t)out->rk.size();
-                out->row_of_pivot[k] = row;
-                out->rk.push_back((uint16_t)k);
-                out->rdiag.push_back(1.0 / t.diag[k]);
-                out->rovf.push_back((int32_t)out->oidx.size());
-                for (int32_t j = 0; j < w; ++j) {
-                    const bool has = j < n;
-                    out->sidx.push_back(has ? (uint16_t)t.idx[t.ptr[k] + j] : 0);
-                    out->sval.push_back(has ? t.val[t.ptr[k] + j] : 0.0);
-                    out->srow.push_back((uint16_t)(row | (lg << 13)));
+                out->rdiag[k] = 1.0 / t.diag[k];
+                out->sidx.push_back((uint16_t)(k | (lg << 12)));             // the row's own unknown: -(-1) x[k]
+                out->sval.push_back(-1.0);
+                for (int32_t j = 1; j < w; ++j) {
+                    const bool has = j - 1 < n;
+                    out->sidx.push_back((uint16_t)((has ? t.idx[t.ptr[k] + j - 1] : 0) | (lg << 12)));
+                    out->sval.push_back(has ? t.val[t.ptr[k] + j - 1] : 0.0);
                 }
-                for (int32_t e = t.ptr[k] + w; e < t.ptr[k + 1]; ++e) { out->oidx.push_back((uint16_t)t.idx[e]); out->oval.push_back(t.val[e]); ovf = 1; }
-                out->rovf.push_back((int32_t)out->oidx.size());
+                out->rovf[2 * (size_t)k] = (int32_t)out->oidx.size();
+                for (int32_t e = t.ptr[k] + w - 1; e < t.ptr[k + 1]; ++e) { out->oidx.push_back((uint16_t)t.idx[e]); out->oval.push_back(t.val[e]); ovf = 1; }
+                out->rovf[2 * (size_t)k + 1] = (int32_t)out->oidx.size();
                 max_lg = std::max(max_lg, lg);
                 pos += w;
                 ++i;
@@ -310,7 +309,7 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
         if (out->passes.size() > first_pass) out->passes.back().info |= 1 << 8;
     }
     out->lvl_pass[nlev] = (int32_t)out->passes.size();
-    if (out->oidx.empty()) out->rovf.clear();            // no row has more than 64 entries: the ranges are never read
+    if (out->oidx.empty()) out->rovf.clear();            // no row has more than 63 entries: the ranges are never read
 }
 
 bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& lcols_in,

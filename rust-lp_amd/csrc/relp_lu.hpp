@@ -45,19 +45,19 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
                std::string* err);
 
 // A triangular schedule packed for the persistent pivot kernel ("ELL by pass"): a level is executed in passes of up to
-// 256 lanes; inside a pass every row owns 2^lg consecutive lanes (lg = ceil(log2(entries)), at most 64 lanes; widths
-// sorted descending so that every row starts at a multiple of its width), lane j of a row holds entry j of the row as an
-// (index, value) slot plus the row's descriptor index.  Thread t of the workgroup finds everything it needs at
-// lane0 + t: no ranges, no searches.  Entries beyond the 64th of a row live in an overflow list (rare).  Padding slots
-// are (0, 0.0).
+// 256 lanes; inside a pass every row owns 2^lg consecutive lanes (widths sorted descending so that every row starts at a
+// multiple of its width).  Lane 0 of a row is the row's own unknown as a slot (k, -1.0), lanes 1.. hold its entries
+// (index, value): the lane sum of -value * x[index] is x[k] - sum_e val_e x[idx_e], which the first lane multiplies by
+// 1 / diagonal (rdiag, indexed by pivot) and stores to x[k].  Thread t of the workgroup finds its slot at lane0 + t: no
+// ranges, no row descriptors.  Entries beyond the 63rd of a row live in an overflow list (rare).  Padding slots are (0, 0.0).
 struct EllPassHost { int32_t lane0, lanes, info, level; };     // info: max lg | (last pass of its level) << 8 | (has overflow rows) << 9
 struct EllPacked {
     std::vector<EllPassHost> passes;
     std::vector<int32_t> lvl_pass;       // level -> first pass (n_levels + 1)
-    std::vector<double> rdiag, sval, oval;
-    std::vector<int32_t> rovf;           // 2 per row: overflow entries [begin, end)
-    std::vector<uint16_t> sidx, srow, rk, oidx;   // srow: row descriptor | lg << 13
-    std::vector<int32_t> row_of_pivot;   // pivot -> row descriptor or -1 (rows without entries of a unit-diagonal factor are left out)
+    std::vector<double> rdiag;           // m: 1 / diagonal by pivot (1.0 for rows that are left out)
+    std::vector<double> sval, oval;
+    std::vector<int32_t> rovf;           // 2 m: overflow entries [begin, end) by pivot; empty when no row overflows
+    std::vector<uint16_t> sidx, oidx;    // sidx: index | lg << 12
 };
 // keep_trivial: also pack the rows without entries whose diagonal is 1 (needed when rows can be masked later: U, U')
 void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out);

@@ -260,13 +260,7 @@ __device__ __forceinline__ void solve_schedule_pipelined(const DeviceSchedule& s
 // ~1,100 clocks whatever its three rows hold.  Here thread t finds its (index, value) slot and its row at lane0 + t; the
 // slots of the pass after next, the row descriptors of the next pass and the operands of this pass are fetched in the
 // same iteration, none of these loads depending on another.
-__host__ __device__ inline int64_t ell_image_bytes(int n_passes, int n_levels, int n_rows, int n_lanes, int n_ovf) {
-    return lu_up16(16LL * n_passes) + lu_up16(4LL * (n_levels + 1)) + lu_up16(8LL * n_rows) + lu_up16(8LL * n_lanes) +
-           lu_up16(8LL * n_ovf) + lu_up16(8LL * n_rows) + lu_up16(2LL * n_lanes) + lu_up16(2LL * n_lanes) + lu_up16(2LL * n_rows) +
-           lu_up16(2LL * n_ovf);
-}
-
-// sel: the reduction variant of the pass = max lg of its rows (0..6), or 7 when a row has more than 64 entries
+// sel: the reduction variant of the pass = max lg of its rows (0..6), or 7 when a row has more than 63 entries
 struct EllHeader { int lane0, lanes, sel, last; };
 __device__ __forceinline__ EllHeader ell_decode(const int4& raw, bool valid) {
     EllHeader h;
@@ -300,11 +294,12 @@ __device__ __forceinline__ double ell_reduce(double sum, int lg) {
 // on (levels below it are known to hold zeros only; 0 = everything, incl. the rows without entries).  x[dummy] is a
 // scratch word behind the vector: lanes that are not the first of their row store there, so the loop body has no
 // divergent branch (its loads are unconditional too: lanes beyond a pass re-read its last slot and contribute 0).
+// Per pass a lane issues: x[idx] (this pass), rdiag (next pass), its slot of the pass after next, one pass header.
 template <bool kStage, int NT, int NTW, class Lap = NoLap>
 __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
     const EllPass* passes = s.passes; const int32_t* lvl_pass = s.lvl_pass; const double* rdiag = s.rdiag;
     const double* sval = s.sval; const double* oval = s.oval; const int32_t* rovf = s.rovf;
-    const uint16_t* sidx = s.sidx; const uint16_t* srow = s.srow; const uint16_t* rk = s.rk; const uint16_t* oidx = s.oidx;
+    const uint16_t* sidx = s.sidx; const uint16_t* oidx = s.oidx;
     const int tid = threadIdx.x;
     if (kStage) {
         const int n16 = s.bytes / 16;
@@ -321,13 +316,11 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         char* q = base;
         passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * s.n_passes);
         lvl_pass = reinterpret_cast<const int32_t*>(q); q += lu_up16(4LL * (s.n_levels + 1));
-        rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_rows);
+        rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.m);
         sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
         oval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_ovf);
-        rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(s.n_ovf > 0 ? 8LL * s.n_rows : 0);
+        rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(s.n_ovf > 0 ? 8LL * s.m : 0);
         sidx = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
-        srow = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
-        rk = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_rows);
         oidx = reinterpret_cast<const uint16_t*>(q);
     }
     lap();
@@ -339,54 +332,41 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
             if ((reinterpret_cast<const int4*>(passes + p)->z >> 8) & 1) __syncthreads();
         return;
     }
-    // c = the pass being solved (slots and row descriptors loaded), n = the next one (slots loaded), f = the one after
+    // c = the pass being solved (slot and 1/diag loaded), n = the next one (slot loaded), f = the one after
     EllHeader hc = ell_header(passes, p0, p1), hn = ell_header(passes, p0 + 1, p1), hf = ell_header(passes, p0 + 2, p1);
     auto slot_of = [&](const EllHeader& h) { const int top = h.lanes > 0 ? h.lanes - 1 : 0; return h.lane0 + (tid < top ? tid : top); };
-    int c_idx, c_rowlg, c_k, n_idx, n_rowlg;
+    int c_iv, n_iv;
     double c_val, c_diag, n_val;
     {
         const int sc = slot_of(hc), sn = slot_of(hn);
-        c_idx = sidx[sc]; c_val = sval[sc]; c_rowlg = srow[sc];
-        n_idx = sidx[sn]; n_val = sval[sn]; n_rowlg = srow[sn];
-        c_k = rk[c_rowlg & 0x1fff]; c_diag = rdiag[c_rowlg & 0x1fff];
+        c_iv = sidx[sc]; c_val = sval[sc];
+        n_iv = sidx[sn]; n_val = sval[sn];
+        c_diag = rdiag[c_iv & 0xfff];
     }
     for (int p = p0; p < p1; ++p) {
         const bool act = tid < hc.lanes;
-        // what the critical path waits for: the operand of this lane's slot and the row's own unknown
-        const double xv = x[c_idx];
-        const double xk = x[c_k];
-        // row descriptors of the next pass, slots of the one after, raw header of the one after that
-        const int nrow = n_rowlg & 0x1fff;
-        const int n_k = rk[nrow];
-        const double n_diag = rdiag[nrow];
+        const int c_idx = c_iv & 0xfff, lg = c_iv >> 12;
+        const double xv = x[c_idx];                    // the one load the critical path waits for
+        const double n_diag = rdiag[n_iv & 0xfff];
         const int sf = slot_of(hf);
-        const int f_idx = sidx[sf], f_rowlg = srow[sf];
+        const int f_iv = sidx[sf];
         const double f_val = sval[sf];
         const int4 raw = *reinterpret_cast<const int4*>(passes + (p + 3 < p1 ? p + 3 : p1 - 1));
-        const int lg = c_rowlg >> 13;
         double sum = act ? -c_val * xv : 0.0;
-        switch (hc.sel) {
-            case 0: break;
-            case 1: sum = ell_reduce<1>(sum, lg); break;
-            case 2: sum = ell_reduce<2>(sum, lg); break;
-            case 3: sum = ell_reduce<3>(sum, lg); break;
-            case 4: sum = ell_reduce<4>(sum, lg); break;
-            case 5: sum = ell_reduce<5>(sum, lg); break;
-            case 6: sum = ell_reduce<6>(sum, lg); break;
-            default: {                                 // a row with more than 64 entries in this pass
-                if (act) {
-                    const int row = c_rowlg & 0x1fff;
-                    for (int e = rovf[2 * row] + (tid & 63); e < rovf[2 * row + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
-                }
-                sum = ell_reduce<6>(sum, lg);
+        if (hc.sel <= 3) sum = ell_reduce<3>(sum, lg);
+        else {
+            if (hc.sel == 7 && act && lg == 6) {       // a row with more than 63 entries: it owns a whole wavefront
+                const int k = __builtin_amdgcn_readfirstlane(c_idx);
+                for (int e = rovf[2 * k] + (tid & 63); e < rovf[2 * k + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
             }
+            sum = ell_reduce<6>(sum, lg);
         }
         const bool lead = act && (tid & ((1 << lg) - 1)) == 0;
-        x[lead ? c_k : dummy] = (xk + sum) * c_diag;
+        x[lead ? c_idx : dummy] = sum * c_diag;
         if (hc.last) __syncthreads();
         hc = hn; hn = hf; hf = ell_decode(raw, p + 3 < p1);
-        c_idx = n_idx; c_val = n_val; c_rowlg = n_rowlg; c_k = n_k; c_diag = n_diag;
-        n_idx = f_idx; n_val = f_val; n_rowlg = f_rowlg;
+        c_iv = n_iv; c_val = n_val; c_diag = n_diag;
+        n_iv = f_iv; n_val = f_val;
     }
 }
 

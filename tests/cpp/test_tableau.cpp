@@ -196,12 +196,39 @@ static void two_phase_tests(InverseMaintenance im) {
     }
 }
 
+// The `BasisInverse` surface (carry/mod.rs:68-157) on every engine: after from_basis((2, 3, 4)) on problem_2 the basis is
+// B = [[1, 0, 0], [1, 1, 0], [1, 0, 1]] (columns 2, 3, 4), B^-1 = [[1, 0, 0], [-1, 1, 0], [-1, 0, 1]]
+static void basis_inverse_tests(InverseMaintenance im) {
+    const MatrixData md = problem_2();
+    Tableau t = tableau(md, im);
+    CHECK(near(t.basis_inverse_row(0), {1, 0, 0}));
+    CHECK(near(t.basis_inverse_row(1), {-1, 1, 0}));
+    CHECK(near(t.basis_inverse_row(2), {-1, 0, 1}));
+    CHECK(!t.should_refactor());
+    // generate_column(original_column) for a column the caller supplies = the provider's column 0, (3, 5, 2)
+    CHECK(near(t.generate_column(SparseVector{{0, 3.0}, {1, 5.0}, {2, 2.0}}), t.generate_column(0)));
+    CHECK(near(t.generate_column(SparseVector{{1, 1.0}}), {0, 1, 0}));
+    // cost_difference = (-pi) . column; the basis costs are all 1, so -pi = -(1, 1, 1) B^-1 = (1, -1, -1)
+    CHECK(near(t.cost_difference(SparseVector{{0, 3.0}, {1, 5.0}, {2, 2.0}}), 3 - 5 - 2));
+    CHECK(near(t.relative_cost(0), 1 + t.cost_difference(SparseVector{{0, 3.0}, {1, 5.0}, {2, 2.0}})));
+    if (im == InverseMaintenance::LUDecomposition) {
+        // change_basis on the inverse alone: column (3, 5, 2) replaces basis position 0, row 0 of the new inverse is
+        // (1/3, 0, 0), and one update is pending
+        t.generate_column(SparseVector{{0, 3.0}, {1, 5.0}, {2, 2.0}});
+        t.lu_change_basis(0);
+        CHECK(t.lu_updates() == 1);
+        CHECK(near(t.basis_inverse_row(0), {1.0 / 3.0, 0, 0}));
+        CHECK(near(t.basis_inverse_row(1), {-5.0 / 3.0 + 0.0, 1, 0}));
+        CHECK(near(t.generate_column(SparseVector{{0, 3.0}, {1, 5.0}, {2, 2.0}}), {1, 0, 0}));
+    }
+}
+
 int main() {
     try {
         const struct { InverseMaintenance im; const char* name; bool from_basis; } kinds[] = {
             {InverseMaintenance::BasisInverseRows, "BasisInverseRows", true},
             {InverseMaintenance::LUDecomposition, "LUDecomposition", true},
-            {InverseMaintenance::DenseTableau, "DenseTableau", false},
+            {InverseMaintenance::DenseTableau, "DenseTableau", true},
         };
         for (const auto& k : kinds) {
             const int before = g_failed;
@@ -210,9 +237,11 @@ int main() {
             two_phase_tests(k.im);
             std::printf("%-18s %s\n", k.name, g_failed == before ? "ok" : "FAILED");
         }
-        {   // the dense tableau has no from_basis (relp_engine.h): reported, not aborted
-            Tableau t(problem_2(), Options().inverse_maintenance(InverseMaintenance::DenseTableau));
-            CHECK_THROWS(t.from_basis({2, 3, 4}), RELP_E_UNSUPPORTED);
+        for (const auto& k : kinds) basis_inverse_tests(k.im);
+        {   // change_basis on the inverse alone is the LU back end's (lower_upper/mod.rs:92-155): reported elsewhere, not aborted
+            Tableau t(problem_2(), Options().inverse_maintenance(InverseMaintenance::BasisInverseRows));
+            CHECK_THROWS(t.lu_change_basis(0), RELP_E_UNSUPPORTED);
+            CHECK_THROWS(t.basis_inverse_row(7), RELP_E_ARG);
         }
         CHECK_THROWS(MatrixData::from_rows({{1, 2}}, 2, {1, 2}, {}, 0, 0, 1, 0, {1, 1}), RELP_E_ARG);
         {   // the loop inside the library on a communicator of one rank (RCCL): the single-engine result
