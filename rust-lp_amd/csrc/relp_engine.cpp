@@ -25,7 +25,7 @@ void Engine::free_all() {
     fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
     fr(d_msg_cand_); fr(d_msg_cands_); fr(d_msg_slice_); fr(d_msg_slices_); fr(d_msg_rho_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
-    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_); fr(d_ft_buf_);
+    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_); fr(d_ft_buf_); fr(d_pe_buf_);
     if (h_ft_hdr_) { (void)hipHostFree(h_ft_hdr_); h_ft_hdr_ = nullptr; }
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);
@@ -988,6 +988,7 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
             HIP_TRY(hipMemcpy(d_cidx_, hc_idx_.data(), sizeof(int32_t) * o, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_cval_, hc_val_.data(), sizeof(double) * o, hipMemcpyHostToDevice));
         }
+        if (ft_) { const relp_status_t pst = ft_build_price_ell(); if (pst) return pst; }
     } else {
         HIP_TRY(hipMemcpy(Bh.data(), dBinv_, Bh.size() * sizeof(double), hipMemcpyDeviceToHost));
     }

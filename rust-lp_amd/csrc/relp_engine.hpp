@@ -192,6 +192,8 @@ class Engine {
     relp_status_t ft_reset();
     relp_status_t ft_read_hdr();
     FtProblem ft_problem(int rule) const;
+    char* d_pe_buf_ = nullptr; PriceEll pe_{};            // PRICE copy of the structural columns (relp_kernels.h: PriceEll)
+    relp_status_t ft_build_price_ell();
     relp_status_t run_ft(int64_t max_iters, int64_t* done, int32_t* outcome);
     DeferredUpdate deferred() const;
     void enqueue_flush();

@@ -88,6 +88,15 @@ relp_status_t Engine::lu_refactor() {
             if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
         }
     }
+    if (const char* dump = std::getenv("RELP_DUMP_BASIS")) {
+        if (lu_refactors_ == 100) {                        // one mid-solve basis as text: m, then per column "n i v i v ..."
+            if (FILE* f = std::fopen(dump, "w")) {
+                std::fprintf(f, "%d\n", m_);
+                for (auto& c : cols) { std::fprintf(f, "%zu", c.size()); for (auto& e : c) std::fprintf(f, " %d %.17g", e.first, e.second); std::fprintf(f, "\n"); }
+                std::fclose(f);
+            }
+        }
+    }
     std::string msg;
     const auto t0 = std::chrono::steady_clock::now();
     if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
@@ -144,7 +153,9 @@ relp_status_t Engine::lu_upload_factors() {
         for (int k = 0; k < 4; ++k) {
             ell_pack(*sch[k], k == 1 || k == 2, &ell[k]);
             const EllPacked& e = ell[k];
-            o_ell[k] = put(e.passes.data(), sizeof(EllPassHost) * e.passes.size());
+            std::vector<EllPassHost> hdrs(e.passes);
+            hdrs.resize(hdrs.size() + 3, EllPassHost{0, 0, 0, 0});        // the kernel reads three headers ahead
+            o_ell[k] = put(hdrs.data(), sizeof(EllPassHost) * hdrs.size());
             put(e.lvl_pass.data(), sizeof(int32_t) * e.lvl_pass.size());
             put(e.rdiag.data(), sizeof(double) * e.rdiag.size());
             put(e.sval.data(), sizeof(double) * e.sval.size());
@@ -224,7 +235,7 @@ relp_status_t Engine::lu_upload_factors() {
                           nov = (int64_t)e.oidx.size();
             char* q = d_lu_buf_ + o_ell[k];
             char* const q0 = q;
-            d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * np);
+            d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * (np + 3));
             d.lvl_pass = reinterpret_cast<const int32_t*>(q); q += up16(4 * nlv);
             d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * (int64_t)m_);
             d.sval = reinterpret_cast<const double*>(q); q += up16(8 * nln);
@@ -297,6 +308,30 @@ relp_status_t Engine::ft_plan_and_alloc() {
     // relp_config_t.update_block = 11 reproduces the reference's cadence)
     fts_.max_updates = cfg_.update_block < 0 ? ft_tcap_ : std::max(1, std::min(cfg_.update_block, ft_tcap_));
     block_ = fts_.max_updates;
+    return ft_build_price_ell();
+}
+
+// k-major copy of the first kPriceSlots entries of every structural column (rebuilt when rows are removed)
+relp_status_t Engine::ft_build_price_ell() {
+    const int64_t ns = std::max(nr_normal_, 1);
+    std::vector<uint16_t> idx((size_t)kPriceSlots * ns, 0);
+    std::vector<double> val((size_t)kPriceSlots * ns, 0.0);
+    std::vector<int32_t> longs;
+    for (int32_t p = 0; p < nr_normal_; ++p) {
+        const int64_t n = hc_ptr_[p + 1] - hc_ptr_[p];
+        if (n > kPriceSlots) { longs.push_back(p); idx[p] = 0xFFFF; continue; }    // slot 0 = 0xFFFF: priced from the CSC arrays
+        for (int64_t k = 0; k < n; ++k) { idx[(size_t)k * ns + p] = (uint16_t)hc_idx_[hc_ptr_[p] + k]; val[(size_t)k * ns + p] = hc_val_[hc_ptr_[p] + k]; }
+    }
+    const size_t b_val = val.size() * 8, b_idx = (idx.size() * 2 + 15) / 16 * 16, b_long = std::max<size_t>(longs.size(), 1) * 4;
+    if (d_pe_buf_) { HIP_TRY(hipFree(d_pe_buf_)); d_pe_buf_ = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pe_buf_), b_val + b_idx + b_long));
+    HIP_TRY(hipMemcpy(d_pe_buf_, val.data(), b_val, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pe_buf_ + b_val, idx.data(), idx.size() * 2, hipMemcpyHostToDevice));
+    if (!longs.empty()) HIP_TRY(hipMemcpy(d_pe_buf_ + b_val + b_idx, longs.data(), longs.size() * 4, hipMemcpyHostToDevice));
+    pe_.val = reinterpret_cast<const double*>(d_pe_buf_);
+    pe_.idx = reinterpret_cast<const uint16_t*>(d_pe_buf_ + b_val);
+    pe_.long_cols = reinterpret_cast<const int32_t*>(d_pe_buf_ + b_val + b_idx);
+    pe_.n_long = (int32_t)longs.size(); pe_.pad_ = 0;
     return RELP_OK;
 }
 
@@ -325,7 +360,7 @@ relp_status_t Engine::ft_read_hdr() {
 
 FtProblem Engine::ft_problem(int rule) const {
     FtProblem pb{};
-    pb.csc = csc(); pb.ct = table();
+    pb.csc = csc(); pb.ct = table(); pb.pe = pe_;
     pb.minus_pi = d_minus_pi_; pb.b = d_b_; pb.alpha = d_alpha_; pb.rho = d_rho_; pb.d = d_d_;
     pb.basis = d_basis_; pb.in_basis = d_in_basis_; pb.trace = d_trace_; pb.trace_cap = trace_cap_;
     pb.rec = d_rec_;

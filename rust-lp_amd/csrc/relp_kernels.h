@@ -168,8 +168,13 @@ struct FtState {
     int32_t  pad_;
     long long* prof;         // 16 phase accumulators of the persistent kernel (shader clocks, thread 0) or nullptr
 };
+// The structural columns once more for PRICE inside the persistent kernel: the first kPriceSlots entries of column p at
+// pe_idx / pe_val[k * nr_normal + p] (k-major: the threads of a wavefront read consecutive columns), padding (0, 0.0);
+// columns with more entries have 0xFFFF in slot 0, are listed in `long_cols` and priced from the CSC arrays.
+static constexpr int kPriceSlots = 8;
+struct PriceEll { const uint16_t* idx; const double* val; const int32_t* long_cols; int32_t n_long, pad_; };
 struct FtProblem {           // what the persistent kernel needs besides the factors
-    DeviceCSC csc; ColumnTable ct;
+    DeviceCSC csc; ColumnTable ct; PriceEll pe;
     double *minus_pi, *b, *alpha, *rho, *d;
     int32_t* basis; uint8_t* in_basis; int32_t* trace; int64_t trace_cap;
     PivotRecord* rec;

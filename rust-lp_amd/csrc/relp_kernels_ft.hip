@@ -127,39 +127,40 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // Triangular chain over the update slots by ONE wavefront (lane = slot), the sequential core of the eta file and of the
-// dense tail of U: for s2 in order, lane s2 publishes (base - sub - acc) * scale, and every lane "after" s2 accumulates its
-// coefficient times that value.  kRow: the coefficient of (lane, s2) is TC[lane][s2], else TC[s2][lane].  `link`: when the
+// dense tail of U: for s2 in order, lane s2 publishes w = (base - sub - acc) * scale, and every lane "after" s2 accumulates
+// its coefficient times that value.  kRow: the coefficient of (lane, s2) is TC[lane][s2], else TC[s2][lane].  `link`: when the
 // published slot is this lane's predecessor (the same pivot updated earlier / later), its value replaces `base`.
-// Coefficients are fetched eight steps ahead, so a step costs two v_readlane and one v_fma, not an LDS round trip.
+// Branch-free: w is kept up to date incrementally (w -= coef * scale * v), the link is folded into the coefficient
+// (coef - 1 at s2 = link adds v to the base), coefficients are fetched eight steps ahead and are 0 wherever a step must not
+// act, so a step is two v_readlane, one select and one v_fma; steps beyond t (the last chunk) multiply by 0.
 template <bool kAsc, bool kRow>
 __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int lane, double base, double sub, double scale,
                                            int link) {
     constexpr int CH = 8;
     const bool in = lane < t;
-    double acc = 0.0, mine = 0.0;
+    const int row = in ? lane : 0;
+    double w = in ? (base - sub) * scale : 0.0, mine = 0.0;
     double cur[CH], nxt[CH];
     auto load = [&](int ch, double* buf) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
-            buf[j] = (in && o < t) ? (kRow ? TC[lane * ldt + s2] : TC[s2 * ldt + lane]) : 0.0;
+            const int sc = s2 < 0 ? 0 : (s2 >= t ? t - 1 : s2);                 // (clamped: the load itself is unconditional)
+            const double cf = kRow ? TC[row * ldt + sc] : TC[sc * ldt + row];
+            const bool after = in && o < t && (kAsc ? lane > s2 : lane < s2);
+            buf[j] = after ? (cf - (link == s2 ? 1.0 : 0.0)) * scale : 0.0;
         }
     };
     const int nch = (t + CH - 1) / CH;
     load(0, cur);
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) load(ch + 1, nxt);
+        load(ch + 1 < nch ? ch + 1 : ch, nxt);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
-            if (o < t) {                                           // wave-uniform
-                const double v = lane_bcast((base - sub - acc) * scale, s2);
-                if (lane == s2) mine = v;
-                if (in && (kAsc ? lane > s2 : lane < s2)) {
-                    acc = fma(cur[j], v, acc);
-                    if (link == s2) base = v;
-                }
-            }
+            const double v = lane_bcast(w, s2 < 0 ? 0 : s2);
+            mine = lane == s2 ? v : mine;
+            w = fma(-cur[j], v, w);
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
@@ -604,55 +605,46 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         fake.last_selected = last_selected;
         double key = INFINITY;
         int kj = 0x7fffffff;
-        // (column offsets and the basis flag of the thread's NEXT column are fetched while this one is priced, and the
-        // entries of a column are fetched eight at a time: one memory round trip per column instead of one per entry)
+        // (structural columns from the k-major PRICE copy: kPriceSlots independent coalesced loads per column, no column
+        // offsets, no entry loop; summation in the column's own order like k_price_csc)
         const int na = ct.nr_artificial, nstr = ct.nr_normal;
-        long long ns0 = 0, ns1 = 0;
-        int nflag = 0;
-        auto prefetch = [&](int j) {
-            if (j < n) {
-                nflag = pb.in_basis[j];
-                const int p = j - na;
-                if (p >= 0 && p < nstr) { ns0 = pb.csc.col_ptr[p]; ns1 = pb.csc.col_ptr[p + 1]; }
-            }
-        };
-        prefetch(tid);
-        for (int j = tid; j < n; j += NT) {
-            const long long s0 = ns0, s1 = ns1;
-            const int flag = nflag;
-            prefetch(j + NT);
-            double v;
-            if (j < na) {
-                v = (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]];
-            } else {
-                const int p = j - na;
-                if (p < nstr) {
-                    v = 0.0;
-                    for (long long e = s0; e < s1; e += 8) {
-                        int ri[8];
-                        double va[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (e + u < s1) { ri[u] = pb.csc.row_idx[e + u]; va[u] = pb.csc.values[e + u]; }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (e + u < s1) v = fma(c.pi[ri[u]], va[u], v);
-                    }
-                    const int br = ct.bound_row[p];
-                    if (br >= 0) v += c.pi[br];
-                    if (cost_mode == 2) v += ct.cost[p];
-                } else {
-                    const int vv = p - nstr;
-                    const int r0 = ct.vrow0[vv], r1 = ct.vrow1[vv];
-                    v = r0 >= 0 ? (double)ct.vsign[vv] * c.pi[r0] : 0.0;
-                    if (r1 >= 0) v += c.pi[r1];
-                }
-            }
+        auto consider = [&](int j, double v) {
             pb.d[j] = v;
-            if (!flag && v < -pb.tol.cost) {
+            if (!pb.in_basis[j] && v < -pb.tol.cost) {
                 const double k = select_key(rule, n, &fake, j, v);
                 if (k < key || (k == key && j < kj)) { key = k; kj = j; }
             }
+        };
+        for (int j = tid; j < na; j += NT) consider(j, (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]]);
+        for (int p = tid; p < nstr; p += NT) {
+            int ri[kPriceSlots];
+            double va[kPriceSlots];
+#pragma unroll
+            for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pb.pe.idx[u * nstr + p]; va[u] = pb.pe.val[u * nstr + p]; }
+            const int br = ct.bound_row[p];
+            const bool is_long = ri[0] == 0xFFFF;                  // more than kPriceSlots entries: priced below
+            if (is_long) ri[0] = 0;
+            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < kPriceSlots; ++u) v = fma(c.pi[ri[u]], va[u], v);
+            if (br >= 0) v += c.pi[br];
+            if (cost_mode == 2) v += ct.cost[p];
+            if (!is_long) consider(na + p, v);
+        }
+        for (int i = tid; i < pb.pe.n_long; i += NT) {             // the few columns with more than kPriceSlots entries
+            const int p = pb.pe.long_cols[i];
+            double v = 0.0;
+            for (int64_t e = pb.csc.col_ptr[p]; e < pb.csc.col_ptr[p + 1]; ++e) v = fma(c.pi[pb.csc.row_idx[e]], pb.csc.values[e], v);
+            const int br = ct.bound_row[p];
+            if (br >= 0) v += c.pi[br];
+            if (cost_mode == 2) v += ct.cost[p];
+            consider(na + p, v);
+        }
+        for (int vv = tid; vv < ct.nr_virtual; vv += NT) {
+            const int r0 = ct.vrow0[vv], r1 = ct.vrow1[vv];
+            double v = r0 >= 0 ? (double)ct.vsign[vv] * c.pi[r0] : 0.0;
+            if (r1 >= 0) v += c.pi[r1];
+            consider(na + nstr + vv, v);
         }
         block_min_key(c, key, kj);
         if (kj != 0x7fffffff && rule == 2 && pb.tol.tie > 0.0) {

@@ -260,22 +260,6 @@ __device__ __forceinline__ void solve_schedule_pipelined(const DeviceSchedule& s
 // ~1,100 clocks whatever its three rows hold.  Here thread t finds its (index, value) slot and its row at lane0 + t; the
 // slots of the pass after next, the row descriptors of the next pass and the operands of this pass are fetched in the
 // same iteration, none of these loads depending on another.
-// sel: the reduction variant of the pass = max lg of its rows (0..6), or 7 when a row has more than 63 entries
-struct EllHeader { int lane0, lanes, sel, last; };
-__device__ __forceinline__ EllHeader ell_decode(const int4& raw, bool valid) {
-    EllHeader h;
-    h.lane0 = valid ? __builtin_amdgcn_readfirstlane(raw.x) : 0;
-    h.lanes = valid ? __builtin_amdgcn_readfirstlane(raw.y) : 0;
-    const int info = valid ? __builtin_amdgcn_readfirstlane(raw.z) : 0;
-    h.sel = (info >> 9) & 1 ? 7 : (info & 0xff);
-    h.last = (info >> 8) & 1;
-    return h;
-}
-__device__ __forceinline__ EllHeader ell_header(const EllPass* passes, int p, int p1) {
-    const int4 raw = *reinterpret_cast<const int4*>(passes + (p < p1 ? p : p1 - 1));
-    return ell_decode(raw, p < p1);
-}
-
 // sum over the 2^lg lanes of every row of a pass whose widest row has 2^MAXLG lanes (rows are aligned to their width; a lane
 // whose row is narrower than a step's reach adds 0).  Straight-line: on this machine a branch costs ~20 clocks, an
 // instruction ~5 (scripts/microbench/issue_rate.hip), so the variant is chosen once per pass, not once per step.
@@ -314,7 +298,7 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         }
         __syncthreads();
         char* q = base;
-        passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * s.n_passes);
+        passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * (s.n_passes + 3));
         lvl_pass = reinterpret_cast<const int32_t*>(q); q += lu_up16(4LL * (s.n_levels + 1));
         rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.m);
         sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
@@ -332,9 +316,13 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
             if ((reinterpret_cast<const int4*>(passes + p)->z >> 8) & 1) __syncthreads();
         return;
     }
-    // c = the pass being solved (slot and 1/diag loaded), n = the next one (slot loaded), f = the one after
-    EllHeader hc = ell_header(passes, p0, p1), hn = ell_header(passes, p0 + 1, p1), hf = ell_header(passes, p0 + 2, p1);
-    auto slot_of = [&](const EllHeader& h) { const int top = h.lanes > 0 ? h.lanes - 1 : 0; return h.lane0 + (tid < top ? tid : top); };
+    // c = the pass being solved (slot and 1/diag loaded), n = the next one (slot loaded), f = the one after.  Pass headers
+    // stay in vector registers (lane0, lanes, info): converting them to scalars every pass (v_readfirstlane after a wait
+    // for the load) cost 210 of a pass's 770 clocks (scripts/microbench/ell_pass.hip); only `info` is made scalar, when it
+    // is used, long after it arrived.  The image ends with three empty headers, so p + 3 needs no bounds check.
+    const int4* hdr = reinterpret_cast<const int4*>(passes);
+    int4 hc = hdr[p0], hn = hdr[p0 + 1], hf = hdr[p0 + 2];
+    auto slot_of = [&](const int4& h) { const int top = h.y > 0 ? h.y - 1 : 0; return h.x + (tid < top ? tid : top); };
     int c_iv, n_iv;
     double c_val, c_diag, n_val;
     {
@@ -344,18 +332,19 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         c_diag = rdiag[c_iv & 0xfff];
     }
     for (int p = p0; p < p1; ++p) {
-        const bool act = tid < hc.lanes;
+        const bool act = tid < hc.y;
         const int c_idx = c_iv & 0xfff, lg = c_iv >> 12;
         const double xv = x[c_idx];                    // the one load the critical path waits for
         const double n_diag = rdiag[n_iv & 0xfff];
         const int sf = slot_of(hf);
         const int f_iv = sidx[sf];
         const double f_val = sval[sf];
-        const int4 raw = *reinterpret_cast<const int4*>(passes + (p + 3 < p1 ? p + 3 : p1 - 1));
+        const int4 hff = hdr[p + 3];
+        const int info = __builtin_amdgcn_readfirstlane(hc.z);
         double sum = act ? -c_val * xv : 0.0;
-        if (hc.sel <= 3) sum = ell_reduce<3>(sum, lg);
+        if ((info & 0x2ff) <= 3) sum = ell_reduce<3>(sum, lg);
         else {
-            if (hc.sel == 7 && act && lg == 6) {       // a row with more than 63 entries: it owns a whole wavefront
+            if ((info & 0x200) && act && lg == 6) {    // a row with more than 63 entries: it owns a whole wavefront
                 const int k = __builtin_amdgcn_readfirstlane(c_idx);
                 for (int e = rovf[2 * k] + (tid & 63); e < rovf[2 * k + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
             }
@@ -363,8 +352,8 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         }
         const bool lead = act && (tid & ((1 << lg) - 1)) == 0;
         x[lead ? c_idx : dummy] = sum * c_diag;
-        if (hc.last) __syncthreads();
-        hc = hn; hn = hf; hf = ell_decode(raw, p + 3 < p1);
+        if (info & 0x100) __syncthreads();
+        hc = hn; hn = hf; hf = hff;
         c_iv = n_iv; c_val = n_val; c_diag = n_diag;
         n_iv = f_iv; n_val = f_val;
     }

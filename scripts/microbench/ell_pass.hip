@@ -54,13 +54,13 @@ int main(int argc, char** argv) {
     EllPacked e; ell_pack(t, true, &e);
     std::vector<char> buf;
     auto put = [&](const void* src, size_t bytes) { size_t o = buf.size(); buf.resize(o + (bytes + 15) / 16 * 16); if (bytes) memcpy(buf.data() + o, src, bytes); return o; };
-    put(e.passes.data(), 16 * e.passes.size()); put(e.lvl_pass.data(), 4 * e.lvl_pass.size()); put(e.rdiag.data(), 8 * e.rdiag.size());
+    { std::vector<EllPassHost> hd(e.passes); hd.resize(hd.size() + 3, EllPassHost{0, 0, 0, 0}); put(hd.data(), 16 * hd.size()); } put(e.lvl_pass.data(), 4 * e.lvl_pass.size()); put(e.rdiag.data(), 8 * e.rdiag.size());
     put(e.sval.data(), 8 * e.sval.size()); put(e.oval.data(), 8 * e.oval.size()); put(e.rovf.data(), 4 * e.rovf.size());
     put(e.sidx.data(), 2 * e.sidx.size()); put(e.oidx.data(), 2 * e.oidx.size());
     char* d; hipMalloc(&d, buf.size()); hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice);
     auto up16 = [](int64_t b) { return (b + 15) / 16 * 16; };
     EllSchedule s{}; char* q = d;
-    s.passes = (const EllPass*)q; q += up16(16 * e.passes.size()); s.lvl_pass = (const int32_t*)q; q += up16(4 * e.lvl_pass.size());
+    s.passes = (const EllPass*)q; q += up16(16 * (e.passes.size() + 3)); s.lvl_pass = (const int32_t*)q; q += up16(4 * e.lvl_pass.size());
     s.rdiag = (double*)q; q += up16(8 * e.rdiag.size()); s.sval = (const double*)q; q += up16(8 * e.sval.size());
     s.oval = (const double*)q; q += up16(8 * e.oval.size()); s.rovf = (const int32_t*)q; q += up16(4 * e.rovf.size());
     s.sidx = (const uint16_t*)q; q += up16(2 * e.sidx.size()); s.oidx = (const uint16_t*)q; q += up16(2 * e.oidx.size());
