@@ -36,5 +36,7 @@ def test_driver_command_emits_one_complete_json_line():
     assert out["c4"]["value"] > 1000 and out["c4"]["roofline"]["kernel"] == "k_tab_flush_lds"
     sp = out["sparse_engine"]
     assert sp["outcome"] == "optimal" and abs(sp["objective"] - 5.5018459e+03) < 1e-4 and sp["tolerances"] == "relp_default_config"
+    assert sp["kernel_launches_per_pivot"] <= 2.0 / 11 and sp["pivot_kernel_phase_share"]["u_solve"] > 0      # persistent pivot kernel
+    assert sp["reference_cadence_update_block_11"]["outcome"] == "optimal"
     for other in ("explicit_inverse_engine", "tableau_engine"):
         assert sp[other]["outcome"] == "optimal" and abs(sp[other]["objective"] - 5.5018459e+03) < 1e-4
