@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def per_kernel(path, value_col=None):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"].split("(")[0].replace("relp::", "").replace("void ", "").split("<")[0]
+        name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("relp::", "").replace("void ", "").split("<")[0]
         dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         val = float(row[value_col]) if value_col else 0.0
         agg[name].append((dur, val))
@@ -47,6 +47,16 @@ def main():
     trace = per_kernel(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])
     fetch = per_kernel(glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
     write = per_kernel(glob.glob(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+    # calibration of the counters for 8-byte-per-lane tile accesses: k_tile<true> in place moves 8 m n bytes each way
+    cal_f = cal_w = None
+    try:
+        cf = per_kernel(glob.glob(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+        cw = per_kernel(glob.glob(os.path.join(src, "cal_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+        known = 8.0 * 10000 * 20000
+        cal_f = known / (cf["k_tile"]["value"] * 1024.0)
+        cal_w = known / (cw["k_tile"]["value"] * 1024.0)
+    except Exception as e:          # noqa: BLE001
+        print("no calibration run:", e)
     lines = [f"# rocprofv3 summary `{tag}` ({workload})", "",
              "Command: `bash profiles/collect.sh` (rocprofv3 --kernel-trace --stats; separate --pmc FETCH_SIZE and",
              "--pmc WRITE_SIZE passes).  Durations from the kernel trace, effective launches only (see",
@@ -67,10 +77,30 @@ def main():
             # (MI355X_MICROARCH.md section HBM: other widths uncalibrated); the raw figure already matches the bytes
             # of the matrix, so raw FETCH_SIZE + WRITE_SIZE is reported for these kernels (k_tab_flush_lds reads its
             # T0 tile 8 bytes per lane and under-reports further: treat its figure as a lower bound)
-            hbm = (f + w) * 1024.0
-            note = " (raw FETCH_SIZE, 8-byte loads)"
+            if cal_f and name in ("k_tab_flush", "k_tab_flush_lds"):
+                hbm = (f * cal_f + w * cal_w) * 1024.0
+                note = f" (8-byte tile accesses: FETCH_SIZE x {cal_f:.3f}, WRITE_SIZE x {cal_w:.3f}, calibrated on scripts/microbench/tile_rmw.hip)"
+            else:
+                hbm = (f + w) * 1024.0
+                note = " (raw FETCH_SIZE, 8-byte loads)"
         traffic[name[2:]] = hbm
         lines.append(f"| {name} | {t['launches']} ({t['effective']}) | {t['avg_us']:.1f} | {f:.1f} | {w:.1f} | {hbm / 1e6:.1f}{note} |")
+    # the sparse path: launches per pivot of the LU engine (one whole 25FV47 solve)
+    try:
+        lstats = glob.glob(os.path.join(src, "lu_trace", "*", "*_kernel_stats.csv"))[0]
+        shutil.copy(lstats, os.path.join(ROOT, "profiles", f"{tag}_lu_25fv47_kernel_stats.csv"))
+        lt = per_kernel(glob.glob(os.path.join(src, "lu_trace", "*", "*_kernel_trace.csv"))[0])
+        log = open(os.path.join(src, "lu_trace.log")).read()
+        pivots = int([ln for ln in log.splitlines() if ln.startswith("optimal")][0].split()[1])
+        total = sum(v["launches"] for k, v in lt.items())
+        lines += ["", f"## LU engine, Netlib 25FV47, whole solve ({pivots} pivots)", "",
+                  f"{total} kernel launches in all = {total / pivots:.3f} per pivot.", "",
+                  "| kernel | launches | avg us | total ms |", "|---|---|---|---|"]
+        for name in sorted(lt, key=lambda k: -lt[k]["avg_us"] * lt[k]["effective"])[:8]:
+            v = lt[name]
+            lines.append(f"| {name} | {v['launches']} | {v['avg_us']:.1f} | {v['avg_us'] * v['effective'] / 1e3:.1f} |")
+    except Exception as e:          # noqa: BLE001
+        print("no LU trace:", e)
     open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
