@@ -325,6 +325,11 @@ relp_status_t relp_shard_set_collectives(relp_engine_t *h, relp_allgather_fn all
  * rank must call it with the same arguments; every rank takes the same decisions from the same gathered data,
  * so *done and *outcome agree on all ranks. */
 relp_status_t relp_shard_run(relp_engine_t *h, int64_t max_iters, int64_t *done, int32_t *outcome);
+/* Failure agreement: a rank whose step fails locally (anything but a collective) keeps the collectives of the current chunk
+ * going and reports at the next poll, where one 16-byte all-gather of the statuses makes every rank return the same error:
+ * nobody is left waiting inside a collective.  relp_shard_inject_failure is the test hook for exactly that: this engine's
+ * relp_shard_run fails locally after `after_pivots` further pivots. */
+relp_status_t relp_shard_inject_failure(relp_engine_t *h, int64_t after_pivots);
 /* RCCL as the collectives: rank 0 makes a unique id (ncclGetUniqueId, 128 bytes), the caller hands it to every
  * rank (any channel; bench.py broadcasts it with torch.distributed), and each rank attaches a communicator of
  * cfg.shard_count ranks on the engine's device (ncclCommInitRank), which installs ncclAllGather / ncclAllReduce

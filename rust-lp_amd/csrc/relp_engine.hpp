@@ -94,6 +94,7 @@ class Engine {
     relp_status_t shard_pivot();
     relp_status_t shard_set_collectives(relp_allgather_fn ag, relp_allreduce_sum_fn ar, void* ctx);
     relp_status_t shard_run(int64_t max_iters, int64_t* done, int32_t* outcome);
+    void shard_inject_failure(int64_t after_pivots) { inject_failure_after_ = after_pivots; }
     relp_status_t rccl_attach(const uint8_t* id);
     relp_status_t poll(int32_t* outcome, int64_t* iterations);
 
@@ -218,6 +219,14 @@ class Engine {
     double* d_msg_slices_ = nullptr;
     double* d_msg_rho_ = nullptr;
     relp_status_t shard_iteration();
+    relp_status_t shard_iteration_comm_only(int from_step);
+    int coll_step_ = 0;                  // collectives of the current pivot already done (a failed pivot is completed from here)
+    int64_t shadow_flush_ = 0;           // pivots since the last flush as every rank counts them
+    relp_status_t shard_agree_on_status(relp_status_t local);
+    double* d_msg_status_ = nullptr;     // this rank's status / all ranks' statuses (agreed on at every poll of relp_shard_run)
+    double* d_msg_statuses_ = nullptr;
+    int64_t inject_failure_after_ = -1;  // test hook (relp_shard_inject_failure)
+    bool coll_broken_ = false;           // a collective hook itself failed: nothing can be agreed on any more
     relp_status_t remove_artificial_basis_variables_sharded(std::vector<int32_t>& rows_to_remove);
     void rccl_release();
 

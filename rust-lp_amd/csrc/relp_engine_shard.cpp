@@ -214,6 +214,8 @@ relp_status_t Engine::shard_set_collectives(relp_allgather_fn ag, relp_allreduce
     coll_allgather_ = ag; coll_allreduce_ = ar; coll_ctx_ = ctx;
     const int64_t g = std::max(cfg_.shard_count, 1);
     if (!d_msg_cand_) {
+        HIP_TRY(dev_alloc(&d_msg_status_, 2));
+        HIP_TRY(dev_alloc(&d_msg_statuses_, 2 * g));
         HIP_TRY(dev_alloc(&d_msg_cand_, cand_len_));
         HIP_TRY(dev_alloc(&d_msg_cands_, cand_len_ * g));
         if (!tableau_) {
@@ -229,22 +231,31 @@ relp_status_t Engine::shard_set_collectives(relp_allgather_fn ag, relp_allreduce
 relp_status_t Engine::shard_iteration() {
     relp_status_t st;
     const int32_t g = std::max(cfg_.shard_count, 1);
+    coll_step_ = 0;
+    shadow_flush_ = since_flush_;
+    if (inject_failure_after_ == 0) { inject_failure_after_ = -1; return fail(RELP_E_STATE, "injected failure (relp_shard_inject_failure)"); }
+    if (inject_failure_after_ > 0) --inject_failure_after_;
+    auto broken = [&](const char* what) { coll_broken_ = true; return fail(RELP_E_HIP, what); };
     if ((st = shard_price(d_msg_cand_))) return st;
     if (coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_))
-        return fail(RELP_E_HIP, "all-gather of the PRICE candidates failed");
+        return broken("all-gather of the PRICE candidates failed");
+    ++coll_step_;
     if ((st = shard_select_column(d_msg_cands_, g))) return st;
     if (tableau_) return shard_pivot();
     if ((st = shard_ftran(d_msg_slice_))) return st;
     if (coll_allgather_(coll_ctx_, d_msg_slice_, d_msg_slices_, row_stride_ * (int64_t)sizeof(double), stream_))
-        return fail(RELP_E_HIP, "all-gather of the FTRAN slices failed");
+        return broken("all-gather of the FTRAN slices failed");
+    ++coll_step_;
     if ((st = shard_ratio(d_msg_slices_, g, d_msg_rho_))) return st;
-    if (coll_allreduce_(coll_ctx_, d_msg_rho_, rho_len(), stream_)) return fail(RELP_E_HIP, "all-reduce of the pivot row failed");
+    if (coll_allreduce_(coll_ctx_, d_msg_rho_, rho_len(), stream_)) return broken("all-reduce of the pivot row failed");
+    ++coll_step_;
     if ((st = shard_update(d_msg_rho_))) return st;
     if (block_ > 0 && since_flush_ >= block_) {
         double* snap = nullptr; int64_t len = 0;
         if ((st = shard_flush_begin(&snap, &len))) return st;
         if (len > 0) {
-            if (coll_allreduce_(coll_ctx_, snap, len, stream_)) return fail(RELP_E_HIP, "all-reduce of the flush snapshot failed");
+            if (coll_allreduce_(coll_ctx_, snap, len, stream_)) return broken("all-reduce of the flush snapshot failed");
+            ++coll_step_;
             if ((st = shard_flush_end())) return st;
         }
         since_flush_ = 0;
@@ -252,20 +263,70 @@ relp_status_t Engine::shard_iteration() {
     return RELP_OK;
 }
 
+// After a LOCAL failure (a kernel launch, an allocation: anything but a collective) this rank keeps the collective sequence
+// of the pivots alive with whatever is in its buffers, so that the other ranks are not left waiting inside a collective; at
+// the next poll every rank learns of the failure (shard_agree_on_status) and all leave relp_shard_run together.
+// `from_step`: the collectives of this pivot with a lower index have happened already (the pivot that failed).
+relp_status_t Engine::shard_iteration_comm_only(int from_step) {
+    auto broken = [&](const char* what) { coll_broken_ = true; return fail(RELP_E_HIP, what); };
+    if (from_step <= 0 && coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_)) return broken("all-gather failed");
+    if (tableau_) return RELP_OK;                          // (its flush is local)
+    if (from_step <= 1 && coll_allgather_(coll_ctx_, d_msg_slice_, d_msg_slices_, row_stride_ * (int64_t)sizeof(double), stream_)) return broken("all-gather failed");
+    if (from_step <= 2 && coll_allreduce_(coll_ctx_, d_msg_rho_, rho_len(), stream_)) return broken("all-reduce failed");
+    ++shadow_flush_;
+    if (block_ > 0 && shadow_flush_ >= block_) {
+        if (from_step <= 3 && coll_allreduce_(coll_ctx_, d_R_, ld_b_ * block_, stream_)) return broken("all-reduce failed");
+        shadow_flush_ = 0;
+    }
+    return RELP_OK;
+}
+
+// One 16-byte all-gather of (status, rank): every rank returns the same verdict.
+relp_status_t Engine::shard_agree_on_status(relp_status_t local) {
+    if (coll_broken_) return local ? local : RELP_E_HIP;
+    const int32_t g = std::max(cfg_.shard_count, 1);
+    const double mine[2] = {(double)local, (double)cfg_.shard_rank};
+    if (hipMemcpyAsync(d_msg_status_, mine, sizeof(mine), hipMemcpyHostToDevice, stream_) != hipSuccess ||
+        hipStreamSynchronize(stream_) != hipSuccess)
+        return local ? local : fail(RELP_E_HIP, "status upload failed");
+    if (coll_allgather_(coll_ctx_, d_msg_status_, d_msg_statuses_, 2 * (int64_t)sizeof(double), stream_)) {
+        coll_broken_ = true;
+        return local ? local : fail(RELP_E_HIP, "all-gather of the rank statuses failed");
+    }
+    std::vector<double> all(2 * (size_t)g, 0.0);
+    if (hipMemcpyAsync(all.data(), d_msg_statuses_, sizeof(double) * all.size(), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+        hipStreamSynchronize(stream_) != hipSuccess)
+        return local ? local : fail(RELP_E_HIP, "status download failed");
+    for (int32_t r = 0; r < g; ++r)
+        if (all[2 * r] != 0.0) {
+            if (local) return local;                               // this rank's own error text stays
+            return fail((relp_status_t)(int)all[2 * r], "rank " + std::to_string(r) + " of the sharded loop failed; all ranks stop");
+        }
+    return RELP_OK;
+}
+
 relp_status_t Engine::shard_run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     if (!coll_allgather_) return fail(RELP_E_STATE, "relp_shard_run needs relp_shard_set_collectives / relp_rccl_attach first");
     int32_t oc = RELP_RUNNING; int64_t start = 0, it = 0;
+    relp_status_t local = RELP_OK;
     relp_status_t st = poll(&oc, &start);
     if (st) return st;
     it = start;
     // every rank polls after the same pivot counts (the outcome is replicated), so the ranks leave the
-    // loop together and the collectives stay matched; phase 1 polls at 1, 2, 4, ... like relp_run
+    // loop together and the collectives stay matched; phase 1 polls at 1, 2, 4, ... like relp_run.  A rank that fails
+    // locally keeps the collectives of the chunk going and reports at the poll: nobody is left inside a collective.
     int64_t chunk = phase_ == 1 ? 1 : cfg_.poll_interval;
     for (int64_t left = max_iters; left > 0 && oc == RELP_RUNNING;) {
         const int64_t n = std::min(left, chunk);
-        for (int64_t k = 0; k < n; ++k)
-            if ((st = shard_iteration())) return st;
+        for (int64_t k = 0; k < n; ++k) {
+            if (!local) {
+                local = shard_iteration();
+                if (local && !coll_broken_ && (st = shard_iteration_comm_only(coll_step_))) return st;   // finish the failed pivot's exchanges
+            } else if ((st = shard_iteration_comm_only(0))) return st;
+            if (coll_broken_) return local;
+        }
         left -= n;
+        if ((st = shard_agree_on_status(local))) return st;       // before the poll: a phase boundary inside it exchanges again
         if ((st = poll(&oc, &it))) return st;
         chunk = std::min<int64_t>(chunk * 2, cfg_.poll_interval);
     }

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "relp_reinversions": (C.c_int64, [C.c_void_p]),
     "relp_shard_set_collectives": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "relp_shard_run": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "relp_shard_inject_failure": (C.c_int, [C.c_void_p, C.c_int64]),
     "relp_rccl_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "relp_rccl_attach": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
     "relp_shard_plan": (C.c_int, [C.POINTER(_MatrixData), C.POINTER(Config), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

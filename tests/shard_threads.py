@@ -52,7 +52,8 @@ class ThreadRank:
             sh.barrier.wait(timeout=60)
             return 0
         except Exception as e:                           # a broken barrier on one rank breaks it for all
-            sh.errors.append(repr(e))
+            import traceback
+            sh.errors.append(repr(e) + " @ " + traceback.format_exc().splitlines()[-3].strip())
             sh.barrier.abort()
             return 1
 

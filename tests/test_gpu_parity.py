@@ -385,6 +385,46 @@ def test_native_shard_loop_with_several_ranks_on_one_gpu(world, m, n, seed, kind
         np.testing.assert_allclose(b, single.b(), rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_TABLEAU, 8), (engine.ENGINE_REVISED, 4)])
+def test_native_shard_loop_agrees_on_a_failure_of_one_rank(kind, block):
+    """A rank whose step fails in the middle of a chunk (relp_shard_inject_failure: after 5 pivots, polls every 8) must not
+    leave the others inside a collective: it keeps the chunk's collectives going, and at the poll one all-gather of the
+    statuses makes EVERY rank return an error."""
+    import ctypes as C
+    import torch
+    from shard_threads import ThreadRank, ThreadWorld, run_ranks
+    lib = engine.load_library()
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    world, m, n = 3, 60, 90
+    lp = synthetic.dense_lp(m, n, 41)
+    shared = ThreadWorld(world)
+    tabs, ranks = [], []
+    for r in range(world):
+        cfg = engine.default_config(shard_rank=r, shard_count=world, engine=kind, update_block=block, poll_interval=8)
+        md = MatrixData(nr_normal=n, nr_eq=0, nr_range=0, nr_le=m, nr_ge=0, b=lp["b"], cost=lp["c"], upper_bound=np.full(n, np.inf))
+        lo, hi = engine.shard_plan(md, cfg)
+        md.dense = np.asfortranarray(lp["A"][:, lo:hi]) if hi > lo else np.zeros((m, 1), order="F")
+        t = engine.Tableau(md, config=cfg)
+        tabs.append(t)
+        ranks.append(ThreadRank(shared, r, lib, t.handle, torch, dev))
+
+    def body(r):
+        t = tabs[r]
+        done, oc = C.c_int64(), C.c_int32()
+        assert lib.relp_shard_run(t.handle, 1, C.byref(done), C.byref(oc)) == 0           # empty phase 1
+        if r == 1:
+            assert lib.relp_shard_inject_failure(t.handle, 5) == 0
+        st = lib.relp_shard_run(t.handle, 1 << 20, C.byref(done), C.byref(oc))
+        return st, lib.relp_last_error(t.handle).decode()
+    out = run_ranks(world, body)
+    assert not shared.errors, shared.errors
+    assert all(st != 0 for st, _ in out), out                     # everybody stops, nobody hangs
+    assert "injected failure" in out[1][1] and all("rank 1" in msg for k, (st, msg) in enumerate(out) if k != 1), out
+    for t in tabs:
+        t.close()
+
+
 def test_sharded_tableau_runs_both_phases_on_general_lps():
     """LPs with ==, >= rows and bounded variables (artificial variables, phase 1, zero-level pivots that remove
     basic artificials, phase switch) on the column-sharded tableau engine, 2 to 4 ranks through the native loop:
