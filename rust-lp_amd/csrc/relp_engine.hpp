@@ -188,6 +188,7 @@ class Engine {
     char* d_ft_buf_ = nullptr;
     int32_t* h_ft_hdr_ = nullptr;                         // pinned copy of fts_.hdr
     int32_t ft_tcap_ = 0, ft_eta_cap_ = 0;
+    int64_t ft_zero_bytes_ = 0, ft_ones_bytes_ = 0;       // the two regions of the state buffer a refactorisation resets
     bool ft_need_refactor_ = false;
     relp_status_t ft_plan_and_alloc();
     relp_status_t ft_reset();

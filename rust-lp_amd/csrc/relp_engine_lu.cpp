@@ -281,9 +281,11 @@ relp_status_t Engine::ft_plan_and_alloc() {
     std::vector<char> dummy;
     int64_t o = 0;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += round_up(bytes, 16); return at; };
-    const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_pv = take(4 * tc), o_lv = take(4 * tc), o_ts = take(4 * m),
-                  o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp), o_so = take(4 * tc * nwp), o_ei = take(4 * (int64_t)ft_eta_cap_),
+    // (what a refactorisation clears to 0 first, then what it clears to -1, then the rest: two memsets per reset)
+    const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_lv = take(4 * tc), o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp),
+                  o_so = take(4 * tc * nwp), o_pv = take(4 * tc), o_ts = take(4 * m), o_ei = take(4 * (int64_t)ft_eta_cap_),
                   o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32);
+    ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_ft_hdr_), 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -337,15 +339,8 @@ relp_status_t Engine::ft_build_price_ell() {
 
 // empty update file: t = 0, every pivot "never updated", TC = 0 (after a refactorisation)
 relp_status_t Engine::ft_reset() {
-    const int64_t tc = ft_tcap_;
-    HIP_TRY(hipMemsetAsync(fts_.hdr, 0, 16, stream_));
-    HIP_TRY(hipMemsetAsync(fts_.slot_pivot, 0, 4 * tc, stream_));
-    HIP_TRY(hipMemsetAsync(fts_.slot_prev, 0xFF, 4 * tc, stream_));
-    HIP_TRY(hipMemsetAsync(fts_.slot_live, 0, 4 * tc, stream_));
-    HIP_TRY(hipMemsetAsync(fts_.tslot, 0xFF, 4 * (int64_t)m_, stream_));
-    HIP_TRY(hipMemsetAsync(fts_.TC, 0, 8 * tc * (tc + 1), stream_));
-    HIP_TRY(hipMemsetAsync(fts_.eta_off, 0, 4 * tc * (kFtWaves + 1), stream_));
-    HIP_TRY(hipMemsetAsync(fts_.spk_off, 0, 4 * tc * (kFtWaves + 1), stream_));
+    HIP_TRY(hipMemsetAsync(fts_.hdr, 0, (size_t)ft_zero_bytes_, stream_));                 // hdr, slot_pivot, slot_live, TC, offsets
+    HIP_TRY(hipMemsetAsync(fts_.slot_prev, 0xFF, (size_t)ft_ones_bytes_, stream_));        // slot_prev, tslot: -1
     ft_need_refactor_ = false;
     return RELP_OK;
 }
