@@ -141,20 +141,29 @@ relp_status_t Engine::lu_upload_factors() {
     }
     const size_t o_irp = put(inv_rp.data(), sizeof(int32_t) * m_), o_icp = put(inv_cp.data(), sizeof(int32_t) * m_);
     const size_t o_tuf = put(task_uf.data(), sizeof(int32_t) * m_), o_tub = put(task_ub.data(), sizeof(int32_t) * m_);
+    // the four schedules once more for the persistent pivot kernel: consecutive levels fused into groups one pass solves
+    // (relp_lu.hpp: fuse_levels), packed "ELL by pass", one contiguous image each (headers | lvl_pass | rdiag | sval | oval |
+    // rovf | sidx | oidx); rows of U and U' without entries are kept, an update may mask them
+    EllPacked ell[4];
+    size_t o_ell[4] = {0, 0, 0, 0}, o_via_ptr[4] = {0, 0, 0, 0}, o_via_pos[4] = {0, 0, 0, 0};
+    int32_t rhs_base[4] = {0, 0, 0, 0};
     std::vector<int32_t> lev_ub(m_, 0);
     for (int32_t l = 0; l + 1 < (int32_t)hlu_.Ub.level_ptr.size(); ++l)
         for (int32_t t = hlu_.Ub.level_ptr[l]; t < hlu_.Ub.level_ptr[l + 1]; ++t) lev_ub[hlu_.Ub.level_rows[t]] = l;
-    const size_t o_lub = put(lev_ub.data(), sizeof(int32_t) * m_);
-    // the four schedules once more, packed "ELL by group" for the persistent pivot kernel: one contiguous image each
-    // (groups | lvl_grp | rdiag | sval | sidx | rk); rows of U and U' without entries are kept, an update may mask them
-    EllPacked ell[4];
-    size_t o_ell[4] = {0, 0, 0, 0};
+    static_assert(kEllLgShift == kEllLg, "host packing and device decoding of sidx");
     if (ft_) {
+        static const int32_t fuse_cap = [] { const char* e = std::getenv("RELP_FUSE_LANES"); return e ? std::atoi(e) : 256; }();
+        const int32_t cap = 2 * (int64_t)m_ + 1 < (1 << kEllLgShift) ? fuse_cap : 0;      // index space of the rhs copy
         for (int k = 0; k < 4; ++k) {
-            ell_pack(*sch[k], k == 1 || k == 2, &ell[k]);
+            const bool maskable = k == 1 || k == 2;
+            FusedSchedule fs;
+            fuse_levels(*sch[k], maskable, maskable, cap, &fs);
+            ell_pack(fs, maskable, &ell[k]);
+            if (k == 2) lev_ub = fs.start_after;
             const EllPacked& e = ell[k];
+            for (int32_t v : fs.s.idx) if (v >= fs.rhs_base) { rhs_base[k] = fs.rhs_base; break; }
             std::vector<EllPassHost> hdrs(e.passes);
-            hdrs.resize(hdrs.size() + 3, EllPassHost{0, 0, 0, 0});        // the kernel reads three headers ahead
+            hdrs.resize(hdrs.size() + kEllPadHeaders, EllPassHost{0, 0, 0, 0});       // the kernel reads headers ahead
             o_ell[k] = put(hdrs.data(), sizeof(EllPassHost) * hdrs.size());
             put(e.lvl_pass.data(), sizeof(int32_t) * e.lvl_pass.size());
             put(e.rdiag.data(), sizeof(double) * e.rdiag.size());
@@ -164,7 +173,12 @@ relp_status_t Engine::lu_upload_factors() {
             put(e.sidx.data(), sizeof(uint16_t) * e.sidx.size());
             put(e.oidx.data(), sizeof(uint16_t) * e.oidx.size());
         }
+        for (int k = 1; k <= 2; ++k) {
+            o_via_ptr[k] = put(ell[k].via_ptr.data(), sizeof(int32_t) * ell[k].via_ptr.size());
+            o_via_pos[k] = put(ell[k].via_pos.data(), sizeof(int32_t) * ell[k].via_pos.size());
+        }
     }
+    const size_t o_lub = put(lev_ub.data(), sizeof(int32_t) * m_);
     size_t o_rows[4], o_idx[4], o_val[4], o_lp[4], o_seg[4];
     int32_t n_seg[4];
     std::vector<LuRow> rows(m_);
@@ -235,10 +249,10 @@ relp_status_t Engine::lu_upload_factors() {
                           nov = (int64_t)e.oidx.size();
             char* q = d_lu_buf_ + o_ell[k];
             char* const q0 = q;
-            d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * (np + 3));
+            d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * (np + kEllPadHeaders));
             d.lvl_pass = reinterpret_cast<const int32_t*>(q); q += up16(4 * nlv);
-            d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * (int64_t)m_);
-            d.sval = reinterpret_cast<const double*>(q); q += up16(8 * nln);
+            d.rdiag = reinterpret_cast<double*>(q); q += up16(8 * ((int64_t)m_ + 1));
+            d.sval = reinterpret_cast<double*>(q); q += up16(8 * nln);
             d.oval = reinterpret_cast<const double*>(q); q += up16(8 * nov);
             d.rovf = reinterpret_cast<const int32_t*>(q); q += up16(4 * (int64_t)e.rovf.size());
             d.sidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
@@ -246,6 +260,10 @@ relp_status_t Engine::lu_upload_factors() {
             const int64_t total = q - q0;
             d.n_passes = (int32_t)np; d.n_levels = (int32_t)nlv - 1; d.m = m_; d.n_lanes = (int32_t)nln; d.n_ovf = (int32_t)nov;
             d.bytes = (int32_t)total;
+            d.rhs_base = rhs_base[k]; d.pad_ = 0;
+            const bool has_via = !e.via_ptr.empty();
+            d.via_ptr = has_via ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_via_ptr[k]) : nullptr;
+            d.via_pos = has_via ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_via_pos[k]) : nullptr;
             fts_.stage[k] = total <= fts_.stage_bytes ? 1 : 0;
             if (fts_.stage[k]) need = std::max(need, total);
         }

@@ -106,18 +106,24 @@ struct DeviceLU {
 };
 // The same solve packed "ELL by pass" for the persistent pivot kernel (relp_lu.hpp: ell_pack; relp_lu_device.h: ell_solve):
 // one image per schedule, contiguous in device memory in the order of the members below, every array padded to 16 bytes.
+static constexpr int kEllLg = 13;                       // sidx = index | lg << kEllLg (relp_lu.hpp: kEllLgShift)
+static constexpr int kEllPadHeaders = 4;                // empty pass headers behind the last one: the solves read ahead unchecked
 struct EllPass { int32_t lane0, lanes, info, level; };     // info: max lg | last-of-level << 8 | overflow << 9
 struct EllSchedule {
-    const EllPass*  passes;      // n_passes
-    const int32_t*  lvl_pass;    // n_levels + 1: first pass of a level
-    double*         rdiag;       // m: 1 / diagonal by pivot; 0 = row masked by a Forrest-Tomlin update (the only mutable part)
-    const double*   sval;        // n_lanes
+    const EllPass*  passes;      // n_passes (+ 3 empty headers)
+    const int32_t*  lvl_pass;    // n_levels + 1: first pass of a level (= group of fused levels, relp_lu.hpp: fuse_levels)
+    double*         rdiag;       // m + 1: 1 / diagonal by pivot; 0 = row masked by a Forrest-Tomlin update
+    double*         sval;        // n_lanes; an update zeroes the entries whose substitution path runs through the masked pivot
     const double*   oval;        // n_ovf: entries beyond the 63rd of a row
     const int32_t*  rovf;        // 2 m (or nothing when n_ovf = 0): overflow range by pivot
-    const uint16_t* sidx;        // n_lanes: index | lg << 12
+    const uint16_t* sidx;        // n_lanes: index | lg << 13; index >= rhs_base: the copy of the right-hand side behind x
     const uint16_t* oidx;        // n_ovf
+    const int32_t*  via_ptr;     // m + 1 (U, U' only, else null): positions in sval to zero when a pivot is masked ...
+    const int32_t*  via_pos;     // ... (not part of the staged image)
     int32_t n_passes, n_levels, m, n_lanes, n_ovf;
     int32_t bytes;               // size of the image
+    int32_t rhs_base;            // m + 1 when some entry reads the right-hand-side copy, else 0 (no copy is made)
+    int32_t pad_;
 };
 // Column indices at or above this value are artificial variables that survived phase 1 (see
 // Engine::switch_to_phase_two): INT32_MAX - (na - 1 - a).  They have no flag, no cost and no column.

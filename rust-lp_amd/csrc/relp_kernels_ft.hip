@@ -32,7 +32,7 @@ __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
     int64_t o = 0;
     const int ldt = tcap + 1;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
-    L.x = take(8LL * (m + 1)); L.sp = take(8LL * m); L.pi = take(8LL * m);      // x[m]: scratch word of ell_solve
+    L.x = take(8LL * (2 * m + 1)); L.sp = take(8LL * m); L.pi = take(8LL * m);  // x[m]: scratch word of ell_solve; x[m + 1 ..]: rhs copy
     L.tc = take(8LL * tcap * ldt);
     L.dots = take(8LL * tcap); L.zt = take(8LL * tcap); L.uv = take(8LL * tcap); L.ct = take(8LL * tcap);
     L.slot_pivot = take(4LL * tcap); L.slot_prev = take(4LL * tcap); L.slot_live = take(4LL * tcap); L.slot_next = take(4LL * tcap);
@@ -176,12 +176,11 @@ __device__ __forceinline__ double sum8(double v) {
     return v;
 }
 
-constexpr int NTS = 256;                               // threads that walk the levels of a solve (one wavefront per SIMD)
 // `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
 __device__ __forceinline__ void sweep(const FtState& st, int which, FtCtx& c, int first_level = 0) {
     auto lap = [&]() { c.clk.lap(FT_STAGE); };
-    if (st.stage[which]) ell_solve<true, NT, NTS>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
-    else ell_solve<false, NT, NTS>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    if (st.stage[which]) ell_solve_pp<true, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    else ell_solve_pp<false, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
 }
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
@@ -478,6 +477,12 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
         if (tid == 0) {
             st.ell[1].rdiag[p] = 0.0;
             st.ell[2].rdiag[p] = 0.0;
+        }
+        // fused levels: the entries of p's group-mates that were substituted through row p go with it
+        for (int w = 1; w <= 2; ++w) {
+            const EllSchedule& es = st.ell[w];
+            if (es.via_ptr)
+                for (int e = es.via_ptr[p] + tid; e < es.via_ptr[p + 1]; e += NT) es.sval[es.via_pos[e]] = 0.0;
         }
     } else {
         if (tid >= s_old && tid < c.tcap) c.TC[s_old * c.ldt + tid] = 0.0;    // (left of the diagonal: eta coefficients, kept)

@@ -12,26 +12,15 @@ namespace relp {
 
 namespace {
 
-struct Entry { int32_t row, pos; double val; };   // L entry: (original row, pivot step of the column, factor)
-
-// rows[k] = list of (dependency, value); `ascending`: dependencies have smaller indices (solve 0..m-1),
-// otherwise larger (solve m-1..0).
-void build_schedule(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& rows,
-                    const std::vector<double>& diag, bool ascending, TriangularSchedule* s) {
-    s->ptr.assign(m + 1, 0);
-    for (int32_t k = 0; k < m; ++k) s->ptr[k + 1] = s->ptr[k] + (int32_t)rows[k].size();
-    s->idx.resize(s->ptr[m]);
-    s->val.resize(s->ptr[m]);
-    for (int32_t k = 0; k < m; ++k) {
-        int32_t o = s->ptr[k];
-        for (auto& e : rows[k]) { s->idx[o] = e.first; s->val[o] = e.second; ++o; }
-    }
+// rows as CSR (ptr / idx / val, entries of a row sorted by index) -> schedule with levels.  `ascending`: dependencies have
+// smaller indices (solve 0..m-1), otherwise larger (solve m-1..0).
+void finish_schedule(int32_t m, const std::vector<double>& diag, bool ascending, TriangularSchedule* s) {
     s->diag = diag;
     std::vector<int32_t> lev(m, 0);
-    int32_t nlev = 0;
+    int32_t nlev = m > 0 ? 1 : 0;
     auto visit = [&](int32_t k) {
         int32_t l = 0;
-        for (auto& e : rows[k]) l = std::max(l, lev[e.first] + 1);
+        for (int32_t e = s->ptr[k]; e < s->ptr[k + 1]; ++e) l = std::max(l, lev[s->idx[e]] + 1);
         lev[k] = l;
         nlev = std::max(nlev, l + 1);
     };
@@ -45,43 +34,141 @@ void build_schedule(int32_t m, const std::vector<std::vector<std::pair<int32_t, 
     for (int32_t k = 0; k < m; ++k) s->level_rows[fill[lev[k]]++] = k;
 }
 
+// (row, index, value) triplets -> the CSR part of a schedule; entries of a row sorted by index
+struct Triplet { int32_t row, idx; double val; };
+void rows_from_triplets(int32_t m, const std::vector<Triplet>& t, TriangularSchedule* s) {
+    s->ptr.assign(m + 1, 0);
+    for (const Triplet& e : t) ++s->ptr[e.row + 1];
+    for (int32_t k = 0; k < m; ++k) s->ptr[k + 1] += s->ptr[k];
+    s->idx.resize(t.size()); s->val.resize(t.size());
+    std::vector<int32_t> fill(s->ptr.begin(), s->ptr.end() - 1);
+    for (const Triplet& e : t) { const int32_t o = fill[e.row]++; s->idx[o] = e.idx; s->val[o] = e.val; }
+    for (int32_t k = 0; k < m; ++k) {                              // insertion sort: rows are short and mostly in order
+        const int32_t b = s->ptr[k], e = s->ptr[k + 1];
+        for (int32_t i = b + 1; i < e; ++i) {
+            const int32_t ci = s->idx[i]; const double cv = s->val[i];
+            int32_t j = i - 1;
+            while (j >= b && s->idx[j] > ci) { s->idx[j + 1] = s->idx[j]; s->val[j + 1] = s->val[j]; --j; }
+            s->idx[j + 1] = ci; s->val[j + 1] = cv;
+        }
+    }
+}
+
+// The active line (row or column) with the smallest (count, index): one bit set per count, lines with 63 or more entries
+// share the last set.  Replaces a lazily-deleted binary heap (same answer: the minimum over the lines' current counts).
+struct CountBuckets {
+    static constexpr int32_t kTop = 63;
+    int32_t words = 0;
+    std::vector<uint64_t> bits;                  // (kTop + 1) x words
+    std::vector<int32_t> members;                // lines per bucket
+    void init(int32_t n) { words = (n + 63) / 64; bits.assign((size_t)(kTop + 1) * words, 0); members.assign(kTop + 1, 0); }
+    static int32_t bucket(int32_t count) { return count < kTop ? count : kTop; }
+    void insert(int32_t line, int32_t count) { const int32_t b = bucket(count); bits[(size_t)b * words + (line >> 6)] |= 1ull << (line & 63); ++members[b]; }
+    void erase(int32_t line, int32_t count) { const int32_t b = bucket(count); bits[(size_t)b * words + (line >> 6)] &= ~(1ull << (line & 63)); --members[b]; }
+    void move(int32_t line, int32_t from, int32_t to) { if (bucket(from) != bucket(to)) { erase(line, from); insert(line, to); } }
+    // smallest (count, line) with count >= min_count; -1 when there is none.  `count_of` is only asked in the shared last set.
+    template <class F> int32_t top(int32_t min_count, F count_of) const {
+        for (int32_t b = bucket(min_count); b <= kTop; ++b) {
+            if (!members[b]) continue;
+            const uint64_t* w = &bits[(size_t)b * words];
+            if (b < kTop) { for (int32_t i = 0; i < words; ++i) if (w[i]) return i * 64 + __builtin_ctzll(w[i]); continue; }
+            int32_t best = -1, bc = 0;
+            for (int32_t i = 0; i < words; ++i)
+                for (uint64_t v = w[i]; v; v &= v - 1) {
+                    const int32_t line = i * 64 + __builtin_ctzll(v), c = count_of(line);
+                    if (best < 0 || c < bc) { best = line; bc = c; }
+                }
+            return best;
+        }
+        return -1;
+    }
+};
+
+// growable lists in one arena: list l = store[beg[l] .. beg[l] + len[l]), relocated to the end with doubled room when full
+template <class T>
+struct ListArena {
+    std::vector<T> store;
+    std::vector<int32_t> beg, len, cap;
+    void init(int32_t lists, size_t reserve) { store.clear(); store.reserve(reserve); beg.assign(lists, 0); len.assign(lists, 0); cap.assign(lists, 0); }
+    int32_t alloc(int32_t room) { const int32_t at = (int32_t)store.size(); store.resize(store.size() + room); return at; }
+    void push(int32_t l, const T& v) {
+        if (len[l] == cap[l]) {
+            const int32_t room = cap[l] ? 2 * cap[l] : 4, at = alloc(room);
+            for (int32_t i = 0; i < len[l]; ++i) store[at + i] = store[beg[l] + i];
+            beg[l] = at; cap[l] = room;
+        }
+        store[beg[l] + len[l]++] = v;
+    }
+};
+
 }  // namespace
 
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err) {
-    std::vector<std::vector<std::pair<int32_t, double>>> rows(m);       // active submatrix, row major: (column, value)
-    std::vector<std::vector<int32_t>> colrows(m);                       // rows that (may) hold an entry of the column
+    // active submatrix, row major: entries (column, value) of row i at rc / rv [rows.beg[i], + rows.len[i]); colrows: the rows
+    // that (may) hold an entry of a column (stale members are dropped whenever the list is scanned for its maximum)
+    size_t nnz = 0;
+    for (int32_t j = 0; j < m; ++j) nnz += columns[j].size();
+    ListArena<int32_t> rows, colrows;
+    std::vector<double> rv;                                            // values parallel to rows.store
+    rows.init(m, 4 * nnz + 8 * (size_t)m); colrows.init(m, 4 * nnz + 8 * (size_t)m);
+    rv.reserve(4 * nnz + 8 * (size_t)m);
     std::vector<int32_t> ccount(m, 0);
-    for (int32_t j = 0; j < m; ++j)
-        for (auto& e : columns[j]) {
-            if (e.second == 0.0) continue;
-            rows[e.first].emplace_back(j, e.second);
-            colrows[j].push_back(e.first);
-            ++ccount[j];
-        }
+    {
+        std::vector<int32_t> rcount(m, 0);
+        for (int32_t j = 0; j < m; ++j)
+            for (auto& e : columns[j]) if (e.second != 0.0) { ++rcount[e.first]; ++ccount[j]; }
+        for (int32_t i = 0; i < m; ++i) { rows.beg[i] = rows.alloc(rcount[i] + 4); rows.cap[i] = rcount[i] + 4; }
+        rv.resize(rows.store.size());
+        for (int32_t j = 0; j < m; ++j) { colrows.beg[j] = colrows.alloc(ccount[j] + 4); colrows.cap[j] = ccount[j] + 4; }
+        for (int32_t j = 0; j < m; ++j)
+            for (auto& e : columns[j]) {
+                if (e.second == 0.0) continue;
+                const int32_t i = e.first, o = rows.beg[i] + rows.len[i]++;
+                rows.store[o] = j; rv[o] = e.second;
+                colrows.store[colrows.beg[j] + colrows.len[j]++] = i;
+            }
+    }
+    // a rewritten row that outgrows its room moves to the end of the arena
+    auto row_store = [&](int32_t i, const std::vector<int32_t>& c, const std::vector<double>& v, int32_t n) {
+        if (n > rows.cap[i]) { rows.beg[i] = rows.alloc(n + 4); rows.cap[i] = n + 4; rv.resize(rows.store.size()); }
+        const int32_t b = rows.beg[i];
+        for (int32_t t = 0; t < n; ++t) { rows.store[b + t] = c[t]; rv[b + t] = v[t]; }
+        rows.len[i] = n;
+    };
+    auto find_in_row = [&](int32_t i, int32_t j) {                     // position of column j in row i, or -1
+        const int32_t b = rows.beg[i], e = b + rows.len[i];
+        for (int32_t t = b; t < e; ++t) if (rows.store[t] == j) return t;
+        return -1;
+    };
     std::vector<char> row_done(m, 0);
     std::vector<int32_t> step_of_row(m, -1), step_of_col(m, -1);
     out->m = m;
     out->rowperm.assign(m, 0);
     out->colperm.assign(m, 0);
-    std::vector<std::vector<std::pair<int32_t, double>>> urows(m);      // U row of step k: (original column, value)
+    std::vector<Triplet> lrow_t, lcol_t, urow_t, ucol_t;               // L / U entries in original (row, column) coordinates
+    lrow_t.reserve(2 * nnz); urow_t.reserve(2 * nnz);
+    std::vector<int32_t> ubeg(m + 1, 0), ucol; std::vector<double> uval;   // U row of step k: (original column, value)
+    ucol.reserve(2 * nnz); uval.reserve(2 * nnz);
     std::vector<double> udiag(m, 1.0);
-    std::vector<Entry> lent;
     std::vector<int32_t> mark(m, -1), pos(m, 0);
     int32_t stamp = 0;
     // Singletons first: most of an LP basis is triangular (slacks, bound rows).  A column with one active
     // entry is a fill-free pivot that always passes the threshold; a row with one active entry is fill-free
-    // and is taken when it passes it.  Both are served from stacks, so the O(m) searches below only run on
+    // and is taken when it passes it.  Both are served from stacks, so the searches below only run on
     // the "bump" that is left.
     std::vector<int32_t> col_single, row_single;
+    col_single.reserve(4 * (size_t)m); row_single.reserve(4 * (size_t)m);
     for (int32_t j = 0; j < m; ++j) if (ccount[j] == 1) col_single.push_back(j);
-    for (int32_t i = 0; i < m; ++i) if (rows[i].size() == 1) row_single.push_back(i);
-    // lazy min-heaps of (count, index) for the sparsest active row / column of the bump: an entry is stale
-    // when the line is done or its count has changed since it was pushed (every change pushes a fresh one)
-    using Item = std::pair<int32_t, int32_t>;
-    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> row_heap, col_heap;
-    for (int32_t i = 0; i < m; ++i) row_heap.emplace((int32_t)rows[i].size(), i);
-    for (int32_t j = 0; j < m; ++j) col_heap.emplace(ccount[j], j);
+    for (int32_t i = 0; i < m; ++i) if (rows.len[i] == 1) row_single.push_back(i);
+    // the sparsest active row / column of the bump, ties to the lower index
+    CountBuckets row_set, col_set;
+    row_set.init(m); col_set.init(m);
+    for (int32_t i = 0; i < m; ++i) row_set.insert(i, rows.len[i]);
+    for (int32_t j = 0; j < m; ++j) col_set.insert(j, ccount[j]);
+    auto col_count_changed = [&](int32_t j, int32_t from) {
+        if (step_of_col[j] < 0) col_set.move(j, from, ccount[j]);
+    };
     // largest active |entry| of column j; the scan also drops the stale members of colrows[j] (finished rows,
     // rows that lost the entry, duplicates), so the lists stay as short as the columns are
     std::vector<int32_t> seen_stamp(m, -1);
@@ -89,32 +176,38 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     auto col_max_of = [&](int32_t j) {
         double mx = 0.0;
         ++seen_tick;
-        size_t o = 0;
-        auto& list = colrows[j];
-        for (size_t t = 0; t < list.size(); ++t) {
-            const int32_t i = list[t];
+        int32_t o = 0;
+        const int32_t b = colrows.beg[j], n = colrows.len[j];
+        for (int32_t t = 0; t < n; ++t) {
+            const int32_t i = colrows.store[b + t];
             if (row_done[i] || seen_stamp[i] == seen_tick) continue;
-            for (auto& e : rows[i]) if (e.first == j) { mx = std::max(mx, std::fabs(e.second)); seen_stamp[i] = seen_tick; list[o++] = i; break; }
+            const int32_t at = find_in_row(i, j);
+            if (at >= 0) { mx = std::max(mx, std::fabs(rv[at])); seen_stamp[i] = seen_tick; colrows.store[b + o++] = i; }
         }
-        list.resize(o);
+        colrows.len[j] = o;
         return mx;
     };
+    std::vector<std::pair<int32_t, int32_t>> order;                    // (column count, column)
+    std::vector<int32_t> nc; std::vector<double> nv;                   // the row being rewritten
+    nc.resize(m); nv.resize(m);
+    constexpr double kThreshold = 0.1;
 
     for (int32_t k = 0; k < m; ++k) {
         int32_t spi = -1, spj = -1; double spv = 0.0;
         while (!col_single.empty() && spj < 0) {
             const int32_t j = col_single.back(); col_single.pop_back();
             if (step_of_col[j] >= 0 || ccount[j] != 1) continue;
-            for (int32_t i : colrows[j]) {
+            for (int32_t t = 0; t < colrows.len[j]; ++t) {
+                const int32_t i = colrows.store[colrows.beg[j] + t];
                 if (row_done[i]) continue;
-                for (auto& e : rows[i]) if (e.first == j && e.second != 0.0) { spi = i; spj = j; spv = e.second; break; }
-                if (spj >= 0) break;
+                const int32_t at = find_in_row(i, j);
+                if (at >= 0 && rv[at] != 0.0) { spi = i; spj = j; spv = rv[at]; break; }
             }
         }
         while (!row_single.empty() && spj < 0) {
             const int32_t i = row_single.back(); row_single.pop_back();
-            if (row_done[i] || rows[i].size() != 1) continue;
-            const int32_t j = rows[i][0].first; const double v = rows[i][0].second;
+            if (row_done[i] || rows.len[i] != 1) continue;
+            const int32_t j = rows.store[rows.beg[i]]; const double v = rv[rows.beg[i]];
             if (v != 0.0 && std::fabs(v) >= 0.1 * col_max_of(j)) { spi = i; spj = j; spv = v; }
         }
         // Markowitz search restricted to the sparsest active row and the sparsest active column
@@ -123,44 +216,39 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
         // count; the lower (r - 1)(c - 1) wins.
         int32_t ra = -1;
         if (spj < 0) {
-            while (!row_heap.empty() && (row_done[row_heap.top().second] ||
-                                         (int32_t)rows[row_heap.top().second].size() != row_heap.top().first)) row_heap.pop();
-            if (row_heap.empty()) { if (err) *err = "singular basis (no active row)"; return false; }
-            ra = row_heap.top().second;
-            if (rows[ra].empty()) { if (err) *err = "singular basis (empty row during LU)"; return false; }
+            ra = row_set.top(0, [&](int32_t i) { return rows.len[i]; });
+            if (ra < 0) { if (err) *err = "singular basis (no active row)"; return false; }
+            if (rows.len[ra] == 0) { if (err) *err = "singular basis (empty row during LU)"; return false; }
         }
         // threshold partial pivoting: a pivot must be at least kThreshold of the largest active entry of
         // its column, which bounds every multiplier of L by 1 / kThreshold
-        auto& col_max = col_max_of;
-        constexpr double kThreshold = 0.1;
         int32_t pi = spi, pj = spj; double pv = spv; int64_t best = spj >= 0 ? 0 : -1;
         if (spj < 0) {
             // candidate A: entries of the sparsest row, by ascending column count
-            std::vector<std::pair<int32_t, int32_t>> order;          // (column count, column)
-            for (auto& e : rows[ra]) if (e.second != 0.0) order.emplace_back(ccount[e.first], e.first);
+            order.clear();
+            const int32_t b = rows.beg[ra], n = rows.len[ra];
+            for (int32_t t = 0; t < n; ++t) if (rv[b + t] != 0.0) order.emplace_back(ccount[rows.store[b + t]], rows.store[b + t]);
             std::sort(order.begin(), order.end());
             for (auto& oc : order) {
-                double v = 0.0;
-                for (auto& e : rows[ra]) if (e.first == oc.second) { v = e.second; break; }
-                if (std::fabs(v) < kThreshold * col_max(oc.second)) continue;
+                const double v = rv[find_in_row(ra, oc.second)];
+                if (std::fabs(v) < kThreshold * col_max_of(oc.second)) continue;
                 pi = ra; pj = oc.second; pv = v;
-                best = (int64_t)(rows[ra].size() - 1) * (ccount[pj] - 1);
+                best = (int64_t)(n - 1) * (ccount[pj] - 1);
                 break;
             }
         }
         if (best != 0) {
-            int32_t cb = -1;
-            while (!col_heap.empty() && (step_of_col[col_heap.top().second] >= 0 || ccount[col_heap.top().second] != col_heap.top().first ||
-                                         col_heap.top().first <= 0)) col_heap.pop();
-            if (!col_heap.empty()) cb = col_heap.top().second;
+            const int32_t cb = col_set.top(1, [&](int32_t j) { return ccount[j]; });
             if (cb >= 0) {
-                const double cmax = col_max(cb);
-                for (int32_t i : colrows[cb]) {
+                const double cmax = col_max_of(cb);
+                for (int32_t t = 0; t < colrows.len[cb]; ++t) {
+                    const int32_t i = colrows.store[colrows.beg[cb] + t];
                     if (row_done[i]) continue;
-                    double v = 0.0; bool has = false;
-                    for (auto& e : rows[i]) if (e.first == cb) { v = e.second; has = true; break; }
-                    if (!has || v == 0.0 || std::fabs(v) < kThreshold * cmax) continue;
-                    const int64_t cost = (int64_t)(rows[i].size() - 1) * (ccount[cb] - 1);
+                    const int32_t at = find_in_row(i, cb);
+                    if (at < 0) continue;
+                    const double v = rv[at];
+                    if (v == 0.0 || std::fabs(v) < kThreshold * cmax) continue;
+                    const int64_t cost = (int64_t)(rows.len[i] - 1) * (ccount[cb] - 1);
                     if (best < 0 || cost < best) { best = cost; pi = i; pj = cb; pv = v; }
                 }
             }
@@ -169,105 +257,232 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
             // no entry of the sparsest row / column passes the threshold: take the largest entry of the
             // sparsest row's best column (always acceptable)
             double bestv = 0.0;
-            for (auto& e : rows[ra]) {
-                const int32_t j = e.first;
-                for (int32_t i : colrows[j]) {
+            for (int32_t t = 0; t < rows.len[ra] && pj < 0; ++t) {
+                const int32_t j = rows.store[rows.beg[ra] + t];
+                for (int32_t u = 0; u < colrows.len[j]; ++u) {
+                    const int32_t i = colrows.store[colrows.beg[j] + u];
                     if (row_done[i]) continue;
-                    for (auto& f : rows[i]) if (f.first == j && std::fabs(f.second) > bestv) { bestv = std::fabs(f.second); pi = i; pj = j; pv = f.second; }
+                    const int32_t at = find_in_row(i, j);
+                    if (at >= 0 && std::fabs(rv[at]) > bestv) { bestv = std::fabs(rv[at]); pi = i; pj = j; pv = rv[at]; }
                 }
-                if (pj >= 0) break;
             }
         }
         if (pj < 0) { if (err) *err = "singular basis (no acceptable pivot)"; return false; }
         out->rowperm[k] = pi; out->colperm[k] = pj;
         step_of_row[pi] = k; step_of_col[pj] = k;
         row_done[pi] = 1;
+        row_set.erase(pi, rows.len[pi]);
+        col_set.erase(pj, ccount[pj]);
         udiag[k] = pv;
-        for (auto& e : rows[pi]) {
-            if (--ccount[e.first] == 1) col_single.push_back(e.first);
-            col_heap.emplace(ccount[e.first], e.first);
-            if (e.first != pj) urows[k].push_back(e);
-        }
-        const std::vector<std::pair<int32_t, double>>& prow = urows[k];
-        // eliminate column pj from the other active rows
-        for (int32_t i : colrows[pj]) {
-            if (row_done[i]) continue;
-            auto& ri = rows[i];
-            double vij = 0.0; bool has = false;
-            for (auto& e : ri) if (e.first == pj) { vij = e.second; has = true; break; }
-            if (!has) continue;                                   // stale list entry
-            const double f = vij / pv;
-            lent.push_back(Entry{i, k, f});
-            ++stamp;
-            std::vector<std::pair<int32_t, double>> nr;
-            nr.reserve(ri.size() + prow.size());
-            for (auto& e : ri) {
-                if (e.first == pj) continue;
-                mark[e.first] = stamp; pos[e.first] = (int32_t)nr.size();
-                nr.push_back(e);
+        ubeg[k] = (int32_t)ucol.size();
+        {
+            const int32_t b = rows.beg[pi], n = rows.len[pi];
+            for (int32_t t = 0; t < n; ++t) {
+                const int32_t c = rows.store[b + t];
+                const int32_t before = ccount[c]--;
+                if (ccount[c] == 1) col_single.push_back(c);
+                col_count_changed(c, before);
+                if (c != pj) { ucol.push_back(c); uval.push_back(rv[b + t]); }
             }
-            for (auto& e : prow) {
-                if (mark[e.first] == stamp) nr[pos[e.first]].second -= f * e.second;
+        }
+        const int32_t pb = ubeg[k], pn = (int32_t)ucol.size() - pb;
+        // eliminate column pj from the other active rows
+        for (int32_t t = 0; t < colrows.len[pj]; ++t) {
+            const int32_t i = colrows.store[colrows.beg[pj] + t];
+            if (row_done[i]) continue;
+            const int32_t at = find_in_row(i, pj);
+            if (at < 0) continue;                                  // stale list entry
+            const double f = rv[at] / pv;
+            lrow_t.push_back(Triplet{i, k, f});
+            ++stamp;
+            const int32_t b = rows.beg[i], n = rows.len[i];
+            int32_t nn = 0;
+            if ((int32_t)nc.size() < n + pn) { nc.resize(n + pn); nv.resize(n + pn); }
+            for (int32_t u = 0; u < n; ++u) {
+                const int32_t c = rows.store[b + u];
+                if (c == pj) continue;
+                mark[c] = stamp; pos[c] = nn;
+                nc[nn] = c; nv[nn] = rv[b + u]; ++nn;
+            }
+            for (int32_t u = 0; u < pn; ++u) {
+                const int32_t c = ucol[pb + u];
+                if (mark[c] == stamp) nv[pos[c]] -= f * uval[pb + u];
                 else {
-                    mark[e.first] = stamp; pos[e.first] = (int32_t)nr.size();
-                    nr.emplace_back(e.first, -f * e.second);
-                    colrows[e.first].push_back(i);
-                    ++ccount[e.first];
-                    col_heap.emplace(ccount[e.first], e.first);
+                    mark[c] = stamp; pos[c] = nn;
+                    nc[nn] = c; nv[nn] = -f * uval[pb + u]; ++nn;
+                    colrows.push(c, i);
+                    const int32_t before = ccount[c]++;
+                    col_count_changed(c, before);
                 }
             }
-            size_t o = 0;
-            for (auto& e : nr) {
-                if (e.second == 0.0) {                                       // exact cancellation (decomposition/mod.rs:178)
-                    if (--ccount[e.first] == 1) col_single.push_back(e.first);
-                    col_heap.emplace(ccount[e.first], e.first);
+            int32_t o = 0;
+            for (int32_t u = 0; u < nn; ++u) {
+                if (nv[u] == 0.0) {                                          // exact cancellation (decomposition/mod.rs:178)
+                    const int32_t c = nc[u];
+                    const int32_t before = ccount[c]--;
+                    if (ccount[c] == 1) col_single.push_back(c);
+                    col_count_changed(c, before);
                     continue;
                 }
-                nr[o++] = e;
+                nc[o] = nc[u]; nv[o] = nv[u]; ++o;
             }
-            nr.resize(o);
-            ri.swap(nr);
-            if (ri.size() == 1) row_single.push_back(i);
-            row_heap.emplace((int32_t)ri.size(), i);
+            row_set.move(i, n, o);
+            row_store(i, nc, nv, o);
+            if (o == 1) row_single.push_back(i);
         }
-        rows[pi].clear();
+        rows.len[pi] = 0;
     }
+    ubeg[m] = (int32_t)ucol.size();
 
-    // L and U in pivot-step coordinates
-    std::vector<std::vector<std::pair<int32_t, double>>> lrows(m), lcols(m), urows_s(m), ucols(m);
-    for (auto& e : lent) {
-        const int32_t k = step_of_row[e.row];
-        lrows[k].emplace_back(e.pos, e.val);          // L[k, l], l < k
-        lcols[e.pos].emplace_back(k, e.val);          // column l of L: rows k > l
-    }
+    // L and U in pivot-step coordinates: rows of L (FTRAN), rows of U, columns of U (BTRAN), columns of L
+    for (Triplet& e : lrow_t) e.row = step_of_row[e.row];             // L[k, l], l < k
+    lcol_t.reserve(lrow_t.size());
+    for (const Triplet& e : lrow_t) lcol_t.push_back(Triplet{e.idx, e.row, e.val});      // column l of L: rows k > l
+    urow_t.clear(); ucol_t.reserve(ucol.size());
     for (int32_t k = 0; k < m; ++k)
-        for (auto& e : urows[k]) {
-            const int32_t l = step_of_col[e.first];
-            urows_s[k].emplace_back(l, e.second);     // U[k, l], l > k
-            ucols[l].emplace_back(k, e.second);       // column l of U: rows k < l
+        for (int32_t t = ubeg[k]; t < ubeg[k + 1]; ++t) {
+            const int32_t l = step_of_col[ucol[t]];
+            urow_t.push_back(Triplet{k, l, uval[t]});                  // U[k, l], l > k
+            ucol_t.push_back(Triplet{l, k, uval[t]});                  // column l of U: rows k < l
         }
-    for (auto& v : lrows) std::sort(v.begin(), v.end());
-    for (auto& v : lcols) std::sort(v.begin(), v.end());
-    for (auto& v : urows_s) std::sort(v.begin(), v.end());
-    for (auto& v : ucols) std::sort(v.begin(), v.end());
     std::vector<double> ones(m, 1.0);
-    build_schedule(m, lrows, ones, true, &out->Lf);
-    build_schedule(m, urows_s, udiag, false, &out->Uf);
-    build_schedule(m, ucols, udiag, true, &out->Ub);
-    build_schedule(m, lcols, ones, false, &out->Lb);
-    out->nnz_l = (int64_t)lent.size();
-    out->nnz_u = 0;
-    for (auto& v : urows) out->nnz_u += (int64_t)v.size() + 1;
+    rows_from_triplets(m, lrow_t, &out->Lf); finish_schedule(m, ones, true, &out->Lf);
+    rows_from_triplets(m, urow_t, &out->Uf); finish_schedule(m, udiag, false, &out->Uf);
+    rows_from_triplets(m, ucol_t, &out->Ub); finish_schedule(m, udiag, true, &out->Ub);
+    rows_from_triplets(m, lcol_t, &out->Lb); finish_schedule(m, ones, false, &out->Lb);
+    out->nnz_l = (int64_t)lrow_t.size();
+    out->nnz_u = (int64_t)ucol.size() + m;
     return true;
 }
 
-void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
+void fuse_levels(const TriangularSchedule& t, bool maskable, bool keep_trivial, int32_t lane_cap, FusedSchedule* out) {
+    const int32_t m = (int32_t)t.diag.size();
+    const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
+    *out = FusedSchedule{};
+    out->rhs_base = m + 1;
+    const int32_t rhs_base = m + 1;
+    // expanded rows, flat: row k = entries [ebeg[k], ebeg[k] + elen[k]) of (esrc, ecoef); maskable: the pivots an entry's
+    // substitution path runs through = pool[ev0[e], ev0[e] + evn[e])
+    std::vector<int32_t> esrc, ev0, evn, ebeg(m, 0), elen(m, 0), pool, grp(m, -1), group_first, level_group(nlev, 0);
+    std::vector<double> ecoef;
+    const size_t room = 3 * t.idx.size() + (size_t)m + 64;
+    esrc.reserve(room); ecoef.reserve(room);
+    if (maskable) { ev0.reserve(room); evn.reserve(room); pool.reserve(room); }
+    std::vector<int32_t> seen(2 * (size_t)m + 2, -1), where(2 * (size_t)m + 2, 0);     // combining the duplicates of a row
+    int32_t seen_tick = 0;
+    auto lanes_of = [](int32_t n) { int32_t lg = 0; while ((1 << lg) < n + 1 && lg < 6) ++lg; return 1 << lg; };
+    auto packed = [&](int32_t k) { return keep_trivial || t.ptr[k + 1] != t.ptr[k] || t.diag[k] != 1.0; };
+    auto push = [&](int32_t src, double coef, int32_t v0, int32_t vn) {
+        esrc.push_back(src); ecoef.push_back(coef);
+        if (maskable) { ev0.push_back(v0); evn.push_back(vn); }
+    };
+    auto truncate = [&](size_t entries, size_t pooled) {
+        esrc.resize(entries); ecoef.resize(entries);
+        if (maskable) { ev0.resize(entries); evn.resize(entries); pool.resize(pooled); }
+    };
+    int32_t g = -1, lanes = 0;
+    for (int32_t l = 0; l < nlev; ++l) {
+        const int32_t r0 = t.level_ptr[l], r1 = t.level_ptr[l + 1];
+        const size_t mark_e = esrc.size(), mark_p = pool.size();
+        bool ok = g >= 0 && lane_cap > 0;
+        int32_t add = 0;
+        if (ok) {                                                    // the rows as they are already overflow the pass: do not try
+            int32_t least = 0;
+            for (int32_t i = r0; i < r1 && lanes + least <= lane_cap; ++i) {
+                const int32_t k = t.level_rows[i];
+                if (packed(k)) least += lanes_of(t.ptr[k + 1] - t.ptr[k]);
+            }
+            ok = lanes + least <= lane_cap;
+        }
+        for (int32_t i = r0; ok && i < r1; ++i) {                    // try the level as part of the open group
+            const int32_t k = t.level_rows[i];
+            const int32_t b = (int32_t)esrc.size();
+            ++seen_tick;
+            auto term = [&](int32_t src, double coef, int32_t v0, int32_t vn) {
+                if (!maskable) {                                     // one entry per index, summed in the order met
+                    if (seen[src] == seen_tick) { ecoef[where[src]] += coef; return; }
+                    seen[src] = seen_tick; where[src] = (int32_t)esrc.size();
+                }
+                push(src, coef, v0, vn);
+            };
+            for (int32_t e = t.ptr[k]; e < t.ptr[k + 1] && (int32_t)esrc.size() - b <= 64; ++e) {
+                const int32_t j = t.idx[e];
+                const double v = t.val[e];
+                if (grp[j] != g) { term(j, v, 0, 0); continue; }
+                const double f = v / t.diag[j];
+                int32_t v0 = (int32_t)pool.size();
+                if (maskable) pool.push_back(j);
+                term(rhs_base + j, f, v0, 1);
+                for (int32_t u = ebeg[j]; u < ebeg[j] + elen[j]; ++u) {
+                    v0 = (int32_t)pool.size();
+                    if (maskable) { for (int32_t a = 0; a < evn[u]; ++a) { const int32_t w = pool[ev0[u] + a]; pool.push_back(w); } pool.push_back(j); }
+                    term(esrc[u], -f * ecoef[u], v0, maskable ? evn[u] + 1 : 0);
+                }
+            }
+            const int32_t n = (int32_t)esrc.size() - b;
+            if (n > 63) { ok = false; break; }
+            ebeg[k] = b; elen[k] = n;                                 // (overwritten below when the level is rejected)
+            if (packed(k)) add += lanes_of(n);
+            if (lanes + add > lane_cap) { ok = false; break; }
+        }
+        if (ok) {
+            for (int32_t i = r0; i < r1; ++i) { const int32_t k = t.level_rows[i]; if (packed(k)) grp[k] = g; }
+            lanes += add;
+        } else {                                                    // the level opens a new group with its rows as they are
+            truncate(mark_e, mark_p);
+            ++g; lanes = 0;
+            group_first.push_back(l);
+            for (int32_t i = r0; i < r1; ++i) {
+                const int32_t k = t.level_rows[i];
+                ebeg[k] = (int32_t)esrc.size(); elen[k] = t.ptr[k + 1] - t.ptr[k];
+                for (int32_t e = t.ptr[k]; e < t.ptr[k + 1]; ++e) push(t.idx[e], t.val[e], 0, 0);
+                if (packed(k)) { grp[k] = g; lanes += lanes_of(elen[k]); }
+            }
+        }
+        level_group[l] = g;
+    }
+    const int32_t ngroups = g + 1;
+    TriangularSchedule& s = out->s;
+    s.diag = t.diag;
+    s.level_rows = t.level_rows;                                    // rows stay in level order: groups are runs of levels
+    s.level_ptr.assign(ngroups + 1, m);
+    for (int32_t q = 0; q < ngroups; ++q) s.level_ptr[q] = t.level_ptr[group_first[q]];
+    if (ngroups == 0) s.level_ptr.assign(1, 0);
+    s.ptr.assign(m + 1, 0);
+    for (int32_t k = 0; k < m; ++k) s.ptr[k + 1] = s.ptr[k] + elen[k];
+    s.idx.resize(s.ptr[m]); s.val.resize(s.ptr[m]);
+    for (int32_t k = 0; k < m; ++k)
+        for (int32_t u = 0; u < elen[k]; ++u) { s.idx[s.ptr[k] + u] = esrc[ebeg[k] + u]; s.val[s.ptr[k] + u] = ecoef[ebeg[k] + u]; }
+    if (maskable) {
+        out->via_ptr.assign(m + 1, 0);
+        for (int32_t k = 0; k < m; ++k)
+            for (int32_t u = ebeg[k]; u < ebeg[k] + elen[k]; ++u)
+                for (int32_t a = 0; a < evn[u]; ++a) ++out->via_ptr[pool[ev0[u] + a] + 1];
+        for (int32_t k = 0; k < m; ++k) out->via_ptr[k + 1] += out->via_ptr[k];
+        out->via_ent.resize(out->via_ptr[m]);
+        std::vector<int32_t> fill(out->via_ptr.begin(), out->via_ptr.end() - 1);
+        for (int32_t k = 0; k < m; ++k)
+            for (int32_t u = 0; u < elen[k]; ++u)
+                for (int32_t a = 0; a < evn[ebeg[k] + u]; ++a) out->via_ent[fill[pool[ev0[ebeg[k] + u] + a]]++] = s.ptr[k] + u;
+    }
+    // where a sweep may start when everything up to and including pivot p's level is zero
+    out->start_after.assign(m, -1);
+    for (int32_t l = 0; l < nlev; ++l) {
+        const int32_t q = level_group[l];
+        const bool last_of_group = l + 1 == nlev || level_group[l + 1] != q;
+        for (int32_t i = t.level_ptr[l]; i < t.level_ptr[l + 1]; ++i) out->start_after[t.level_rows[i]] = last_of_group ? q : q - 1;
+    }
+}
+
+void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out) {
+    const TriangularSchedule& t = f.s;
     const int32_t m = (int32_t)t.diag.size();
     const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
     *out = EllPacked{};
     out->lvl_pass.assign(nlev + 1, 0);
-    out->rdiag.assign(m, 1.0);
+    out->rdiag.assign((size_t)m + 1, 1.0);
     out->rovf.assign(2 * (size_t)m, 0);
+    std::vector<int32_t> lane_of(t.idx.size(), -1);      // entry -> its slot (entries in overflow lists: -1)
     constexpr int32_t kLanes = 256;                      // threads that walk the passes (relp_lu_device.h: ell_solve)
     struct Row { int32_t lg, k; };
     for (int32_t l = 0; l < nlev; ++l) {
@@ -288,11 +503,12 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
             while (i < rows.size() && pos + (1 << rows[i].lg) <= kLanes) {
                 const int32_t k = rows[i].k, lg = rows[i].lg, w = 1 << lg, n = t.ptr[k + 1] - t.ptr[k];
                 out->rdiag[k] = 1.0 / t.diag[k];
-                out->sidx.push_back((uint16_t)(k | (lg << 12)));             // the row's own unknown: -(-1) x[k]
+                out->sidx.push_back((uint16_t)(k | (lg << kEllLgShift)));    // the row's own unknown: -(-1) x[k]
                 out->sval.push_back(-1.0);
                 for (int32_t j = 1; j < w; ++j) {
                     const bool has = j - 1 < n;
-                    out->sidx.push_back((uint16_t)((has ? t.idx[t.ptr[k] + j - 1] : 0) | (lg << 12)));
+                    if (has) lane_of[t.ptr[k] + j - 1] = (int32_t)out->sidx.size();
+                    out->sidx.push_back((uint16_t)((has ? t.idx[t.ptr[k] + j - 1] : 0) | (lg << kEllLgShift)));
                     out->sval.push_back(has ? t.val[t.ptr[k] + j - 1] : 0.0);
                 }
                 out->rovf[2 * (size_t)k] = (int32_t)out->oidx.size();
@@ -310,6 +526,11 @@ void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out) {
     }
     out->lvl_pass[nlev] = (int32_t)out->passes.size();
     if (out->oidx.empty()) out->rovf.clear();            // no row has more than 63 entries: the ranges are never read
+    if (!f.via_ptr.empty()) {                            // (substituted entries never overflow: fuse_levels caps rows at 63)
+        out->via_ptr = f.via_ptr;
+        out->via_pos.resize(f.via_ent.size());
+        for (size_t a = 0; a < f.via_ent.size(); ++a) out->via_pos[a] = lane_of[f.via_ent[a]];
+    }
 }
 
 bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& lcols_in,
@@ -335,10 +556,17 @@ bool lu_from_triangles(int32_t m, const std::vector<std::vector<std::pair<int32_
     out->m = m;
     out->rowperm.resize(m); out->colperm.resize(m);
     for (int32_t k = 0; k < m; ++k) { out->rowperm[k] = k; out->colperm[k] = k; }
-    build_schedule(m, lrows, ones, true, &out->Lf);
-    build_schedule(m, urows, udiag, false, &out->Uf);
-    build_schedule(m, ucols, udiag, true, &out->Ub);
-    build_schedule(m, lcols, ones, false, &out->Lb);
+    auto build = [&](const std::vector<std::vector<std::pair<int32_t, double>>>& r, const std::vector<double>& d, bool asc,
+                     TriangularSchedule* sch) {
+        std::vector<Triplet> t;
+        for (int32_t k = 0; k < m; ++k) for (auto& e : r[k]) t.push_back(Triplet{k, e.first, e.second});
+        rows_from_triplets(m, t, sch);
+        finish_schedule(m, d, asc, sch);
+    };
+    build(lrows, ones, true, &out->Lf);
+    build(urows, udiag, false, &out->Uf);
+    build(ucols, udiag, true, &out->Ub);
+    build(lcols, ones, false, &out->Lb);
     return true;
 }
 

@@ -44,23 +44,46 @@ struct LUFactors {
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err);
 
-// A triangular schedule packed for the persistent pivot kernel ("ELL by pass"): a level is executed in passes of up to
-// 256 lanes; inside a pass every row owns 2^lg consecutive lanes (widths sorted descending so that every row starts at a
+// Level fusion by local inversion.  A basis factor of an LP has dozens of levels of a handful of rows each, and on the device a
+// level costs a fixed ~800 clocks whatever it holds, so consecutive levels are merged into GROUPS that one
+// pass solves: a row r of the group that depends on a row j of the same group gets j's equation substituted,
+//     x_r = (b_r - sum_k v_rk x_k - v_rj x_j) / d_r,   x_j = (b_j - sum_k v_jk x_k) / d_j
+//  => x_r = (b_r - sum_k v_rk x_k - (v_rj / d_j) b_j + sum_k (v_rj v_jk / d_j) x_k) / d_r,
+// recursively over the levels of the group: every row then reads solved values x_k of EARLIER groups and raw right-hand
+// sides b_j of its own group only, so the rows of a group are independent of each other.  The solve keeps a copy of the
+// right-hand side behind x for this: an entry index >= rhs_base means b[index - rhs_base].  A group is closed when a row
+// would exceed 63 entries or the group one pass (lane_cap lanes).
+// `maskable` (U, U'): a Forrest-Tomlin update deletes row and column p of U by masking pivot p (1 / d_p := 0), which must
+// also cancel every substituted term that ran through p.  Such schedules keep one entry per substitution PATH (duplicates
+// of an index are not combined) and list, per pivot, the entries whose path runs through it (`via`): the update zeroes them.
+struct FusedSchedule {
+    TriangularSchedule s;                // levels = groups; idx may be >= rhs_base
+    int32_t rhs_base = 0;                // m + 1 (x[m] is the solve's scratch word)
+    std::vector<int32_t> start_after;    // by pivot p: a right-hand side that is zero on p and on everything solved before p
+                                         // lets the sweep start at group start_after[p] + 1
+    std::vector<int32_t> via_ptr, via_ent;   // maskable: CSR by pivot of entry positions in s.idx / s.val
+};
+void fuse_levels(const TriangularSchedule& t, bool maskable, bool keep_trivial, int32_t lane_cap, FusedSchedule* out);
+
+// A triangular schedule packed for the persistent pivot kernel ("ELL by pass"): a level (group) is executed in passes of up
+// to 256 lanes; inside a pass every row owns 2^lg consecutive lanes (widths sorted descending so that every row starts at a
 // multiple of its width).  Lane 0 of a row is the row's own unknown as a slot (k, -1.0), lanes 1.. hold its entries
 // (index, value): the lane sum of -value * x[index] is x[k] - sum_e val_e x[idx_e], which the first lane multiplies by
 // 1 / diagonal (rdiag, indexed by pivot) and stores to x[k].  Thread t of the workgroup finds its slot at lane0 + t: no
 // ranges, no row descriptors.  Entries beyond the 63rd of a row live in an overflow list (rare).  Padding slots are (0, 0.0).
 struct EllPassHost { int32_t lane0, lanes, info, level; };     // info: max lg | (last pass of its level) << 8 | (has overflow rows) << 9
+constexpr int32_t kEllLgShift = 13;      // sidx = index | lg << 13: indices up to 2 m + 1 (right-hand-side copies) need m <= 4095
 struct EllPacked {
     std::vector<EllPassHost> passes;
     std::vector<int32_t> lvl_pass;       // level -> first pass (n_levels + 1)
-    std::vector<double> rdiag;           // m: 1 / diagonal by pivot (1.0 for rows that are left out)
+    std::vector<double> rdiag;           // m + 1: 1 / diagonal by pivot (1.0 for rows that are left out and for the scratch word)
     std::vector<double> sval, oval;
     std::vector<int32_t> rovf;           // 2 m: overflow entries [begin, end) by pivot; empty when no row overflows
-    std::vector<uint16_t> sidx, oidx;    // sidx: index | lg << 12
+    std::vector<uint16_t> sidx, oidx;    // sidx: index | lg << kEllLgShift
+    std::vector<int32_t> via_ptr, via_pos;   // maskable schedules: CSR by pivot of positions in sval to zero when the pivot is masked
 };
 // keep_trivial: also pack the rows without entries whose diagonal is 1 (needed when rows can be masked later: U, U')
-void ell_pack(const TriangularSchedule& t, bool keep_trivial, EllPacked* out);
+void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out);
 
 // Factors given literally (P = Q = I), the way the reference's tests build a `LUDecomposition { lower_triangular,
 // upper_triangular, .. }` (lower_upper/mod.rs:44-52): L column-major, unit diagonal implied, entries (row > column);

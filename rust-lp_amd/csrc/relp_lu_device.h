@@ -274,17 +274,19 @@ __device__ __forceinline__ double ell_reduce(double sum, int lg) {
     return sum;
 }
 
-// NT threads stage the image and keep the barrier count; the first NTW threads walk the passes from level `first_level`
-// on (levels below it are known to hold zeros only; 0 = everything, incl. the rows without entries).  x[dummy] is a
-// scratch word behind the vector: lanes that are not the first of their row store there, so the loop body has no
-// divergent branch (its loads are unconditional too: lanes beyond a pass re-read its last slot and contribute 0).
-// Per pass a lane issues: x[idx] (this pass), rdiag (next pass), its slot of the pass after next, one pass header.
-template <bool kStage, int NT, int NTW, class Lap = NoLap>
-__device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
-    const EllPass* passes = s.passes; const int32_t* lvl_pass = s.lvl_pass; const double* rdiag = s.rdiag;
-    const double* sval = s.sval; const double* oval = s.oval; const int32_t* rovf = s.rovf;
-    const uint16_t* sidx = s.sidx; const uint16_t* oidx = s.oidx;
+constexpr int kEllIdxMask = (1 << kEllLg) - 1;
+
+// Image -> LDS (one contiguous copy), right-hand side -> its copy behind x (fused schedules); ends with a barrier when
+// anything was written.  Returns the pointers of the image the solve should read.
+struct EllImage {
+    const EllPass* passes; const int32_t* lvl_pass; const double* rdiag; const double* sval; const double* oval;
+    const int32_t* rovf; const uint16_t* sidx; const uint16_t* oidx;
+};
+template <bool kStage, int NT>
+__device__ __forceinline__ EllImage ell_stage(const EllSchedule& s, char* base, double* x) {
+    EllImage im{s.passes, s.lvl_pass, s.rdiag, s.sval, s.oval, s.rovf, s.sidx, s.oidx};
     const int tid = threadIdx.x;
+    if (s.rhs_base) for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i];
     if (kStage) {
         const int n16 = s.bytes / 16;
         const int4* src = reinterpret_cast<const int4*>(s.passes);
@@ -296,20 +298,35 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; if (i < n16) dst[i] = buf[u]; }
         }
-        __syncthreads();
         char* q = base;
-        passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * (s.n_passes + 3));
-        lvl_pass = reinterpret_cast<const int32_t*>(q); q += lu_up16(4LL * (s.n_levels + 1));
-        rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.m);
-        sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
-        oval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_ovf);
-        rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(s.n_ovf > 0 ? 8LL * s.m : 0);
-        sidx = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
-        oidx = reinterpret_cast<const uint16_t*>(q);
+        im.passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * (s.n_passes + kEllPadHeaders));
+        im.lvl_pass = reinterpret_cast<const int32_t*>(q); q += lu_up16(4LL * (s.n_levels + 1));
+        im.rdiag = reinterpret_cast<const double*>(q); q += lu_up16(8LL * (s.m + 1));
+        im.sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
+        im.oval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_ovf);
+        im.rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(s.n_ovf > 0 ? 8LL * s.m : 0);
+        im.sidx = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
+        im.oidx = reinterpret_cast<const uint16_t*>(q);
     }
+    if (kStage || s.rhs_base) __syncthreads();
+    return im;
+}
+
+// NT threads stage the image and keep the barrier count; the first NTW threads walk the passes from level `first_level`
+// on (levels below it are known to hold zeros only; 0 = everything, incl. the rows without entries).  x[dummy] is a
+// scratch word behind the vector: lanes that are not the first of their row store there, so the loop body has no
+// divergent branch (its loads are unconditional too: lanes beyond a pass re-read its last slot and contribute 0).
+// Per pass a lane issues: x[idx] (this pass), rdiag (next pass), its slot of the pass after next, one pass header.
+template <bool kStage, int NT, int NTW, class Lap = NoLap>
+__device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
+    const EllImage im = ell_stage<kStage, NT>(s, base, x);
+    const EllPass* passes = im.passes; const double* rdiag = im.rdiag;
+    const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
+    const uint16_t* sidx = im.sidx; const uint16_t* oidx = im.oidx;
+    const int tid = threadIdx.x;
     lap();
     const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
-    const int p0 = __builtin_amdgcn_readfirstlane(lvl_pass[fl]), p1 = s.n_passes;
+    const int p0 = __builtin_amdgcn_readfirstlane(im.lvl_pass[fl]), p1 = s.n_passes;
     if (p0 >= p1) return;                              // (uniform)
     if (tid >= NTW) {                                  // wavefronts that only keep the barrier count
         for (int p = p0; p < p1; ++p)
@@ -319,23 +336,24 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
     // c = the pass being solved (slot and 1/diag loaded), n = the next one (slot loaded), f = the one after.  Pass headers
     // stay in vector registers (lane0, lanes, info): converting them to scalars every pass (v_readfirstlane after a wait
     // for the load) cost 210 of a pass's 770 clocks (scripts/microbench/ell_pass.hip); only `info` is made scalar, when it
-    // is used, long after it arrived.  The image ends with three empty headers, so p + 3 needs no bounds check.
+    // is used, long after it arrived.  The image ends with empty headers (kEllPadHeaders), so p + 3 needs no bounds check.
     const int4* hdr = reinterpret_cast<const int4*>(passes);
     int4 hc = hdr[p0], hn = hdr[p0 + 1], hf = hdr[p0 + 2];
     auto slot_of = [&](const int4& h) { const int top = h.y > 0 ? h.y - 1 : 0; return h.x + (tid < top ? tid : top); };
+    const int mm = s.m;
     int c_iv, n_iv;
     double c_val, c_diag, n_val;
     {
         const int sc = slot_of(hc), sn = slot_of(hn);
         c_iv = sidx[sc]; c_val = sval[sc];
         n_iv = sidx[sn]; n_val = sval[sn];
-        c_diag = rdiag[c_iv & 0xfff];
+        c_diag = rdiag[min(c_iv & kEllIdxMask, mm)];
     }
     for (int p = p0; p < p1; ++p) {
         const bool act = tid < hc.y;
-        const int c_idx = c_iv & 0xfff, lg = c_iv >> 12;
+        const int c_idx = c_iv & kEllIdxMask, lg = c_iv >> kEllLg;
         const double xv = x[c_idx];                    // the one load the critical path waits for
-        const double n_diag = rdiag[n_iv & 0xfff];
+        const double n_diag = rdiag[min(n_iv & kEllIdxMask, mm)];
         const int sf = slot_of(hf);
         const int f_iv = sidx[sf];
         const double f_val = sval[sf];
@@ -356,6 +374,69 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
         hc = hn; hn = hf; hf = hff;
         c_iv = n_iv; c_val = n_val; c_diag = n_diag;
         n_iv = f_iv; n_val = f_val;
+    }
+}
+
+// The same solve with the passes dealt alternately to two sets of four wavefronts (threads 0-255: passes p0, p0 + 2, ..;
+// threads 256-511: p0 + 1, p0 + 3, ..).  Wavefront w and w + 4 share a SIMD, so while one set is on the critical path of
+// its pass (gather x -> multiply -> lane sums -> store -> barrier) the other fetches the slot, the 1 / diagonal and the header
+// of its next pass: the bookkeeping that was half of a pass's clocks in ell_solve above overlaps with the other set's pass.
+// Every wavefront joins the barrier that ends a level, whoever owned its last pass; two passes of one level may run at the
+// same time (they are independent).
+template <bool kStage, int NT, class Lap = NoLap>
+__device__ __forceinline__ void ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
+    static_assert(NT == 512, "two sets of 256 lanes");
+    const EllImage im = ell_stage<kStage, NT>(s, base, x);
+    const double* rdiag = im.rdiag; const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
+    const uint16_t* sidx = im.sidx; const uint16_t* oidx = im.oidx;
+    lap();
+    const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
+    const int p0 = __builtin_amdgcn_readfirstlane(im.lvl_pass[fl]), p1 = s.n_passes;
+    if (p0 >= p1) return;                              // (uniform)
+    const int set = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), lt = threadIdx.x & 255;
+    const int4* hdr = reinterpret_cast<const int4*>(im.passes);
+    const int mm = s.m;
+    auto slot_of = [&](const int4& h) { const int top = h.y > 0 ? h.y - 1 : 0; return h.x + (lt < top ? lt : top); };
+    // my next pass (header, slot, 1 / diagonal in registers) and the header of the one after it; `z` = info word of the
+    // pass the loop is at, `zn` of the next one (both sets need every pass's level-end flag)
+    int4 hm = hdr[p0 + set], hm2 = hdr[p0 + set + 2];
+    int m_iv = sidx[slot_of(hm)];
+    double m_val = sval[slot_of(hm)];
+    double m_diag = rdiag[min(m_iv & kEllIdxMask, mm)];
+    int z = hdr[p0].z, zn = hdr[p0 + 1].z;
+    for (int p = p0; p < p1; ++p) {
+        const int znn = hdr[p + 2].z;
+        const int info = __builtin_amdgcn_readfirstlane(z);
+        const bool mine = ((p - p0) & 1) == set;       // (uniform per wavefront)
+        if (mine) {
+            const bool act = lt < hm.y;
+            const int c_idx = m_iv & kEllIdxMask, lg = m_iv >> kEllLg;
+            const double xv = x[c_idx];
+            double sum = act ? -m_val * xv : 0.0;
+            if ((info & 0x2ff) <= 3) sum = ell_reduce<3>(sum, lg);
+            else {
+                if ((info & 0x200) && act && lg == 6) {
+                    const int k = __builtin_amdgcn_readfirstlane(c_idx);
+                    for (int e = rovf[2 * k] + (lt & 63); e < rovf[2 * k + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
+                }
+                sum = ell_reduce<6>(sum, lg);
+            }
+            const bool lead = act && (lt & ((1 << lg) - 1)) == 0;
+#ifdef ELL_PRED_STORE
+            if (lead) x[c_idx] = sum * m_diag;
+#else
+            x[lead ? c_idx : dummy] = sum * m_diag;
+#endif
+        }
+        if (info & 0x100) __syncthreads();
+        if (mine) {                                    // off the critical path: the other set is solving pass p + 1
+            hm = hm2;
+            hm2 = hdr[p + 4];
+            const int sm = slot_of(hm);
+            m_iv = sidx[sm]; m_val = sval[sm];
+            m_diag = rdiag[min(m_iv & kEllIdxMask, mm)];
+        }
+        z = zn; zn = znn;
     }
 }
 
