@@ -283,8 +283,13 @@ relp_status_t Engine::lu_upload_factors() {
 relp_status_t Engine::ft_plan_and_alloc() {
     ft_ = false;
     if (m_ > kFtMaxRows) return RELP_OK;
-    // the largest tail that leaves room for an eta pool of at least 2 m entries (one eta never exceeds m)
+    // The dense tail of U (tcap x tcap in LDS) is as large as the refactorisation interval asks for, not larger: what it does
+    // not take stages the triangular factors, and an image that does not fit is solved from L2 at several times the cost.
+    // Default interval 48: with a refactorisation at ~0.7 ms and ~1,100 clocks per pending update and pivot, the optimum is
+    // flat between 40 and 64, and 48 x 49 doubles leave 14 KB more for the images than 64 x 65.
+    const int32_t want = cfg_.update_block < 0 ? 48 : std::max(1, std::min(cfg_.update_block, kFtMaxSlots));
     for (int32_t tcap : {64, 48, 32, 16}) {
+        if (tcap != 16 && tcap - 16 >= want) continue;              // a smaller tail serves the interval
         for (int64_t eta_cap : {(int64_t)2 * m_ + 64}) {     // (one eta never exceeds m entries; the rest of the LDS stages the schedules)
             eta_cap = std::max<int64_t>(eta_cap, 1024);
             if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap) + 4096 <= kFtLdsBudget) {
@@ -331,27 +336,51 @@ relp_status_t Engine::ft_plan_and_alloc() {
     return ft_build_price_ell();
 }
 
-// k-major copy of the first kPriceSlots entries of every structural column (rebuilt when rows are removed)
+// k-major PRICE copy of the structural columns (relp_kernels.h: PriceEll; rebuilt when rows are removed)
 relp_status_t Engine::ft_build_price_ell() {
     const int64_t ns = std::max(nr_normal_, 1);
     std::vector<uint16_t> idx((size_t)kPriceSlots * ns, 0);
     std::vector<double> val((size_t)kPriceSlots * ns, 0.0);
-    std::vector<int32_t> longs;
+    std::vector<int32_t> longs, very_long;
     for (int32_t p = 0; p < nr_normal_; ++p) {
         const int64_t n = hc_ptr_[p + 1] - hc_ptr_[p];
-        if (n > kPriceSlots) { longs.push_back(p); idx[p] = 0xFFFF; continue; }    // slot 0 = 0xFFFF: priced from the CSC arrays
-        for (int64_t k = 0; k < n; ++k) { idx[(size_t)k * ns + p] = (uint16_t)hc_idx_[hc_ptr_[p] + k]; val[(size_t)k * ns + p] = hc_val_[hc_ptr_[p] + k]; }
+        for (int64_t k = 0; k < std::min<int64_t>(n, kPriceSlots); ++k) {
+            idx[(size_t)k * ns + p] = (uint16_t)hc_idx_[hc_ptr_[p] + k]; val[(size_t)k * ns + p] = hc_val_[hc_ptr_[p] + k];
+        }
+        if (n > kPriceSlots) {
+            idx[p] |= kPriceLongFlag;
+            (n > kPriceLongSlots ? very_long : longs).push_back(p);
+        }
     }
-    const size_t b_val = val.size() * 8, b_idx = (idx.size() * 2 + 15) / 16 * 16, b_long = std::max<size_t>(longs.size(), 1) * 4;
+    const int64_t nl = std::max<int64_t>((int64_t)longs.size(), 1);
+    std::vector<uint16_t> lidx((size_t)kPriceLongSlots * nl, 0);
+    std::vector<double> lval((size_t)kPriceLongSlots * nl, 0.0);
+    for (size_t i = 0; i < longs.size(); ++i) {
+        const int32_t p = longs[i];
+        for (int64_t k = 0; k < hc_ptr_[p + 1] - hc_ptr_[p]; ++k) {
+            lidx[(size_t)k * nl + i] = (uint16_t)hc_idx_[hc_ptr_[p] + k]; lval[(size_t)k * nl + i] = hc_val_[hc_ptr_[p] + k];
+        }
+    }
+    std::vector<char> buf;
+    auto put = [&](const void* src, size_t bytes) {
+        const size_t o = buf.size();
+        buf.resize(o + (std::max<size_t>(bytes, 1) + 15) / 16 * 16);
+        if (bytes) std::memcpy(buf.data() + o, src, bytes);
+        return o;
+    };
+    const size_t o_val = put(val.data(), val.size() * 8), o_lval = put(lval.data(), lval.size() * 8);
+    const size_t o_idx = put(idx.data(), idx.size() * 2), o_lidx = put(lidx.data(), lidx.size() * 2);
+    const size_t o_long = put(longs.data(), longs.size() * 4), o_vl = put(very_long.data(), very_long.size() * 4);
     if (d_pe_buf_) { HIP_TRY(hipFree(d_pe_buf_)); d_pe_buf_ = nullptr; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pe_buf_), b_val + b_idx + b_long));
-    HIP_TRY(hipMemcpy(d_pe_buf_, val.data(), b_val, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_pe_buf_ + b_val, idx.data(), idx.size() * 2, hipMemcpyHostToDevice));
-    if (!longs.empty()) HIP_TRY(hipMemcpy(d_pe_buf_ + b_val + b_idx, longs.data(), longs.size() * 4, hipMemcpyHostToDevice));
-    pe_.val = reinterpret_cast<const double*>(d_pe_buf_);
-    pe_.idx = reinterpret_cast<const uint16_t*>(d_pe_buf_ + b_val);
-    pe_.long_cols = reinterpret_cast<const int32_t*>(d_pe_buf_ + b_val + b_idx);
-    pe_.n_long = (int32_t)longs.size(); pe_.pad_ = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pe_buf_), buf.size()));
+    HIP_TRY(hipMemcpy(d_pe_buf_, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    pe_.val = reinterpret_cast<const double*>(d_pe_buf_ + o_val);
+    pe_.lval = reinterpret_cast<const double*>(d_pe_buf_ + o_lval);
+    pe_.idx = reinterpret_cast<const uint16_t*>(d_pe_buf_ + o_idx);
+    pe_.lidx = reinterpret_cast<const uint16_t*>(d_pe_buf_ + o_lidx);
+    pe_.long_cols = reinterpret_cast<const int32_t*>(d_pe_buf_ + o_long);
+    pe_.very_long = reinterpret_cast<const int32_t*>(d_pe_buf_ + o_vl);
+    pe_.n_long = (int32_t)longs.size(); pe_.n_very_long = (int32_t)very_long.size();
     return RELP_OK;
 }
 

@@ -174,11 +174,22 @@ struct FtState {
     int32_t  pad_;
     long long* prof;         // 16 phase accumulators of the persistent kernel (shader clocks, thread 0) or nullptr
 };
-// The structural columns once more for PRICE inside the persistent kernel: the first kPriceSlots entries of column p at
-// pe_idx / pe_val[k * nr_normal + p] (k-major: the threads of a wavefront read consecutive columns), padding (0, 0.0);
-// columns with more entries have 0xFFFF in slot 0, are listed in `long_cols` and priced from the CSC arrays.
+// PRICE copy of the structural columns for the persistent kernel, k-major ("ELL"): slot k of column p at [k * n + p], so
+// that a thread pricing column p issues all its loads at once, coalesced, with no column offsets and no entry loop.
+// Tier A: the first kPriceSlots entries of EVERY column (bit 15 of slot 0's index marks a column that has more).  Tier B:
+// the long columns once more, complete (up to kPriceLongSlots entries, k-major over n_long), with their column number, so a
+// long column is priced by one thread in the column's own order from loads that do not depend on each other.  Columns
+// beyond kPriceLongSlots entries (`very_long`) are priced from the CSC arrays.  Padding slots are (0, 0.0).
 static constexpr int kPriceSlots = 8;
-struct PriceEll { const uint16_t* idx; const double* val; const int32_t* long_cols; int32_t n_long, pad_; };
+static constexpr int kPriceLongSlots = 24;
+static constexpr int kPriceLongFlag = 0x8000;
+struct PriceEll {
+    const uint16_t* idx; const double* val;            // kPriceSlots x nr_normal
+    const uint16_t* lidx; const double* lval;          // kPriceLongSlots x n_long
+    const int32_t* long_cols;                          // n_long
+    const int32_t* very_long;                          // n_very_long
+    int32_t n_long, n_very_long;
+};
 struct FtProblem {           // what the persistent kernel needs besides the factors
     DeviceCSC csc; ColumnTable ct; PriceEll pe;
     double *minus_pi, *b, *alpha, *rho, *d;

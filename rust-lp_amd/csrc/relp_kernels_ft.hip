@@ -466,7 +466,7 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
         c.TC[tn * c.ldt + tid] = y;
         if (y != 0.0) part = fma(y, c.sp[c.slot_pivot[tid]], part);
     }
-    part = wave_sum(part);
+    part = group_sum(part, 64);
     if (lane == 0) c.red_d[wave] = part;
     __syncthreads();
     double rdot = 0.0;
@@ -533,30 +533,32 @@ __device__ __forceinline__ void ft_scatter_column(const FtState& st, const FtPro
 }
 
 // workgroup minimum of (key, j), lexicographic; result in every thread
-__device__ __forceinline__ void block_min_key(FtCtx& c, double& key, int& kj) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ok = __shfl_down(key, off, 64);
-        const int oj = __shfl_down(kj, off, 64);
-        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
-    }
-    __syncthreads();
-    if (lane == 0) { c.red_d[wave] = key; c.red_i[wave] = kj; }
-    __syncthreads();
-    key = c.red_d[0]; kj = c.red_i[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) {
-        const double ok = c.red_d[w];
-        const int oj = c.red_i[w];
-        if (ok < key || (ok == key && oj < kj)) { key = ok; kj = oj; }
-    }
+// Minimum over the wavefront, valid in lane 0: lane swaps and DPP row shifts, register to register (the same tree as
+// group_sum; __shfl_down goes through the LDS crossbar, ~100 clocks a step, and a pivot has six block reductions).
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = fmin(v, lane_plus_32(v));
+    v = fmin(v, lane_plus_16(v));
+    v = fmin(v, dpp_row_shl<0x108>(v));
+    v = fmin(v, dpp_row_shl<0x104>(v));
+    v = fmin(v, dpp_row_shl<0x102>(v));
+    v = fmin(v, dpp_row_shl<0x101>(v));
+    return v;
+}
+template <int kCtrl>
+__device__ __forceinline__ int dpp_row_shl_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kCtrl, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_min_i32(int v) {
+    { const auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = min(v, (int)a[1]); }
+    { const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = min(v, (int)a[1]); }
+    v = min(v, dpp_row_shl_i32<0x108>(v));
+    v = min(v, dpp_row_shl_i32<0x104>(v));
+    v = min(v, dpp_row_shl_i32<0x102>(v));
+    v = min(v, dpp_row_shl_i32<0x101>(v));
+    return v;
 }
 
 __device__ __forceinline__ int block_min_int(FtCtx& c, int v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
+    v = wave_min_i32(v);
     __syncthreads();
     if (lane == 0) c.red_i[wave] = v;
     __syncthreads();
@@ -568,8 +570,7 @@ __device__ __forceinline__ int block_min_int(FtCtx& c, int v) {
 
 __device__ __forceinline__ double block_min_double(FtCtx& c, double v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    v = wave_min_f64(v);
     __syncthreads();
     if (lane == 0) c.red_d[wave] = v;
     __syncthreads();
@@ -577,6 +578,13 @@ __device__ __forceinline__ double block_min_double(FtCtx& c, double v) {
 #pragma unroll
     for (int w = 1; w < NW; ++w) v = fmin(v, c.red_d[w]);
     return v;
+}
+
+// lexicographic minimum of (key, j) over the workgroup: the smallest key, then the lowest j among the threads that hold it
+__device__ __forceinline__ void block_min_key(FtCtx& c, double& key, int& kj) {
+    const double kmin = block_min_double(c, key);
+    kj = block_min_int(c, key == kmin ? kj : 0x7fffffff);
+    key = kmin;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -608,68 +616,119 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (need_refactor || c.t >= st.max_updates || c.t >= c.tcap) { need_refactor = 1; break; }
         // ---- PRICE (pivot_rule.rs:38-126 over tableau/mod.rs:102-108): d_j = c_j + (-pi) . a_j, thread per column ----------
         fake.last_selected = last_selected;
-        double key = INFINITY;
+        double key = INFINITY, kv = 0.0;
         int kj = 0x7fffffff;
-        // (structural columns from the k-major PRICE copy: kPriceSlots independent coalesced loads per column, no column
-        // offsets, no entry loop; summation in the column's own order like k_price_csc)
+        // (structural columns from the k-major PRICE copy: every load of a column is issued before the first is used, incl.
+        // its basis flag, bound row and cost; summation in the column's own order like k_price_csc)
         const int na = ct.nr_artificial, nstr = ct.nr_normal;
-        auto consider = [&](int j, double v) {
+        auto consider = [&](int j, double v, int basic) {
             pb.d[j] = v;
-            if (!pb.in_basis[j] && v < -pb.tol.cost) {
+            if (!basic && v < -pb.tol.cost) {
                 const double k = select_key(rule, n, &fake, j, v);
-                if (k < key || (k == key && j < kj)) { key = k; kj = j; }
+                if (k < key || (k == key && j < kj)) { key = k; kj = j; kv = v; }
             }
         };
-        for (int j = tid; j < na; j += NT) consider(j, (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]]);
+        const double* costs = cost_mode == 2 ? ct.cost : nullptr;
+        for (int j = tid; j < na; j += NT) consider(j, (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]], pb.in_basis[j]);
         for (int p = tid; p < nstr; p += NT) {
             int ri[kPriceSlots];
-            double va[kPriceSlots];
+            double va[kPriceSlots], px[kPriceSlots];
 #pragma unroll
             for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pb.pe.idx[u * nstr + p]; va[u] = pb.pe.val[u * nstr + p]; }
             const int br = ct.bound_row[p];
-            const bool is_long = ri[0] == 0xFFFF;                  // more than kPriceSlots entries: priced below
-            if (is_long) ri[0] = 0;
+            const int basic = pb.in_basis[na + p];
+            const double cp = costs ? costs[p] : 0.0;
+            const bool is_long = (ri[0] & kPriceLongFlag) != 0;    // more than kPriceSlots entries: priced below
+            ri[0] &= kPriceLongFlag - 1;
+#pragma unroll
+            for (int u = 0; u < kPriceSlots; ++u) px[u] = c.pi[ri[u]];
+            const double pb_r = c.pi[br >= 0 ? br : 0];
             double v = 0.0;
 #pragma unroll
-            for (int u = 0; u < kPriceSlots; ++u) v = fma(c.pi[ri[u]], va[u], v);
-            if (br >= 0) v += c.pi[br];
-            if (cost_mode == 2) v += ct.cost[p];
-            if (!is_long) consider(na + p, v);
+            for (int u = 0; u < kPriceSlots; ++u) v = fma(px[u], va[u], v);
+            if (br >= 0) v += pb_r;
+            if (costs) v += cp;
+            if (!is_long) consider(na + p, v, basic);
         }
-        for (int i = tid; i < pb.pe.n_long; i += NT) {             // the few columns with more than kPriceSlots entries
+        for (int i = tid; i < pb.pe.n_long; i += NT) {             // columns of kPriceSlots + 1 .. kPriceLongSlots entries
+            const int nl = pb.pe.n_long;
             const int p = pb.pe.long_cols[i];
+            int ri[kPriceLongSlots];
+            double va[kPriceLongSlots], px[kPriceLongSlots];
+#pragma unroll
+            for (int u = 0; u < kPriceLongSlots; ++u) { ri[u] = pb.pe.lidx[u * nl + i]; va[u] = pb.pe.lval[u * nl + i]; }
+            const int br = ct.bound_row[p];
+            const int basic = pb.in_basis[na + p];
+            const double cp = costs ? costs[p] : 0.0;
+#pragma unroll
+            for (int u = 0; u < kPriceLongSlots; ++u) px[u] = c.pi[ri[u]];
+            const double pb_r = c.pi[br >= 0 ? br : 0];
+            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < kPriceLongSlots; ++u) v = fma(px[u], va[u], v);
+            if (br >= 0) v += pb_r;
+            if (costs) v += cp;
+            consider(na + p, v, basic);
+        }
+        for (int i = tid; i < pb.pe.n_very_long; i += NT) {        // the few columns beyond that
+            const int p = pb.pe.very_long[i];
             double v = 0.0;
             for (int64_t e = pb.csc.col_ptr[p]; e < pb.csc.col_ptr[p + 1]; ++e) v = fma(c.pi[pb.csc.row_idx[e]], pb.csc.values[e], v);
             const int br = ct.bound_row[p];
             if (br >= 0) v += c.pi[br];
             if (cost_mode == 2) v += ct.cost[p];
-            consider(na + p, v);
+            consider(na + p, v, pb.in_basis[na + p]);
         }
         for (int vv = tid; vv < ct.nr_virtual; vv += NT) {
             const int r0 = ct.vrow0[vv], r1 = ct.vrow1[vv];
             double v = r0 >= 0 ? (double)ct.vsign[vv] * c.pi[r0] : 0.0;
             if (r1 >= 0) v += c.pi[r1];
-            consider(na + nstr + vv, v);
+            consider(na + nstr + vv, v, pb.in_basis[na + nstr + vv]);
         }
+#ifdef PRICE_DIAG
+        c.clk.lap(FT_PRICE);
+#endif
+        int my_j = kj;                                              // this thread's own candidate and its reduced cost
+        double my_v = kv;
         block_min_key(c, key, kj);
+#ifdef PRICE_DIAG
+        c.clk.lap(FT_LOAD_STORE);
+#endif
         if (kj != 0x7fffffff && rule == 2 && pb.tol.tie > 0.0) {
-            // Dantzig ties: lowest index within the tie band of the minimum (every thread re-reads its own columns)
+            // Dantzig ties: lowest index within the tie band of the minimum (every thread re-reads a stripe of d, eight
+            // columns per round so that the loads of a round are in flight together)
             const double bound = key + pb.tol.tie * fmax(1.0, fabs(key));
-            int lowest = 0x7fffffff;
-            for (int j = tid; j < n; j += NT) {
-                const double v = pb.d[j];
-                if (!pb.in_basis[j] && v < -pb.tol.cost && v <= bound && j < lowest) lowest = j;
+            my_j = 0x7fffffff;
+            for (int j0 = tid; j0 < n; j0 += 8 * NT) {
+                double dv[8];
+                int ib[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = min(j0 + u * NT, n - 1); dv[u] = pb.d[j]; ib[u] = pb.in_basis[j]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * NT;
+                    if (j < n && !ib[u] && dv[u] < -pb.tol.cost && dv[u] <= bound && j < my_j) { my_j = j; my_v = dv[u]; }
+                }
             }
-            kj = block_min_int(c, lowest);
+            kj = block_min_int(c, my_j);
         }
         if (kj == 0x7fffffff) {
             outcome = DEV_NO_CANDIDATE;
             if (rule == 1) last_selected = -1;
             break;
         }
-        q = kj; key1 = key; d_q = pb.d[q];
+#ifdef PRICE_DIAG
+        c.clk.lap(FT_B);
+#endif
+        if (my_j == kj) c.red_d[NW] = my_v;                         // the owner publishes d_q
+        __syncthreads();
+        q = kj; key1 = key; d_q = c.red_d[NW];
         if (rule == 1) last_selected = q;
+#ifdef PRICE_DIAG
+        c.clk.lap(FT_SCATTER);
+#else
         c.clk.lap(FT_PRICE);
+#endif
 
         // ---- FTRAN (mod.rs:157-190) ------------------------------------------------------------------------------------
         ft_scatter_column(st, pb, c, q);
@@ -677,8 +736,19 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         ft_ftran(lu, st, c);
 
         // ---- RATIO TEST (tableau/mod.rs:221-247; two passes as relp_device_common.h ratio_body) ------------------------
-        double mn = INFINITY;
-        for (int i = tid; i < m; i += NT) {
+        // Rows tid and tid + NT of this thread stay in registers through the three passes and the update of b (one round of
+        // global loads for m <= 2 NT); rows beyond that take the generic loops.
+        const int i0 = tid, i1 = tid + NT;
+        const bool h0 = i0 < m, h1 = i1 < m;
+        const int p0 = st.inv_colperm[h0 ? i0 : 0], p1 = st.inv_colperm[h1 ? i1 : 0];
+        double b0 = pb.b[h0 ? i0 : 0], b1 = pb.b[h1 ? i1 : 0];
+        const int s0 = pb.basis[h0 ? i0 : 0], s1 = pb.basis[h1 ? i1 : 0];
+        const double a0 = c.x[p0], a1 = c.x[p1];
+        if (h0) pb.alpha[i0] = a0;
+        if (h1) pb.alpha[i1] = a1;
+        const double t0 = h0 ? row_ratio(a0, b0, pb.tol) : INFINITY, t1 = h1 ? row_ratio(a1, b1, pb.tol) : INFINITY;
+        double mn = fmin(t0, t1);
+        for (int i = tid + 2 * NT; i < m; i += NT) {
             const double a = c.x[st.inv_colperm[i]];
             pb.alpha[i] = a;
             mn = fmin(mn, row_ratio(a, pb.b[i], pb.tol));
@@ -687,24 +757,32 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (gmin == INFINITY) { outcome = DEV_NO_ROW; break; }
         const double bound = gmin + pb.tol.tie * fmax(1.0, fabs(gmin));
         int best_leave = 0x7fffffff;
-        for (int i = tid; i < m; i += NT) {
+        if (t0 <= bound) best_leave = s0;
+        if (t1 <= bound) best_leave = min(best_leave, s1);
+        for (int i = tid + 2 * NT; i < m; i += NT) {
             const double a = c.x[st.inv_colperm[i]];
             if (row_ratio(a, pb.b[i], pb.tol) <= bound) best_leave = min(best_leave, pb.basis[i]);
         }
         leaving = block_min_int(c, best_leave);
         // the row of the leaving column
         int rr = 0x7fffffff;
-        for (int i = tid; i < m; i += NT)
+        if (h0 && s0 == leaving && t0 <= bound) rr = i0;
+        if (h1 && s1 == leaving && t1 <= bound) rr = i1;             // (a column is basic in one row)
+        for (int i = tid + 2 * NT; i < m; i += NT)
             if (pb.basis[i] == leaving && row_ratio(c.x[st.inv_colperm[i]], pb.b[i], pb.tol) <= bound) rr = i;
         r = block_min_int(c, rr);
-        alpha_r = c.x[st.inv_colperm[r]];
-        b_r = pb.b[r];
+        // alpha_r and b_r from their owner
+        if (rr == r) { c.red_d[NW] = c.x[st.inv_colperm[r]]; c.red_d[NW + 1] = pb.b[r]; }
+        __syncthreads();
+        alpha_r = c.red_d[NW];
+        b_r = c.red_d[NW + 1];
         c.clk.lap(FT_RATIO);
 
         // ---- b (carry/mod.rs:283-313) while alpha is still in x -----------------------------------------------------
         const double br = b_r / alpha_r;
-        __syncthreads();
-        for (int i = tid; i < m; i += NT) {
+        if (h0) { if (i0 == r) pb.b[i0] = br; else if (a0 != 0.0) pb.b[i0] = fma(-a0, br, b0); }
+        if (h1) { if (i1 == r) pb.b[i1] = br; else if (a1 != 0.0) pb.b[i1] = fma(-a1, br, b1); }
+        for (int i = tid + 2 * NT; i < m; i += NT) {
             if (i == r) pb.b[i] = br;
             else {
                 const double a = c.x[st.inv_colperm[i]];

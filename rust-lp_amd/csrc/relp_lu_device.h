@@ -211,14 +211,15 @@ __device__ __forceinline__ void solve_schedule_pipelined(const DeviceSchedule& s
                       b_val = lu_up16(8 * (int64_t)s.nnz), b_lp = lu_up16(4 * ((int64_t)s.n_levels + 1)),
                       b_seg = lu_up16(12 * (int64_t)s.n_seg);
         const int n16 = (int)((b_rows + b_idx + b_val + b_lp + b_seg) / 16);
-        const int4* src = reinterpret_cast<const int4*>(s.rows);
-        int4* dst = reinterpret_cast<int4*>(base);
-        for (int i0 = threadIdx.x; i0 < n16; i0 += 8 * NT) {
-            int4 buf[8];
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i* src = reinterpret_cast<const v4i*>(s.rows);
+        v4i* dst = reinterpret_cast<v4i*>(base);
+        for (int i0 = threadIdx.x; i0 < n16; i0 += 8 * NT) {           // (clamped, unconditional: see ell_stage)
+            v4i buf[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) buf[u] = src[i0 + u * NT];
+            for (int u = 0; u < 8; ++u) buf[u] = src[min(i0 + u * NT, n16 - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (i0 + u * NT < n16) dst[i0 + u * NT] = buf[u];
+            for (int u = 0; u < 8; ++u) dst[min(i0 + u * NT, n16 - 1)] = buf[u];
         }
         __syncthreads();
         rows = reinterpret_cast<const LuRow*>(base);
@@ -289,14 +290,18 @@ __device__ __forceinline__ EllImage ell_stage(const EllSchedule& s, char* base, 
     if (s.rhs_base) for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i];
     if (kStage) {
         const int n16 = s.bytes / 16;
-        const int4* src = reinterpret_cast<const int4*>(s.passes);
-        int4* dst = reinterpret_cast<int4*>(base);
+        typedef int v4i __attribute__((ext_vector_type(4)));            // (an array of HIP's int4 struct ends up in scratch)
+        const v4i* src = reinterpret_cast<const v4i*>(s.passes);
+        v4i* dst = reinterpret_cast<v4i*>(base);
+        // (loads AND stores at clamped indices, no conditions: with `if (i < n16) dst[i] = ..` the compiler sank each load
+        // into its conditional block, i.e. eight dependent round trips to L2 per staging, 6,000 clocks whatever the size;
+        // the threads beyond the end rewrite the last 16 bytes with the same value)
         for (int i0 = tid; i0 < n16; i0 += 8 * NT) {
-            int4 buf[8];
+            v4i buf[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; buf[u] = src[i < n16 ? i : n16 - 1]; }
+            for (int u = 0; u < 8; ++u) { const int i = min(i0 + u * NT, n16 - 1); buf[u] = src[i]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; if (i < n16) dst[i] = buf[u]; }
+            for (int u = 0; u < 8; ++u) { const int i = min(i0 + u * NT, n16 - 1); dst[i] = buf[u]; }
         }
         char* q = base;
         im.passes = reinterpret_cast<const EllPass*>(q); q += lu_up16(16LL * (s.n_passes + kEllPadHeaders));

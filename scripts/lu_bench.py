@@ -31,7 +31,7 @@ def problems(argv):
 def main():
     argv = sys.argv[1:] or ["synth", "400", "800", "77"]
     for name, md in problems(argv):
-        for label, kw in (("lu", dict(engine=engine.ENGINE_LU)), ("lu32", dict(engine=engine.ENGINE_LU, update_block=32)),
+        for label, kw in (("lu", dict(engine=engine.ENGINE_LU)), ("lu64", dict(engine=engine.ENGINE_LU, update_block=64)), ("lu32", dict(engine=engine.ENGINE_LU, update_block=32)),
                           ("lu11", dict(engine=engine.ENGINE_LU, update_block=11)),
                           ("revised", dict(engine=engine.ENGINE_REVISED, update_block=0)),
                           ("tableau", dict(engine=engine.ENGINE_TABLEAU, update_block=32))):

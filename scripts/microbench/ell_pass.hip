@@ -31,9 +31,10 @@ __global__ __launch_bounds__(512) void k_bench(EllSchedule s, int m, int reps, l
     long long t0 = clock64();
     solve();
     long long t1 = clock64();
+    const long long first_stage = stage_ticks;
     for (int r = 1; r < reps; ++r) solve();
     long long t2 = clock64();
-    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = (t2 - t1) / (reps > 1 ? reps - 1 : 1); out[2] = stage_ticks / reps; }
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = (t2 - t1) / (reps > 1 ? reps - 1 : 1); out[2] = (stage_ticks - first_stage) / (reps > 1 ? reps - 1 : 1); }
     for (int k = threadIdx.x; k < m; k += 512) xg[k] = x[k];
 }
 
@@ -60,7 +61,7 @@ static void run(const char* name, const TriangularSchedule& t, bool maskable, in
     long long* out; double* xg; (void)hipMalloc(&out, 64); (void)hipMalloc(&xg, 8 * m);
     const size_t lds = (size_t)up16(8 * (2 * m + 1)) + s.bytes;
     if (lds > 156 * 1024) { printf("%s: image %d bytes does not fit\n", name, s.bytes); return; }
-    const int reps = 3;                                // (the solve is applied `reps` times to its own result)
+    const int reps = getenv("ELL_REPS") ? atoi(getenv("ELL_REPS")) : 3;    // (the solve is applied `reps` times to its own result)
     (void)hipFuncSetAttribute((const void*)k_bench<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     (void)hipFuncSetAttribute((const void*)k_bench<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (variant == 0) hipLaunchKernelGGL(k_bench<0>, dim3(1), dim3(512), lds, 0, s, m, reps, out, xg);

@@ -9,11 +9,20 @@
 constexpr int NT = 512, REPS = 6;
 
 template <int kVariant>
-__global__ __launch_bounds__(NT) void k_stage(const int4* src, int n16, long long* out, int* sink) {
+__global__ __launch_bounds__(NT) void k_stage(const int4* src, int n16, long long* out, int* sink, const int* other = nullptr, int other_n = 0) {
     extern __shared__ __align__(16) char lds[];
     int4* dst = reinterpret_cast<int4*>(lds);
     const int tid = threadIdx.x;
     for (int r = 0; r < REPS; ++r) {
+        if (other_n < 0) {                                // no memory traffic at all for -other_n clocks (LDS / ALU work only)
+            const long long until = clock64() - other_n;
+            while (clock64() < until) { dst[tid].x += 1; }
+        } else
+        if (other) {                                      // what the pivot kernel does between two stagings: other memory
+            int acc = 0;
+            for (int i = tid; i < other_n; i += NT) acc += other[i];
+            if (acc == 0x12345678) sink[tid] = acc;
+        }
         __syncthreads();
         const long long t0 = clock64();
         if (kVariant == 0) {                              // 8 x 16-byte loads in flight per thread, then 8 LDS stores
@@ -73,7 +82,7 @@ int main(int argc, char** argv) {
     long long* out; int* sink; (void)hipMalloc(&out, 8 * REPS); (void)hipMalloc(&sink, 4 * NT);
     auto go = [&](auto kern, const char* name) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        hipLaunchKernelGGL(kern, dim3(1), dim3(NT), (size_t)n16 * 16, 0, d, n16, out, sink);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(NT), (size_t)n16 * 16, 0, d, n16, out, sink, (const int*)nullptr, 0);
         (void)hipDeviceSynchronize();
         long long t[REPS]; (void)hipMemcpy(t, out, 8 * REPS, hipMemcpyDeviceToHost);
         printf("%-34s %6d bytes:", name, n16 * 16);
@@ -81,6 +90,17 @@ int main(int argc, char** argv) {
         printf("  clocks (%.1f bytes/clock in the last)\n", n16 * 16.0 / t[REPS - 1]);
     };
     go(k_stage<0>, "8 x 16 B in flight, strided");
+    {   // the same with 1 MB of other traffic between the repetitions (L1 and TLB no longer hold the image)
+        const int other_n = argc > 2 ? atoi(argv[2]) : 256 * 1024;
+        int* other; (void)hipMalloc(&other, 4 * (size_t)(other_n > 0 ? other_n : 1)); if (other_n > 0) (void)hipMemset(other, 0, 4 * (size_t)other_n);
+        (void)hipFuncSetAttribute((const void*)k_stage<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        hipLaunchKernelGGL(k_stage<0>, dim3(1), dim3(NT), (size_t)n16 * 16, 0, d, n16, out, sink, (const int*)other, other_n);
+        (void)hipDeviceSynchronize();
+        long long t[REPS]; (void)hipMemcpy(t, out, 8 * REPS, hipMemcpyDeviceToHost);
+        printf("%-34s %6d bytes:", other_n < 0 ? "  ... after an idle gap" : "  ... with other traffic between", n16 * 16);
+        for (int r = 0; r < REPS; ++r) printf(" %6lld", t[r]);
+        printf("  clocks\n");
+    }
     go(k_stage<1>, "2 x 16 B in flight, strided");
     go(k_stage<2>, "8 x 16 B, contiguous per thread");
     go(k_stage<3>, "loads only");
