@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -22,7 +23,12 @@ void Engine::free_all() {
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
     fr(d_part_k1_); fr(d_part_j_);
-    fr(dT0_); fr(dR0_); fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
+    fr(dT0_); fr(dR0_); fr(dT_alt_); fr(d_W_alt_); fr(dR0_alt_); fr(d_prev_p_);
+    if (ev_boundary_) { (void)hipEventDestroy(ev_boundary_); ev_boundary_ = nullptr; }
+    if (ev_flushed_) { (void)hipEventDestroy(ev_flushed_); ev_flushed_ = nullptr; }
+    if (flush_stream_) { (void)hipStreamDestroy(flush_stream_); flush_stream_ = nullptr; }
+    d_W_prev_ = nullptr; dR0_prev_ = nullptr; ovl_pending_ = false;
+    fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
     fr(d_msg_cand_); fr(d_msg_cands_); fr(d_msg_slice_); fr(d_msg_slices_); fr(d_msg_rho_); fr(d_msg_status_); fr(d_msg_statuses_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
     fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_); fr(d_ft_buf_); fr(d_pe_buf_);
@@ -62,6 +68,9 @@ TableauView Engine::tview() const {
     tv.col_off = phase_ == 1 ? 0 : tab_na_;
     tv.n = nr_columns();
     tv.c_lo = sc_lo_; tv.c_hi = sc_hi_;
+    tv.Wp = ovl_pending_ ? d_W_prev_ : nullptr;
+    tv.R0p = ovl_pending_ ? dR0_prev_ - (int64_t)sc_lo_ : nullptr;
+    tv.pp = ovl_pending_ ? d_prev_p_ : nullptr;
     return tv;
 }
 
@@ -290,6 +299,13 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         ld_r_ = round_up(n_owned, 2);
         HIP_TRY(dev_alloc(&dT0_, ld_t_ * n_owned));
         HIP_TRY(dev_alloc(&dR0_, ld_r_ * (block_ + 1)));        // + one scratch row (d_aq_big)
+        {
+            const char* e = std::getenv("RELP_FLUSH_OVERLAP");
+            const char* w = std::getenv("RELP_FLUSH_OVERLAP_PIVOTS");
+            ovl_enabled_ = e && std::atoi(e) != 0;
+            ovl_pivots_ = std::max(1, std::min(w ? std::atoi(w) : block_ / 2, block_ - 1));
+            if (block_ < 8) ovl_enabled_ = false;
+        }
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
         HIP_TRY(dev_alloc(&d_idcol_, m_));
     }
@@ -384,23 +400,24 @@ relp_status_t Engine::profile_enable(bool enable, int64_t max_launches, int32_t 
     return RELP_OK;
 }
 
-void Engine::prof_begin(int kid) {
+void Engine::prof_begin(int kid, hipStream_t on) {
     prof_open_ = false;
     if (!prof_on_ || (prof_kid_.size() + 1) * 2 > prof_ev_.size()) return;
     if (kid != RELP_K_FLUSH && (prof_tick_ % prof_stride_) != 0) return;   // sampled pivots only
-    (void)hipEventRecord(prof_ev_[2 * prof_kid_.size()], stream_);
+    (void)hipEventRecord(prof_ev_[2 * prof_kid_.size()], on ? on : stream_);
     prof_kid_.push_back(kid);
     prof_open_ = true;
 }
 
-void Engine::prof_end() {
+void Engine::prof_end(hipStream_t on) {
     if (!prof_open_) return;
-    (void)hipEventRecord(prof_ev_[2 * (prof_kid_.size() - 1) + 1], stream_);
+    (void)hipEventRecord(prof_ev_[2 * (prof_kid_.size() - 1) + 1], on ? on : stream_);
     prof_open_ = false;
 }
 
 relp_status_t Engine::profile_read(int kernel_id, int64_t* launches, double* total_ms) {
     HIP_TRY(hipStreamSynchronize(stream_));
+    if (flush_stream_) HIP_TRY(hipStreamSynchronize(flush_stream_));
     int64_t n = 0; double ms = 0.0;
     for (size_t k = 0; k < prof_kid_.size(); ++k) {
         if (prof_kid_[k] != kernel_id) continue;
@@ -447,6 +464,7 @@ void Engine::enqueue_iteration_tableau(int rule) {
     prof_begin(RELP_K_PRICE);
     launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
+    if (ovl_pending_ && --ovl_left_ <= 0) tab_settle();
     if (++since_flush_ >= block_) enqueue_flush();
 }
 
@@ -521,6 +539,56 @@ void Engine::enqueue_iteration(int rule) {
     if (++since_flush_ >= block_) enqueue_flush();
 }
 
+// Overlapped flush of the tableau engine (relp_engine.hpp): opt-in (RELP_FLUSH_OVERLAP=1, RELP_FLUSH_OVERLAP_PIVOTS = window,
+// default half a block).  Measured on dense10k: 30,400 it/s with the overlap against 31,960 without.  The
+// pivots that run beside the flush are chains of dependent loads, and with HBM busy at 60 % every link of the chain takes
+// twice as long, so the 620 us a flush takes are paid anyway, as slower pivots; reserving CUs for the pivot stream
+// (RELP_FLUSH_RESERVE_CUS) changes nothing: it is memory latency under load, not a lack of free CUs.
+bool Engine::ovl_prepare() {
+    if (!ovl_enabled_) return false;
+    if (flush_stream_) return true;
+    const int64_t n_owned = std::max(sc_hi_ - sc_lo_, 1);
+    auto give_up = [&]() { (void)hipGetLastError(); ovl_enabled_ = false; return false; };
+    if (hipMalloc(reinterpret_cast<void**>(&dT_alt_), sizeof(double) * (size_t)(ld_t_ * n_owned)) != hipSuccess) return give_up();
+    if (hipMalloc(reinterpret_cast<void**>(&d_W_alt_), sizeof(double) * (size_t)(ld_b_ * block_)) != hipSuccess) return give_up();
+    if (hipMalloc(reinterpret_cast<void**>(&dR0_alt_), sizeof(double) * (size_t)(ld_r_ * (block_ + 1))) != hipSuccess) return give_up();
+    if (hipMalloc(reinterpret_cast<void**>(&d_prev_p_), sizeof(int32_t)) != hipSuccess) return give_up();
+    if (hipMemset(d_prev_p_, 0, sizeof(int32_t)) != hipSuccess) return give_up();
+    // The flush fills every CU (two 512-thread workgroups, all vector registers), and the pivot kernels behind it are three
+    // dependent launches of a few microseconds that need a free CU at once: the flush stream runs at the lowest priority
+    // and (RELP_FLUSH_RESERVE_CUS = r > 0) leaves r CUs of every group of eight to the pivot stream.
+    {
+        const char* rs = std::getenv("RELP_FLUSH_RESERVE_CUS");
+        const int reserve = rs ? std::atoi(rs) : 0;
+        hipError_t e = hipErrorUnknown;
+        if (reserve > 0 && reserve < 8) {
+            int cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg_.device);
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0);
+            for (int i = 0; i < cus; ++i)
+                if (((i % 8) + (i / 8)) % 8 >= reserve) mask[i / 32] |= 1u << (i % 32);      // (even over XCDs whichever way bits map to CUs)
+            e = hipExtStreamCreateWithCUMask(&flush_stream_, (uint32_t)mask.size(), mask.data());
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            e = hipStreamCreateWithPriority(&flush_stream_, hipStreamNonBlocking, least);
+        }
+        if (e != hipSuccess) { flush_stream_ = nullptr; return give_up(); }
+    }
+    if (hipEventCreateWithFlags(&ev_boundary_, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_flushed_, hipEventDisableTiming) != hipSuccess) return give_up();
+    return true;
+}
+
+void Engine::tab_settle() {
+    if (!ovl_pending_) return;
+    (void)hipStreamWaitEvent(stream_, ev_flushed_, 0);
+    std::swap(dT0_, dT_alt_);
+    ovl_pending_ = false;
+}
+
 // Fold the pending pivots into the explicit inverse: B0inv += W (S' B0inv).  Valid in any state
 // (also after the loop froze): (B0inv, W, S) is consistent after every completed pivot.
 void Engine::enqueue_flush() {
@@ -534,6 +602,25 @@ void Engine::enqueue_flush() {
         return;
     }
     if (tableau_) {
+        tab_settle();                                  // (a block shorter than the overlap window, or a flush outside the loop)
+        if (in_loop_ && flushes_since_reprice_ + 1 < kRepriceEveryFlushes && ovl_prepare()) {
+            // T_other = T0 + W R0 on the second stream; the next block starts against (T0, W, R0) of this one
+            const DeferredUpdate dut = deferred();
+            const TableauView tv = tview();
+            launch_tab_block_rollover(dut, d_rec_, d_prev_p_, stream_);
+            (void)hipEventRecord(ev_boundary_, stream_);
+            (void)hipStreamWaitEvent(flush_stream_, ev_boundary_, 0);
+            prof_begin(RELP_K_FLUSH, flush_stream_);
+            launch_tab_flush(tv, dut, d_rec_, flush_stream_, dT_alt_ - (int64_t)sc_lo_ * ld_t_, d_prev_p_);
+            prof_end(flush_stream_);
+            (void)hipEventRecord(ev_flushed_, flush_stream_);
+            d_W_prev_ = d_W_; dR0_prev_ = dR0_;
+            std::swap(d_W_, d_W_alt_); std::swap(dR0_, dR0_alt_);
+            ovl_pending_ = true; ovl_left_ = ovl_pivots_;
+            since_flush_ = 0;
+            ++flushes_since_reprice_;
+            return;
+        }
         // T0 += W R0 on the f64 matrix cores
         const DeferredUpdate dut = deferred();
         prof_begin(RELP_K_FLUSH);
@@ -565,6 +652,7 @@ void Engine::enqueue_flush() {
 }
 
 relp_status_t Engine::flush() {
+    tab_settle();
     if (cfg_.shard_count > 1 && block_ > 0 && !tableau_) {
         // the rows S' B0inv live on different ranks: with the collective hooks attached the library completes the
         // snapshot itself (every rank must call), otherwise the caller drives relp_shard_flush_begin / _end
@@ -770,6 +858,8 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
         tab_partials_valid_ = true;
     }
     int64_t next_poll = phase_ == 1 ? 1 : cfg_.poll_interval;
+    {
+    LoopScope loop(*this);
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
         enqueue_iteration(rule);
         if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
@@ -783,6 +873,7 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
             if ((st = download_rec())) return st;
             if (h_rec_->outcome != DEV_RUNNING) break;
         }
+    }
     }
     if ((st = download_rec())) return st;
     if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
@@ -813,6 +904,7 @@ relp_status_t Engine::solve_relaxation(int64_t max_iters, int32_t* outcome) {
 
 // phase_one.rs:146-166: objective == 0 -> feasible (remove artificials, switch) else infeasible
 relp_status_t Engine::finish_phase_one(int32_t* outcome) {
+    tab_settle();
     const double obj = -h_rec_->minus_objective;
     if (std::fabs(obj) > cfg_.tol_feas * std::max(1.0, initial_phase1_objective_)) { *outcome = RELP_INFEASIBLE; return RELP_OK; }
     std::vector<int32_t> rows_to_remove;
@@ -1091,6 +1183,7 @@ relp_status_t Engine::build_basis_columns(const std::vector<int32_t>& basis,
 // a fresh factorisation of the basis (one launch: workgroup c solves stored column c), b = B^-1 rhs, d re-priced
 // from the new T0, -obj from b.  T0 is otherwise only ever updated (every flush adds W R0 to it).
 relp_status_t Engine::retabulate() {
+    SettledScope settled(*this);
     since_reinvert_ = 0;
     retab_done_ = false;
     enqueue_flush();
@@ -1139,6 +1232,7 @@ relp_status_t Engine::retabulate() {
 }
 
 relp_status_t Engine::reinvert() {
+    SettledScope settled(*this);
     if (lu_ || cfg_.shard_count > 1) return fail(RELP_E_UNSUPPORTED, "re-inversion is for the unsharded revised and tableau engines");
     if (tableau_) return retabulate();
     since_reinvert_ = 0;

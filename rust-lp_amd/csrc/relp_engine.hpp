@@ -154,6 +154,28 @@ class Engine {
     int32_t flushes_since_reprice_ = 0;
     std::vector<int32_t> idcol_h_;
     std::vector<double> cost_store_h_;
+    // Overlapped flush (enqueue_flush, relp_kernels.h: TableauView): at the end of a block inside the pivot loop the product
+    // T0 + W R0 is written to the OTHER tableau buffer on `flush_stream_` while `stream_` runs the first `ovl_pivots_` pivots
+    // of the next block against the old buffer plus the previous block's (W, R0); then `stream_` waits for the flush and
+    // switches buffers.  The schedule is fixed (a pivot count, not a completion flag), so results do not depend on timing.
+    bool ovl_enabled_ = false, ovl_pending_ = false, in_loop_ = false;
+    int32_t ovl_pivots_ = 0, ovl_left_ = 0;
+    double *dT_alt_ = nullptr, *d_W_alt_ = nullptr, *dR0_alt_ = nullptr, *d_W_prev_ = nullptr, *dR0_prev_ = nullptr;
+    int32_t* d_prev_p_ = nullptr;
+    hipStream_t flush_stream_ = nullptr;
+    hipEvent_t ev_boundary_ = nullptr, ev_flushed_ = nullptr;
+    bool ovl_prepare();                  // buffers, stream, events (lazily); false = not available
+    void tab_settle();                   // wait for a flush in flight and switch to the flushed buffer
+    struct LoopScope {                   // marks the pivot loops in which flushes may overlap; settles on every way out
+        Engine& e;
+        explicit LoopScope(Engine& en) : e(en) { e.in_loop_ = true; }
+        ~LoopScope() { e.in_loop_ = false; e.tab_settle(); }
+    };
+    struct SettledScope {                // work that reads or rebuilds the tableau from inside a pivot loop (re-tabulation)
+        Engine& e; bool was;
+        explicit SettledScope(Engine& en) : e(en), was(en.in_loop_) { e.in_loop_ = false; e.tab_settle(); }
+        ~SettledScope() { e.in_loop_ = was; }
+    };
     TableauView tview() const;
     double* d_aq_big() { return dR0_ + (int64_t)block_ * ld_r_; }         // scratch row behind R0 (owned columns)
     SelectPartials tab_partials(int rule) const;
@@ -248,8 +270,8 @@ class Engine {
     relp_status_t fail(relp_status_t code, const std::string& msg) { err_ = msg; return code; }
     relp_status_t download_rec();
     relp_status_t upload_rec();
-    void prof_begin(int kid);
-    void prof_end();
+    void prof_begin(int kid, hipStream_t on = nullptr);
+    void prof_end(hipStream_t on = nullptr);
     void enqueue_price(int cost_mode, const double* vec, const PivotRecord* rec, int32_t p_lo, int32_t p_hi);
     void enqueue_iteration(int rule);
     relp_status_t finish_phase_one(int32_t* outcome);

@@ -30,6 +30,7 @@ relp_status_t Engine::shard_pivot() {
     launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
     tab_partials_valid_ = true;
+    if (ovl_pending_ && --ovl_left_ <= 0) tab_settle();
     if (++since_flush_ >= block_) enqueue_flush();
     ++prof_tick_;
     return RELP_OK;
@@ -318,6 +319,7 @@ relp_status_t Engine::shard_run(int64_t max_iters, int64_t* done, int32_t* outco
     int64_t chunk = phase_ == 1 ? 1 : cfg_.poll_interval;
     for (int64_t left = max_iters; left > 0 && oc == RELP_RUNNING;) {
         const int64_t n = std::min(left, chunk);
+        LoopScope loop(*this);                             // (ends before the poll: a phase boundary reads the settled tableau)
         for (int64_t k = 0; k < n; ++k) {
             if (!local) {
                 local = shard_iteration();
@@ -326,6 +328,8 @@ relp_status_t Engine::shard_run(int64_t max_iters, int64_t* done, int32_t* outco
             if (coll_broken_) return local;
         }
         left -= n;
+        tab_settle();
+        in_loop_ = false;
         if ((st = shard_agree_on_status(local))) return st;       // before the poll: a phase boundary inside it exchanges again
         if ((st = poll(&oc, &it))) return st;
         chunk = std::min<int64_t>(chunk * 2, cfg_.poll_interval);

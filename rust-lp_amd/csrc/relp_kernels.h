@@ -305,6 +305,12 @@ struct TableauView {
     int32_t  n;       // tableau columns of the current phase
     int32_t  c_lo, c_hi;  // storage columns owned by this rank (T0, R0 hold only these; pointers are
                           // pre-shifted so that kernels index by global storage column)
+    // Overlapped flush: while the previous block (W', R0', p' pivots rows) is being folded into the OTHER tableau buffer on a
+    // second stream, the pivots of the current block read T0 + W' R0' for the tableau they start from.  Null = no
+    // previous block pending.  R0p is pre-shifted like R0; W' has the pitch of the current W.
+    const double* Wp;
+    const double* R0p;
+    const int32_t* pp;    // device: p'
 };
 // T0 := original matrix in row space (artificial unit columns | A + bound rows | virtual unit columns)
 void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s);
@@ -367,7 +373,11 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
                            const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,
                            int64_t trace_cap, PivotRecord* rec, hipStream_t s);
 // flush: T0 += W R0 with v_mfma_f64_16x16x4_f64 tiles
-void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s);
+// T_dst = T0 + W R0 with p = *p_dev pivots rows (T_dst = nullptr: in place, p from the record)
+void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s,
+                      double* T_dst = nullptr, const int32_t* p_dev = nullptr);
+// end of a block whose flush is overlapped: *prev_p = pivot rows of the block, then the record / row map start a new block
+void launch_tab_block_rollover(const DeferredUpdate& du, PivotRecord* rec, int32_t* prev_p, hipStream_t s);
 // out[i, k] = T0[i, cols[k]] (row-major m x m): B^-1 from the identity columns
 void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s);
 // tableau row `row` of the CURRENT T into out[0..n_store) (remove_artificial_basis_variables)

@@ -164,10 +164,13 @@ __global__ __launch_bounds__(kThreads) void k_tab_column(TableauView tv, Deferre
 __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const DeferredUpdate& du,
                                                     const SelectPartials& sp, const PivotRecord& R, int block) {
     __shared__ double s_wr[kMaxEta];
+    __shared__ double s_wp[kMaxEta];                   // row r of the previous block's W (overlapped flush)
     const PivotRecord* rec = &R;
     const int p_old = R.n_eta_old, jt = R.eta_target, r = R.r, q = R.q, leaving = R.leaving;
+    const int pp = (tv.pp && jt >= p_old) ? *tv.pp : 0;
     // fetched without waiting for p_old (entries beyond it are never used)
     if ((int)threadIdx.x < du.kmax) s_wr[threadIdx.x] = du.wr[threadIdx.x];
+    if ((int)threadIdx.x < pp) s_wp[threadIdx.x] = tv.Wp[(int64_t)threadIdx.x * du.ld + r];
     const int c = tv.c_lo + block * kThreads + threadIdx.x;
     const double d_old = c < tv.c_hi ? tv.d[c] : 0.0;
     __syncthreads();
@@ -176,7 +179,13 @@ __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const
     if (c < tv.c_hi) {
         double base;
         if (jt < p_old) base = tv.R0[(int64_t)jt * tv.ld_r + c];
-        else { base = tv.T0[(int64_t)c * tv.ld_t + r]; tv.R0[(int64_t)jt * tv.ld_r + c] = base; }
+        else {
+            // row r is new in this block: its row of the tableau the block started from (T0, plus the previous block's
+            // update while that is still being folded in)
+            base = tv.T0[(int64_t)c * tv.ld_t + r];
+            for (int j = 0; j < pp; ++j) base = fma(s_wp[j], tv.R0p[(int64_t)j * tv.ld_r + c], base);
+            tv.R0[(int64_t)jt * tv.ld_r + c] = base;
+        }
         double row = base;
         for (int j = 0; j < p_old; ++j) row = fma(s_wr[j], tv.R0[(int64_t)j * tv.ld_r + c], row);
         const double theta = R.d_q / R.alpha_r;
@@ -372,12 +381,16 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
             if (sp.rule == 1) rec->last_selected = bj;
         }
     }
+    __shared__ double s_vp[kMaxEta];                   // column q of the previous block's R0 (overlapped flush)
+    const int pp = tv.pp ? *tv.pp : 0;
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
+    if ((int)threadIdx.x < pp) s_vp[threadIdx.x] = tv.R0p[(int64_t)threadIdx.x * tv.ld_r + cq];
     const double t0 = i < tv.m ? tv.T0[(int64_t)cq * tv.ld_t + i] : 0.0;     // in flight together with the R0 column
     __syncthreads();
     double ratio = INFINITY;
     if (i < tv.m) {
         double a = t0;
+        for (int j = 0; j < pp; ++j) a = fma(tv.Wp[(int64_t)j * du.ld + i], s_vp[j], a);
         for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
         alpha[i] = a;
         // the same expression as the ratio test's first pass (ratio_body), so min over the block minima is
@@ -516,10 +529,11 @@ __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, do
 // Wavefront tile 64 columns x 64 rows (4 x 4 MFMA tiles, 8 operand loads per 16 MFMAs), workgroup
 // 128 x 128.
 template <int MT, int NT>
-__global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, DeferredUpdate du, const PivotRecord* rec) {
+__global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, DeferredUpdate du, const int32_t* p_dev,
+                                                        double* T_dst) {
     constexpr int kFlushMT = MT, kFlushNT = NT;
-    const int p = rec->n_eta;
-    if (p == 0) return;
+    const int p = *p_dev;
+    if (p == 0 && T_dst == tv.T0) return;            // (out of place: an empty block is still a copy)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c_wave = tv.c_lo + blockIdx.x * (2 * 16 * MT) + (wave & 1) * (16 * MT);   // first T0 column of this wavefront
     const int i_wave = blockIdx.y * (2 * 16 * NT) + (wave >> 1) * (16 * NT);            // first T0 row
@@ -575,7 +589,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
             for (int g = 0; g < 4; ++g) {
                 const int c = c_wave + a * 16 + lk + 4 * g;
                 const int i = i_wave + b * 16 + lm;
-                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+                if (c < tv.c_hi && i < tv.m) T_dst[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
             }
 }
 
@@ -586,13 +600,14 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
 // each wavefront fetches its own operands from L2 / Infinity Cache: 48 KB per 32 KB of T0 traffic
 // (4.7 GB per flush at 10k x 20k against 3.2 GB of HBM traffic); with a 256 x 128 tile it is 12 KB.
 template <int WC, int WR, int KC>
-__global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, DeferredUpdate du, const PivotRecord* rec) {
+__global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, DeferredUpdate du, const int32_t* p_dev,
+                                                                double* T_dst) {
     constexpr int MT = 4, NT = 2;                     // wavefront tile: 64 columns x 32 rows
     constexpr int TC = WC * 16 * MT, TR = WR * 16 * NT, NTHR = WC * WR * 64;
     constexpr int RA = KC * TC / 2 / NTHR, RB = KC * TR / 2 / NTHR;
     static_assert(RA * NTHR * 2 == KC * TC && RB * NTHR * 2 == KC * TR, "staging must divide evenly");
-    const int p = rec->n_eta;
-    if (p == 0) return;
+    const int p = *p_dev;
+    if (p == 0 && T_dst == tv.T0) return;            // (out of place: an empty block is still a copy)
     __shared__ __align__(16) double As[2][KC][TC];
     __shared__ __align__(16) double Bs[2][KC][TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -677,8 +692,17 @@ __global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, 
             for (int g = 0; g < 4; ++g) {
                 const int c = c_wave + a * 16 + lk + 4 * g;
                 const int i = i_wave + b * 16 + lm;
-                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+                if (c < tv.c_hi && i < tv.m) T_dst[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
             }
+}
+
+// End of a block whose flush runs on another stream: remember its number of pivot rows for that flush and for the
+// pivots that overlap with it, and start the next block (k_flush_reset).
+__global__ void k_tab_block_rollover(DeferredUpdate du, PivotRecord* rec, int32_t* prev_p) {
+    const int p = rec->n_eta;
+    for (int j = threadIdx.x; j < p; j += blockDim.x) du.pos_of_row[du.S[j]] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) { *prev_p = p; rec->n_eta = 0; rec->n_eta_old = 0; rec->eta_target = 0; }
 }
 
 __global__ void k_tab_gather_columns(TableauView tv, const int32_t* __restrict__ cols, double* __restrict__ out) {
@@ -826,21 +850,28 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
                        basis_indices, in_basis, trace, trace_cap, rec);
 }
 
-void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
+void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s, double* T_dst,
+                      const int32_t* p_dev) {
     if (tv.c_hi <= tv.c_lo) return;
     const int ncols = tv.c_hi - tv.c_lo;
+    if (!T_dst) T_dst = tv.T0;                        // in place
+    if (!p_dev) p_dev = &rec->n_eta;
     if ((int64_t)ncols * tv.m >= (1 << 16)) {
         // LDS-staged operands: 8 wavefronts, 128 columns x 128 rows per workgroup, chunks of 16 pivots
         // (64 KB of LDS, <= 128 VGPRs: two workgroups per CU, so one streams its T0 tile while the
         // other one is in its MFMA loop)
         constexpr int WC = 2, WR = 4, KC = 16;
         dim3 grid(cdiv(tv.m, WR * 32), cdiv(ncols, WC * 64));
-        hipLaunchKernelGGL((k_tab_flush_lds<WC, WR, KC>), grid, dim3(WC * WR * 64), 0, s, tv, du, rec);
+        hipLaunchKernelGGL((k_tab_flush_lds<WC, WR, KC>), grid, dim3(WC * WR * 64), 0, s, tv, du, p_dev, T_dst);
         return;
     }
     constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
     dim3 grid(cdiv(ncols, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
-    hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, rec);
+    hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, p_dev, T_dst);
+}
+
+void launch_tab_block_rollover(const DeferredUpdate& du, PivotRecord* rec, int32_t* prev_p, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_block_rollover, dim3(1), dim3(128), 0, s, du, rec, prev_p);
 }
 
 void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s) {
