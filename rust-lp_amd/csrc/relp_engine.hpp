@@ -145,6 +145,7 @@ class Engine {
     double* dR0_ = nullptr; int64_t ld_r_ = 0;
     double* d_cost_store_ = nullptr;     // cost per stored column in the current phase
     int32_t* d_idcol_ = nullptr;         // stored column that was e_k originally, per row k
+    int32_t* d_ticket_ = nullptr;        // k_tab_select_column: tickets of the finished workgroups (fused ratio test)
     double* d_rmin_ = nullptr;           // minimum ratio per block of 256 rows (k_tab_select_column -> k_ratio_blocks)
     int32_t n_store_ = 0;                // stored columns = original artificials + provider columns
     int32_t tab_na_ = 0;                 // original number of artificial columns (their block is kept)

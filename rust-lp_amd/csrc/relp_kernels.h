@@ -346,9 +346,11 @@ void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, S
                               double* alpha, PivotRecord* rec, hipStream_t s);
 // single-GPU loop: also leaves the minimum ratio of every block of 256 rows in `rmin`, and the ratio test that
 // starts from those minima (re-reads only the row blocks inside the tie band)
+// `ticket` (a device int, 0 between launches): the last workgroup to finish also runs the ratio test (launch_ratio_blocks
+// is then not needed)
 void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                    double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
-                                   hipStream_t s);
+                                   hipStream_t s, const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr);
 void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
                          const DeferredUpdate& du, const double* rmin, PivotRecord* rec, hipStream_t s);
 // sharded engines: this rank's candidate message [key, j, d_j, alpha (m), minimum ratio per block of 256 rows

@@ -289,10 +289,15 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, Def
 // of the record; a rank without a candidate sends key = +inf and stays RUNNING (another rank may have one).
 // `rmin` (single-GPU loop): the minimum ratio b_i / alpha_i over this workgroup's 256 rows, for
 // k_ratio_blocks.
+// `ticket` (single-GPU loop, optional): the ratio test runs in the LAST workgroup of this launch to finish instead of in a
+// launch of its own (k_ratio_blocks): every workgroup releases its rows of alpha and its block minimum (agent-scope fence)
+// and draws a ticket; the one that draws the last ticket acquires and does what k_ratio_blocks does.  One kernel boundary
+// and the record's round trip less per pivot.
 __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, DeferredUpdate du, SelectPartials sp,
-                                                                int count, double* __restrict__ alpha, double* msg,
-                                                                const double* __restrict__ b, Tolerances tol,
-                                                                double* __restrict__ rmin, PivotRecord* rec) {
+                                                                int count, double* alpha, double* msg,
+                                                                const double* b, Tolerances tol,
+                                                                double* rmin, PivotRecord* rec,
+                                                                const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr) {
     const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both ...
     // ... and for the first PRICE partial and b of this thread's row, which do not depend on the record
     double k1 = INFINITY;
@@ -404,6 +409,16 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
     if (lane == 0) s_k1[wave] = ratio;
     __syncthreads();
     if (threadIdx.x == 0) rmin[blockIdx.x] = fmin(fmin(s_k1[0], s_k1[1]), fmin(s_k1[2], s_k1[3]));
+    if (!ticket) return;
+    __shared__ int s_last;
+    __threadfence();                                   // release alpha[rows of this workgroup], rmin[blockIdx.x]
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // acquire what the other workgroups released
+    if (threadIdx.x == 0) *ticket = 0;                 // (the next pivot's launch starts behind this kernel)
+    ratio_blocks_body<kThreads>(alpha, b, basis_indices, tv.m, tol, du, rmin, (int)gridDim.x, p, rec);
 }
 
 // Ratio test from the per-block minima of k_tab_select_column (ratio_blocks_body): one workgroup.
@@ -805,14 +820,15 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                               double* alpha, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       (double*)nullptr, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec);
+                       (double*)nullptr, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec, (const int32_t*)nullptr,
+                       (int32_t*)nullptr);
 }
 
 void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                    double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
-                                   hipStream_t s) {
+                                   hipStream_t s, const int32_t* basis_indices, int32_t* ticket) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       (double*)nullptr, b, tol, rmin, rec);
+                       (double*)nullptr, b, tol, rmin, rec, basis_indices, ticket);
 }
 
 void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
@@ -824,7 +840,7 @@ void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* ba
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                   double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
-                       msg, b, tol, msg + 3 + tv.m, rec);
+                       msg, b, tol, msg + 3 + tv.m, rec, (const int32_t*)nullptr, (int32_t*)nullptr);
 }
 
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
