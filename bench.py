@@ -370,7 +370,7 @@ def main():
     ap.add_argument("--no-c2", action="store_true", help="skip the configs[1] (dense 2,000 x 2,000) section")
     ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] (dense 10,000 x 50,000) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--event-stride", type=int, default=16,
+    ap.add_argument("--event-stride", type=int, default=64,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
     ap.add_argument("--shard-loop", default="native", choices=["native", "python"],
                     help="N > 1: pivot loop inside the library calling RCCL itself, or the Python loop over torch.distributed")

@@ -132,23 +132,31 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 // published slot is this lane's predecessor (the same pivot updated earlier / later), its value replaces `base`.
 // Branch-free: w is kept up to date incrementally (w -= coef * scale * v), the link is folded into the coefficient
 // (coef - 1 at s2 = link adds v to the base), coefficients are fetched eight steps ahead and are 0 wherever a step must not
-// act, so a step is two v_readlane, one select and one v_fma; steps beyond t (the last chunk) multiply by 0.
+// act, so a step is two v_readlane and one v_fma; steps beyond t (the last chunk) multiply by 0.  A lane's w no longer
+// changes once its own step has passed (its later coefficients are exact zeros), so the value it published is simply its
+// final w: no per-step capture.
 template <bool kAsc, bool kRow>
 __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int lane, double base, double sub, double scale,
                                            int link) {
     constexpr int CH = 8;
     const bool in = lane < t;
     const int row = in ? lane : 0;
-    double w = in ? (base - sub) * scale : 0.0, mine = 0.0;
+    double w = in ? (base - sub) * scale : 0.0;
     double cur[CH], nxt[CH];
     auto load = [&](int ch, double* buf) {
+        double cf[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
             const int sc = s2 < 0 ? 0 : (s2 >= t ? t - 1 : s2);                 // (clamped: the load itself is unconditional)
-            const double cf = kRow ? TC[row * ldt + sc] : TC[sc * ldt + row];
+            cf[j] = kRow ? TC[row * ldt + sc] : TC[sc * ldt + row];
+            asm volatile("" : "+v"(cf[j]));                                     // (keeps the compiler from sinking the load into a branch)
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
             const bool after = in && o < t && (kAsc ? lane > s2 : lane < s2);
-            buf[j] = after ? (cf - (link == s2 ? 1.0 : 0.0)) * scale : 0.0;
+            buf[j] = after ? (cf[j] - (link == s2 ? 1.0 : 0.0)) * scale : 0.0;
         }
     };
     const int nch = (t + CH - 1) / CH;
@@ -159,13 +167,12 @@ __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int
         for (int j = 0; j < CH; ++j) {
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
             const double v = lane_bcast(w, s2 < 0 ? 0 : s2);
-            mine = lane == s2 ? v : mine;
             w = fma(-cur[j], v, w);
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
     }
-    return mine;
+    return w;
 }
 
 // sum over the 8 lanes of a group (valid in the group's lane 0), register to register

@@ -23,6 +23,16 @@ def test_cpp_host_header_compiles_and_links():
     assert "hip/" not in src
 
 
+def test_host_lu_factorisation_fusion_and_packing():
+    """tests/cpp/test_lu_host.cpp (no GPU): P B Q = L U on the reference's factorisation cases (decomposition/mod.rs:301-491)
+    and seeded LP-like bases, FTRAN / BTRAN against dense elimination, and the fused, ELL-packed schedules executed pass by pass
+    like the device does, with pivots masked the way a Forrest-Tomlin update masks them."""
+    subprocess.check_call(["make", "-C", CPP, "test_lu_host"], stdout=subprocess.DEVNULL)
+    res = subprocess.run([os.path.join(CPP, "test_lu_host")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert " 0 failed" in res.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_host_tests_pass_on_the_gpu():
     if not os.access(BINARY, os.X_OK):
