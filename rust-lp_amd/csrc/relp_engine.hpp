@@ -188,6 +188,8 @@ class Engine {
     int64_t* d_cptr_ = nullptr; int32_t* d_cidx_ = nullptr; double* d_cval_ = nullptr;         // device CSC of A
     LUFactors hlu_;
     char* d_lu_buf_ = nullptr; int64_t lu_cap_ = 0;       // packed factors (permutations, rows, entries, levels)
+    char* h_lu_buf_ = nullptr; size_t h_lu_cap_ = 0;      // the same, assembled in pinned host memory
+    int32_t* h_basis_ = nullptr; int32_t m_alloc_rows_ = 0;   // pinned: the basis a refactorisation downloads
     double* d_lu_scratch_ = nullptr;
     DeviceLU dlu_{};
     relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop

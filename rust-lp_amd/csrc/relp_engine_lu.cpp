@@ -65,8 +65,9 @@ relp_status_t Engine::lu_load_matrix(const relp_matrix_data_t& md) {
 // columns, P B Q = L U on the host, schedules to the device, W := empty.  Synchronises the stream.
 relp_status_t Engine::lu_refactor() {
     const auto tb = std::chrono::steady_clock::now();
-    std::vector<int32_t> basis(m_);
-    HIP_TRY(hipMemcpyAsync(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
+    if (!h_basis_) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_basis_), sizeof(int32_t) * (size_t)std::max(m_alloc_rows_, m_), hipHostMallocDefault));
+    int32_t* const basis = h_basis_;
+    HIP_TRY(hipMemcpyAsync(basis, d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     std::vector<std::vector<std::pair<int32_t, double>>> cols(m_);
     for (int32_t i = 0; i < m_; ++i) {
@@ -125,11 +126,21 @@ relp_status_t Engine::lu_upload_factors() {
     // pack everything into one buffer (16-byte aligned pieces): rowperm, colperm, then per schedule the
     // rows in solve order, the entry indices / values and the level offsets
     const TriangularSchedule* sch[4] = {&hlu_.Lf, &hlu_.Uf, &hlu_.Ub, &hlu_.Lb};
-    std::vector<char> buf;
+    // (assembled in pinned memory that lives as long as the engine: the copy to the device is one DMA, not a staged one)
+    size_t buf_size = 0;
+    bool buf_failed = false;
     auto put = [&](const void* src, size_t bytes) {
-        const size_t o = buf.size();
-        buf.resize(o + (bytes + 15) / 16 * 16);
-        if (bytes) std::memcpy(buf.data() + o, src, bytes);
+        const size_t o = buf_size, need = o + (bytes + 15) / 16 * 16;
+        if (need > h_lu_cap_) {
+            const size_t cap = std::max<size_t>(need * 2, size_t(1) << 20);
+            char* grown = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&grown), cap, hipHostMallocDefault) != hipSuccess) { buf_failed = true; return o; }
+            if (buf_size) std::memcpy(grown, h_lu_buf_, buf_size);
+            if (h_lu_buf_) (void)hipHostFree(h_lu_buf_);
+            h_lu_buf_ = grown; h_lu_cap_ = cap;
+        }
+        if (bytes) std::memcpy(h_lu_buf_ + o, src, bytes);
+        buf_size = need;
         return o;
     };
     const size_t o_rp = put(hlu_.rowperm.data(), sizeof(int32_t) * m_), o_cp = put(hlu_.colperm.data(), sizeof(int32_t) * m_);
@@ -179,11 +190,31 @@ relp_status_t Engine::lu_upload_factors() {
         }
     }
     const size_t o_lub = put(lev_ub.data(), sizeof(int32_t) * m_);
+    size_t o_pinfo = 0;
+    if (ft_) {
+        std::vector<FtPivotInfo> pinfo(m_);
+        for (int32_t p = 0; p < m_; ++p) {
+            FtPivotInfo& q = pinfo[p];
+            q.u_e0 = hlu_.Uf.ptr[p]; q.u_e1 = hlu_.Uf.ptr[p + 1];
+            const bool v1 = !ell[1].via_ptr.empty(), v2 = !ell[2].via_ptr.empty();
+            q.via_u0 = v1 ? ell[1].via_ptr[p] : 0; q.via_u1 = v1 ? ell[1].via_ptr[p + 1] : 0;
+            q.via_t0 = v2 ? ell[2].via_ptr[p] : 0; q.via_t1 = v2 ? ell[2].via_ptr[p + 1] : 0;
+            q.lev_ub = lev_ub[p]; q.pad_ = 0;
+        }
+        o_pinfo = put(pinfo.data(), sizeof(FtPivotInfo) * pinfo.size());
+    }
     size_t o_rows[4], o_idx[4], o_val[4], o_lp[4], o_seg[4];
-    int32_t n_seg[4];
+    int32_t n_seg[4] = {0, 0, 0, 0};
     std::vector<LuRow> rows(m_);
     for (int k = 0; k < 4; ++k) {
         const TriangularSchedule& t = *sch[k];
+        o_rows[k] = o_idx[k] = o_val[k] = o_lp[k] = o_seg[k] = 0;
+        if (ft_) {
+            // the Forrest-Tomlin kernels solve from the ELL images; of the row-wise schedules they read one thing, the
+            // entries of a row of U (the u_bar of an update)
+            if (k == 1) { o_idx[k] = put(t.idx.data(), sizeof(int32_t) * t.idx.size()); o_val[k] = put(t.val.data(), sizeof(double) * t.val.size()); }
+            continue;
+        }
         for (int32_t i = 0; i < m_; ++i) {
             const int32_t r = t.level_rows[i];
             rows[i] = LuRow{r, t.ptr[r], t.ptr[r + 1], 0, 1.0 / t.diag[r]};
@@ -209,12 +240,13 @@ relp_status_t Engine::lu_upload_factors() {
         n_seg[k] = (int32_t)segs.size() / 3;
         o_seg[k] = put(segs.data(), sizeof(int32_t) * segs.size());
     }
-    if ((int64_t)buf.size() > lu_cap_) {
+    if (buf_failed) return fail(RELP_E_ALLOC, "pinned staging buffer for the factors");
+    if ((int64_t)buf_size > lu_cap_) {
         if (d_lu_buf_) HIP_TRY(hipFree(d_lu_buf_));
-        lu_cap_ = (int64_t)buf.size() * 3 / 2 + 256;
+        lu_cap_ = (int64_t)buf_size * 3 / 2 + 256;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_buf_), (size_t)lu_cap_));
     }
-    HIP_TRY(hipMemcpyAsync(d_lu_buf_, buf.data(), buf.size(), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(d_lu_buf_, h_lu_buf_, buf_size, hipMemcpyHostToDevice, stream_));
     dlu_.m = m_; dlu_.pad_ = 0;
     dlu_.rowperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rp);
     dlu_.colperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_cp);
@@ -229,7 +261,7 @@ relp_status_t Engine::lu_upload_factors() {
         ds[k]->seg = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_seg[k]);
         ds[k]->n_seg = n_seg[k]; ds[k]->pad_ = 0;
     }
-    HIP_TRY(hipStreamSynchronize(stream_));             // buf is stack-owned
+    HIP_TRY(hipStreamSynchronize(stream_));             // (the pinned buffer is rewritten by the next refactorisation)
     if (ft_) {
         fts_.m = m_;
         fts_.inv_rowperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_irp);
@@ -237,6 +269,7 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.task_uf = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tuf);
         fts_.task_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_tub);
         fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
+        fts_.pinfo = reinterpret_cast<const FtPivotInfo*>(d_lu_buf_ + o_pinfo);
         // what is left of the CU's LDS after the work vectors stages one schedule image at a time
         const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_);
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);

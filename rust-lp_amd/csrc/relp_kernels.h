@@ -148,6 +148,14 @@ static constexpr int kFtWaves = kFtThreads / 64;       // sparse lists are bucke
 static constexpr int kFtMaxSlots = 64;                 // one lane of a wavefront per slot in the chains over TC
 static constexpr int kFtMaxRows = 4096;                // work vectors (x, spike, -pi) live in LDS
 static constexpr int kFtLdsBudget = 156 * 1024;        // of the CU's 160 KB
+// Everything the Forrest-Tomlin update needs to know about the leaving pivot p, together in one cache line segment (it was
+// five dependent global round trips: task -> row header -> entries, via_ptr -> via_pos, twice).
+struct FtPivotInfo {
+    int32_t u_e0, u_e1;          // row p of U right of the diagonal: entries [u_e0, u_e1) of DeviceLU::Uf idx / val
+    int32_t via_u0, via_u1;      // EllSchedule::via_pos range of p in the U image ...
+    int32_t via_t0, via_t1;      // ... and in the U' image
+    int32_t lev_ub, pad_;
+};
 struct FtState {
     int32_t  m, tcap, ldt, eta_cap;
     int32_t* hdr;            // [0] updates since the refactorisation (t), [1] eta pool entries in use, [2] refactor requested
@@ -166,6 +174,7 @@ struct FtState {
     const int32_t* task_ub;                // pivot -> index of its row in the U' (BTRAN) schedule
     EllSchedule ell[4];                    // L, U, U', L' packed for the persistent kernel
     const int32_t* lev_ub;                 // pivot -> level of its row in the U' schedule (a solve with e_p or u_bar starts there)
+    const struct FtPivotInfo* pinfo;       // per pivot: what an update of that pivot needs, one 32-byte load
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
     int32_t  stage_bytes;

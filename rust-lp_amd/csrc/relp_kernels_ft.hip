@@ -24,7 +24,7 @@ __host__ __device__ inline int64_t up16(int64_t b) { return (b + 15) / 16 * 16; 
 
 // byte offsets of the dynamic LDS arrays
 struct FtLayout {
-    int64_t x, sp, pi, tc, dots, zt, uv, ct, slot_pivot, slot_prev, slot_live, slot_next, eta_off, spk_off, tslot, eta_idx,
+    int64_t x, sp, pi, perm, tc, dots, zt, uv, ct, slot_pivot, slot_prev, slot_live, slot_next, eta_off, spk_off, tslot, eta_idx,
         eta_val, red_d, red_i, stage, total;
 };
 __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
@@ -33,6 +33,7 @@ __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
     const int ldt = tcap + 1;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
     L.x = take(8LL * (2 * m + 1)); L.sp = take(8LL * m); L.pi = take(8LL * m);  // x[m]: scratch word of ell_solve; x[m + 1 ..]: rhs copy
+    L.perm = take(2LL * 3 * m);                      // inv_rowperm | inv_colperm | rowperm as 16-bit indices
     L.tc = take(8LL * tcap * ldt);
     L.dots = take(8LL * tcap); L.zt = take(8LL * tcap); L.uv = take(8LL * tcap); L.ct = take(8LL * tcap);
     L.slot_pivot = take(4LL * tcap); L.slot_prev = take(4LL * tcap); L.slot_live = take(4LL * tcap); L.slot_next = take(4LL * tcap);
@@ -66,6 +67,7 @@ struct FtCtx {
     double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;
     int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
     signed char* tslot;
+    const unsigned short *irp, *icp, *rp;              // original row -> pivot, basis position -> pivot, pivot -> original row
     char* stage;
     int m, tcap, ldt, t, eta_used, eta_cap;
     FtClock clk;
@@ -74,6 +76,7 @@ struct FtCtx {
 __device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) {
     const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap);
     c.x = (double*)(lds + L.x); c.sp = (double*)(lds + L.sp); c.pi = (double*)(lds + L.pi); c.TC = (double*)(lds + L.tc);
+    c.irp = (const unsigned short*)(lds + L.perm); c.icp = c.irp + st.m; c.rp = c.icp + st.m;
     c.dots = (double*)(lds + L.dots); c.zt = (double*)(lds + L.zt); c.uv = (double*)(lds + L.uv); c.ct = (double*)(lds + L.ct);
     c.slot_pivot = (int*)(lds + L.slot_pivot); c.slot_prev = (int*)(lds + L.slot_prev); c.slot_live = (int*)(lds + L.slot_live);
     c.slot_next = (int*)(lds + L.slot_next); c.eta_off = (int*)(lds + L.eta_off); c.spk_off = (int*)(lds + L.spk_off);
@@ -84,9 +87,16 @@ __device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) 
 }
 
 // global state -> LDS (ends with a barrier)
-__device__ __forceinline__ void ft_load(FtCtx& c, const FtState& st, const double* minus_pi) {
+__device__ __forceinline__ void ft_load(FtCtx& c, const DeviceLU& lu, const FtState& st, const double* minus_pi) {
     const int tid = threadIdx.x;
     c.t = st.hdr[0]; c.eta_used = st.hdr[1];
+    {   // the permutations as 16-bit copies: every pivot needs a few entries of each, a global round trip apiece otherwise
+        unsigned short* w = const_cast<unsigned short*>(c.irp);
+        for (int k = tid; k < c.m; k += NT) {
+            w[k] = (unsigned short)st.inv_rowperm[k]; w[c.m + k] = (unsigned short)st.inv_colperm[k];
+            w[2 * c.m + k] = (unsigned short)lu.rowperm[k];
+        }
+    }
     for (int i = tid; i < c.tcap * c.ldt; i += NT) c.TC[i] = st.TC[i];
     for (int s = tid; s < c.tcap; s += NT) {
         c.slot_pivot[s] = st.slot_pivot[s]; c.slot_prev[s] = st.slot_prev[s]; c.slot_live[s] = st.slot_live[s];
@@ -426,15 +436,15 @@ __device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip,
 __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st, FtCtx& c, int r) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
-    const int p = st.inv_colperm[r];                   // the pivot whose column leaves (mod.rs:99-107)
+    const int p = c.icp[r];                            // the pivot whose column leaves (mod.rs:99-107)
+    const FtPivotInfo pin = st.pinfo[p];               // (one load; its entries and lists follow in a second round trip)
     const int s_old = c.tslot[p];
     // u_bar = row p of U right of the diagonal (mod.rs:110-121), scattered into x
     for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
     __syncthreads();
     int any = 0;
     if (s_old < 0) {
-        const LuRow row = lu.Uf.rows[st.task_uf[p]];
-        for (int e = row.e0 + tid; e < row.e1; e += NT) {
+        for (int e = pin.u_e0 + tid; e < pin.u_e1; e += NT) {
             const int l = lu.Uf.idx[e];
             if (c.tslot[l] < 0) { c.x[l] = lu.Uf.val[e]; any = 1; }
         }
@@ -453,7 +463,7 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
     const bool do_sweep = __syncthreads_or(any) != 0;
     c.clk.lap(FT_UBAR);
     // r' = u_bar' U^-1 (mod.rs:122); u_bar lives on pivots after p, i.e. in levels above p's own
-    ft_ut_solve(lu, st, c, do_sweep, st.lev_ub[p] + 1);
+    ft_ut_solve(lu, st, c, do_sweep, pin.lev_ub + 1);
     // R = I - e_p r' (eta_file.rs:10-18): sparse part over the never-updated pivots into the eta pool, bucketed ...
     const int tn = t;                                  // the new slot
     int eta_n = 0;
@@ -486,11 +496,8 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
             st.ell[2].rdiag[p] = 0.0;
         }
         // fused levels: the entries of p's group-mates that were substituted through row p go with it
-        for (int w = 1; w <= 2; ++w) {
-            const EllSchedule& es = st.ell[w];
-            if (es.via_ptr)
-                for (int e = es.via_ptr[p] + tid; e < es.via_ptr[p + 1]; e += NT) es.sval[es.via_pos[e]] = 0.0;
-        }
+        for (int e = pin.via_u0 + tid; e < pin.via_u1; e += NT) st.ell[1].sval[st.ell[1].via_pos[e]] = 0.0;
+        for (int e = pin.via_t0 + tid; e < pin.via_t1; e += NT) st.ell[2].sval[st.ell[2].via_pos[e]] = 0.0;
     } else {
         if (tid >= s_old && tid < c.tcap) c.TC[s_old * c.ldt + tid] = 0.0;    // (left of the diagonal: eta coefficients, kept)
         __syncthreads();
@@ -521,19 +528,19 @@ __device__ __forceinline__ void ft_scatter_column(const FtState& st, const FtPro
     for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
     __syncthreads();
     if (q < ct.nr_artificial) {
-        if (tid == 0) c.x[st.inv_rowperm[ct.column_to_row[q]]] = 1.0;
+        if (tid == 0) c.x[c.irp[ct.column_to_row[q]]] = 1.0;
     } else {
         const int p = q - ct.nr_artificial;
         if (p < ct.nr_normal) {
             const int64_t s0 = pb.csc.col_ptr[p], s1 = pb.csc.col_ptr[p + 1];
-            for (int64_t e = s0 + tid; e < s1; e += NT) c.x[st.inv_rowperm[pb.csc.row_idx[e]]] = pb.csc.values[e];
+            for (int64_t e = s0 + tid; e < s1; e += NT) c.x[c.irp[pb.csc.row_idx[e]]] = pb.csc.values[e];
             const int br = ct.bound_row[p];
-            if (tid == 0 && br >= 0) c.x[st.inv_rowperm[br]] = 1.0;
+            if (tid == 0 && br >= 0) c.x[c.irp[br]] = 1.0;
         } else if (tid == 0) {
             const int v = p - ct.nr_normal;
             const int r0 = ct.vrow0[v], r1 = ct.vrow1[v];
-            if (r0 >= 0) c.x[st.inv_rowperm[r0]] = (double)ct.vsign[v];
-            if (r1 >= 0) c.x[st.inv_rowperm[r1]] = 1.0;
+            if (r0 >= 0) c.x[c.irp[r0]] = (double)ct.vsign[v];
+            if (r1 >= 0) c.x[c.irp[r1]] = 1.0;
         }
     }
     __syncthreads();
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     FtCtx c;
     ft_bind(c, lds, st);
     c.clk.start(st.prof);
-    ft_load(c, st, pb.minus_pi);
+    ft_load(c, lu, st, pb.minus_pi);
     c.clk.lap(FT_LOAD_STORE);
     const int tid = threadIdx.x;
     const ColumnTable& ct = pb.ct;
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         // global loads for m <= 2 NT); rows beyond that take the generic loops.
         const int i0 = tid, i1 = tid + NT;
         const bool h0 = i0 < m, h1 = i1 < m;
-        const int p0 = st.inv_colperm[h0 ? i0 : 0], p1 = st.inv_colperm[h1 ? i1 : 0];
+        const int p0 = c.icp[h0 ? i0 : 0], p1 = c.icp[h1 ? i1 : 0];
         double b0 = pb.b[h0 ? i0 : 0], b1 = pb.b[h1 ? i1 : 0];
         const int s0 = pb.basis[h0 ? i0 : 0], s1 = pb.basis[h1 ? i1 : 0];
         const double a0 = c.x[p0], a1 = c.x[p1];
@@ -756,7 +763,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         const double t0 = h0 ? row_ratio(a0, b0, pb.tol) : INFINITY, t1 = h1 ? row_ratio(a1, b1, pb.tol) : INFINITY;
         double mn = fmin(t0, t1);
         for (int i = tid + 2 * NT; i < m; i += NT) {
-            const double a = c.x[st.inv_colperm[i]];
+            const double a = c.x[c.icp[i]];
             pb.alpha[i] = a;
             mn = fmin(mn, row_ratio(a, pb.b[i], pb.tol));
         }
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (t0 <= bound) best_leave = s0;
         if (t1 <= bound) best_leave = min(best_leave, s1);
         for (int i = tid + 2 * NT; i < m; i += NT) {
-            const double a = c.x[st.inv_colperm[i]];
+            const double a = c.x[c.icp[i]];
             if (row_ratio(a, pb.b[i], pb.tol) <= bound) best_leave = min(best_leave, pb.basis[i]);
         }
         leaving = block_min_int(c, best_leave);
@@ -776,10 +783,10 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (h0 && s0 == leaving && t0 <= bound) rr = i0;
         if (h1 && s1 == leaving && t1 <= bound) rr = i1;             // (a column is basic in one row)
         for (int i = tid + 2 * NT; i < m; i += NT)
-            if (pb.basis[i] == leaving && row_ratio(c.x[st.inv_colperm[i]], pb.b[i], pb.tol) <= bound) rr = i;
+            if (pb.basis[i] == leaving && row_ratio(c.x[c.icp[i]], pb.b[i], pb.tol) <= bound) rr = i;
         r = block_min_int(c, rr);
         // alpha_r and b_r from their owner
-        if (rr == r) { c.red_d[NW] = c.x[st.inv_colperm[r]]; c.red_d[NW + 1] = pb.b[r]; }
+        if (rr == r) { c.red_d[NW] = c.x[c.icp[r]]; c.red_d[NW + 1] = pb.b[r]; }
         __syncthreads();
         alpha_r = c.red_d[NW];
         b_r = c.red_d[NW + 1];
@@ -792,7 +799,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         for (int i = tid + 2 * NT; i < m; i += NT) {
             if (i == r) pb.b[i] = br;
             else {
-                const double a = c.x[st.inv_colperm[i]];
+                const double a = c.x[c.icp[i]];
                 if (a != 0.0) pb.b[i] = fma(-a, br, pb.b[i]);
             }
         }
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         c.clk.lap(FT_B);
         // ---- basis inverse: the Forrest-Tomlin update, then row r of the new inverse (mod.rs:92-155, 204-222) --------------
         const bool updated = ft_update(lu, st, c, r);
-        const int pl = st.inv_colperm[r];
+        const int pl = c.icp[r];
         for (int k = tid; k < m; k += NT) c.x[k] = 0.0;
         __syncthreads();
         if (tid == 0) c.x[pl] = 1.0;
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         }
         // ---- -pi, -obj, basis (carry/mod.rs:326-333, 549-570) ----------------------------------------------------------
         for (int k = tid; k < m; k += NT) {
-            const int i = lu.rowperm[k];
+            const int i = c.rp[k];
             const double rho = c.x[k] * rho_scale;
             pb.rho[i] = rho;
             c.pi[i] = fma(-d_q, rho, c.pi[i]);
@@ -856,7 +863,7 @@ __global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProb
     extern __shared__ __align__(16) char lds[];
     FtCtx c;
     ft_bind(c, lds, st);
-    ft_load(c, st, nullptr);
+    ft_load(c, lu, st, nullptr);
     const int tid = threadIdx.x;
     if (rhs) {
         for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.rowperm[k]];
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
     extern __shared__ __align__(16) char lds[];
     FtCtx c;
     ft_bind(c, lds, st);
-    ft_load(c, st, nullptr);
+    ft_load(c, lu, st, nullptr);
     const int tid = threadIdx.x;
     bool sweep_u = true;
     int first = 0;
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtPro
     extern __shared__ __align__(16) char lds[];
     FtCtx c;
     ft_bind(c, lds, st);
-    ft_load(c, st, nullptr);
+    ft_load(c, lu, st, nullptr);
     for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
     __syncthreads();
     const bool updated = ft_update(lu, st, c, pb.rec->r);
