@@ -10,12 +10,17 @@ half of that kernel's 90th-percentile launch (not the longest: one slow outlier 
 """
 import collections
 import csv
-import glob
+import glob as _glob
 import json
 import os
 import shutil
 import statistics
 import sys
+
+
+def newest(pattern):
+    """Matches of `pattern`, newest first: gpurun merges every collection into the same directory, older runs stay."""
+    return sorted(_glob.glob(pattern), key=os.path.getmtime, reverse=True)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -42,16 +47,16 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     workload = sys.argv[2] if len(sys.argv) > 2 else "dense10k"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
-    trace = per_kernel(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])
-    fetch = per_kernel(glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
-    write = per_kernel(glob.glob(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+    trace = per_kernel(newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])
+    fetch = per_kernel(newest(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+    write = per_kernel(newest(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
     # calibration of the counters for 8-byte-per-lane tile accesses: k_tile<true> in place moves 8 m n bytes each way
     cal_f = cal_w = None
     try:
-        cf = per_kernel(glob.glob(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
-        cw = per_kernel(glob.glob(os.path.join(src, "cal_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+        cf = per_kernel(newest(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+        cw = per_kernel(newest(os.path.join(src, "cal_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
         known = 8.0 * 10000 * 20000
         cal_f = known / (cf["k_tile"]["value"] * 1024.0)
         cal_w = known / (cw["k_tile"]["value"] * 1024.0)
@@ -87,9 +92,9 @@ def main():
         lines.append(f"| {name} | {t['launches']} ({t['effective']}) | {t['avg_us']:.1f} | {f:.1f} | {w:.1f} | {hbm / 1e6:.1f}{note} |")
     # the sparse path: launches per pivot of the LU engine (one whole 25FV47 solve)
     try:
-        lstats = glob.glob(os.path.join(src, "lu_trace", "*", "*_kernel_stats.csv"))[0]
+        lstats = newest(os.path.join(src, "lu_trace", "*", "*_kernel_stats.csv"))[0]
         shutil.copy(lstats, os.path.join(ROOT, "profiles", f"{tag}_lu_25fv47_kernel_stats.csv"))
-        lt = per_kernel(glob.glob(os.path.join(src, "lu_trace", "*", "*_kernel_trace.csv"))[0])
+        lt = per_kernel(newest(os.path.join(src, "lu_trace", "*", "*_kernel_trace.csv"))[0])
         log = open(os.path.join(src, "lu_trace.log")).read()
         pivots = int([ln for ln in log.splitlines() if ln.startswith("optimal")][0].split()[1])
         total = sum(v["launches"] for k, v in lt.items())
