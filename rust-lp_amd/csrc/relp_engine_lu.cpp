@@ -404,6 +404,9 @@ relp_status_t Engine::ft_build_price_ell() {
     const size_t o_val = put(val.data(), val.size() * 8), o_lval = put(lval.data(), lval.size() * 8);
     const size_t o_idx = put(idx.data(), idx.size() * 2), o_lidx = put(lidx.data(), lidx.size() * 2);
     const size_t o_long = put(longs.data(), longs.size() * 4), o_vl = put(very_long.data(), very_long.size() * 4);
+    std::vector<uint16_t> long_of((size_t)ns, 0xFFFF);
+    if (longs.size() < 0xFFFF) for (size_t i = 0; i < longs.size(); ++i) long_of[longs[i]] = (uint16_t)i;
+    const size_t o_lof = put(long_of.data(), long_of.size() * 2);
     if (d_pe_buf_) { HIP_TRY(hipFree(d_pe_buf_)); d_pe_buf_ = nullptr; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pe_buf_), buf.size()));
     HIP_TRY(hipMemcpy(d_pe_buf_, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -413,6 +416,7 @@ relp_status_t Engine::ft_build_price_ell() {
     pe_.lidx = reinterpret_cast<const uint16_t*>(d_pe_buf_ + o_lidx);
     pe_.long_cols = reinterpret_cast<const int32_t*>(d_pe_buf_ + o_long);
     pe_.very_long = reinterpret_cast<const int32_t*>(d_pe_buf_ + o_vl);
+    pe_.long_of = reinterpret_cast<const uint16_t*>(d_pe_buf_ + o_lof);
     pe_.n_long = (int32_t)longs.size(); pe_.n_very_long = (int32_t)very_long.size();
     return RELP_OK;
 }

@@ -197,6 +197,7 @@ struct PriceEll {
     const uint16_t* lidx; const double* lval;          // kPriceLongSlots x n_long
     const int32_t* long_cols;                          // n_long
     const int32_t* very_long;                          // n_very_long
+    const uint16_t* long_of;                           // nr_normal: index of a column in tier B, 0xFFFF = not there
     int32_t n_long, n_very_long;
 };
 struct FtProblem {           // what the persistent kernel needs besides the factors

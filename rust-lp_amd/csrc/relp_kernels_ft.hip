@@ -643,6 +643,76 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             }
         };
         const double* costs = cost_mode == 2 ? ct.cost : nullptr;
+        int my_j = 0x7fffffff;                                      // this thread's own candidate and its reduced cost
+        double my_v = 0.0;
+        if (rule != 2) {
+            // FirstProfitable / FirstProfitableWithMemory (pivot_rule.rs:38-95) take the first profitable column of a fixed
+            // search order: the columns are priced NT at a time along that order and the scan stops at the first chunk that
+            // holds one -- the same column as a full scan would choose, for a fraction of the loads.  (d is not refreshed
+            // here; nothing reads it under these rules.)
+            const int start = (rule == 1 && last_selected >= 0) ? last_selected : 0;
+            for (int base = 0; base < n; base += NT) {
+                const int k = base + tid;
+                int my_k = 0x7fffffff;
+                if (k < n) {
+                    int j = start + k;
+                    if (j >= n) j -= n;
+                    const int basic = pb.in_basis[j];
+                    double v;
+                    if (j < na) {
+                        v = (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]];
+                    } else if (j < na + nstr) {
+                        const int p = j - na;
+                        int ri[kPriceSlots];
+                        double va[kPriceSlots], px[kPriceSlots];
+#pragma unroll
+                        for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pb.pe.idx[u * nstr + p]; va[u] = pb.pe.val[u * nstr + p]; }
+                        const int br = ct.bound_row[p];
+                        const int li = pb.pe.long_of[p];
+                        const double cp = costs ? costs[p] : 0.0;
+                        const bool is_long = (ri[0] & kPriceLongFlag) != 0;
+                        ri[0] &= kPriceLongFlag - 1;
+#pragma unroll
+                        for (int u = 0; u < kPriceSlots; ++u) px[u] = c.pi[ri[u]];
+                        const double pb_r = c.pi[br >= 0 ? br : 0];
+                        v = 0.0;
+#pragma unroll
+                        for (int u = 0; u < kPriceSlots; ++u) v = fma(px[u], va[u], v);
+                        if (is_long && li != 0xFFFF) {              // its entries 8.. from the second tier, same order
+                            const int nl = pb.pe.n_long;
+                            constexpr int kRest = kPriceLongSlots - kPriceSlots;
+                            int rj[kRest];
+                            double vb[kRest], py[kRest];
+#pragma unroll
+                            for (int u = 0; u < kRest; ++u) { rj[u] = pb.pe.lidx[(kPriceSlots + u) * nl + li]; vb[u] = pb.pe.lval[(kPriceSlots + u) * nl + li]; }
+#pragma unroll
+                            for (int u = 0; u < kRest; ++u) py[u] = c.pi[rj[u]];
+#pragma unroll
+                            for (int u = 0; u < kRest; ++u) v = fma(py[u], vb[u], v);
+                        } else if (is_long) {                       // beyond the second tier: the whole column from the CSC arrays
+                            v = 0.0;
+                            for (int64_t e = pb.csc.col_ptr[p]; e < pb.csc.col_ptr[p + 1]; ++e) v = fma(c.pi[pb.csc.row_idx[e]], pb.csc.values[e], v);
+                        }
+                        if (br >= 0) v += pb_r;
+                        if (costs) v += cp;
+                    } else {
+                        const int vv = j - na - nstr;
+                        const int r0 = ct.vrow0[vv], r1 = ct.vrow1[vv];
+                        v = r0 >= 0 ? (double)ct.vsign[vv] * c.pi[r0] : 0.0;
+                        if (r1 >= 0) v += c.pi[r1];
+                    }
+                    if (!basic && v < -pb.tol.cost) { my_k = k; my_v = v; }
+                }
+                const int kmin = block_min_int(c, my_k);
+                if (kmin != 0x7fffffff) {
+                    key = (double)kmin;                             // (= select_key: the position in the search order)
+                    kj = start + kmin;
+                    if (kj >= n) kj -= n;
+                    if (my_k == kmin) my_j = kj;
+                    break;
+                }
+            }
+        } else {
         for (int j = tid; j < na; j += NT) consider(j, (cost_mode == 1 ? 1.0 : 0.0) + c.pi[ct.column_to_row[j]], pb.in_basis[j]);
         for (int p = tid; p < nstr; p += NT) {
             int ri[kPriceSlots];
@@ -702,8 +772,8 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
 #ifdef PRICE_DIAG
         c.clk.lap(FT_PRICE);
 #endif
-        int my_j = kj;                                              // this thread's own candidate and its reduced cost
-        double my_v = kv;
+        my_j = kj;
+        my_v = kv;
         block_min_key(c, key, kj);
 #ifdef PRICE_DIAG
         c.clk.lap(FT_LOAD_STORE);
@@ -725,6 +795,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
                 }
             }
             kj = block_min_int(c, my_j);
+        }
         }
         if (kj == 0x7fffffff) {
             outcome = DEV_NO_CANDIDATE;
