@@ -33,7 +33,7 @@ void Engine::free_all() {
     fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
     fr(d_msg_cand_); fr(d_msg_cands_); fr(d_msg_slice_); fr(d_msg_slices_); fr(d_msg_rho_); fr(d_msg_status_); fr(d_msg_statuses_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);
-    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_scratch_); fr(d_ft_buf_); fr(d_pe_buf_);
+    fr(d_cptr_); fr(d_cidx_); fr(d_cval_); fr(d_lu_buf_); fr(d_lu_buf_alt_); fr(d_lu_scratch_); fr(d_ft_buf_); fr(d_pe_buf_);
     if (h_ft_hdr_) { (void)hipHostFree(h_ft_hdr_); h_ft_hdr_ = nullptr; }
     if (h_rec_) { (void)hipHostFree(h_rec_); h_rec_ = nullptr; }
     for (auto e : prof_ev_) (void)hipEventDestroy(e);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,11 @@ class Engine {
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
     relp_status_t lu_phase_cycles(int64_t* out16);
+    relp_status_t lu_download_basis();
+    relp_status_t lu_factor_downloaded_basis();
+    relp_status_t lu_refactor_lookahead(int rule, int64_t budget);
+    void lu_refactor_clock(std::chrono::steady_clock::time_point tb, std::chrono::steady_clock::time_point t0,
+                           std::chrono::steady_clock::time_point t1, std::chrono::steady_clock::time_point t2);
     // BasisInverse surface of the LU engine (carry/mod.rs:68-157, lower_upper/mod.rs:199-222)
     relp_status_t basis_inverse_row(int32_t row, double* out_m);
     relp_status_t should_refactor(int32_t* out);
@@ -189,6 +195,7 @@ class Engine {
     LUFactors hlu_;
     char* d_lu_buf_ = nullptr; int64_t lu_cap_ = 0;       // packed factors (permutations, rows, entries, levels)
     char* h_lu_buf_ = nullptr; size_t h_lu_cap_ = 0;      // the same, assembled in pinned host memory
+    char* d_lu_buf_alt_ = nullptr; int64_t lu_cap_alt_ = 0;   // second device buffer: the factors the host prepares while the kernel runs
     int32_t* h_basis_ = nullptr; int32_t m_alloc_rows_ = 0;   // pinned: the basis a refactorisation downloads
     double* d_lu_scratch_ = nullptr;
     DeviceLU dlu_{};

@@ -61,14 +61,17 @@ relp_status_t Engine::lu_load_matrix(const relp_matrix_data_t& md) {
     return RELP_OK;
 }
 
-// Refactorisation (lower_upper/mod.rs:199-202 + carry/mod.rs:602-614): B from the current basis
-// columns, P B Q = L U on the host, schedules to the device, W := empty.  Synchronises the stream.
-relp_status_t Engine::lu_refactor() {
-    const auto tb = std::chrono::steady_clock::now();
+// The basis as it is on the device -> pinned host memory.  Synchronises the stream.
+relp_status_t Engine::lu_download_basis() {
     if (!h_basis_) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_basis_), sizeof(int32_t) * (size_t)std::max(m_alloc_rows_, m_), hipHostMallocDefault));
-    int32_t* const basis = h_basis_;
-    HIP_TRY(hipMemcpyAsync(basis, d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(h_basis_, d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    return RELP_OK;
+}
+
+// P B Q = L U on the host for the basis in h_basis_ (hlu_ is overwritten)
+relp_status_t Engine::lu_factor_downloaded_basis() {
+    const int32_t* const basis = h_basis_;
     std::vector<std::vector<std::pair<int32_t, double>>> cols(m_);
     for (int32_t i = 0; i < m_; ++i) {
         const int32_t j = basis[i];
@@ -99,15 +102,12 @@ relp_status_t Engine::lu_refactor() {
         }
     }
     std::string msg;
-    const auto t0 = std::chrono::steady_clock::now();
     if (!lu_factor(m_, cols, &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
-    const auto t1 = std::chrono::steady_clock::now();
-    relp_status_t st = lu_upload_factors();
-    if (st) return st;
-    if (ft_) { if ((st = ft_reset())) return st; }
-    else launch_flush_reset(deferred(), d_rec_, stream_);
-    HIP_TRY(hipStreamSynchronize(stream_));
-    const auto t2 = std::chrono::steady_clock::now();
+    return RELP_OK;
+}
+
+void Engine::lu_refactor_clock(std::chrono::steady_clock::time_point tb, std::chrono::steady_clock::time_point t0,
+                               std::chrono::steady_clock::time_point t1, std::chrono::steady_clock::time_point t2) {
     refactor_us_[0] += std::chrono::duration<double, std::micro>(t0 - tb).count();
     refactor_us_[1] += std::chrono::duration<double, std::micro>(t1 - t0).count();
     refactor_us_[2] += std::chrono::duration<double, std::micro>(t2 - t1).count();
@@ -115,7 +115,84 @@ relp_status_t Engine::lu_refactor() {
         std::fprintf(stderr, "[relp] refactorisations so far %lld: basis download + columns %.0f us, lu_factor %.0f us, schedules + upload %.0f us (averages)\n",
                      (long long)lu_refactors_ + 1, refactor_us_[0] / (lu_refactors_ + 1), refactor_us_[1] / (lu_refactors_ + 1),
                      refactor_us_[2] / (lu_refactors_ + 1));
+}
+
+// Refactorisation (lower_upper/mod.rs:199-202 + carry/mod.rs:602-614): B from the current basis
+// columns, P B Q = L U on the host, schedules to the device, W := empty.  Synchronises the stream.
+relp_status_t Engine::lu_refactor() {
+    const auto tb = std::chrono::steady_clock::now();
+    relp_status_t st = lu_download_basis();
+    if (st) return st;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((st = lu_factor_downloaded_basis())) return st;
+    const auto t1 = std::chrono::steady_clock::now();
+    if ((st = lu_upload_factors())) return st;
+    if (ft_) { if ((st = ft_reset())) return st; }
+    else launch_flush_reset(deferred(), d_rec_, stream_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    lu_refactor_clock(tb, t0, t1, std::chrono::steady_clock::now());
     since_flush_ = 0;
+    ++lu_refactors_;
+    return RELP_OK;
+}
+
+// Refactorisation without stopping the pivot kernel (persistent-kernel mode).  The kernel has just returned with
+// `max_updates - lookahead` updates pending.  Its basis is downloaded, the kernel is launched again on the OLD factors (it
+// may fill the rest of the update file), and while it pivots the host factorises the downloaded basis into the other
+// device buffer.  When both are done the new factors are installed and the basis changes made meanwhile (the kernel's
+// journal) are applied to them as Forrest-Tomlin updates by k_ft_replay: the device pivots for the ~0.6 ms it used to
+// wait.  If the kernel ended the phase meanwhile, the new factors are dropped: the old ones with their update file
+// describe the final basis.
+relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget) {
+    const auto tb = std::chrono::steady_clock::now();
+    relp_status_t st = lu_download_basis();
+    if (st) return st;
+    FtState go = fts_;
+    go.max_updates = std::max(go.max_updates, std::min(cfg_.update_block < 0 ? ft_tcap_ : cfg_.update_block, ft_tcap_));
+    prof_tick_ = 0;
+    prof_begin(RELP_K_FT_RUN);
+    launch_ft_run(dlu_, go, ft_problem(rule), budget, stream_);
+    prof_end();
+    const auto t0 = std::chrono::steady_clock::now();
+    // the current factors stay valid (and in use) until the new ones are installed
+    LUFactors old_h = std::move(hlu_);
+    const DeviceLU old_d = dlu_;
+    const FtState old_f = fts_;
+    char* const old_buf = d_lu_buf_;
+    const int64_t old_cap = lu_cap_;
+    d_lu_buf_ = d_lu_buf_alt_; lu_cap_ = lu_cap_alt_;
+    hlu_ = LUFactors{};
+    auto restore = [&]() {
+        d_lu_buf_alt_ = d_lu_buf_; lu_cap_alt_ = lu_cap_;
+        hlu_ = std::move(old_h); dlu_ = old_d; fts_ = old_f; d_lu_buf_ = old_buf; lu_cap_ = old_cap;
+    };
+    st = lu_factor_downloaded_basis();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (!st) st = lu_upload_factors();                     // (its copy queues behind the kernel; it returns when both are done)
+    if (st) {                                              // keep what works; the kernel's result decides what happens next
+        restore();
+        (void)hipStreamSynchronize(stream_);
+        HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
+        relp_status_t st2 = ft_read_hdr();
+        ft_need_refactor_ = true;
+        return st2 ? st2 : st;
+    }
+    HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
+    if ((st = ft_read_hdr())) { restore(); return st; }
+    const int32_t changes = h_ft_hdr_[3];
+    if (h_rec_->outcome != DEV_RUNNING || h_ft_hdr_[2] == 2 || changes > ft_tcap_) {
+        restore();                                         // phase over (or something off): nothing to install
+        if (h_ft_hdr_[2] == 2 || changes > ft_tcap_) ft_need_refactor_ = true;
+        return RELP_OK;
+    }
+    d_lu_buf_alt_ = old_buf; lu_cap_alt_ = old_cap;
+    if ((st = ft_reset())) return st;
+    prof_begin(RELP_K_FLUSH);
+    launch_ft_replay(dlu_, fts_, ft_problem(rule), changes, stream_);
+    prof_end();
+    lu_refactor_clock(tb, t0, t1, std::chrono::steady_clock::now());
+    since_flush_ = changes;
+    ft_need_refactor_ = false;                             // (a replay that fails marks the header; the next launch returns at once)
     ++lu_refactors_;
     return RELP_OK;
 }
@@ -340,7 +417,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
     // (what a refactorisation clears to 0 first, then what it clears to -1, then the rest: two memsets per reset)
     const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_lv = take(4 * tc), o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp),
                   o_so = take(4 * tc * nwp), o_pv = take(4 * tc), o_ts = take(4 * m), o_ei = take(4 * (int64_t)ft_eta_cap_),
-                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32);
+                  o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32),
+                  o_journal = take(8 * tc);
     ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
@@ -362,6 +440,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spk_val = reinterpret_cast<double*>(d_ft_buf_ + o_sv);
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
     fts_.prof = reinterpret_cast<long long*>(d_ft_buf_ + o_prof);
+    fts_.journal = reinterpret_cast<int32_t*>(d_ft_buf_ + o_journal);
     // refactor when this many updates are pending (lower_upper/mod.rs:199-202 refactors when updates.len() > 10, i.e.
     // relp_config_t.update_block = 11 reproduces the reference's cadence)
     fts_.max_updates = cfg_.update_block < 0 ? ft_tcap_ : std::max(1, std::min(cfg_.update_block, ft_tcap_));
@@ -456,17 +535,30 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     const long long start = h_rec_->iterations;
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     struct Tick { int64_t& t; ~Tick() { ++t; } };
+    // Look-ahead refactorisation (lu_refactor_lookahead): the kernel returns `la` updates before the file is full, and fills
+    // the rest while the host factorises.  On for refactorisation intervals from 24 on; RELP_LU_LOOKAHEAD = 0 switches it off.
+    static const int32_t la_env = [] { const char* e = std::getenv("RELP_LU_LOOKAHEAD"); return e ? std::atoi(e) : 8; }();
+    const int32_t la = (fts_.max_updates >= 24 && la_env > 0) ? std::min(la_env, fts_.max_updates / 3) : 0;
     while (h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters) {
         if (ft_need_refactor_) {
+            const bool ahead = la > 0 && h_ft_hdr_[2] == 1 && h_ft_hdr_[0] == fts_.max_updates - la;
             prof_tick_ = 0;                                // refactorisations are always bracketed (like the flush)
-            prof_begin(RELP_K_FLUSH);
-            st = lu_refactor();
-            prof_end();
-            if (st) return st;
+            if (ahead) {
+                if ((st = lu_refactor_lookahead(rule, max_iters - (h_rec_->iterations - start)))) return st;
+                if (ft_need_refactor_ || h_rec_->outcome != DEV_RUNNING) continue;      // (re-examined at the loop head)
+            } else {
+                prof_begin(RELP_K_FLUSH);
+                st = lu_refactor();
+                prof_end();
+                if (st) return st;
+            }
+            if (h_rec_->iterations - start >= max_iters) break;
         }
         prof_tick_ = 0;
         prof_begin(RELP_K_FT_RUN);
-        launch_ft_run(dlu_, fts_, ft_problem(rule), max_iters - (h_rec_->iterations - start), stream_);
+        FtState go = fts_;
+        go.max_updates = fts_.max_updates - la;
+        launch_ft_run(dlu_, go, ft_problem(rule), max_iters - (h_rec_->iterations - start), stream_);
         prof_end();
         HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
         if ((st = ft_read_hdr())) return st;

@@ -175,6 +175,8 @@ struct FtState {
     EllSchedule ell[4];                    // L, U, U', L' packed for the persistent kernel
     const int32_t* lev_ub;                 // pivot -> level of its row in the U' schedule (a solve with e_p or u_bar starts there)
     const struct FtPivotInfo* pinfo;       // per pivot: what an update of that pivot needs, one 32-byte load
+    int32_t* journal;                      // (basis position, entering column) of every basis change of the last k_ft_run
+                                           // launch, hdr[3] of them: what k_ft_replay applies to freshly computed factors
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
     int32_t  stage_bytes;
@@ -437,6 +439,8 @@ void launch_ft_btran(const DeviceLU& lu, const FtState& st, const FtProblem& pb,
                      hipStream_t s);
 // the Forrest-Tomlin update for the basis change in position rec->r with the spike in st.spike
 void launch_ft_update(const DeviceLU& lu, const FtState& st, const FtProblem& pb, hipStream_t s);
+// the first `count` basis changes of the journal as Forrest-Tomlin updates of the (fresh) factors; hdr[2] = 2 when one fails
+void launch_ft_replay(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t count, hipStream_t s);
 
 // sharded helpers
 void launch_pack_candidate(const double* aq, int32_t m, double* msg, PivotRecord* rec, hipStream_t s);

@@ -69,7 +69,7 @@ struct FtCtx {
     signed char* tslot;
     const unsigned short *irp, *icp, *rp;              // original row -> pivot, basis position -> pivot, pivot -> original row
     char* stage;
-    int m, tcap, ldt, t, eta_used, eta_cap;
+    int m, tcap, ldt, t, eta_used, eta_cap, journal_n;
     FtClock clk;
 };
 
@@ -82,7 +82,7 @@ __device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) 
     c.slot_next = (int*)(lds + L.slot_next); c.eta_off = (int*)(lds + L.eta_off); c.spk_off = (int*)(lds + L.spk_off);
     c.tslot = (signed char*)(lds + L.tslot); c.eta_idx = (int*)(lds + L.eta_idx); c.eta_val = (double*)(lds + L.eta_val);
     c.red_d = (double*)(lds + L.red_d); c.red_i = (int*)(lds + L.red_i); c.stage = lds + L.stage;
-    c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap;
+    c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap; c.journal_n = 0;
     c.clk.start(nullptr);
 }
 
@@ -123,7 +123,7 @@ __device__ __forceinline__ void ft_store(const FtCtx& c, const FtState& st, doub
     for (int k = tid; k < c.m; k += NT) st.tslot[k] = c.tslot[k];
     for (int e = tid; e < c.eta_used; e += NT) { st.eta_idx[e] = c.eta_idx[e]; st.eta_val[e] = c.eta_val[e]; }
     if (minus_pi) for (int i = tid; i < c.m; i += NT) minus_pi[i] = c.pi[i];
-    if (tid == 0) { st.hdr[0] = c.t; st.hdr[1] = c.eta_used; st.hdr[2] = need_refactor; }
+    if (tid == 0) { st.hdr[0] = c.t; st.hdr[1] = c.eta_used; st.hdr[2] = need_refactor; st.hdr[3] = c.journal_n; }
 }
 
 // value of lane `src` (wave-uniform) in every lane
@@ -202,7 +202,8 @@ __device__ __forceinline__ void sweep(const FtState& st, int which, FtCtx& c, in
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
 // lower_upper/mod.rs:157-190
-__device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, FtCtx& c) {
+// spike_only: stop once the spike (what an update needs) is formed, before the solve with U
+__device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool spike_only = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     sweep(st, 0, c);
@@ -238,6 +239,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
     }
     c.clk.lap(FT_ETA_FWD);
     for (int k = tid; k < c.m; k += NT) c.sp[k] = c.x[k];          // the spike (mod.rs:176)
+    if (spike_only) { __syncthreads(); return; }
     if (t > 0) {
         __syncthreads();
         // the spike columns of the updated pivots act on the never-updated rows: x[k] -= U[k, p_s] z_s.  One wavefront per
@@ -620,14 +622,14 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     double minus_objective = rec->minus_objective;
     long long iterations = rec->iterations;
     int degenerate = rec->degenerate;
-    int outcome = DEV_RUNNING, need_refactor = 0;
+    int outcome = DEV_RUNNING, need_refactor = st.hdr[2] >= 2 ? 2 : 0;       // (2: a replay failed, the factors are unusable)
     int q = rec->q, r = rec->r, leaving = rec->leaving;
     double d_q = rec->d_q, alpha_r = rec->alpha_r, b_r = rec->b_r, key1 = rec->key1;
     PivotRecord fake;                                  // select_key reads rule memory through a record
     fake.last_selected = last_selected;
 
     for (long long it = 0; it < max_pivots; ++it) {
-        if (need_refactor || c.t >= st.max_updates || c.t >= c.tcap) { need_refactor = 1; break; }
+        if (need_refactor || c.t >= st.max_updates || c.t >= c.tcap) { if (!need_refactor) need_refactor = 1; break; }
         // ---- PRICE (pivot_rule.rs:38-126 over tableau/mod.rs:102-108): d_j = c_j + (-pi) . a_j, thread per column ----------
         fake.last_selected = last_selected;
         double key = INFINITY, kv = 0.0;
@@ -879,6 +881,8 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         c.clk.lap(FT_B);
         // ---- basis inverse: the Forrest-Tomlin update, then row r of the new inverse (mod.rs:92-155, 204-222) --------------
         const bool updated = ft_update(lu, st, c, r);
+        if (tid == 0 && c.journal_n < c.tcap) { st.journal[2 * c.journal_n] = r; st.journal[2 * c.journal_n + 1] = q; }
+        c.journal_n += 1;
         const int pl = c.icp[r];
         for (int k = tid; k < m; k += NT) c.x[k] = 0.0;
         __syncthreads();
@@ -1007,6 +1011,32 @@ void launch_ft_btran(const DeviceLU& lu, const FtState& st, const FtProblem& pb,
                      hipStream_t s) {
     ft_allow_lds(reinterpret_cast<const void*>(k_ft_btran), st.lds_bytes);
     hipLaunchKernelGGL(k_ft_btran, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, row, rhs, rho);
+}
+
+// The basis changes the pivot kernel made while the host was factorising an earlier basis, applied to those fresh factors:
+// per change the spike of the entering column (L solve + the etas replayed so far) and the Forrest-Tomlin update of the
+// leaving position -- what Carry::bring_into_basis does minus everything that is not the factorisation (b, -pi, the basis
+// array are already current).
+__global__ __launch_bounds__(NT) void k_ft_replay(DeviceLU lu, FtState st, FtProblem pb, int count) {
+    extern __shared__ __align__(16) char lds[];
+    FtCtx c;
+    ft_bind(c, lds, st);
+    ft_load(c, lu, st, nullptr);
+    int need = 0;
+    for (int i = 0; i < count; ++i) {
+        if (c.t >= c.tcap) { need = 2; break; }
+        const int r = st.journal[2 * i], q = st.journal[2 * i + 1];
+        ft_scatter_column(st, pb, c, q);
+        ft_ftran(lu, st, c, true);
+        if (!ft_update(lu, st, c, r)) { need = 2; break; }
+    }
+    if (!need && (c.t >= st.max_updates || c.t >= c.tcap)) need = 1;
+    ft_store(c, st, nullptr, need);
+}
+
+void launch_ft_replay(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t count, hipStream_t s) {
+    ft_allow_lds(reinterpret_cast<const void*>(k_ft_replay), st.lds_bytes);
+    hipLaunchKernelGGL(k_ft_replay, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, (int)count);
 }
 
 void launch_ft_update(const DeviceLU& lu, const FtState& st, const FtProblem& pb, hipStream_t s) {
