@@ -583,6 +583,14 @@ relp_status_t Engine::lu_phase_cycles(int64_t* out16) {
     if (!lu_ || !ft_) return fail(RELP_E_UNSUPPORTED, "phase clocks are the persistent pivot kernel's");
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemcpy(out16, fts_.prof, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (std::getenv("RELP_DEBUG")) {                       // passes walked per sweep of L, U, U', L' against the whole schedule
+        int64_t ex[12];
+        HIP_TRY(hipMemcpy(ex, fts_.prof + 16, sizeof ex, hipMemcpyDeviceToHost));
+        static const char* nm[4] = {"L", "U", "U'", "L'"};
+        for (int k = 0; k < 4; ++k)
+            if (ex[4 + k]) std::fprintf(stderr, "[relp] %s: %lld sweeps, %.1f passes walked of %.1f on average\n", nm[k], (long long)ex[4 + k],
+                                        (double)ex[k] / ex[4 + k], (double)ex[8 + k] / ex[4 + k]);
+    }
     return RELP_OK;
 }
 

@@ -50,16 +50,21 @@ enum FtPhase { FT_PRICE = 0, FT_SCATTER, FT_L, FT_ETA_FWD, FT_PUSH, FT_U, FT_RAT
                FT_LT, FT_VECTORS, FT_LOAD_STORE, FT_STAGE, FT_PHASES };
 struct FtClock {
     long long acc[FT_PHASES]; long long last; bool on;
+    long long passes[4], sweeps[4], total[4];        // per schedule: passes walked, sweeps, passes of the whole schedule
     __device__ __forceinline__ void start(const long long* out) {
         on = out != nullptr && threadIdx.x == 0;
         for (int k = 0; k < FT_PHASES; ++k) acc[k] = 0;
+        for (int k = 0; k < 4; ++k) { passes[k] = 0; sweeps[k] = 0; total[k] = 0; }
         last = on ? clock64() : 0;
     }
     __device__ __forceinline__ void lap(int phase) {            // phase is a constant at every call site: acc stays in registers
         if (on) { const long long now = clock64(); acc[phase] += now - last; last = now; }
     }
     __device__ __forceinline__ void flush(long long* out) {
-        if (on) for (int k = 0; k < FT_PHASES; ++k) out[k] += acc[k];
+        if (on) {
+            for (int k = 0; k < FT_PHASES; ++k) out[k] += acc[k];
+            for (int k = 0; k < 4; ++k) { out[16 + k] += passes[k]; out[20 + k] += sweeps[k]; out[24 + k] += total[k]; }
+        }
     }
 };
 
@@ -160,13 +165,17 @@ __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
             const int sc = s2 < 0 ? 0 : (s2 >= t ? t - 1 : s2);                 // (clamped: the load itself is unconditional)
             cf[j] = kRow ? TC[row * ldt + sc] : TC[sc * ldt + row];
-            asm volatile("" : "+v"(cf[j]));                                     // (keeps the compiler from sinking the load into a branch)
         }
+        // (all eight loads are issued before any is used, and none is sunk into the branch below: one wait per chunk)
+        asm volatile("" : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(cf[4]), "+v"(cf[5]), "+v"(cf[6]), "+v"(cf[7]));
+        // (straight-line selects: "after" is false by itself for the steps beyond t -- s2 >= t > lane ascending, s2 < 0 <= lane
+        // descending -- and written as a branch per element this block cost more than the eight chain steps it feeds)
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
-            const bool after = in && o < t && (kAsc ? lane > s2 : lane < s2);
-            buf[j] = after ? (cf[j] - (link == s2 ? 1.0 : 0.0)) * scale : 0.0;
+            const bool after = in && (kAsc ? lane > s2 : lane < s2);
+            const double msk = after ? scale : 0.0, lnk = link == s2 ? 1.0 : 0.0;
+            buf[j] = (cf[j] - lnk) * msk;
         }
     };
     const int nch = (t + CH - 1) / CH;
@@ -185,6 +194,9 @@ __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int
     return w;
 }
 
+// lanes per update slot when all t slots are worked on at once: 64, 32, 16 or 8 (as a shift)
+__device__ __forceinline__ int slot_lanes_shift(int t) { return t <= NT / 64 ? 6 : t <= NT / 32 ? 5 : t <= NT / 16 ? 4 : 3; }
+
 // sum over the 8 lanes of a group (valid in the group's lane 0), register to register
 __device__ __forceinline__ double sum8(double v) {
     v += dpp_row_shl<0x104>(v);
@@ -196,8 +208,10 @@ __device__ __forceinline__ double sum8(double v) {
 // `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
 __device__ __forceinline__ void sweep(const FtState& st, int which, FtCtx& c, int first_level = 0) {
     auto lap = [&]() { c.clk.lap(FT_STAGE); };
-    if (st.stage[which]) ell_solve_pp<true, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
-    else ell_solve_pp<false, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    int passes;
+    if (st.stage[which]) passes = ell_solve_pp<true, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    else passes = ell_solve_pp<false, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    if (c.clk.on) { c.clk.passes[which] += passes; c.clk.sweeps[which] += 1; c.clk.total[which] += st.ell[which].n_passes; }
 }
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
@@ -211,15 +225,16 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
     if (t > 0) {
         // eta.apply_right for every update (eta_file.rs:72-109): w[p_s] -= r_s . w.  The sparse parts read entries no
         // eta modifies (pivots never updated at the time), so all of them are formed first, a slot per wavefront ...
-        {   // eight lanes per slot: all slots at once
-            const int s = tid >> 3, l8 = tid & 7;
+        {   // all slots at once, 8 to 64 lanes per slot (as many as the workgroup has for t slots)
+            const int lg = slot_lanes_shift(t), G = 1 << lg;
+            const int s = tid >> lg, l = tid & (G - 1);
             double sum = 0.0;
             if (s < t) {
                 const int e0 = c.eta_off[s * (NW + 1)], e1 = c.eta_off[s * (NW + 1) + NW];
-                for (int e = e0 + l8; e < e1; e += 8) sum = fma(c.eta_val[e], c.x[c.eta_idx[e]], sum);
+                for (int e = e0 + l; e < e1; e += G) sum = fma(c.eta_val[e], c.x[c.eta_idx[e]], sum);
             }
-            sum = sum8(sum);
-            if (s < t && l8 == 0) c.dots[s] = sum;
+            sum = group_sum(sum, G);
+            if (s < t && l == 0) c.dots[s] = sum;
         }
         __syncthreads();
         // ... then the chain over the updated pivots (lane = slot), followed by the solve with the dense tail of U
@@ -304,25 +319,42 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
         }
         __syncthreads();
     }
+#ifdef UT_DIAG
+    c.clk.lap(FT_LOAD_STORE);
+#endif
     if (do_sweep) sweep(st, 2, c, first_level);
+#ifdef UT_DIAG
+    c.clk.lap(FT_UT);
+#endif
     if (t > 0) {
-        {   // spike column of slot s against y over the never-updated pivots: eight lanes per slot, all slots at once
-            const int s = tid >> 3, l8 = tid & 7;
+        {   // spike column of slot s against y over the never-updated pivots: all slots at once, 8 to 64 lanes per slot.  The
+            // spike pool is global (L2): four entries per lane are requested before the first is used -- a spike has up to a
+            // few hundred entries, and one entry per dependent round trip made this loop a tenth of the pivot.
+            const int lg = slot_lanes_shift(t), G = 1 << lg;
+            const int s = tid >> lg, l = tid & (G - 1);
             double sum = 0.0;
             if (s < t && do_sweep && c.slot_live[s]) {
                 const int base = s * c.m;
                 const int e0 = c.spk_off[s * (NW + 1)], e1 = c.spk_off[s * (NW + 1) + NW];
-#pragma unroll 4
-                for (int e = e0 + l8; e < e1; e += 8) {
-                    const int k = st.spk_idx[base + e];
-                    const double v = st.spk_val[base + e];
-                    if (c.tslot[k] < 0) sum = fma(v, c.x[k], sum);
+                for (int e = e0 + l; e < e1; e += 4 * G) {
+                    int k[4];
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int ee = min(e + u * G, e1 - 1); k[u] = st.spk_idx[base + ee]; v[u] = st.spk_val[base + ee]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool on = e + u * G < e1 && c.tslot[k[u]] < 0;
+                        sum = fma(on ? v[u] : 0.0, c.x[k[u]], sum);
+                    }
                 }
             }
-            sum = sum8(sum);
-            if (s < t && l8 == 0) c.dots[s] = sum;
+            sum = group_sum(sum, G);
+            if (s < t && l == 0) c.dots[s] = sum;
         }
         __syncthreads();
+#ifdef UT_DIAG
+        c.clk.lap(FT_B);
+#endif
         if (wave == 0) {
             const int s = lane;
             const bool in = s < t;
@@ -332,7 +364,11 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
         }
         __syncthreads();
     }
+#ifdef UT_DIAG
+    c.clk.lap(FT_VECTORS);
+#else
     c.clk.lap(FT_UT);
+#endif
 }
 
 // ---- BTRAN: c (pivot-indexed, i.e. Q' c) in x on entry; w = P z with z' B = c' on exit (mod.rs:204-222) ------------------

@@ -389,7 +389,7 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
 // Every wavefront joins the barrier that ends a level, whoever owned its last pass; two passes of one level may run at the
 // same time (they are independent).
 template <bool kStage, int NT, class Lap = NoLap>
-__device__ __forceinline__ void ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
+__device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
     static_assert(NT == 512, "two sets of 256 lanes");
     const EllImage im = ell_stage<kStage, NT>(s, base, x);
     const double* rdiag = im.rdiag; const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
@@ -397,7 +397,7 @@ __device__ __forceinline__ void ell_solve_pp(const EllSchedule& s, char* base, d
     lap();
     const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
     const int p0 = __builtin_amdgcn_readfirstlane(im.lvl_pass[fl]), p1 = s.n_passes;
-    if (p0 >= p1) return;                              // (uniform)
+    if (p0 >= p1) return 0;                            // (uniform)
     const int set = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), lt = threadIdx.x & 255;
     const int4* hdr = reinterpret_cast<const int4*>(im.passes);
     const int mm = s.m;
@@ -443,6 +443,7 @@ __device__ __forceinline__ void ell_solve_pp(const EllSchedule& s, char* base, d
         }
         z = zn; zn = znn;
     }
+    return p1 - p0;
 }
 
 }  // namespace relp
