@@ -1242,3 +1242,23 @@ def test_overlapped_flush_walks_the_same_pivots(path, fixed, monkeypatch):
     ident, basic, min_b = t.check_basis()
     assert ident <= 1e-9
     t.close()
+
+
+@pytest.mark.parametrize("path,fixed,objective,tol", FILES)
+def test_reference_problem_files_on_the_lu_engine_with_lookahead_refactorisation(path, fixed, objective, tol):
+    """The LU engine at a refactorisation interval of 24 (from 24 on the pivot kernel is relaunched on the old factors while
+    the host factorises a snapshot of the basis, and the basis changes made meanwhile are replayed on the new factors,
+    `Engine::lu_refactor_lookahead`): the pivot sequence of the f64 oracle and the reference's objective pin, like at the
+    reference's own cadence."""
+    from lp_files import load
+    gf, ex, md, emd = load(path, fixed=fixed)
+    t = engine.Tableau(md, trace_capacity=1 << 15, engine=engine.ENGINE_LU, update_block=24)
+    assert t.solve_relaxation() == engine.OPTIMAL
+    ref = relp_f64.OracleF64(md)
+    assert ref.run() == "optimal"
+    assert t.trace() == ref.trace
+    got = t.objective_function_value() + float(gf.fixed_cost)
+    assert abs(got - objective) < max(tol, 1e-9 * abs(objective))
+    if len(ref.trace) > 40:
+        assert t.lu_stats()["refactorisations"] >= 2
+    t.close()
