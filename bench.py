@@ -301,7 +301,8 @@ def sparse_path(events, with_cpu):
         out["kernels"] = kt
     if "ft_run" in kt and res["pivots"]:
         runs = kt["ft_run"]["launches"]
-        out["kernel_launches_per_pivot"] = round(stats["refactorisations"] / res["pivots"], 4)
+        # k_ft_run launches plus, with the look-ahead refactorisation, one k_ft_replay per refactorisation (bracketed as "flush")
+        out["kernel_launches_per_pivot"] = round((runs + kt.get("flush", {}).get("launches", 0)) / res["pivots"], 4)
         out["pivot_kernel_us_per_pivot"] = round(kt["ft_run"]["avg_us"] * runs / res["pivots"], 2)
     tot = sum(phases.values())
     if tot:
