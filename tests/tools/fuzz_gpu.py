@@ -21,7 +21,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # multiplies the problem sizes (multi-workgroup kernels)
 rng = np.random.default_rng(seed0)
-KINDS = [(engine.ENGINE_REVISED, (0, 1, 3, 7, 64)), (engine.ENGINE_TABLEAU, (1, 2, 5, 64)), (engine.ENGINE_LU, (1, 2, 6, 64))]
+KINDS = [(engine.ENGINE_REVISED, (0, 1, 3, 7, 64)), (engine.ENGINE_TABLEAU, (1, 2, 5, 64)), (engine.ENGINE_LU, (1, 2, 6, 24, 64))]     # 24: the smallest interval with the look-ahead refactorisation
 bad = 0
 undefined = 0
 stats = {"optimal": 0, "unbounded": 0, "infeasible": 0, "other": 0}
