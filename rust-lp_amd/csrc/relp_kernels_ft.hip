@@ -150,7 +150,9 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 // act, so a step is two v_readlane and one v_fma; steps beyond t (the last chunk) multiply by 0.  A lane's w no longer
 // changes once its own step has passed (its later coefficients are exact zeros), so the value it published is simply its
 // final w: no per-step capture.
-template <bool kAsc, bool kRow>
+// kLink / kScale: the chain uses `link` / a `scale` other than 1 (the eta chains link and do not scale, the solves with the
+// dense tail scale and do not link: three to four instructions less per coefficient)
+template <bool kAsc, bool kRow, bool kLink, bool kScale>
 __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int lane, double base, double sub, double scale,
                                            int link) {
     constexpr int CH = 8;
@@ -174,8 +176,8 @@ __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int
         for (int j = 0; j < CH; ++j) {
             const int o = ch * CH + j, s2 = kAsc ? o : t - 1 - o;
             const bool after = in && (kAsc ? lane > s2 : lane < s2);
-            const double msk = after ? scale : 0.0, lnk = link == s2 ? 1.0 : 0.0;
-            buf[j] = (cf[j] - lnk) * msk;
+            const double v = kLink ? cf[j] - (link == s2 ? 1.0 : 0.0) : cf[j];
+            buf[j] = kScale ? v * (after ? scale : 0.0) : (after ? v : 0.0);
         }
     };
     const int nch = (t + CH - 1) / CH;
@@ -243,11 +245,11 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
             const bool in = s < t;
             const int prev = in ? c.slot_prev[s] : -1, piv = in ? c.slot_pivot[s] : 0;
             const bool live = in && c.slot_live[s];
-            const double val = tc_chain<true, true>(c.TC, c.ldt, t, s, (in && prev < 0) ? c.x[piv] : 0.0, in ? c.dots[s] : 0.0, 1.0, prev);
+            const double val = tc_chain<true, true, true, false>(c.TC, c.ldt, t, s, (in && prev < 0) ? c.x[piv] : 0.0, in ? c.dots[s] : 0.0, 1.0, prev);
             if (live) c.x[piv] = val;
             // U z = w on the updated pivots: they are last in the order, so they are solved first (from the back)
             const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
-            const double z = tc_chain<false, true>(c.TC, c.ldt, t, s, live ? val : 0.0, 0.0, rdiag, -1);
+            const double z = tc_chain<false, true, false, true>(c.TC, c.ldt, t, s, live ? val : 0.0, 0.0, rdiag, -1);
             if (in) c.zt[s] = live ? z : 0.0;
         }
         __syncthreads();
@@ -359,7 +361,7 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
             const int s = lane;
             const bool in = s < t;
             const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
-            const double y = tc_chain<true, false>(c.TC, c.ldt, t, s, in ? c.ct[s] - c.dots[s] : 0.0, 0.0, rdiag, -1);
+            const double y = tc_chain<true, false, false, true>(c.TC, c.ldt, t, s, in ? c.ct[s] - c.dots[s] : 0.0, 0.0, rdiag, -1);
             if (in) c.zt[s] = c.slot_live[s] ? y : 0.0;
         }
         __syncthreads();
@@ -383,7 +385,7 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
             const bool in = s < t;
             const int nxt = in ? c.slot_next[s] : -1, prev = in ? c.slot_prev[s] : -1;
             // (a slot without successor is live: its value starts from y)
-            const double u = tc_chain<false, false>(c.TC, c.ldt, t, s, (in && nxt < 0) ? c.zt[s] : 0.0, 0.0, 1.0, nxt);
+            const double u = tc_chain<false, false, true, false>(c.TC, c.ldt, t, s, (in && nxt < 0) ? c.zt[s] : 0.0, 0.0, 1.0, nxt);
             if (in) {
                 c.uv[s] = u;
                 if (prev < 0) c.x[c.slot_pivot[s]] = u;          // the value every earlier eta (sparse part) and L' see
