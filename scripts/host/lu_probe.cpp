@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
                 x[r] = sum / t.diag[r]; } }
         double err = 0, nrm = 0;
         for (int i = 0; i < m; ++i) { err = std::max(err, std::fabs(x[i] - xr[i])); nrm = std::max(nrm, std::fabs(xr[i])); }
+        { int hist[8] = {0}; for (auto& ps : e.passes) ++hist[ps.info & 7]; std::printf("%s passes by widest row (2^lg lanes), lg 0..6:", nm[k]); for (int q = 0; q < 7; ++q) std::printf(" %d", hist[q]); std::printf("\n"); }
         std::printf("%s: %zu levels / %zu passes / %zu lanes  ->  %zu groups / %zu passes / %zu lanes (+%zu ovf), via %zu, fuse %.0f us, pack %.0f us, |dx| %.2e of %.2e\n",
                     nm[k], s[k]->level_ptr.size() - 1, e0.passes.size(), e0.sidx.size(), fs.s.level_ptr.size() - 1, e.passes.size(),
                     e.sidx.size(), e.oidx.size(), e.via_pos.size(), us, us_pack, err, nrm);
