@@ -341,6 +341,75 @@ __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alp
     ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
 }
 
+// The same choice without the bookkeeping: every thread of the workgroup returns with (row, leaving column), row = -1 when
+// no row qualifies.  For launches in which every workgroup needs the pivot row (k_tab_ratio_update_all).
+template <int BS>
+__device__ __forceinline__ void ratio_blocks_pick(const double* alpha, const double* b, const int32_t* basis_indices, int m,
+                                                  const Tolerances& tol, const double* rmin, int nblk, int* row_out, int* leave_out,
+                                                  double first = INFINITY, bool have_first = false, int rpb = kThreads) {
+    __shared__ double s_min[BS / 64];
+    __shared__ double s_bcast;
+    constexpr int kListMax = 64;
+    __shared__ int s_list[kListMax];
+    __shared__ int s_cnt;
+    __shared__ int s_cl[BS / 64];
+    __shared__ int s_cr[BS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // `first` = rmin[threadIdx.x] when the caller loaded it together with the record (have_first)
+    double mn = have_first ? first : INFINITY;
+    for (int t = threadIdx.x + (have_first ? BS : 0); t < nblk; t += BS) mn = fmin(mn, rmin[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+    if (lane == 0) s_min[wave] = mn;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double g = s_min[0];
+        for (int w = 1; w < BS / 64; ++w) g = fmin(g, s_min[w]);
+        s_bcast = g;
+    }
+    __syncthreads();
+    const double gmin = s_bcast;
+    if (gmin == INFINITY) { *row_out = -1; *leave_out = 0x7fffffff; return; }
+    const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
+    for (int t = threadIdx.x; t < nblk; t += BS) {
+        if (!(rmin[t] <= bound)) continue;
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < kListMax) s_list[pos] = t;
+    }
+    __syncthreads();
+    const int listed = s_cnt;
+    const bool use_list = listed <= kListMax;
+    const int total = (use_list ? listed : nblk) * rpb;
+    int best_leave = 0x7fffffff, best_row = -1;
+    for (int idx = threadIdx.x; idx < total; idx += BS) {
+        const int t = use_list ? s_list[idx / rpb] : idx / rpb;
+        const int i = t * rpb + idx % rpb;
+        if (i >= m) continue;
+        const double a = alpha[i];
+        double bi = b[i];
+        int lv = basis_indices[i];                     // with alpha and b: one round trip, not two
+        asm volatile("" : "+v"(lv));
+        if (bi <= tol.zero) bi = 0.0;
+        if (a > tol.pivot && bi / a <= bound) {
+            if (lv < best_leave) { best_leave = lv; best_row = i; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ol = __shfl_down(best_leave, off, 64);
+        const int orow = __shfl_down(best_row, off, 64);
+        if (ol < best_leave) { best_leave = ol; best_row = orow; }
+    }
+    if (lane == 0) { s_cl[wave] = best_leave; s_cr[wave] = best_row; }
+    __syncthreads();
+    best_leave = s_cl[0]; best_row = s_cr[0];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w)
+        if (s_cl[w] < best_leave) { best_leave = s_cl[w]; best_row = s_cr[w]; }
+    *row_out = best_row; *leave_out = best_leave;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace relp

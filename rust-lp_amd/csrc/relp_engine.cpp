@@ -2,7 +2,9 @@
 #include "relp_engine_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -23,7 +25,7 @@ void Engine::free_all() {
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
     fr(d_part_k1_); fr(d_part_j_);
-    fr(dT0_); fr(dR0_); fr(d_ticket_); fr(dT_alt_); fr(d_W_alt_); fr(dR0_alt_); fr(d_prev_p_);
+    fr(dT0_); fr(dR0_); fr(d_ticket_); fr(d_b_alt_); fr(d_basis_alt_); fr(d_shadow_); fr(d_shadow_meta_); fr(dT_alt_); fr(d_W_alt_); fr(dR0_alt_); fr(d_prev_p_);
     if (ev_boundary_) { (void)hipEventDestroy(ev_boundary_); ev_boundary_ = nullptr; }
     if (ev_flushed_) { (void)hipEventDestroy(ev_flushed_); ev_flushed_ = nullptr; }
     if (flush_stream_) { (void)hipStreamDestroy(flush_stream_); flush_stream_ = nullptr; }
@@ -308,6 +310,18 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
             ovl_pivots_ = std::max(1, std::min(w ? std::atoi(w) : block_ / 2, block_ - 1));
             if (block_ < 8) ovl_enabled_ = false;
         }
+        {   // two launches per pivot instead of three in the single-GPU loop (RELP_FUSED_UPDATE=0: k_ratio_blocks + k_tab_update_all)
+            const char* e = std::getenv("RELP_FUSED_UPDATE");
+            fused_update_ = cfg_.shard_count <= 1 && !ovl_enabled_ && !(e && std::atoi(e) == 0);
+            if (fused_update_) {
+                HIP_TRY(dev_alloc(&d_b_alt_, ld_b_));
+                HIP_TRY(dev_alloc(&d_basis_alt_, m_));
+                HIP_TRY(dev_alloc(&d_shadow_, std::max(block_, 1) + 1));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_shadow_meta_), 2 * sizeof(int32_t)));
+                const int32_t none[2] = {-1, 0};
+                HIP_TRY(hipMemcpy(d_shadow_meta_, none, sizeof none, hipMemcpyHostToDevice));
+            }
+        }
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
         {   // RELP_FUSED_RATIO=1: the ratio test inside the column kernel's last workgroup instead of a launch of its own.
             // Measured on dense10k: 30,500 it/s fused against 32,000 with three launches -- the two agent-scope fences
@@ -465,6 +479,24 @@ void Engine::enqueue_iteration_tableau(int rule) {
     const SelectPartials sp = tab_partials(rule);
     // 3 launches: [PRICE's final reduction + tableau column] -> [ratio test + block bookkeeping] ->
     // [tableau row / reduced costs / next PRICE partials  ||  W, b, basis]
+    if (fused_update_ && in_loop_) {
+        // 2 launches: [PRICE's final reduction + tableau column + block minima of the ratios] -> [ratio test in every
+        // workgroup + tableau row / reduced costs / next PRICE partials || W, b, basis]
+        prof_begin(RELP_K_FTRAN);
+        launch_tab_select_column_rmin(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_b_, tolerances(), d_rmin_,
+                                      d_rec_, stream_, nullptr, nullptr, d_shadow_, d_shadow_meta_);
+        prof_end();
+        prof_begin(RELP_K_PRICE);
+        launch_tab_ratio_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_b_alt_, d_basis_, d_basis_alt_, d_in_basis_, d_trace_,
+                                    trace_cap_, tolerances(), d_rmin_, d_shadow_, d_shadow_meta_, d_rec_, stream_);
+        prof_end();
+        std::swap(d_b_, d_b_alt_);
+        std::swap(d_basis_, d_basis_alt_);
+        shadow_pending_ = true;
+        if (++since_flush_ >= block_) enqueue_flush();
+        return;
+    }
+    tab_settle();
     prof_begin(RELP_K_FTRAN);
     launch_tab_select_column_rmin(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_b_, tolerances(), d_rmin_,
                                   d_rec_, stream_, d_basis_, d_ticket_);
@@ -596,6 +628,10 @@ bool Engine::ovl_prepare() {
 }
 
 void Engine::tab_settle() {
+    if (shadow_pending_) {                             // the fused update's new row r of W is still in its shadow row
+        launch_tab_apply_shadow(deferred(), d_shadow_, d_shadow_meta_, stream_);
+        shadow_pending_ = false;
+    }
     if (!ovl_pending_) return;
     (void)hipStreamWaitEvent(stream_, ev_flushed_, 0);
     std::swap(dT0_, dT_alt_);
@@ -871,10 +907,13 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
         tab_partials_valid_ = true;
     }
     int64_t next_poll = phase_ == 1 ? 1 : cfg_.poll_interval;
+    const auto t_enq0 = std::chrono::steady_clock::now();
+    int64_t enqueued = 0;
     {
     LoopScope loop(*this);
     for (int64_t it = 0; it < max_iters && h_rec_->outcome == DEV_RUNNING; ++it) {
         enqueue_iteration(rule);
+        ++enqueued;
         if (lu_status_) { const relp_status_t e = lu_status_; lu_status_ = RELP_OK; return e; }
         if (reinvert_interval_ > 0 && ++since_reinvert_ >= reinvert_interval_) {
             if ((st = download_rec())) return st;
@@ -888,6 +927,9 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
         }
     }
     }
+    if (std::getenv("RELP_DEBUG") && enqueued >= 64)
+        std::fprintf(stderr, "[relp] run: %lld pivots enqueued in %.1f us of host time each\n", (long long)enqueued,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq0).count() / enqueued);
     if ((st = download_rec())) return st;
     if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
     int32_t oc = RELP_RUNNING;

@@ -152,6 +152,11 @@ class Engine {
     double* d_cost_store_ = nullptr;     // cost per stored column in the current phase
     int32_t* d_idcol_ = nullptr;         // stored column that was e_k originally, per row k
     int32_t* d_ticket_ = nullptr;        // k_tab_select_column: tickets of the finished workgroups (fused ratio test)
+    // Ratio test + update in one launch (single-GPU loop, relp_kernels.h: launch_tab_ratio_update_all): the second copies of b
+    // and the basis array it writes (swapped with d_b_ / d_basis_ after every pivot), the shadow row of W and its {row, length}
+    bool fused_update_ = false, shadow_pending_ = false;
+    double *d_b_alt_ = nullptr, *d_shadow_ = nullptr;
+    int32_t *d_basis_alt_ = nullptr, *d_shadow_meta_ = nullptr;
     double* d_rmin_ = nullptr;           // minimum ratio per block of 256 rows (k_tab_select_column -> k_ratio_blocks)
     int32_t n_store_ = 0;                // stored columns = original artificials + provider columns
     int32_t tab_na_ = 0;                 // original number of artificial columns (their block is kept)

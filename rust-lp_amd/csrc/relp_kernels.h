@@ -34,6 +34,9 @@ struct PivotRecord {
     int32_t eta_target;     // deferred update: column of W that receives this pivot's u
     int32_t n_eta_old;      // deferred update: n_eta before this pivot
     int32_t degenerate;     // pivots so far whose ratio b_r / alpha_r was exactly 0 (reported for config C5)
+    int32_t p_now;          // n_eta as the column kernel of this pivot saw it (the fused ratio + update launch reads this copy:
+                            // its first workgroup rewrites n_eta while later ones may not have started)
+    int32_t pad2_;
 };
 
 // Deferred (blocked) update of the explicit inverse:  B^-1 = (I + W S') B0inv, where B0inv is the
@@ -362,7 +365,8 @@ void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, S
 // is then not needed)
 void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                    double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
-                                   hipStream_t s, const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr);
+                                   hipStream_t s, const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr,
+                                   const double* shadow = nullptr, int32_t* shadow_meta = nullptr);
 void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
                          const DeferredUpdate& du, const double* rmin, PivotRecord* rec, hipStream_t s);
 // sharded engines: this rank's candidate message [key, j, d_j, alpha (m), minimum ratio per block of 256 rows
@@ -390,6 +394,16 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
 // T_dst = T0 + W R0 with p = *p_dev pivots rows (T_dst = nullptr: in place, p from the record)
 void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s,
                       double* T_dst = nullptr, const int32_t* p_dev = nullptr);
+// Ratio test + update in ONE launch (single-GPU loop): every workgroup repeats the ratio test from the block minima the column
+// kernel left (same code, same answer), then does its share of the update.  What one workgroup rewrites while another may
+// still read it is double-buffered: b and the basis array (in -> out, the caller swaps them), row r of W (its new values go
+// to `shadow`, {row, length} to `shadow_meta`; the next column kernel or launch_tab_apply_shadow folds them into W), n_eta
+// (read as PivotRecord::p_now).
+void launch_tab_ratio_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
+                                 const double* alpha, const double* b_in, double* b_out, const int32_t* basis_in,
+                                 int32_t* basis_out, uint8_t* in_basis, int32_t* trace, int64_t trace_cap, Tolerances tol,
+                                 const double* rmin, double* shadow, int32_t* shadow_meta, PivotRecord* rec, hipStream_t s);
+void launch_tab_apply_shadow(const DeferredUpdate& du, double* shadow, int32_t* shadow_meta, hipStream_t s);
 // end of a block whose flush is overlapped: *prev_p = pivot rows of the block, then the record / row map start a new block
 void launch_tab_block_rollover(const DeferredUpdate& du, PivotRecord* rec, int32_t* prev_p, hipStream_t s);
 // out[i, k] = T0[i, cols[k]] (row-major m x m): B^-1 from the identity columns

@@ -161,15 +161,14 @@ __global__ __launch_bounds__(kThreads) void k_tab_column(TableauView tv, Deferre
 // `block` = index of this workgroup among the row-update workgroups.
 // `R` is the workgroup's snapshot of the PivotRecord (one cache line, fetched once at kernel start: reading
 // it field by field between stores costs a dependent memory round trip each time).
-__device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const DeferredUpdate& du,
-                                                    const SelectPartials& sp, const PivotRecord& R, int block) {
-    __shared__ double s_wr[kMaxEta];
+// `wr` (shared memory) = row r of W before this pivot; the pivot itself as plain arguments (the fused launch computes them
+// per workgroup, the others take them from the record).  `R` is only read for the selection key's rule memory.
+__device__ __forceinline__ void tab_row_update_core(const TableauView& tv, const DeferredUpdate& du, const SelectPartials& sp,
+                                                    const PivotRecord& R, int block, const double* s_wr, int p_old, int jt, int r,
+                                                    int q, int leaving, double d_q, double alpha_r) {
     __shared__ double s_wp[kMaxEta];                   // row r of the previous block's W (overlapped flush)
     const PivotRecord* rec = &R;
-    const int p_old = R.n_eta_old, jt = R.eta_target, r = R.r, q = R.q, leaving = R.leaving;
     const int pp = (tv.pp && jt >= p_old) ? *tv.pp : 0;
-    // fetched without waiting for p_old (entries beyond it are never used)
-    if ((int)threadIdx.x < du.kmax) s_wr[threadIdx.x] = du.wr[threadIdx.x];
     if ((int)threadIdx.x < pp) s_wp[threadIdx.x] = tv.Wp[(int64_t)threadIdx.x * du.ld + r];
     const int c = tv.c_lo + block * kThreads + threadIdx.x;
     const double d_old = c < tv.c_hi ? tv.d[c] : 0.0;
@@ -188,7 +187,7 @@ __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const
         }
         double row = base;
         for (int j = 0; j < p_old; ++j) row = fma(s_wr[j], tv.R0[(int64_t)j * tv.ld_r + c], row);
-        const double theta = R.d_q / R.alpha_r;
+        const double theta = d_q / alpha_r;
         const int j = c - tv.col_off;
         double dn = fma(-theta, row, d_old);
         if (j == q) dn = 0.0;
@@ -200,6 +199,14 @@ __device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const
         }
     }
     block_partial_min(key, kj, sp, block);
+}
+
+__device__ __forceinline__ void tab_row_update_body(const TableauView& tv, const DeferredUpdate& du,
+                                                    const SelectPartials& sp, const PivotRecord& R, int block) {
+    __shared__ double s_wr[kMaxEta];
+    // fetched without waiting for p_old (entries beyond it are never used)
+    if ((int)threadIdx.x < du.kmax) s_wr[threadIdx.x] = du.wr[threadIdx.x];
+    tab_row_update_core(tv, du, sp, R, block, s_wr, R.n_eta_old, R.eta_target, R.r, R.q, R.leaving, R.d_q, R.alpha_r);
 }
 
 __global__ __launch_bounds__(kThreads) void k_tab_row_update(TableauView tv, DeferredUpdate du, SelectPartials sp,
@@ -283,6 +290,111 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, Def
     else tab_update_w_vectors_body(du, m, alpha, b, basis_indices, in_basis, trace, trace_cap, R, rec, blockIdx.x - nb_row);
 }
 
+// Ratio test + both halves of the update in ONE launch (relp_kernels.h: launch_tab_ratio_update_all).  Workgroups
+// [0, nb_row): tableau row / reduced costs / PRICE partials; [nb_row, ..): W, b, basis, bookkeeping.  Every workgroup repeats
+// the ratio test (ratio_blocks_pick: same inputs, same code, same row) and fetches row r of W, alpha_r, b_r and the slot of
+// row r itself.  Nothing a workgroup reads is rewritten by another one in this launch: b and the basis array go in -> out,
+// the new row r of W goes to `shadow`, n_eta is read as p_now; the basis flags are read through the expression that is
+// the same for old and new flags; pos_of_row[r] reads as -1 or as the value it is about to get.  Same arithmetic as
+// k_ratio_blocks + k_tab_update_all, bit for bit.
+__global__ __launch_bounds__(kThreads) void k_tab_ratio_update_all(TableauView tv, DeferredUpdate du, SelectPartials sp, int nb_row,
+                                                                   int m, const double* __restrict__ alpha,
+                                                                   const double* __restrict__ b_in, double* __restrict__ b_out,
+                                                                   const int32_t* __restrict__ basis_in,
+                                                                   int32_t* __restrict__ basis_out, uint8_t* in_basis,
+                                                                   int32_t* __restrict__ trace, int64_t trace_cap, Tolerances tol,
+                                                                   const double* __restrict__ rmin, int nblk,
+                                                                   double* __restrict__ shadow, int32_t* __restrict__ shadow_meta,
+                                                                   PivotRecord* rec) {
+    const double first = (int)threadIdx.x < nblk ? rmin[threadIdx.x] : INFINITY;      // in flight with the record
+    const PivotRecord R = *rec;
+    const bool w_half = (int)blockIdx.x >= nb_row;
+    const int wblock = (int)blockIdx.x - nb_row;
+    const int i = wblock * kThreads + threadIdx.x;
+    // the loop has ended (or ends here): the double buffers still advance, because the host keeps swapping them
+    const bool mine = w_half && i < m;
+    if (R.outcome != DEV_RUNNING) {
+        if (mine) { b_out[i] = b_in[i]; basis_out[i] = basis_in[i]; }
+        return;
+    }
+    int r, leaving;
+    ratio_blocks_pick<kThreads>(alpha, b_in, basis_in, m, tol, rmin, nblk, &r, &leaving, first, true);
+    if (r < 0) {
+        if (mine) { b_out[i] = b_in[i]; basis_out[i] = basis_in[i]; }
+        if (wblock == 0 && threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
+        return;
+    }
+    __shared__ double s_wr[kMaxEta];
+    __shared__ double s_ab[2];
+    __shared__ int s_jt;
+    const int p_old = R.p_now;
+    if ((int)threadIdx.x < p_old) s_wr[threadIdx.x] = du.W[(int64_t)threadIdx.x * du.ld + r];
+    if (threadIdx.x == 0) {
+        s_ab[0] = alpha[r]; s_ab[1] = b_in[r];
+        const int slot = du.pos_of_row[r];
+        s_jt = slot < 0 ? p_old : slot;
+    }
+    __syncthreads();
+    const double alpha_r = s_ab[0], b_r = s_ab[1];
+    const int jt = s_jt, q = R.q;
+    if (!w_half) {
+        tab_row_update_core(tv, du, sp, R, blockIdx.x, s_wr, p_old, jt, r, q, leaving, R.d_q, alpha_r);
+        return;
+    }
+    const double br = b_r / alpha_r;
+    if (i < m) {
+        const double a = alpha[i], b_i = b_in[i];
+        const double u = (i == r) ? (1.0 / alpha_r - 1.0) : (-a / alpha_r);
+        if (i != r) {
+            if (u != 0.0) {
+                for (int j = 0; j < p_old; ++j) {
+                    const double w = s_wr[j];
+                    if (w != 0.0) du.W[(int64_t)j * du.ld + i] = fma(u, w, du.W[(int64_t)j * du.ld + i]);
+                }
+            }
+            double* tgt = du.W + (int64_t)jt * du.ld + i;
+            if (jt < p_old) *tgt += u; else *tgt = u;
+        } else {
+            // row r itself: other workgroups are reading its old values right now, the new ones go to the shadow row
+            for (int j = 0; j < p_old; ++j) {
+                const double w = s_wr[j];
+                shadow[j] = (u != 0.0 && w != 0.0) ? fma(u, w, w) : w;
+            }
+            if (jt < p_old) shadow[jt] += u; else shadow[jt] = u;
+            shadow_meta[0] = r;
+            shadow_meta[1] = jt < p_old ? p_old : p_old + 1;
+        }
+        b_out[i] = (i == r) ? br : (a != 0.0 ? fma(-a, br, b_i) : b_i);
+        basis_out[i] = (i == r) ? q : basis_in[i];
+    }
+    if (i == 0) {
+        rec->r = r; rec->leaving = leaving; rec->alpha_r = alpha_r; rec->b_r = b_r;
+        rec->n_eta_old = p_old; rec->eta_target = jt;
+        if (jt >= p_old) { du.S[p_old] = r; du.pos_of_row[r] = p_old; rec->n_eta = p_old + 1; }
+        rec->minus_objective = fma(-R.d_q, br, R.minus_objective);
+        if (leaving < kWrappedArtificialBase) in_basis[leaving] = 0;   // a wrapped artificial has no flag
+        in_basis[q] = 1;
+        const long long it = R.iterations;
+        if (trace && it < trace_cap) {
+            trace[0 * trace_cap + it] = R.phase;
+            trace[1 * trace_cap + it] = q;
+            trace[2 * trace_cap + it] = r;
+            trace[3 * trace_cap + it] = leaving;
+        }
+        if (br == 0.0) rec->degenerate += 1;
+        rec->iterations = it + 1;
+    }
+}
+
+// Folds a pending shadow row (k_tab_ratio_update_all) into W; {row, length} = {-1, 0} afterwards.
+__global__ void k_tab_apply_shadow(DeferredUpdate du, double* __restrict__ shadow, int32_t* __restrict__ shadow_meta) {
+    const int row = shadow_meta[0], len = shadow_meta[1];
+    if (row < 0) return;
+    for (int j = threadIdx.x; j < len; j += blockDim.x) du.W[(int64_t)j * du.ld + row] = shadow[j];
+    __syncthreads();
+    if (threadIdx.x == 0) shadow_meta[0] = -1;
+}
+
 // PRICE's final reduction and the tableau column in one launch: every workgroup reduces the (few)
 // partials to the same entering column q, then forms alpha = T0[:,q] + W R0[:,q] for its rows.
 // `msg` (sharded engines): the candidate message [key, j, d_j, alpha(m)] of this rank is written instead
@@ -297,8 +409,20 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
                                                                 int count, double* alpha, double* msg,
                                                                 const double* b, Tolerances tol,
                                                                 double* rmin, PivotRecord* rec,
-                                                                const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr) {
+                                                                const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr,
+                                                                const double* shadow = nullptr, int32_t* shadow_meta = nullptr) {
     const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both ...
+    // ... and for the shadow row of the previous pivot's fused update: the workgroup that owns the row folds it into W before
+    // it reads the row (no other workgroup reads it)
+    if (shadow_meta) {
+        const int srow = shadow_meta[0], slen = shadow_meta[1];
+        if (srow >= 0 && srow / kThreads == (int)blockIdx.x) {
+            if ((int)threadIdx.x < slen) du.W[(int64_t)threadIdx.x * du.ld + srow] = shadow[threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x == 0) shadow_meta[0] = -1;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) rec->p_now = p;
+    }
     // ... and for the first PRICE partial and b of this thread's row, which do not depend on the record
     double k1 = INFINITY;
     int bj = 0x7fffffff;
@@ -821,14 +945,29 @@ void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, S
                               double* alpha, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
                        (double*)nullptr, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec, (const int32_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, (const double*)nullptr, (int32_t*)nullptr);
 }
 
 void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                    double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
-                                   hipStream_t s, const int32_t* basis_indices, int32_t* ticket) {
+                                   hipStream_t s, const int32_t* basis_indices, int32_t* ticket, const double* shadow,
+                                   int32_t* shadow_meta) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       (double*)nullptr, b, tol, rmin, rec, basis_indices, ticket);
+                       (double*)nullptr, b, tol, rmin, rec, basis_indices, ticket, shadow, shadow_meta);
+}
+
+void launch_tab_ratio_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
+                                 const double* alpha, const double* b_in, double* b_out, const int32_t* basis_in,
+                                 int32_t* basis_out, uint8_t* in_basis, int32_t* trace, int64_t trace_cap, Tolerances tol,
+                                 const double* rmin, double* shadow, int32_t* shadow_meta, PivotRecord* rec, hipStream_t s) {
+    const int nb_row = tv.c_hi > tv.c_lo ? tab_scan_blocks(tv.c_hi - tv.c_lo) : 0;
+    const int nb_w = cdiv(m, kThreads);
+    hipLaunchKernelGGL(k_tab_ratio_update_all, dim3(nb_row + nb_w), dim3(kThreads), 0, s, tv, du, sp, nb_row, m, alpha, b_in,
+                       b_out, basis_in, basis_out, in_basis, trace, trace_cap, tol, rmin, nb_w, shadow, shadow_meta, rec);
+}
+
+void launch_tab_apply_shadow(const DeferredUpdate& du, double* shadow, int32_t* shadow_meta, hipStream_t s) {
+    hipLaunchKernelGGL(k_tab_apply_shadow, dim3(1), dim3(128), 0, s, du, shadow, shadow_meta);
 }
 
 void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
@@ -840,7 +979,8 @@ void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* ba
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                   double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
-                       msg, b, tol, msg + 3 + tv.m, rec, (const int32_t*)nullptr, (int32_t*)nullptr);
+                       msg, b, tol, msg + 3 + tv.m, rec, (const int32_t*)nullptr, (int32_t*)nullptr, (const double*)nullptr,
+                       (int32_t*)nullptr);
 }
 
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
