@@ -14,7 +14,11 @@
 
 #include <cstdint>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/relp_engine.h"
@@ -199,6 +203,39 @@ class Engine {
     int64_t* d_cptr_ = nullptr; int32_t* d_cidx_ = nullptr; double* d_cval_ = nullptr;         // device CSC of A
     LUFactors hlu_;
     char* d_lu_buf_ = nullptr; int64_t lu_cap_ = 0;       // packed factors (permutations, rows, entries, levels)
+    std::vector<std::vector<std::pair<int32_t, double>>> basis_cols_;      // the basis columns handed to lu_factor
+    // two helper threads for the host side of a refactorisation (created at first use, joined with the engine)
+    struct HostPool {
+        struct Slot { std::thread th; std::mutex mu; std::condition_variable cv; std::function<void()> job; bool busy = false, stop = false; };
+        Slot slot[2];
+        void run(int i, std::function<void()> f) {
+            Slot& s = slot[i];
+            if (!s.th.joinable())
+                s.th = std::thread([&s] {
+                    std::unique_lock<std::mutex> lk(s.mu);
+                    for (;;) {
+                        s.cv.wait(lk, [&s] { return s.busy || s.stop; });
+                        if (s.stop) return;
+                        lk.unlock(); s.job(); lk.lock();
+                        s.busy = false;
+                        s.cv.notify_all();
+                    }
+                });
+            { std::lock_guard<std::mutex> lk(s.mu); s.job = std::move(f); s.busy = true; }
+            s.cv.notify_all();
+        }
+        void wait() {
+            for (Slot& s : slot) { std::unique_lock<std::mutex> lk(s.mu); s.cv.wait(lk, [&s] { return !s.busy; }); }
+        }
+        ~HostPool() {
+            for (Slot& s : slot) {
+                if (!s.th.joinable()) continue;
+                { std::lock_guard<std::mutex> lk(s.mu); s.stop = true; }
+                s.cv.notify_all();
+                s.th.join();
+            }
+        }
+    } host_pool_;
     char* h_lu_buf_ = nullptr; size_t h_lu_cap_ = 0;      // the same, assembled in pinned host memory
     char* d_lu_buf_alt_ = nullptr; int64_t lu_cap_alt_ = 0;   // second device buffer: the factors the host prepares while the kernel runs
     int32_t* h_basis_ = nullptr; int32_t m_alloc_rows_ = 0;   // pinned: the basis a refactorisation downloads

@@ -72,10 +72,12 @@ relp_status_t Engine::lu_download_basis() {
 // P B Q = L U on the host for the basis in h_basis_ (hlu_ is overwritten)
 relp_status_t Engine::lu_factor_downloaded_basis() {
     const int32_t* const basis = h_basis_;
-    std::vector<std::vector<std::pair<int32_t, double>>> cols(m_);
+    std::vector<std::vector<std::pair<int32_t, double>>>& cols = basis_cols_;     // (kept: no 790 allocations per refactorisation)
+    cols.resize(m_);
     for (int32_t i = 0; i < m_; ++i) {
         const int32_t j = basis[i];
         auto& c = cols[i];
+        c.clear();
         if (j < nr_artificial_) { c.emplace_back(column_to_row_[j], 1.0); continue; }
         if (j >= kWrappedArtificialBase) {                      // artificial that survived phase 1: still e_row
             c.emplace_back(column_to_row_[wrapped_na_ - 1 - (INT32_MAX - j)], 1.0);
@@ -242,14 +244,27 @@ relp_status_t Engine::lu_upload_factors() {
     if (ft_) {
         static const int32_t fuse_cap = [] { const char* e = std::getenv("RELP_FUSE_LANES"); return e ? std::atoi(e) : 256; }();
         const int32_t cap = 2 * (int64_t)m_ + 1 < (1 << kEllLgShift) ? fuse_cap : 0;      // index space of the rhs copy
-        for (int k = 0; k < 4; ++k) {
+        // fusion and packing of the four schedules are independent: U on this thread, U' and L + L' on two helpers (the
+        // refactorisation runs beside the pivot kernel, and what the host takes longer than the kernel's look-ahead the
+        // device waits)
+        auto prepare = [&](int k) {
             const bool maskable = k == 1 || k == 2;
             FusedSchedule fs;
             fuse_levels(*sch[k], maskable, maskable, cap, &fs);
             ell_pack(fs, maskable, &ell[k]);
             if (k == 2) lev_ub = fs.start_after;
-            const EllPacked& e = ell[k];
             for (int32_t v : fs.s.idx) if (v >= fs.rhs_base) { rhs_base[k] = fs.rhs_base; break; }
+        };
+        if (m_ >= 256) {
+            host_pool_.run(0, [&] { prepare(2); });
+            host_pool_.run(1, [&] { prepare(0); prepare(3); });
+            prepare(1);
+            host_pool_.wait();
+        } else {
+            for (int k = 0; k < 4; ++k) prepare(k);
+        }
+        for (int k = 0; k < 4; ++k) {
+            const EllPacked& e = ell[k];
             std::vector<EllPassHost> hdrs(e.passes);
             hdrs.resize(hdrs.size() + kEllPadHeaders, EllPassHost{0, 0, 0, 0});       // the kernel reads headers ahead
             o_ell[k] = put(hdrs.data(), sizeof(EllPassHost) * hdrs.size());
