@@ -32,6 +32,7 @@ void Engine::free_all() {
     d_W_prev_ = nullptr; dR0_prev_ = nullptr; ovl_pending_ = false;
     if (h_lu_buf_) { (void)hipHostFree(h_lu_buf_); h_lu_buf_ = nullptr; h_lu_cap_ = 0; }
     if (h_basis_) { (void)hipHostFree(h_basis_); h_basis_ = nullptr; }
+    if (h_mirror_) { (void)hipHostFree(h_mirror_); h_mirror_ = nullptr; d_mirror_ = nullptr; }
     fr(d_cost_store_); fr(d_idcol_); fr(d_rmin_);
     fr(d_msg_cand_); fr(d_msg_cands_); fr(d_msg_slice_); fr(d_msg_slices_); fr(d_msg_rho_); fr(d_msg_status_); fr(d_msg_statuses_);
     fr(d_v_); fr(d_W_); fr(d_wr_); fr(d_R_); fr(d_S_); fr(d_pos_of_row_);

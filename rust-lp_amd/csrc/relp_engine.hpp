@@ -56,7 +56,8 @@ class Engine {
     relp_status_t lu_phase_cycles(int64_t* out16);
     relp_status_t lu_download_basis();
     relp_status_t lu_factor_downloaded_basis();
-    relp_status_t lu_refactor_lookahead(int rule, int64_t budget);
+    relp_status_t lu_refactor_lookahead(int rule, int64_t budget, bool have_basis);
+    relp_status_t ft_read_report(bool* have_basis);
     void lu_refactor_clock(std::chrono::steady_clock::time_point tb, std::chrono::steady_clock::time_point t0,
                            std::chrono::steady_clock::time_point t1, std::chrono::steady_clock::time_point t2);
     // BasisInverse surface of the LU engine (carry/mod.rs:68-157, lower_upper/mod.rs:199-222)
@@ -239,6 +240,7 @@ class Engine {
     char* h_lu_buf_ = nullptr; size_t h_lu_cap_ = 0;      // the same, assembled in pinned host memory
     char* d_lu_buf_alt_ = nullptr; int64_t lu_cap_alt_ = 0;   // second device buffer: the factors the host prepares while the kernel runs
     int32_t* h_basis_ = nullptr; int32_t m_alloc_rows_ = 0;   // pinned: the basis a refactorisation downloads
+    FtMirror* h_mirror_ = nullptr; FtMirror* d_mirror_ = nullptr;   // pinned + mapped: what k_ft_run reports (relp_kernels.h)
     double* d_lu_scratch_ = nullptr;
     DeviceLU dlu_{};
     relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop

@@ -145,9 +145,9 @@ relp_status_t Engine::lu_refactor() {
 // journal) are applied to them as Forrest-Tomlin updates by k_ft_replay: the device pivots for the ~0.6 ms it used to
 // wait.  If the kernel ended the phase meanwhile, the new factors are dropped: the old ones with their update file
 // describe the final basis.
-relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget) {
+relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget, bool have_basis) {
     const auto tb = std::chrono::steady_clock::now();
-    relp_status_t st = lu_download_basis();
+    relp_status_t st = have_basis ? RELP_OK : lu_download_basis();       // (have_basis: the kernel's own report held it)
     if (st) return st;
     FtState go = fts_;
     go.max_updates = std::max(go.max_updates, std::min(cfg_.update_block < 0 ? ft_tcap_ : cfg_.update_block, ft_tcap_));
@@ -173,14 +173,11 @@ relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget) {
     if (!st) st = lu_upload_factors();                     // (its copy queues behind the kernel; it returns when both are done)
     if (st) {                                              // keep what works; the kernel's result decides what happens next
         restore();
-        (void)hipStreamSynchronize(stream_);
-        HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
-        relp_status_t st2 = ft_read_hdr();
+        relp_status_t st2 = ft_read_report(nullptr);
         ft_need_refactor_ = true;
         return st2 ? st2 : st;
     }
-    HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
-    if ((st = ft_read_hdr())) { restore(); return st; }
+    if ((st = ft_read_report(nullptr))) { restore(); return st; }
     const int32_t changes = h_ft_hdr_[3];
     if (h_rec_->outcome != DEV_RUNNING || h_ft_hdr_[2] == 2 || changes > ft_tcap_) {
         restore();                                         // phase over (or something off): nothing to install
@@ -439,6 +436,17 @@ relp_status_t Engine::ft_plan_and_alloc() {
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_ft_hdr_), 4 * sizeof(int32_t), hipHostMallocDefault));
     std::memset(h_ft_hdr_, 0, 4 * sizeof(int32_t));
+    {   // the kernel's report in mapped host memory; without it (allocation refused) the copies below do the same job
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(FtMirror) + sizeof(int32_t) * (size_t)m_, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            h_mirror_ = static_cast<FtMirror*>(hp); d_mirror_ = static_cast<FtMirror*>(dp);
+            std::memset(h_mirror_, 0, sizeof(FtMirror));
+        } else {
+            if (hp) (void)hipHostFree(hp);
+            (void)hipGetLastError();
+        }
+    }
     fts_ = FtState{};
     fts_.m = m_; fts_.tcap = ft_tcap_; fts_.ldt = (int32_t)ldt; fts_.eta_cap = ft_eta_cap_;
     fts_.hdr = reinterpret_cast<int32_t*>(d_ft_buf_ + o_hdr);
@@ -531,12 +539,33 @@ relp_status_t Engine::ft_read_hdr() {
     return RELP_OK;
 }
 
+// After a k_ft_run launch: record, header and (mirror only) the basis on the host.  Synchronises the stream.
+relp_status_t Engine::ft_read_report(bool* have_basis) {
+    if (have_basis) *have_basis = false;
+    if (!h_mirror_) {
+        HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
+        return ft_read_hdr();
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *h_rec_ = h_mirror_->rec;
+    std::memcpy(h_ft_hdr_, h_mirror_->hdr, 4 * sizeof(int32_t));
+    since_flush_ = h_ft_hdr_[0];
+    ft_need_refactor_ = h_ft_hdr_[2] != 0;
+    if (have_basis) {
+        if (!h_basis_) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_basis_), sizeof(int32_t) * (size_t)std::max(m_alloc_rows_, m_), hipHostMallocDefault));
+        std::memcpy(h_basis_, h_mirror_->basis, sizeof(int32_t) * (size_t)m_);     // (the next launch rewrites the mirror)
+        *have_basis = true;
+    }
+    return RELP_OK;
+}
+
 FtProblem Engine::ft_problem(int rule) const {
     FtProblem pb{};
     pb.csc = csc(); pb.ct = table(); pb.pe = pe_;
     pb.minus_pi = d_minus_pi_; pb.b = d_b_; pb.alpha = d_alpha_; pb.rho = d_rho_; pb.d = d_d_;
     pb.basis = d_basis_; pb.in_basis = d_in_basis_; pb.trace = d_trace_; pb.trace_cap = trace_cap_;
     pb.rec = d_rec_;
+    pb.mirror = d_mirror_;
     pb.tol = tolerances();
     pb.rule = rule; pb.n = nr_columns(); pb.phase = phase_;
     return pb;
@@ -554,12 +583,14 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     // the rest while the host factorises.  On for refactorisation intervals from 24 on; RELP_LU_LOOKAHEAD = 0 switches it off.
     static const int32_t la_env = [] { const char* e = std::getenv("RELP_LU_LOOKAHEAD"); return e ? std::atoi(e) : 8; }();
     const int32_t la = (fts_.max_updates >= 24 && la_env > 0) ? std::min(la_env, fts_.max_updates / 3) : 0;
+    bool have_basis = false;                               // h_basis_ holds the basis as the last launch left it
     while (h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters) {
         if (ft_need_refactor_) {
             const bool ahead = la > 0 && h_ft_hdr_[2] == 1 && h_ft_hdr_[0] == fts_.max_updates - la;
             prof_tick_ = 0;                                // refactorisations are always bracketed (like the flush)
             if (ahead) {
-                if ((st = lu_refactor_lookahead(rule, max_iters - (h_rec_->iterations - start)))) return st;
+                if ((st = lu_refactor_lookahead(rule, max_iters - (h_rec_->iterations - start), have_basis))) return st;
+                have_basis = false;                        // (the relaunched kernel has changed the basis since)
                 if (ft_need_refactor_ || h_rec_->outcome != DEV_RUNNING) continue;      // (re-examined at the loop head)
             } else {
                 prof_begin(RELP_K_FLUSH);
@@ -575,8 +606,7 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
         go.max_updates = fts_.max_updates - la;
         launch_ft_run(dlu_, go, ft_problem(rule), max_iters - (h_rec_->iterations - start), stream_);
         prof_end();
-        HIP_TRY(hipMemcpyAsync(h_rec_, d_rec_, sizeof(PivotRecord), hipMemcpyDeviceToHost, stream_));
-        if ((st = ft_read_hdr())) return st;
+        if ((st = ft_read_report(&have_basis))) return st;
         if (!ft_need_refactor_ && h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters)
             return fail(RELP_E_STATE, "the pivot kernel stopped without a reason");
     }

@@ -205,11 +205,20 @@ struct PriceEll {
     const uint16_t* long_of;                           // nr_normal: index of a column in tier B, 0xFFFF = not there
     int32_t n_long, n_very_long;
 };
+// What the host wants to know when the pivot kernel returns, written by the kernel itself into pinned, device-mapped host
+// memory: after the stream is synchronised it is simply there (no copies, no second synchronisation): the record, the
+// header of the update file and the basis (the snapshot a look-ahead refactorisation factorises).
+struct FtMirror {
+    PivotRecord rec;
+    int32_t hdr[4];
+    int32_t basis[1];            // m entries
+};
 struct FtProblem {           // what the persistent kernel needs besides the factors
     DeviceCSC csc; ColumnTable ct; PriceEll pe;
     double *minus_pi, *b, *alpha, *rho, *d;
     int32_t* basis; uint8_t* in_basis; int32_t* trace; int64_t trace_cap;
     PivotRecord* rec;
+    FtMirror* mirror;        // or null
     Tolerances tol;
     int32_t rule, n, phase, pad_;
 };

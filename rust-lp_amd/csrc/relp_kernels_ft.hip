@@ -968,6 +968,13 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         rec->b_r = b_r; rec->minus_objective = minus_objective; rec->iterations = iterations;
         rec->last_selected = last_selected; rec->key1 = key1; rec->degenerate = degenerate;
     }
+    if (pb.mirror) {                                   // (the host reads these after synchronising the stream)
+        if (tid == 0) {
+            pb.mirror->rec = *rec;
+            pb.mirror->hdr[0] = c.t; pb.mirror->hdr[1] = c.eta_used; pb.mirror->hdr[2] = need_refactor; pb.mirror->hdr[3] = c.journal_n;
+        }
+        for (int i = tid; i < m; i += NT) pb.mirror->basis[i] = pb.basis[i];
+    }
 }
 
 // ---- single steps (step-wise API, phase boundaries) ------------------------------------------------------------------
