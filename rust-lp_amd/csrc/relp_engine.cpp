@@ -313,7 +313,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         }
         {   // two launches per pivot instead of three in the single-GPU loop (RELP_FUSED_UPDATE=0: k_ratio_blocks + k_tab_update_all)
             const char* e = std::getenv("RELP_FUSED_UPDATE");
-            fused_update_ = cfg_.shard_count <= 1 && !ovl_enabled_ && !(e && std::atoi(e) == 0);
+            fused_update_ = !ovl_enabled_ && !(e && std::atoi(e) == 0);      // (also the native sharded loop, relp_shard_run)
             if (fused_update_) {
                 HIP_TRY(dev_alloc(&d_b_alt_, ld_b_));
                 HIP_TRY(dev_alloc(&d_basis_alt_, m_));

@@ -237,6 +237,34 @@ relp_status_t Engine::shard_iteration() {
     if (inject_failure_after_ == 0) { inject_failure_after_ = -1; return fail(RELP_E_STATE, "injected failure (relp_shard_inject_failure)"); }
     if (inject_failure_after_ > 0) --inject_failure_after_;
     auto broken = [&](const char* what) { coll_broken_ = true; return fail(RELP_E_HIP, what); };
+    if (tableau_ && fused_update_ && in_loop_) {
+        // two launches around the all-gather: [local PRICE winner + its tableau column into the message] -> gather ->
+        // [winner among the messages + ratio test in every workgroup + the update] (relp_kernels.h: launch_tab_ratio_update_all)
+        if (g > 64) return fail(RELP_E_UNSUPPORTED, "at most 64 shards");
+        const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
+        const TableauView tv = tview();
+        const DeferredUpdate du = deferred();
+        const SelectPartials sp = tab_partials(rule);
+        if (!tab_partials_valid_) { launch_tab_scan(tv, sp, d_rec_, stream_); tab_partials_valid_ = true; }
+        prof_begin(RELP_K_FTRAN);
+        launch_tab_select_column_msg(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_msg_cand_, d_b_, tolerances(), d_rec_, stream_,
+                                     d_shadow_, d_shadow_meta_);
+        prof_end();
+        if (coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_))
+            return broken("all-gather of the PRICE candidates failed");
+        ++coll_step_;
+        prof_begin(RELP_K_PRICE);
+        launch_tab_ratio_update_all(tv, du, sp, m_, nullptr, d_b_, d_b_alt_, d_basis_, d_basis_alt_, d_in_basis_, d_trace_,
+                                    trace_cap_, tolerances(), nullptr, d_shadow_, d_shadow_meta_, d_rec_, stream_, d_msg_cands_, g,
+                                    cand_len_, rule);
+        prof_end();
+        std::swap(d_b_, d_b_alt_);
+        std::swap(d_basis_, d_basis_alt_);
+        shadow_pending_ = true;
+        if (++since_flush_ >= block_) enqueue_flush();
+        ++prof_tick_;
+        return RELP_OK;
+    }
     if ((st = shard_price(d_msg_cand_))) return st;
     if (coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_))
         return broken("all-gather of the PRICE candidates failed");

@@ -382,7 +382,8 @@ void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* ba
 // (cdiv(m, 256))] instead of the record, and the choice among the gathered messages + ratio test from the
 // winner's block minima
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
-                                  double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s);
+                                  double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s,
+                                  const double* shadow = nullptr, int32_t* shadow_meta = nullptr);
 // forced_row >= 0: the winner enters in that row at zero level (no ratio test), phase_one.rs:246-250
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
                                        const double* b, const int32_t* basis_indices, int32_t rule, Tolerances tol,
@@ -411,7 +412,10 @@ void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const Piv
 void launch_tab_ratio_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
                                  const double* alpha, const double* b_in, double* b_out, const int32_t* basis_in,
                                  int32_t* basis_out, uint8_t* in_basis, int32_t* trace, int64_t trace_cap, Tolerances tol,
-                                 const double* rmin, double* shadow, int32_t* shadow_meta, PivotRecord* rec, hipStream_t s);
+                                 const double* rmin, double* shadow, int32_t* shadow_meta, PivotRecord* rec, hipStream_t s,
+                                 const double* msgs = nullptr, int32_t count = 0, int64_t msg_len = 0, int32_t rule = 0);
+// (msgs: sharded loop -- the gathered candidate messages; the winner's column and block minima are taken from there and
+// `alpha` / `rmin` are ignored)
 void launch_tab_apply_shadow(const DeferredUpdate& du, double* shadow, int32_t* shadow_meta, hipStream_t s);
 // end of a block whose flush is overlapped: *prev_p = pivot rows of the block, then the record / row map start a new block
 void launch_tab_block_rollover(const DeferredUpdate& du, PivotRecord* rec, int32_t* prev_p, hipStream_t s);

@@ -298,16 +298,17 @@ __global__ __launch_bounds__(kThreads) void k_tab_update_all(TableauView tv, Def
 // the same for old and new flags; pos_of_row[r] reads as -1 or as the value it is about to get.  Same arithmetic as
 // k_ratio_blocks + k_tab_update_all, bit for bit.
 __global__ __launch_bounds__(kThreads) void k_tab_ratio_update_all(TableauView tv, DeferredUpdate du, SelectPartials sp, int nb_row,
-                                                                   int m, const double* __restrict__ alpha,
+                                                                   int m, const double* alpha,
                                                                    const double* __restrict__ b_in, double* __restrict__ b_out,
                                                                    const int32_t* __restrict__ basis_in,
                                                                    int32_t* __restrict__ basis_out, uint8_t* in_basis,
                                                                    int32_t* __restrict__ trace, int64_t trace_cap, Tolerances tol,
-                                                                   const double* __restrict__ rmin, int nblk,
+                                                                   const double* rmin, int nblk,
                                                                    double* __restrict__ shadow, int32_t* __restrict__ shadow_meta,
-                                                                   PivotRecord* rec) {
-    const double first = (int)threadIdx.x < nblk ? rmin[threadIdx.x] : INFINITY;      // in flight with the record
-    const PivotRecord R = *rec;
+                                                                   PivotRecord* rec, const double* __restrict__ msgs, int count,
+                                                                   int64_t msg_len, int rule) {
+    const double first = (!msgs && (int)threadIdx.x < nblk) ? rmin[threadIdx.x] : INFINITY;      // in flight with the record
+    PivotRecord R = *rec;
     const bool w_half = (int)blockIdx.x >= nb_row;
     const int wblock = (int)blockIdx.x - nb_row;
     const int i = wblock * kThreads + threadIdx.x;
@@ -317,8 +318,47 @@ __global__ __launch_bounds__(kThreads) void k_tab_ratio_update_all(TableauView t
         if (mine) { b_out[i] = b_in[i]; basis_out[i] = basis_in[i]; }
         return;
     }
+    if (msgs) {
+        // sharded loop: the entering column is the winner among the gathered candidates [key, j, d_j, alpha (m), block
+        // minima of the ratios]; every workgroup picks it with the rules of k_tab_select_candidate_ratio
+        constexpr int kMaxRanks = 64;
+        __shared__ double s_key[kMaxRanks], s_idx[kMaxRanks], s_dq[kMaxRanks];
+        __shared__ int s_win;
+        for (int g = threadIdx.x; g < count && g < kMaxRanks; g += kThreads) {
+            s_key[g] = msgs[g * msg_len + 0]; s_idx[g] = msgs[g * msg_len + 1]; s_dq[g] = msgs[g * msg_len + 2];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int win = -1; double k1 = INFINITY; double kj = 0.0;
+            for (int g = 0; g < count; ++g) {
+                const double a = s_key[g], j = s_idx[g];
+                if (a < k1 || (a == k1 && win >= 0 && j < kj)) { k1 = a; kj = j; win = g; }
+            }
+            if (win >= 0 && rule == 2 && tol.tie > 0.0) {
+                const double bound = k1 + tol.tie * fmax(1.0, fabs(k1));
+                for (int g = 0; g < count; ++g)
+                    if (s_key[g] <= bound && s_idx[g] < kj) { kj = s_idx[g]; win = g; }
+            }
+            s_win = win;
+        }
+        __syncthreads();
+        const int win = s_win;
+        if (win < 0) {
+            if (mine) { b_out[i] = b_in[i]; basis_out[i] = basis_in[i]; }
+            if (wblock == 0 && threadIdx.x == 0) {
+                rec->outcome = DEV_NO_CANDIDATE;
+                if (rule == 1) rec->last_selected = -1;
+            }
+            return;
+        }
+        R.q = (int)s_idx[win];
+        R.d_q = s_dq[win];
+        if (rule == 1) R.last_selected = R.q;                      // (what the row update's selection keys start from)
+        alpha = msgs + win * msg_len + 3;
+        rmin = alpha + m;
+    }
     int r, leaving;
-    ratio_blocks_pick<kThreads>(alpha, b_in, basis_in, m, tol, rmin, nblk, &r, &leaving, first, true);
+    ratio_blocks_pick<kThreads>(alpha, b_in, basis_in, m, tol, rmin, nblk, &r, &leaving, first, !msgs);
     if (r < 0) {
         if (mine) { b_out[i] = b_in[i]; basis_out[i] = basis_in[i]; }
         if (wblock == 0 && threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
@@ -368,6 +408,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_ratio_update_all(TableauView t
         basis_out[i] = (i == r) ? q : basis_in[i];
     }
     if (i == 0) {
+        if (msgs) { rec->q = q; rec->d_q = R.d_q; if (rule == 1) rec->last_selected = q; }
         rec->r = r; rec->leaving = leaving; rec->alpha_r = alpha_r; rec->b_r = b_r;
         rec->n_eta_old = p_old; rec->eta_target = jt;
         if (jt >= p_old) { du.S[p_old] = r; du.pos_of_row[r] = p_old; rec->n_eta = p_old + 1; }
@@ -959,11 +1000,13 @@ void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& 
 void launch_tab_ratio_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
                                  const double* alpha, const double* b_in, double* b_out, const int32_t* basis_in,
                                  int32_t* basis_out, uint8_t* in_basis, int32_t* trace, int64_t trace_cap, Tolerances tol,
-                                 const double* rmin, double* shadow, int32_t* shadow_meta, PivotRecord* rec, hipStream_t s) {
+                                 const double* rmin, double* shadow, int32_t* shadow_meta, PivotRecord* rec, hipStream_t s,
+                                 const double* msgs, int32_t count, int64_t msg_len, int32_t rule) {
     const int nb_row = tv.c_hi > tv.c_lo ? tab_scan_blocks(tv.c_hi - tv.c_lo) : 0;
     const int nb_w = cdiv(m, kThreads);
     hipLaunchKernelGGL(k_tab_ratio_update_all, dim3(nb_row + nb_w), dim3(kThreads), 0, s, tv, du, sp, nb_row, m, alpha, b_in,
-                       b_out, basis_in, basis_out, in_basis, trace, trace_cap, tol, rmin, nb_w, shadow, shadow_meta, rec);
+                       b_out, basis_in, basis_out, in_basis, trace, trace_cap, tol, rmin, nb_w, shadow, shadow_meta, rec, msgs,
+                       (int)count, msg_len, (int)rule);
 }
 
 void launch_tab_apply_shadow(const DeferredUpdate& du, double* shadow, int32_t* shadow_meta, hipStream_t s) {
@@ -977,10 +1020,10 @@ void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* ba
 }
 
 void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
-                                  double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s) {
+                                  double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s,
+                                  const double* shadow, int32_t* shadow_meta) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
-                       msg, b, tol, msg + 3 + tv.m, rec, (const int32_t*)nullptr, (int32_t*)nullptr, (const double*)nullptr,
-                       (int32_t*)nullptr);
+                       msg, b, tol, msg + 3 + tv.m, rec, (const int32_t*)nullptr, (int32_t*)nullptr, shadow, shadow_meta);
 }
 
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
