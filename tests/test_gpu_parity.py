@@ -1262,3 +1262,26 @@ def test_reference_problem_files_on_the_lu_engine_with_lookahead_refactorisation
     if len(ref.trace) > 40:
         assert t.lu_stats()["refactorisations"] >= 2
     t.close()
+
+
+def test_two_launch_pivot_equals_three_launch_pivot_bit_for_bit(monkeypatch):
+    """The tableau engine's loop runs the ratio test inside the update launch (k_tab_ratio_update_all: every workgroup repeats
+    it; b, the basis array, row r of W and n_eta double-buffered); RELP_FUSED_UPDATE=0 is the three-launch pivot of round 1
+    (k_ratio_blocks + k_tab_update_all, still the path of the step-wise API and the Python sharded loop).  Same arithmetic:
+    identical traces, objectives and right-hand sides on a dense LP and on a two-phase sparse one, over several flushes."""
+    from lp_files import load
+    cases = []
+    lp = synthetic.dense_lp(300, 500, 4242)
+    cases.append(MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]))
+    cases.append(load("netlib/SC205.SIF", fixed=True)[2])
+    for md in cases:
+        got = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("RELP_FUSED_UPDATE", fused)
+            t = engine.Tableau(md, trace_capacity=1 << 15, engine=engine.ENGINE_TABLEAU, update_block=16)
+            assert t.solve_relaxation() == engine.OPTIMAL
+            got.append((t.trace(), t.objective_function_value(), np.array(t.b())))
+            t.close()
+        assert got[0][0] == got[1][0] and len(got[0][0]) > 64
+        assert got[0][1] == got[1][1]
+        assert np.array_equal(got[0][2], got[1][2])
