@@ -45,7 +45,10 @@ __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
     return L;
 }
 
-// Phase clock of the persistent kernel (thread 0, s_memtime): where a pivot's time goes (relp_lu_phase_cycles)
+// Phase clock of the persistent kernel (thread 0, s_memtime): where a pivot's time goes (relp_lu_phase_cycles).
+// Diagnostic builds (make CXXFLAGS="... -DPRICE_DIAG" / -DUT_DIAG) put extra laps inside PRICE / the U' solve and book
+// them on the small phases FT_LOAD_STORE, FT_B, FT_SCATTER, FT_VECTORS (subtract those phases' normal shares): that is how
+// the per-element branches of the chain coefficients and the dependent loads of the long columns were found.
 enum FtPhase { FT_PRICE = 0, FT_SCATTER, FT_L, FT_ETA_FWD, FT_PUSH, FT_U, FT_RATIO, FT_B, FT_UBAR, FT_UT, FT_COMPACT, FT_BT_CHAIN,
                FT_LT, FT_VECTORS, FT_LOAD_STORE, FT_STAGE, FT_PHASES };
 struct FtClock {
