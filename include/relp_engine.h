@@ -106,7 +106,26 @@ typedef struct {
     int32_t update_block;
     /* relp_engine_kind_t: which device representation maintains the basis inverse */
     int32_t engine;
+    /* ---- f64 safeguards the exact reference has no need for; 0 (relp_default_config) = the reference's rule ----
+     * relp_ratio_rule_t.  RELP_RATIO_LARGEST_PIVOT: among the rows inside the tie band of the minimum ratio the largest pivot
+     * element wins (compared at float precision), then the lowest leaving column; tableau/mod.rs:229-239 has only the latter.
+     * On degenerate LPs with badly scaled columns (Netlib GREENBEA / GREENBEB, which the reference `#[ignore]`s) the
+     * reference's choice among dozens of ratio-0 rows regularly lands on a pivot of 1e-4 beside candidates of 1e+2; exact
+     * arithmetic does not care, an f64 basis inverse is destroyed within ~1,000 pivots. */
+    int32_t ratio_rule;
+    /* relp_artificial_removal_t.  RELP_ARTIFICIAL_TEXTBOOK: at the end of phase 1 a basic artificial variable is pivoted out
+     * in the row it is basic in (phase_one.rs:236 takes the row it started in: an artificial that re-entered the basis in
+     * another row survives into phase 2 as a free column on that row -- Netlib GREENBEA ends 73,482 below its optimum that
+     * way), on the first non-basic column with a non-zero element in that row, whatever that column's reduced cost (the
+     * pivot is at zero level either way; phase_one.rs:239-244 only tries columns whose reduced cost is exactly zero), and
+     * a row without such a column is removed as itself (phase_one.rs:252 pushes the artificial's INDEX, which names another
+     * row as soon as `<=` rows lie in front of the artificial's row: the reference then deletes a non-redundant row and
+     * optimises a relaxation -- Netlib 80BAU3B ends at 964,593.50 instead of 987,224.19 that way). */
+    int32_t artificial_removal;
 } relp_config_t;
+
+typedef enum { RELP_RATIO_REFERENCE = 0, RELP_RATIO_LARGEST_PIVOT = 1 } relp_ratio_rule_t;
+typedef enum { RELP_ARTIFICIAL_REFERENCE = 0, RELP_ARTIFICIAL_TEXTBOOK = 1 } relp_artificial_removal_t;
 
 typedef enum {
     /* revised simplex with the explicit dense inverse (`Carry<_, BasisInverseRows<_>>`): PRICE and FTRAN
@@ -115,7 +134,8 @@ typedef enum {
     /* dense tableau T = B^-1 [A | slacks] kept as (I + W S') T0: PRICE is one tableau row, FTRAN one
      * tableau column per pivot, and T0 is updated by an m x K x n GEMM on the f64 matrix cores every
      * update_block pivots (needs 8 m n bytes; same pivots as the revised engine up to f64 rounding).
-     * Restrictions: no relp_from_basis.  Column-sharded across GPUs through relp_shard_* / relp_shard_run: both
+     * relp_from_basis re-tabulates T0 = B^-1 [A | I] from a factorisation of the given basis.  Column-sharded across GPUs
+     * through relp_shard_* / relp_shard_run: both
      * phases, artificial removal and redundant-row removal included (the revised engine shards only LPs with a full
      * slack basis). */
     RELP_ENGINE_TABLEAU = 1,
@@ -167,7 +187,8 @@ relp_status_t relp_solve_relaxation(relp_engine_t *h, int64_t max_iters, int32_t
  * one per row; switches to phase 2.  RELP_ENGINE_LU: any basis (factorise, b = FTRAN(rhs), -pi = BTRAN(-c_B));
  * RELP_ENGINE_REVISED: any basis (basis_inverse_rows.rs:103-129: LU - factorised on the host like every
  * refactorisation - then m unit solves, b and -pi on the device; slack bases are a signed permutation and take a
- * shortcut); RELP_ENGINE_TABLEAU: RELP_E_UNSUPPORTED. */
+ * shortcut); RELP_ENGINE_TABLEAU (unsharded): any basis -- the tableau B^-1 [A | I] is re-tabulated column by column from the
+ * factors, then b, the reduced costs and -obj (tests/cpp/test_tableau.cpp, tests/test_gpu_parity.py::test_from_basis_*). */
 relp_status_t relp_from_basis(relp_engine_t *h, const int32_t *basis_columns_m);
 /* RELP_ENGINE_REVISED and RELP_ENGINE_TABLEAU (unsharded), an f64 matter (the exact reference never needs it,
  * `should_refactor() = false`, basis_inverse_rows.rs:175-179): every `pivots` basis changes inside relp_run the state is
@@ -187,6 +208,11 @@ int32_t       relp_update_block(const relp_engine_t *h);
  * nnz(L) (off-diagonal), nnz(U) (with diagonal), levels of the four solve schedules L, U (FTRAN) and
  * U', L' (BTRAN) }.  Levels bound the length of the dependent chain of a triangular solve. */
 relp_status_t relp_lu_stats(const relp_engine_t *h, int64_t *out8);
+/* RELP_ENGINE_LU: the look-ahead refactorisation (a refactorisation prepared on the host while the pivot kernel keeps
+ * going on the old factors; carry/mod.rs:602-614 refactorises synchronously): out[4] = { look-ahead factorisations
+ * installed, basis changes replayed onto them, the look-ahead length in effect (RELP_LU_LOOKAHEAD, 0 = off), the lane
+ * budget of a fused group of levels (RELP_FUSE_LANES) }; both switches are read when the engine is created. */
+relp_status_t relp_lu_lookahead_stats(const relp_engine_t *h, int64_t *out4);
 
 /* RELP_ENGINE_LU in Forrest-Tomlin mode: shader clocks spent per phase of the pivot inside the persistent kernel since create
  * (thread 0): out[16] = { PRICE, entering-column scatter, L solve, eta file forward, spike push, U solve, ratio test, b update,

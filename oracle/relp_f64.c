@@ -201,6 +201,7 @@ static int32_t select_primal_pivot_row(const oracle_engine_t *e, const svec *alp
     if (!any) return -1;
     double bound = min_ratio + c->tol_tie * fmax(1.0, fabs(min_ratio));
     int32_t best_row = -1, best_leaving = 0;
+    uint32_t best_size = 0;     /* ratio_rule 1 (an f64 extension, not the reference's rule): largest pivot first */
     for (int64_t k = 0; k < alpha->n; k++) {
         double x = alpha->d[k].val;
         if (x > c->tol_pivot) {
@@ -210,7 +211,12 @@ static int32_t select_primal_pivot_row(const oracle_engine_t *e, const svec *alp
             double ratio = bi / x;
             if (ratio <= bound) {
                 int32_t leaving = e->basis_indices[row];
-                if (best_row < 0 || leaving < best_leaving) { best_row = row; best_leaving = leaving; }
+                /* the pivot's size at float precision, larger = smaller key (relp_device_common.h: tie_key) */
+                uint32_t size = 0;
+                if (c->ratio_rule) { float f = (float)x; memcpy(&size, &f, 4); size = 0x7fffffffu - size; }
+                if (best_row < 0 || size < best_size || (size == best_size && leaving < best_leaving)) {
+                    best_row = row; best_leaving = leaving; best_size = size;
+                }
             }
         }
     }
@@ -437,12 +443,14 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
     svec alpha; sv_init(&alpha);
     for (int32_t a = 0; a < e->nr_artificial; a++) {        /* sorted artificial indices */
         if (!e->in_basis[a]) continue;
-        int32_t pivot_row = e->column_to_row[a];
+        int32_t pivot_row = e->column_to_row[a];            /* phase_one.rs:236: the artificial's ORIGINAL row */
+        if (e->cfg.artificial_removal)                      /* extension: the row it is basic in now */
+            for (int32_t i = 0; i < e->m; i++) if (e->basis_indices[i] == a) { pivot_row = i; break; }
         int found = 0; int32_t q = -1; double cost = 0.0;
         for (int32_t j = e->nr_artificial; j < n && !found; j++) {
             if (e->in_basis[j]) continue;
             double d = relative_cost(e, j);
-            if (fabs(d) > e->cfg.tol_cost) continue;                       /* cost.is_zero() */
+            if (!e->cfg.artificial_removal && fabs(d) > e->cfg.tol_cost) continue;   /* cost.is_zero() */
             kind_original_column(e, j, &e->scratch_col);
             double el = sparse_inner(&e->rows[pivot_row], &e->scratch_col); /* generate_element */
             if (fabs(el) > e->cfg.tol_pivot) { found = 1; q = j; cost = d; }
@@ -453,7 +461,9 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
             record(n_done, cap, tp, te, tr, tl, 1, q, pivot_row, leaving);
             e->nr_zero_level++;
         } else {
-            rows_to_remove[nrem++] = a;                     /* NB: the artificial index (phase_one.rs:252) */
+            /* NB: the reference pushes the artificial's INDEX (phase_one.rs:252); artificial_removal 1 (an extension)
+             * marks the row the artificial is basic in */
+            rows_to_remove[nrem++] = e->cfg.artificial_removal ? pivot_row : a;
         }
     }
     sv_free(&alpha);

@@ -30,7 +30,8 @@ class _MatrixData(C.Structure):
 class _Config(C.Structure):
     _fields_ = [("tol_cost", C.c_double), ("tol_pivot", C.c_double), ("tol_zero", C.c_double),
                 ("tol_tie", C.c_double), ("tol_feas", C.c_double),
-                ("phase_one_rule", C.c_int32), ("phase_two_rule", C.c_int32)]
+                ("phase_one_rule", C.c_int32), ("phase_two_rule", C.c_int32),
+                ("ratio_rule", C.c_int32), ("artificial_removal", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -76,7 +77,7 @@ class OracleF64:
     """One f64 CPU solve state (`Tableau<Carry<f64, BasisInverseRows<f64>>, _>`)."""
 
     def __init__(self, problem, phase_one_rule=RULE_FIRST_PROFITABLE_WITH_MEMORY,
-                 phase_two_rule=RULE_STEEPEST_DESCENT, **tolerances):
+                 phase_two_rule=RULE_STEEPEST_DESCENT, ratio_rule=0, artificial_removal=0, **tolerances):
         tol = dict(DEFAULT_TOLERANCES)
         tol.update(tolerances)
         self._keep = [np.ascontiguousarray(problem.col_ptr, dtype=np.int64),
@@ -89,7 +90,7 @@ class OracleF64:
         md = _MatrixData(problem.nr_normal, problem.nr_eq, problem.nr_range, problem.nr_le, problem.nr_ge,
                          *[a.ctypes.data for a in self._keep])
         cfg = _Config(tol["tol_cost"], tol["tol_pivot"], tol["tol_zero"], tol["tol_tie"], tol["tol_feas"],
-                      phase_one_rule, phase_two_rule)
+                      phase_one_rule, phase_two_rule, ratio_rule, artificial_removal)
         self._h = lib().oracle_create(C.byref(md), C.byref(cfg))
         self.trace = []          # (phase, entering, row, leaving)
 

@@ -47,6 +47,16 @@ typedef struct {
     double tol_cost, tol_pivot, tol_zero, tol_tie, tol_feas;
     int32_t phase_one_rule;                  /* 0 FirstProfitable, 1 FirstProfitableWithMemory, 2 SteepestDescent */
     int32_t phase_two_rule;
+    /* Extensions the exact reference has no need for (0 = the reference's rule, the default everywhere):
+     * ratio_rule 1: among the rows inside the tie band the largest pivot element wins (compared at float precision), then the
+     *   lowest leaving column (tableau/mod.rs:229-239 has only the latter);
+     * artificial_removal 1: a basic artificial is pivoted out in the row it is basic IN (phase_one.rs:236 takes the row it
+     *   started in, so one that re-entered elsewhere survives into phase 2 as a free column) on ANY non-basic column with a
+     *   non-zero element in that row (phase_one.rs:239-244 tries only columns with zero reduced cost), and a row without one
+     *   is removed as ITSELF (phase_one.rs:252 pushes the artificial's index, which is another row once `<=` rows lie in
+     *   front). */
+    int32_t ratio_rule;
+    int32_t artificial_removal;
 } oracle_config_t;
 
 enum { ORACLE_RULE_FIRST_PROFITABLE = 0, ORACLE_RULE_FIRST_PROFITABLE_WITH_MEMORY = 1, ORACLE_RULE_STEEPEST_DESCENT = 2 };

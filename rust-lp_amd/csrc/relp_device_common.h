@@ -151,29 +151,60 @@ static constexpr int kMaxEta = 128;
 // RATIO TEST (single workgroup; two passes: strict minimum, then Bland tie-break on the leaving
 // column among rows within the tie band -- identical to tableau/mod.rs:221-247 for zero tolerances)
 // ------------------------------------------------------------------------------------------------
-// Last step of the ratio test: every thread brings its best (leaving column, row) among the rows inside the
-// tie band; the workgroup's minimum leaving column wins (Bland, tableau/mod.rs:229-239), the record is
-// written and the block bookkeeping of the deferred update (row r of W saved, slot of W chosen) is done.
+// Tie-break key of a row inside the tie band (smaller wins).  ratio_rule 0 = the reference: the leaving column
+// (tableau/mod.rs:229-239).  ratio_rule 1 (an f64 safeguard, relp_engine.h: RELP_RATIO_LARGEST_PIVOT): the pivot element's
+// size first -- at float precision, larger = smaller key -- then the leaving column.  Order-independent either way.
+typedef unsigned long long tie_key_t;
+static constexpr tie_key_t kNoTieKey = ~0ull;
+__device__ __forceinline__ tie_key_t tie_key(double a, int leave, int ratio_rule) {
+    const unsigned size = ratio_rule ? 0x7fffffffu - __float_as_uint((float)a) : 0u;      // (a > tol.pivot > 0)
+    return ((tie_key_t)size << 32) | (unsigned)leave;
+}
+__device__ __forceinline__ int tie_key_leaving(tie_key_t k) { return (int)(unsigned)(k & 0xffffffffull); }
+
+// Workgroup minimum of (key, row) over BS threads, result in every thread; s_k / s_r: BS / 64 words of LDS each.  `wide`
+// (uniform) = the keys use their upper half; otherwise the reduction runs on the 32-bit leaving columns as it always did.
 template <int BS>
-__device__ __forceinline__ void ratio_commit(int best_leave, int best_row, const double* alpha, const double* b,
-                                             const DeferredUpdate& du, int p, PivotRecord* rec) {
-    __shared__ int s_cl[BS / 64];
-    __shared__ int s_cr[BS / 64];
+__device__ __forceinline__ void tie_reduce(tie_key_t& key, int& row, tie_key_t* s_k, int* s_r, bool wide) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wide) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int ol = __shfl_down(best_leave, off, 64);
-        const int orow = __shfl_down(best_row, off, 64);
-        if (ol < best_leave) { best_leave = ol; best_row = orow; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const tie_key_t ok = __shfl_down(key, off, 64);
+            const int orow = __shfl_down(row, off, 64);
+            if (ok < key) { key = ok; row = orow; }
+        }
+    } else {
+        int lv = (int)(unsigned)key;                   // (kNoTieKey -> -1: mapped to INT_MAX below)
+        if (key == kNoTieKey) lv = 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int ol = __shfl_down(lv, off, 64);
+            const int orow = __shfl_down(row, off, 64);
+            if (ol < lv) { lv = ol; row = orow; }
+        }
+        key = (unsigned)lv;
     }
-    if (lane == 0) { s_cl[wave] = best_leave; s_cr[wave] = best_row; }
+    if (lane == 0) { s_k[wave] = key; s_r[wave] = row; }
     __syncthreads();
-    // every thread finishes the reduction itself (BS / 64 LDS words): no second barrier, and everything the
-    // epilogue reads from memory -- alpha_r, b_r, row r of W, the slot of row r -- goes out in ONE round trip
-    best_leave = s_cl[0]; best_row = s_cr[0];
+    // every thread finishes the reduction itself (BS / 64 LDS words): no second barrier
+    key = s_k[0]; row = s_r[0];
 #pragma unroll
     for (int w = 1; w < BS / 64; ++w)
-        if (s_cl[w] < best_leave) { best_leave = s_cl[w]; best_row = s_cr[w]; }
+        if (s_k[w] < key) { key = s_k[w]; row = s_r[w]; }
+}
+
+// Last step of the ratio test: every thread brings its best (tie key, row) among the rows inside the
+// tie band; the workgroup's minimum wins (Bland on the leaving column, tableau/mod.rs:229-239), the record is
+// written and the block bookkeeping of the deferred update (row r of W saved, slot of W chosen) is done.
+template <int BS>
+__device__ __forceinline__ void ratio_commit(tie_key_t best_key, int best_row, const double* alpha, const double* b,
+                                             const DeferredUpdate& du, int p, PivotRecord* rec, bool wide = false) {
+    __shared__ tie_key_t s_cl[BS / 64];
+    __shared__ int s_cr[BS / 64];
+    // (everything the epilogue reads from memory -- alpha_r, b_r, row r of W, the slot of row r -- goes out in ONE round trip)
+    tie_reduce<BS>(best_key, best_row, s_cl, s_cr, wide);
+    const int best_leave = tie_key_leaving(best_key);
     const int r = best_row;
     const bool deferred = du.kmax > 0;
     double a_r = 0.0, b_r = 0.0;
@@ -213,7 +244,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
     // memory round trip); both passes then run out of registers.  m > 16 * 1024 falls back to re-reading.
     constexpr int kItems = ITEMS;
     const bool cached = m <= kItems * BS;
-    double ratio_r[kItems];
+    double ratio_r[kItems], alpha_r[kItems];
     int leave_r[kItems];
     double mn = INFINITY;
     if (cached) {
@@ -224,6 +255,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
             const double a = in ? alpha[i] : 0.0;
             double bi = in ? b[i] : 0.0;
             leave_r[k] = in ? basis_indices[i] : 0x7fffffff;
+            alpha_r[k] = a;
             if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
             ratio_r[k] = (in && a > tol.pivot) ? bi / a : INFINITY;
             mn = fmin(mn, ratio_r[k]);
@@ -254,12 +286,16 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
         return;
     }
     const double bound = gmin + tol.tie * fmax(1.0, fabs(gmin));
-    int best_leave = 0x7fffffff, best_row = -1;
+    tie_key_t best_key = kNoTieKey;
+    int best_row = -1;
     if (cached) {
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             // ratio_r is +inf for rows that do not take part, so `<= bound` excludes them
-            if (ratio_r[k] <= bound && leave_r[k] < best_leave) { best_leave = leave_r[k]; best_row = threadIdx.x + k * BS; }
+            if (ratio_r[k] <= bound) {
+                const tie_key_t key = tie_key(alpha_r[k], leave_r[k], tol.ratio_rule);
+                if (key < best_key) { best_key = key; best_row = threadIdx.x + k * BS; }
+            }
         }
     } else {
 #pragma unroll 4
@@ -268,10 +304,13 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
             double bi = b[i];
             const int lv = basis_indices[i];
             if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
-            if (a > tol.pivot && bi / a <= bound && lv < best_leave) { best_leave = lv; best_row = i; }
+            if (a > tol.pivot && bi / a <= bound) {
+                const tie_key_t key = tie_key(a, lv, tol.ratio_rule);
+                if (key < best_key) { best_key = key; best_row = i; }
+            }
         }
     }
-    ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
+    ratio_commit<BS>(best_key, best_row, alpha, b, du, p, rec, tol.ratio_rule != 0);
 }
 
 // Ratio test of a workgroup of BS threads from the minimum ratio of every block of `rpb` rows (`rmin`, nblk
@@ -325,7 +364,8 @@ __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alp
     const int listed = s_cnt;
     const bool use_list = listed <= kListMax;
     const int total = (use_list ? listed : nblk) * rpb;
-    int best_leave = 0x7fffffff, best_row = -1;
+    tie_key_t best_key = kNoTieKey;
+    int best_row = -1;
     for (int idx = threadIdx.x; idx < total; idx += BS) {
         const int t = use_list ? s_list[idx / rpb] : idx / rpb;
         const int i = t * rpb + idx % rpb;
@@ -334,11 +374,11 @@ __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alp
         double bi = b[i];
         if (bi <= tol.zero) bi = 0.0;   // also clamps a b_i that rounding pushed below 0: no negative step
         if (a > tol.pivot && bi / a <= bound) {
-            const int lv = basis_indices[i];
-            if (lv < best_leave) { best_leave = lv; best_row = i; }
+            const tie_key_t key = tie_key(a, basis_indices[i], tol.ratio_rule);
+            if (key < best_key) { best_key = key; best_row = i; }
         }
     }
-    ratio_commit<BS>(best_leave, best_row, alpha, b, du, p, rec);
+    ratio_commit<BS>(best_key, best_row, alpha, b, du, p, rec, tol.ratio_rule != 0);
 }
 
 // The same choice without the bookkeeping: every thread of the workgroup returns with (row, leaving column), row = -1 when
@@ -352,7 +392,7 @@ __device__ __forceinline__ void ratio_blocks_pick(const double* alpha, const dou
     constexpr int kListMax = 64;
     __shared__ int s_list[kListMax];
     __shared__ int s_cnt;
-    __shared__ int s_cl[BS / 64];
+    __shared__ tie_key_t s_cl[BS / 64];
     __shared__ int s_cr[BS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // `first` = rmin[threadIdx.x] when the caller loaded it together with the record (have_first)
@@ -381,7 +421,8 @@ __device__ __forceinline__ void ratio_blocks_pick(const double* alpha, const dou
     const int listed = s_cnt;
     const bool use_list = listed <= kListMax;
     const int total = (use_list ? listed : nblk) * rpb;
-    int best_leave = 0x7fffffff, best_row = -1;
+    tie_key_t best_key = kNoTieKey;
+    int best_row = -1;
     for (int idx = threadIdx.x; idx < total; idx += BS) {
         const int t = use_list ? s_list[idx / rpb] : idx / rpb;
         const int i = t * rpb + idx % rpb;
@@ -392,22 +433,12 @@ __device__ __forceinline__ void ratio_blocks_pick(const double* alpha, const dou
         asm volatile("" : "+v"(lv));
         if (bi <= tol.zero) bi = 0.0;
         if (a > tol.pivot && bi / a <= bound) {
-            if (lv < best_leave) { best_leave = lv; best_row = i; }
+            const tie_key_t key = tie_key(a, lv, tol.ratio_rule);
+            if (key < best_key) { best_key = key; best_row = i; }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int ol = __shfl_down(best_leave, off, 64);
-        const int orow = __shfl_down(best_row, off, 64);
-        if (ol < best_leave) { best_leave = ol; best_row = orow; }
-    }
-    if (lane == 0) { s_cl[wave] = best_leave; s_cr[wave] = best_row; }
-    __syncthreads();
-    best_leave = s_cl[0]; best_row = s_cr[0];
-#pragma unroll
-    for (int w = 1; w < BS / 64; ++w)
-        if (s_cl[w] < best_leave) { best_leave = s_cl[w]; best_row = s_cr[w]; }
-    *row_out = best_row; *leave_out = best_leave;
+    tie_reduce<BS>(best_key, best_row, s_cl, s_cr, tol.ratio_rule != 0);
+    *row_out = best_row; *leave_out = tie_key_leaving(best_key);
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

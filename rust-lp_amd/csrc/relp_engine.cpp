@@ -25,11 +25,7 @@ void Engine::free_all() {
     fr(d_basis_); fr(d_column_to_row_); fr(d_bound_row_); fr(d_vrow0_); fr(d_vrow1_); fr(d_vsign_); fr(d_trace_);
     fr(d_in_basis_); fr(d_rec_);
     fr(d_part_k1_); fr(d_part_j_);
-    fr(dT0_); fr(dR0_); fr(d_ticket_); fr(d_b_alt_); fr(d_basis_alt_); fr(d_shadow_); fr(d_shadow_meta_); fr(dT_alt_); fr(d_W_alt_); fr(dR0_alt_); fr(d_prev_p_);
-    if (ev_boundary_) { (void)hipEventDestroy(ev_boundary_); ev_boundary_ = nullptr; }
-    if (ev_flushed_) { (void)hipEventDestroy(ev_flushed_); ev_flushed_ = nullptr; }
-    if (flush_stream_) { (void)hipStreamDestroy(flush_stream_); flush_stream_ = nullptr; }
-    d_W_prev_ = nullptr; dR0_prev_ = nullptr; ovl_pending_ = false;
+    fr(dT0_); fr(dR0_); fr(d_b_alt_); fr(d_basis_alt_); fr(d_shadow_); fr(d_shadow_meta_);
     if (h_lu_buf_) { (void)hipHostFree(h_lu_buf_); h_lu_buf_ = nullptr; h_lu_cap_ = 0; }
     if (h_basis_) { (void)hipHostFree(h_basis_); h_basis_ = nullptr; }
     if (h_mirror_) { (void)hipHostFree(h_mirror_); h_mirror_ = nullptr; d_mirror_ = nullptr; }
@@ -62,7 +58,7 @@ ColumnTable Engine::table() const {
     return ct;
 }
 
-Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie}; }
+Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie, cfg_.ratio_rule, 0}; }
 
 TableauView Engine::tview() const {
     TableauView tv;
@@ -73,9 +69,6 @@ TableauView Engine::tview() const {
     tv.col_off = phase_ == 1 ? 0 : tab_na_;
     tv.n = nr_columns();
     tv.c_lo = sc_lo_; tv.c_hi = sc_hi_;
-    tv.Wp = ovl_pending_ ? d_W_prev_ : nullptr;
-    tv.R0p = ovl_pending_ ? dR0_prev_ - (int64_t)sc_lo_ : nullptr;
-    tv.pp = ovl_pending_ ? d_prev_p_ : nullptr;
     return tv;
 }
 
@@ -292,6 +285,12 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         // here an update is one column of W, so longer blocks are cheap)
         block_ = cfg_.update_block < 0 ? 128 : std::max(1, std::min(cfg_.update_block, 128));
         HIP_TRY(dev_alloc(&d_lu_scratch_, ld_b_));
+        {   // environment switches of the LU engine, read once per engine
+            const char* la = std::getenv("RELP_LU_LOOKAHEAD");
+            const char* fl = std::getenv("RELP_FUSE_LANES");
+            lu_lookahead_env_ = la ? std::atoi(la) : 8;
+            lu_fuse_lanes_env_ = fl ? std::atoi(fl) : 256;
+        }
         relp_status_t fst = ft_plan_and_alloc();           // Forrest-Tomlin on the device when the LDS budget allows
         if (fst) return fst;
     }
@@ -304,16 +303,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         ld_r_ = round_up(n_owned, 2);
         HIP_TRY(dev_alloc(&dT0_, ld_t_ * n_owned));
         HIP_TRY(dev_alloc(&dR0_, ld_r_ * (block_ + 1)));        // + one scratch row (d_aq_big)
-        {
-            const char* e = std::getenv("RELP_FLUSH_OVERLAP");
-            const char* w = std::getenv("RELP_FLUSH_OVERLAP_PIVOTS");
-            ovl_enabled_ = e && std::atoi(e) != 0;
-            ovl_pivots_ = std::max(1, std::min(w ? std::atoi(w) : block_ / 2, block_ - 1));
-            if (block_ < 8) ovl_enabled_ = false;
-        }
         {   // two launches per pivot instead of three in the single-GPU loop (RELP_FUSED_UPDATE=0: k_ratio_blocks + k_tab_update_all)
             const char* e = std::getenv("RELP_FUSED_UPDATE");
-            fused_update_ = !ovl_enabled_ && !(e && std::atoi(e) == 0);      // (also the native sharded loop, relp_shard_run)
+            fused_update_ = !(e && std::atoi(e) == 0);      // (also the native sharded loop, relp_shard_run)
             if (fused_update_) {
                 HIP_TRY(dev_alloc(&d_b_alt_, ld_b_));
                 HIP_TRY(dev_alloc(&d_basis_alt_, m_));
@@ -324,15 +316,6 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
             }
         }
         HIP_TRY(dev_alloc(&d_cost_store_, n_store_));
-        {   // RELP_FUSED_RATIO=1: the ratio test inside the column kernel's last workgroup instead of a launch of its own.
-            // Measured on dense10k: 30,500 it/s fused against 32,000 with three launches -- the two agent-scope fences
-            // every workgroup needs (L2 write-back and invalidate across the eight XCDs) cost more than the kernel boundary.
-            const char* e = std::getenv("RELP_FUSED_RATIO");
-            if (e && std::atoi(e) != 0) {
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ticket_), sizeof(int32_t)));
-                HIP_TRY(hipMemset(d_ticket_, 0, sizeof(int32_t)));
-            }
-        }
         HIP_TRY(dev_alloc(&d_idcol_, m_));
     }
     if (block_ > 0 && ft_) {
@@ -443,7 +426,6 @@ void Engine::prof_end(hipStream_t on) {
 
 relp_status_t Engine::profile_read(int kernel_id, int64_t* launches, double* total_ms) {
     HIP_TRY(hipStreamSynchronize(stream_));
-    if (flush_stream_) HIP_TRY(hipStreamSynchronize(flush_stream_));
     int64_t n = 0; double ms = 0.0;
     for (size_t k = 0; k < prof_kid_.size(); ++k) {
         if (prof_kid_[k] != kernel_id) continue;
@@ -485,7 +467,7 @@ void Engine::enqueue_iteration_tableau(int rule) {
         // workgroup + tableau row / reduced costs / next PRICE partials || W, b, basis]
         prof_begin(RELP_K_FTRAN);
         launch_tab_select_column_rmin(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_b_, tolerances(), d_rmin_,
-                                      d_rec_, stream_, nullptr, nullptr, d_shadow_, d_shadow_meta_);
+                                      d_rec_, stream_, d_shadow_, d_shadow_meta_);
         prof_end();
         prof_begin(RELP_K_PRICE);
         launch_tab_ratio_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_b_alt_, d_basis_, d_basis_alt_, d_in_basis_, d_trace_,
@@ -500,17 +482,14 @@ void Engine::enqueue_iteration_tableau(int rule) {
     tab_settle();
     prof_begin(RELP_K_FTRAN);
     launch_tab_select_column_rmin(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_alpha_, d_b_, tolerances(), d_rmin_,
-                                  d_rec_, stream_, d_basis_, d_ticket_);
+                                  d_rec_, stream_);
     prof_end();
-    if (!d_ticket_) {
-        prof_begin(RELP_K_RATIO);
-        launch_ratio_blocks(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rmin_, d_rec_, stream_);
-        prof_end();
-    }
+    prof_begin(RELP_K_RATIO);
+    launch_ratio_blocks(d_alpha_, d_b_, d_basis_, m_, tolerances(), du, d_rmin_, d_rec_, stream_);
+    prof_end();
     prof_begin(RELP_K_PRICE);
     launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
-    if (ovl_pending_ && --ovl_left_ <= 0) tab_settle();
     if (++since_flush_ >= block_) enqueue_flush();
 }
 
@@ -585,58 +564,11 @@ void Engine::enqueue_iteration(int rule) {
     if (++since_flush_ >= block_) enqueue_flush();
 }
 
-// Overlapped flush of the tableau engine (relp_engine.hpp): opt-in (RELP_FLUSH_OVERLAP=1, RELP_FLUSH_OVERLAP_PIVOTS = window,
-// default half a block).  Measured on dense10k: 30,400 it/s with the overlap against 31,960 without.  The
-// pivots that run beside the flush are chains of dependent loads, and with HBM busy at 60 % every link of the chain takes
-// twice as long, so the 620 us a flush takes are paid anyway, as slower pivots; reserving CUs for the pivot stream
-// (RELP_FLUSH_RESERVE_CUS) changes nothing: it is memory latency under load, not a lack of free CUs.
-bool Engine::ovl_prepare() {
-    if (!ovl_enabled_) return false;
-    if (flush_stream_) return true;
-    const int64_t n_owned = std::max(sc_hi_ - sc_lo_, 1);
-    auto give_up = [&]() { (void)hipGetLastError(); ovl_enabled_ = false; return false; };
-    if (hipMalloc(reinterpret_cast<void**>(&dT_alt_), sizeof(double) * (size_t)(ld_t_ * n_owned)) != hipSuccess) return give_up();
-    if (hipMalloc(reinterpret_cast<void**>(&d_W_alt_), sizeof(double) * (size_t)(ld_b_ * block_)) != hipSuccess) return give_up();
-    if (hipMalloc(reinterpret_cast<void**>(&dR0_alt_), sizeof(double) * (size_t)(ld_r_ * (block_ + 1))) != hipSuccess) return give_up();
-    if (hipMalloc(reinterpret_cast<void**>(&d_prev_p_), sizeof(int32_t)) != hipSuccess) return give_up();
-    if (hipMemset(d_prev_p_, 0, sizeof(int32_t)) != hipSuccess) return give_up();
-    // The flush fills every CU (two 512-thread workgroups, all vector registers), and the pivot kernels behind it are three
-    // dependent launches of a few microseconds that need a free CU at once: the flush stream runs at the lowest priority
-    // and (RELP_FLUSH_RESERVE_CUS = r > 0) leaves r CUs of every group of eight to the pivot stream.
-    {
-        const char* rs = std::getenv("RELP_FLUSH_RESERVE_CUS");
-        const int reserve = rs ? std::atoi(rs) : 0;
-        hipError_t e = hipErrorUnknown;
-        if (reserve > 0 && reserve < 8) {
-            int cus = 0;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg_.device);
-            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0);
-            for (int i = 0; i < cus; ++i)
-                if (((i % 8) + (i / 8)) % 8 >= reserve) mask[i / 32] |= 1u << (i % 32);      // (even over XCDs whichever way bits map to CUs)
-            e = hipExtStreamCreateWithCUMask(&flush_stream_, (uint32_t)mask.size(), mask.data());
-        }
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            e = hipStreamCreateWithPriority(&flush_stream_, hipStreamNonBlocking, least);
-        }
-        if (e != hipSuccess) { flush_stream_ = nullptr; return give_up(); }
-    }
-    if (hipEventCreateWithFlags(&ev_boundary_, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_flushed_, hipEventDisableTiming) != hipSuccess) return give_up();
-    return true;
-}
-
 void Engine::tab_settle() {
     if (shadow_pending_) {                             // the fused update's new row r of W is still in its shadow row
         launch_tab_apply_shadow(deferred(), d_shadow_, d_shadow_meta_, stream_);
         shadow_pending_ = false;
     }
-    if (!ovl_pending_) return;
-    (void)hipStreamWaitEvent(stream_, ev_flushed_, 0);
-    std::swap(dT0_, dT_alt_);
-    ovl_pending_ = false;
 }
 
 // Fold the pending pivots into the explicit inverse: B0inv += W (S' B0inv).  Valid in any state
@@ -652,25 +584,7 @@ void Engine::enqueue_flush() {
         return;
     }
     if (tableau_) {
-        tab_settle();                                  // (a block shorter than the overlap window, or a flush outside the loop)
-        if (in_loop_ && flushes_since_reprice_ + 1 < kRepriceEveryFlushes && ovl_prepare()) {
-            // T_other = T0 + W R0 on the second stream; the next block starts against (T0, W, R0) of this one
-            const DeferredUpdate dut = deferred();
-            const TableauView tv = tview();
-            launch_tab_block_rollover(dut, d_rec_, d_prev_p_, stream_);
-            (void)hipEventRecord(ev_boundary_, stream_);
-            (void)hipStreamWaitEvent(flush_stream_, ev_boundary_, 0);
-            prof_begin(RELP_K_FLUSH, flush_stream_);
-            launch_tab_flush(tv, dut, d_rec_, flush_stream_, dT_alt_ - (int64_t)sc_lo_ * ld_t_, d_prev_p_);
-            prof_end(flush_stream_);
-            (void)hipEventRecord(ev_flushed_, flush_stream_);
-            d_W_prev_ = d_W_; dR0_prev_ = dR0_;
-            std::swap(d_W_, d_W_alt_); std::swap(dR0_, dR0_alt_);
-            ovl_pending_ = true; ovl_left_ = ovl_pivots_;
-            since_flush_ = 0;
-            ++flushes_since_reprice_;
-            return;
-        }
+        tab_settle();
         // T0 += W R0 on the f64 matrix cores
         const DeferredUpdate dut = deferred();
         prof_begin(RELP_K_FLUSH);
@@ -986,8 +900,10 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
     std::vector<double> d(n), tau(n);
     std::vector<uint8_t> inb(n);
     relp_status_t st;
+    const bool textbook = cfg_.artificial_removal == RELP_ARTIFICIAL_TEXTBOOK;
     for (int32_t a : arts) {
-        const int32_t pivot_row = column_to_row_[a];
+        int32_t pivot_row = column_to_row_[a];             // phase_one.rs:236: the row the artificial STARTED in
+        if (textbook) pivot_row = (int32_t)(std::find(basis.begin(), basis.end(), a) - basis.begin());   // the row it is basic in
         if ((st = relative_costs(d.data()))) return st;
         // tableau row pivot_row over every column: (row of B^-1) . a_j, no cost term
         if (tableau_) {
@@ -1008,12 +924,14 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
         int32_t q = -1;
         for (int32_t j = nr_artificial_; j < n; ++j) {
             if (inb[j]) continue;
-            if (std::fabs(d[j]) > cfg_.tol_cost) continue;
+            if (!textbook && std::fabs(d[j]) > cfg_.tol_cost) continue;        // phase_one.rs:241: cost.is_zero()
             if (std::fabs(tau[j]) > cfg_.tol_pivot) { q = j; break; }
         }
-        if (q < 0) { rows_to_remove.push_back(a); continue; }
+        // phase_one.rs:252 pushes the artificial's index; RELP_ARTIFICIAL_TEXTBOOK the row it is basic in (relp_engine.h)
+        if (q < 0) { rows_to_remove.push_back(textbook ? pivot_row : a); continue; }
         if ((st = generate_column(q, nullptr))) return st;
         if ((st = bring_into_basis(q, pivot_row, d[q], nullptr))) return st;
+        basis[pivot_row] = q;
     }
     return RELP_OK;
 }

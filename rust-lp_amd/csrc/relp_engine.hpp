@@ -53,6 +53,7 @@ class Engine {
     relp_status_t flush();
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
+    relp_status_t lu_lookahead_stats(int64_t* out4) const;
     relp_status_t lu_phase_cycles(int64_t* out16);
     relp_status_t lu_download_basis();
     relp_status_t lu_factor_downloaded_basis();
@@ -156,7 +157,6 @@ class Engine {
     double* dR0_ = nullptr; int64_t ld_r_ = 0;
     double* d_cost_store_ = nullptr;     // cost per stored column in the current phase
     int32_t* d_idcol_ = nullptr;         // stored column that was e_k originally, per row k
-    int32_t* d_ticket_ = nullptr;        // k_tab_select_column: tickets of the finished workgroups (fused ratio test)
     // Ratio test + update in one launch (single-GPU loop, relp_kernels.h: launch_tab_ratio_update_all): the second copies of b
     // and the basis array it writes (swapped with d_b_ / d_basis_ after every pivot), the shadow row of W and its {row, length}
     bool fused_update_ = false, shadow_pending_ = false;
@@ -171,19 +171,9 @@ class Engine {
     int32_t flushes_since_reprice_ = 0;
     std::vector<int32_t> idcol_h_;
     std::vector<double> cost_store_h_;
-    // Overlapped flush (enqueue_flush, relp_kernels.h: TableauView): at the end of a block inside the pivot loop the product
-    // T0 + W R0 is written to the OTHER tableau buffer on `flush_stream_` while `stream_` runs the first `ovl_pivots_` pivots
-    // of the next block against the old buffer plus the previous block's (W, R0); then `stream_` waits for the flush and
-    // switches buffers.  The schedule is fixed (a pivot count, not a completion flag), so results do not depend on timing.
-    bool ovl_enabled_ = false, ovl_pending_ = false, in_loop_ = false;
-    int32_t ovl_pivots_ = 0, ovl_left_ = 0;
-    double *dT_alt_ = nullptr, *d_W_alt_ = nullptr, *dR0_alt_ = nullptr, *d_W_prev_ = nullptr, *dR0_prev_ = nullptr;
-    int32_t* d_prev_p_ = nullptr;
-    hipStream_t flush_stream_ = nullptr;
-    hipEvent_t ev_boundary_ = nullptr, ev_flushed_ = nullptr;
-    bool ovl_prepare();                  // buffers, stream, events (lazily); false = not available
-    void tab_settle();                   // wait for a flush in flight and switch to the flushed buffer
-    struct LoopScope {                   // marks the pivot loops in which flushes may overlap; settles on every way out
+    bool in_loop_ = false;               // inside relp_run / relp_shard_run (the two-launch pivot keeps a shadow row pending)
+    void tab_settle();                   // fold the fused update's shadow row into W
+    struct LoopScope {                   // marks the pivot loops; settles on every way out
         Engine& e;
         explicit LoopScope(Engine& en) : e(en) { e.in_loop_ = true; }
         ~LoopScope() { e.in_loop_ = false; e.tab_settle(); }
@@ -245,6 +235,8 @@ class Engine {
     DeviceLU dlu_{};
     relp_status_t lu_status_ = RELP_OK;                   // a failed refactorisation inside the loop
     int64_t lu_refactors_ = 0;
+    int64_t lu_lookahead_installs_ = 0, lu_replayed_changes_ = 0;     // look-ahead refactorisations installed, journal entries replayed
+    int32_t lu_lookahead_env_ = 8, lu_fuse_lanes_env_ = 256;          // RELP_LU_LOOKAHEAD, RELP_FUSE_LANES (read at create)
     double refactor_us_[3] = {0.0, 0.0, 0.0};            // host time: basis + columns, factorisation, schedules + upload
     // revised engine: B^-1 is re-inverted from the basis columns every `reinvert_interval_` pivots (0 = never)
     int64_t reinvert_interval_ = 0, since_reinvert_ = 0, reinversions_ = 0;
@@ -264,6 +256,7 @@ class Engine {
     char* d_ft_buf_ = nullptr;
     int32_t* h_ft_hdr_ = nullptr;                         // pinned copy of fts_.hdr
     int32_t ft_tcap_ = 0, ft_eta_cap_ = 0;
+    bool ft_big_ = false, ft_fused_ = true;              // layout of the persistent kernel (relp_kernels_ft.hip: ft_layout)
     int64_t ft_zero_bytes_ = 0, ft_ones_bytes_ = 0;       // the two regions of the state buffer a refactorisation resets
     bool ft_need_refactor_ = false;
     relp_status_t ft_plan_and_alloc();

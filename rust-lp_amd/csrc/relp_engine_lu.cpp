@@ -165,7 +165,7 @@ relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget, bool have_
     d_lu_buf_ = d_lu_buf_alt_; lu_cap_ = lu_cap_alt_;
     hlu_ = LUFactors{};
     auto restore = [&]() {
-        d_lu_buf_alt_ = d_lu_buf_; lu_cap_alt_ = lu_cap_;
+        d_lu_buf_alt_ = d_lu_buf_; lu_cap_alt_ = d_lu_buf_ ? lu_cap_ : 0;      // (null after a failed re-allocation)
         hlu_ = std::move(old_h); dlu_ = old_d; fts_ = old_f; d_lu_buf_ = old_buf; lu_cap_ = old_cap;
     };
     st = lu_factor_downloaded_basis();
@@ -193,6 +193,8 @@ relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget, bool have_
     since_flush_ = changes;
     ft_need_refactor_ = false;                             // (a replay that fails marks the header; the next launch returns at once)
     ++lu_refactors_;
+    ++lu_lookahead_installs_;
+    lu_replayed_changes_ += changes;
     return RELP_OK;
 }
 
@@ -239,8 +241,9 @@ relp_status_t Engine::lu_upload_factors() {
         for (int32_t t = hlu_.Ub.level_ptr[l]; t < hlu_.Ub.level_ptr[l + 1]; ++t) lev_ub[hlu_.Ub.level_rows[t]] = l;
     static_assert(kEllLgShift == kEllLg, "host packing and device decoding of sidx");
     if (ft_) {
-        static const int32_t fuse_cap = [] { const char* e = std::getenv("RELP_FUSE_LANES"); return e ? std::atoi(e) : 256; }();
-        const int32_t cap = 2 * (int64_t)m_ + 1 < (1 << kEllLgShift) ? fuse_cap : 0;      // index space of the rhs copy
+        const int32_t fuse_cap = lu_fuse_lanes_env_;       // (RELP_FUSE_LANES, read at create)
+        // (fused schedules read a copy of the right-hand side behind x: 2 m + 1 words of LDS and of index space)
+        const int32_t cap = ft_big_ ? (ft_fused_ ? fuse_cap : 0) : (2 * (int64_t)m_ + 1 < (1 << kEllLgShift) ? fuse_cap : 0);
         // fusion and packing of the four schedules are independent: U on this thread, U' and L + L' on two helpers (the
         // refactorisation runs beside the pivot kernel, and what the host takes longer than the kernel's look-ahead the
         // device waits)
@@ -248,7 +251,7 @@ relp_status_t Engine::lu_upload_factors() {
             const bool maskable = k == 1 || k == 2;
             FusedSchedule fs;
             fuse_levels(*sch[k], maskable, maskable, cap, &fs);
-            ell_pack(fs, maskable, &ell[k]);
+            ell_pack(fs, maskable, &ell[k], ft_big_);
             if (k == 2) lev_ub = fs.start_after;
             for (int32_t v : fs.s.idx) if (v >= fs.rhs_base) { rhs_base[k] = fs.rhs_base; break; }
         };
@@ -270,8 +273,8 @@ relp_status_t Engine::lu_upload_factors() {
             put(e.sval.data(), sizeof(double) * e.sval.size());
             put(e.oval.data(), sizeof(double) * e.oval.size());
             put(e.rovf.data(), sizeof(int32_t) * e.rovf.size());
-            put(e.sidx.data(), sizeof(uint16_t) * e.sidx.size());
-            put(e.oidx.data(), sizeof(uint16_t) * e.oidx.size());
+            if (ft_big_) { put(e.sidx32.data(), sizeof(uint32_t) * e.sidx32.size()); put(e.oidx32.data(), sizeof(uint32_t) * e.oidx32.size()); }
+            else { put(e.sidx.data(), sizeof(uint16_t) * e.sidx.size()); put(e.oidx.data(), sizeof(uint16_t) * e.oidx.size()); }
         }
         for (int k = 1; k <= 2; ++k) {
             o_via_ptr[k] = put(ell[k].via_ptr.data(), sizeof(int32_t) * ell[k].via_ptr.size());
@@ -331,9 +334,14 @@ relp_status_t Engine::lu_upload_factors() {
     }
     if (buf_failed) return fail(RELP_E_ALLOC, "pinned staging buffer for the factors");
     if ((int64_t)buf_size > lu_cap_) {
-        if (d_lu_buf_) HIP_TRY(hipFree(d_lu_buf_));
-        lu_cap_ = (int64_t)buf_size * 3 / 2 + 256;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_buf_), (size_t)lu_cap_));
+        // (pointer and capacity are cleared before the new allocation: if it fails nothing dangles, and the look-ahead's
+        // restore() below skips an empty buffer)
+        char* const stale = d_lu_buf_;
+        d_lu_buf_ = nullptr; lu_cap_ = 0;
+        if (stale) HIP_TRY(hipFree(stale));
+        const int64_t want = (int64_t)buf_size * 3 / 2 + 256;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lu_buf_), (size_t)want));
+        lu_cap_ = want;
     }
     HIP_TRY(hipMemcpyAsync(d_lu_buf_, h_lu_buf_, buf_size, hipMemcpyHostToDevice, stream_));
     dlu_.m = m_; dlu_.pad_ = 0;
@@ -360,15 +368,16 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
         fts_.pinfo = reinterpret_cast<const FtPivotInfo*>(d_lu_buf_ + o_pinfo);
         // what is left of the CU's LDS after the work vectors stages one schedule image at a time
-        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_);
+        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_fused_);
+        const int64_t idx_bytes = ft_big_ ? 4 : 2;
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
         int64_t need = 0;
         auto up16 = [](int64_t b) { return (b + 15) / 16 * 16; };
         for (int k = 0; k < 4; ++k) {
             const EllPacked& e = ell[k];
             EllSchedule& d = fts_.ell[k];
-            const int64_t np = (int64_t)e.passes.size(), nlv = (int64_t)e.lvl_pass.size(), nln = (int64_t)e.sidx.size(),
-                          nov = (int64_t)e.oidx.size();
+            const int64_t np = (int64_t)e.passes.size(), nlv = (int64_t)e.lvl_pass.size(), nln = (int64_t)e.lanes(),
+                          nov = (int64_t)e.overflow();
             char* q = d_lu_buf_ + o_ell[k];
             char* const q0 = q;
             d.passes = reinterpret_cast<const EllPass*>(q); q += up16(16 * (np + kEllPadHeaders));
@@ -377,8 +386,8 @@ relp_status_t Engine::lu_upload_factors() {
             d.sval = reinterpret_cast<double*>(q); q += up16(8 * nln);
             d.oval = reinterpret_cast<const double*>(q); q += up16(8 * nov);
             d.rovf = reinterpret_cast<const int32_t*>(q); q += up16(4 * (int64_t)e.rovf.size());
-            d.sidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nln);
-            d.oidx = reinterpret_cast<const uint16_t*>(q); q += up16(2 * nov);
+            d.sidx = reinterpret_cast<const uint16_t*>(q); q += up16(idx_bytes * nln);      // (uint32_t when FtState::big)
+            d.oidx = reinterpret_cast<const uint16_t*>(q); q += up16(idx_bytes * nov);
             const int64_t total = q - q0;
             d.n_passes = (int32_t)np; d.n_levels = (int32_t)nlv - 1; d.m = m_; d.n_lanes = (int32_t)nln; d.n_ovf = (int32_t)nov;
             d.bytes = (int32_t)total;
@@ -403,25 +412,41 @@ relp_status_t Engine::lu_upload_factors() {
 // Forrest-Tomlin mode (relp_kernels_ft.hip)
 // ------------------------------------------------------------------------------------------------
 relp_status_t Engine::ft_plan_and_alloc() {
-    ft_ = false;
+    ft_ = false; ft_big_ = false; ft_fused_ = true;
     if (m_ > kFtMaxRows) return RELP_OK;
     // The dense tail of U (tcap x tcap in LDS) is as large as the refactorisation interval asks for, not larger: what it does
     // not take stages the triangular factors, and an image that does not fit is solved from L2 at several times the cost.
     // Default interval 48: with a refactorisation at ~0.7 ms and ~1,100 clocks per pending update and pivot, the optimum is
     // flat between 40 and 64, and 48 x 49 doubles leave 14 KB more for the images than 64 x 65.
     const int32_t want = cfg_.update_block < 0 ? 48 : std::max(1, std::min(cfg_.update_block, kFtMaxSlots));
-    for (int32_t tcap : {64, 48, 32, 16}) {
-        if (tcap != 16 && tcap - 16 >= want) continue;              // a smaller tail serves the interval
-        for (int64_t eta_cap : {(int64_t)2 * m_ + 64}) {     // (one eta never exceeds m entries; the rest of the LDS stages the schedules)
-            eta_cap = std::max<int64_t>(eta_cap, 1024);
-            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap) + 4096 <= kFtLdsBudget) {
-                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_ = true;
-                break;
+    // Two layouts (relp_kernels_ft.hip: ft_layout).  "All in LDS": x with its right-hand-side copy, spike, -pi, permutations,
+    // eta pool -- 63 bytes per row.  "big": x, -pi and the slot tables only (17 bytes per row, 25 with the right-hand-side
+    // copy), the rest read from L2; slot indices of the images 32 bits wide.  The first is taken while it leaves the dense
+    // tail the interval asks for AND >= kFtMinStage bytes to stage the factor images (an image that is not staged is solved
+    // from L2 at several times the cost); RELP_FT_BIG = 0 / 1 forces one of them.
+    const int64_t eta_cap = std::max<int64_t>((int64_t)2 * m_ + 64, 1024);   // (one eta never exceeds m entries)
+    constexpr int64_t kFtMinStage = 64 * 1024;
+    const char* big_env = std::getenv("RELP_FT_BIG");
+    const int force_big = big_env ? std::atoi(big_env) : -1;
+    auto plan = [&](bool big, bool fused, int64_t min_stage) {
+        for (int32_t tcap : {64, 48, 32, 16}) {
+            if (tcap != 16 && tcap - 16 >= want) continue;              // a smaller tail serves the interval
+            if (tcap < want && min_stage > 4096) return false;          // (only the last resort shortens the interval)
+            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap, big, fused) + min_stage <= kFtLdsBudget) {
+                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_big_ = big; ft_fused_ = fused; ft_ = true;
+                return true;
             }
         }
-        if (ft_) break;
-    }
+        return false;
+    };
+    if (force_big != 1 && plan(false, true, force_big == 0 ? 4096 : kFtMinStage)) {}
+    else if (force_big != 0 && (plan(true, true, kFtMinStage) || plan(true, true, 16 * 1024) || plan(true, false, 4096))) {}
+    else if (force_big != 1) plan(false, true, 4096);
     if (!ft_) return RELP_OK;
+    if (std::getenv("RELP_DEBUG"))
+        std::fprintf(stderr, "[relp] persistent pivot kernel: m %d, layout %s%s, dense tail %d, LDS base %zu bytes\n", m_,
+                     ft_big_ ? "big" : "all-in-LDS", ft_fused_ ? "" : " (no fused levels)", ft_tcap_,
+                     ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_fused_));
     const int64_t tc = ft_tcap_, ldt = tc + 1, m = m_, nwp = kFtWaves + 1;
     std::vector<char> dummy;
     int64_t o = 0;
@@ -430,7 +455,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_lv = take(4 * tc), o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp),
                   o_so = take(4 * tc * nwp), o_pv = take(4 * tc), o_ts = take(4 * m), o_ei = take(4 * (int64_t)ft_eta_cap_),
                   o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32),
-                  o_journal = take(8 * tc);
+                  o_journal = take(8 * tc), o_spw = take(8 * m);
     ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
@@ -462,6 +487,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spk_idx = reinterpret_cast<int32_t*>(d_ft_buf_ + o_si);
     fts_.spk_val = reinterpret_cast<double*>(d_ft_buf_ + o_sv);
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
+    fts_.sp_work = reinterpret_cast<double*>(d_ft_buf_ + o_spw);
+    fts_.big = ft_big_ ? 1 : 0; fts_.fused_x = ft_fused_ ? 1 : 0;
     fts_.prof = reinterpret_cast<long long*>(d_ft_buf_ + o_prof);
     fts_.journal = reinterpret_cast<int32_t*>(d_ft_buf_ + o_journal);
     // refactor when this many updates are pending (lower_upper/mod.rs:199-202 refactors when updates.len() > 10, i.e.
@@ -581,7 +608,7 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     struct Tick { int64_t& t; ~Tick() { ++t; } };
     // Look-ahead refactorisation (lu_refactor_lookahead): the kernel returns `la` updates before the file is full, and fills
     // the rest while the host factorises.  On for refactorisation intervals from 24 on; RELP_LU_LOOKAHEAD = 0 switches it off.
-    static const int32_t la_env = [] { const char* e = std::getenv("RELP_LU_LOOKAHEAD"); return e ? std::atoi(e) : 8; }();
+    const int32_t la_env = lu_lookahead_env_;              // (RELP_LU_LOOKAHEAD, read at create)
     const int32_t la = (fts_.max_updates >= 24 && la_env > 0) ? std::min(la_env, fts_.max_updates / 3) : 0;
     bool have_basis = false;                               // h_basis_ holds the basis as the last launch left it
     while (h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters) {
@@ -644,6 +671,12 @@ relp_status_t Engine::lu_stats(int64_t* out8) const {
     out8[0] = lu_refactors_; out8[1] = hlu_.m; out8[2] = hlu_.nnz_l; out8[3] = hlu_.nnz_u;
     out8[4] = (int64_t)hlu_.Lf.level_ptr.size() - 1; out8[5] = (int64_t)hlu_.Uf.level_ptr.size() - 1;
     out8[6] = (int64_t)hlu_.Ub.level_ptr.size() - 1; out8[7] = (int64_t)hlu_.Lb.level_ptr.size() - 1;
+    return RELP_OK;
+}
+
+relp_status_t Engine::lu_lookahead_stats(int64_t* out4) const {
+    if (!lu_) return RELP_E_STATE;
+    out4[0] = lu_lookahead_installs_; out4[1] = lu_replayed_changes_; out4[2] = lu_lookahead_env_; out4[3] = lu_fuse_lanes_env_;
     return RELP_OK;
 }
 

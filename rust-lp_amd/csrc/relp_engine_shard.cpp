@@ -30,7 +30,6 @@ relp_status_t Engine::shard_pivot() {
     launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
     prof_end();
     tab_partials_valid_ = true;
-    if (ovl_pending_ && --ovl_left_ <= 0) tab_settle();
     if (++since_flush_ >= block_) enqueue_flush();
     ++prof_tick_;
     return RELP_OK;
@@ -185,25 +184,30 @@ relp_status_t Engine::remove_artificial_basis_variables_sharded(std::vector<int3
     std::sort(arts.begin(), arts.end());
     relp_status_t st;
     const int32_t g = std::max(cfg_.shard_count, 1);
+    const bool textbook = cfg_.artificial_removal == RELP_ARTIFICIAL_TEXTBOOK;
     for (int32_t a : arts) {
-        const int32_t pivot_row = column_to_row_[a];
+        int32_t pivot_row = column_to_row_[a];             // phase_one.rs:236: the row the artificial STARTED in
+        if (textbook) pivot_row = (int32_t)(std::find(basis.begin(), basis.end(), a) - basis.begin());   // the row it is basic in
         if ((st = download_rec())) return st;
         h_rec_->outcome = DEV_RUNNING;
         if ((st = upload_rec())) return st;
         const TableauView tv = tview();
         const DeferredUpdate du = deferred();
         const SelectPartials sp = tab_partials(RELP_RULE_FIRST_PROFITABLE);        // key = column index
-        launch_tab_zero_level_scan(tv, du, sp, pivot_row, nr_artificial_, tolerances(), d_rec_, stream_);
+        Tolerances zt = tolerances();
+        if (textbook) zt.cost = INFINITY;               // any reduced cost will do: the pivot is at zero level
+        launch_tab_zero_level_scan(tv, du, sp, pivot_row, nr_artificial_, zt, d_rec_, stream_);
         launch_tab_select_column_msg(tv, du, sp, tab_scan_blocks(sc_hi_ - sc_lo_), d_msg_cand_, d_b_, tolerances(), d_rec_, stream_);
         if (coll_allgather_(coll_ctx_, d_msg_cand_, d_msg_cands_, cand_len_ * (int64_t)sizeof(double), stream_))
             return fail(RELP_E_HIP, "all-gather of the zero-level candidates failed");
         launch_tab_select_candidate_ratio(d_msg_cands_, g, cand_len_, m_, d_alpha_, d_b_, d_basis_, RELP_RULE_FIRST_PROFITABLE,
                                           tolerances(), du, pivot_row, d_rec_, stream_);
         if ((st = download_rec())) return st;
-        if (h_rec_->outcome == DEV_NO_CANDIDATE) { rows_to_remove.push_back(a); continue; }
+        if (h_rec_->outcome == DEV_NO_CANDIDATE) { rows_to_remove.push_back(textbook ? pivot_row : a); continue; }
         if (h_rec_->alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
         launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
         tab_partials_valid_ = false;
+        basis[pivot_row] = h_rec_->q;
         if (++since_flush_ >= block_) enqueue_flush();
     }
     return RELP_OK;

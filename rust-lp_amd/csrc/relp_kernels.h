@@ -70,7 +70,7 @@ struct ColumnTable {
     const double*  cost;          // structural p -> phase-2 cost             (nr_normal)
 };
 
-struct Tolerances { double cost, pivot, zero, tie; };
+struct Tolerances { double cost, pivot, zero, tie; int32_t ratio_rule, pad_; };   // ratio_rule: relp_ratio_rule_t
 
 // PRICE -> entering-column choice without a second pass over d: every PRICE workgroup leaves the
 // best (key, j) of its own columns here (key as in k_select_column), k_select_partials reduces them.
@@ -110,6 +110,7 @@ struct DeviceLU {
 // The same solve packed "ELL by pass" for the persistent pivot kernel (relp_lu.hpp: ell_pack; relp_lu_device.h: ell_solve):
 // one image per schedule, contiguous in device memory in the order of the members below, every array padded to 16 bytes.
 static constexpr int kEllLg = 13;                       // sidx = index | lg << kEllLg (relp_lu.hpp: kEllLgShift)
+static constexpr int kEllLgWide = 24;                   // the same in the 32-bit images of large bases (FtState::big)
 static constexpr int kEllPadHeaders = 4;                // empty pass headers behind the last one: the solves read ahead unchecked
 struct EllPass { int32_t lane0, lanes, info, level; };     // info: max lg | last-of-level << 8 | overflow << 9
 struct EllSchedule {
@@ -149,7 +150,7 @@ struct DeviceCSC { const int64_t* col_ptr; const int32_t* row_idx; const double*
 static constexpr int kFtThreads = 512;                 // the persistent pivot workgroup: 8 wavefronts
 static constexpr int kFtWaves = kFtThreads / 64;       // sparse lists are bucketed by (pivot % kFtWaves): one wavefront per bucket
 static constexpr int kFtMaxSlots = 64;                 // one lane of a wavefront per slot in the chains over TC
-static constexpr int kFtMaxRows = 4096;                // work vectors (x, spike, -pi) live in LDS
+static constexpr int kFtMaxRows = 16384;               // x, -pi and the slot tables must fit one CU's LDS (ft_layout decides)
 static constexpr int kFtLdsBudget = 156 * 1024;        // of the CU's 160 KB
 // Everything the Forrest-Tomlin update needs to know about the leaving pivot p, together in one cache line segment (it was
 // five dependent global round trips: task -> row header -> entries, via_ptr -> via_pos, twice).
@@ -181,6 +182,9 @@ struct FtState {
     int32_t* journal;                      // (basis position, entering column) of every basis change of the last k_ft_run
                                            // launch, hdr[3] of them: what k_ft_replay applies to freshly computed factors
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
+    double*  sp_work;        // m: the spike inside the kernels when it does not live in LDS (big)
+    int32_t  big;            // 1: spike, permutations and eta pool in global memory, 32-bit slot indices (relp_kernels_ft.hip: ft_layout)
+    int32_t  fused_x;        // x holds the right-hand-side copy of the fused schedules (2 m + 1 words instead of m + 1)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
     int32_t  stage_bytes;
     int32_t  lds_bytes;      // dynamic LDS of every FT kernel
@@ -329,12 +333,6 @@ struct TableauView {
     int32_t  n;       // tableau columns of the current phase
     int32_t  c_lo, c_hi;  // storage columns owned by this rank (T0, R0 hold only these; pointers are
                           // pre-shifted so that kernels index by global storage column)
-    // Overlapped flush: while the previous block (W', R0', p' pivots rows) is being folded into the OTHER tableau buffer on a
-    // second stream, the pivots of the current block read T0 + W' R0' for the tableau they start from.  Null = no
-    // previous block pending.  R0p is pre-shifted like R0; W' has the pitch of the current W.
-    const double* Wp;
-    const double* R0p;
-    const int32_t* pp;    // device: p'
 };
 // T0 := original matrix in row space (artificial unit columns | A + bound rows | virtual unit columns)
 void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s);
@@ -370,12 +368,9 @@ void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, S
                               double* alpha, PivotRecord* rec, hipStream_t s);
 // single-GPU loop: also leaves the minimum ratio of every block of 256 rows in `rmin`, and the ratio test that
 // starts from those minima (re-reads only the row blocks inside the tie band)
-// `ticket` (a device int, 0 between launches): the last workgroup to finish also runs the ratio test (launch_ratio_blocks
-// is then not needed)
 void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                    double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
-                                   hipStream_t s, const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr,
-                                   const double* shadow = nullptr, int32_t* shadow_meta = nullptr);
+                                   hipStream_t s, const double* shadow = nullptr, int32_t* shadow_meta = nullptr);
 void launch_ratio_blocks(const double* alpha, const double* b, const int32_t* basis_indices, int32_t m, Tolerances tol,
                          const DeferredUpdate& du, const double* rmin, PivotRecord* rec, hipStream_t s);
 // sharded engines: this rank's candidate message [key, j, d_j, alpha (m), minimum ratio per block of 256 rows
@@ -401,9 +396,7 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
                            const double* alpha, double* b, int32_t* basis_indices, uint8_t* in_basis, int32_t* trace,
                            int64_t trace_cap, PivotRecord* rec, hipStream_t s);
 // flush: T0 += W R0 with v_mfma_f64_16x16x4_f64 tiles
-// T_dst = T0 + W R0 with p = *p_dev pivots rows (T_dst = nullptr: in place, p from the record)
-void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s,
-                      double* T_dst = nullptr, const int32_t* p_dev = nullptr);
+void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s);
 // Ratio test + update in ONE launch (single-GPU loop): every workgroup repeats the ratio test from the block minima the column
 // kernel left (same code, same answer), then does its share of the update.  What one workgroup rewrites while another may
 // still read it is double-buffered: b and the basis array (in -> out, the caller swaps them), row r of W (its new values go
@@ -417,8 +410,6 @@ void launch_tab_ratio_update_all(const TableauView& tv, const DeferredUpdate& du
 // (msgs: sharded loop -- the gathered candidate messages; the winner's column and block minima are taken from there and
 // `alpha` / `rmin` are ignored)
 void launch_tab_apply_shadow(const DeferredUpdate& du, double* shadow, int32_t* shadow_meta, hipStream_t s);
-// end of a block whose flush is overlapped: *prev_p = pivot rows of the block, then the record / row map start a new block
-void launch_tab_block_rollover(const DeferredUpdate& du, PivotRecord* rec, int32_t* prev_p, hipStream_t s);
 // out[i, k] = T0[i, cols[k]] (row-major m x m): B^-1 from the identity columns
 void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s);
 // tableau row `row` of the CURRENT T into out[0..n_store) (remove_artificial_basis_variables)
@@ -451,7 +442,7 @@ void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double
 
 // ---- Forrest-Tomlin engine (relp_kernels_ft.hip) ---------------------------------------------------------------
 // bytes of dynamic LDS the FT kernels need besides the staging area
-size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap);
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big = false, bool fused = true);
 // LDS bytes a schedule needs to be staged (relp_lu_device.h: schedule_lds_bytes)
 int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg);
 // up to `max_pivots` whole pivots (PRICE -> FTRAN -> RATIO -> FT update -> BTRAN -> b, -pi, basis) in ONE launch of one

@@ -10,6 +10,7 @@
 // behind __syncthreads only.
 #include "relp_lu_device.h"
 
+#include <type_traits>
 #include <vector>
 
 namespace relp {
@@ -27,19 +28,23 @@ struct FtLayout {
     int64_t x, sp, pi, perm, tc, dots, zt, uv, ct, slot_pivot, slot_prev, slot_live, slot_next, eta_off, spk_off, tslot, eta_idx,
         eta_val, red_d, red_i, stage, total;
 };
-__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap) {
+// `big` (FtState::big, m beyond ~2,400 rows): only what a pass of a solve touches stays in LDS -- x (with the right-hand-side
+// copy of the fused schedules when `fused`), -pi (PRICE gathers from it), the slot tables and the dense tail; the spike, the
+// permutations and the eta pool, each read a few times per pivot, are read from global memory (L2).
+__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap, bool big = false, bool fused = true) {
     FtLayout L;
     int64_t o = 0;
     const int ldt = tcap + 1;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
-    L.x = take(8LL * (2 * m + 1)); L.sp = take(8LL * m); L.pi = take(8LL * m);  // x[m]: scratch word of ell_solve; x[m + 1 ..]: rhs copy
-    L.perm = take(2LL * 3 * m);                      // inv_rowperm | inv_colperm | rowperm as 16-bit indices
+    L.x = take(8LL * ((big && !fused ? m : 2 * m) + 1));       // x[m]: scratch word of ell_solve; x[m + 1 ..]: rhs copy
+    L.sp = take(big ? 0 : 8LL * m); L.pi = take(8LL * m);
+    L.perm = take(big ? 0 : 2LL * 3 * m);            // inv_rowperm | inv_colperm | rowperm as 16-bit indices
     L.tc = take(8LL * tcap * ldt);
     L.dots = take(8LL * tcap); L.zt = take(8LL * tcap); L.uv = take(8LL * tcap); L.ct = take(8LL * tcap);
     L.slot_pivot = take(4LL * tcap); L.slot_prev = take(4LL * tcap); L.slot_live = take(4LL * tcap); L.slot_next = take(4LL * tcap);
     L.eta_off = take(4LL * tcap * (NW + 1)); L.spk_off = take(4LL * tcap * (NW + 1));
     L.tslot = take(m);
-    L.eta_idx = take(4LL * eta_cap); L.eta_val = take(8LL * eta_cap);
+    L.eta_idx = take(big ? 0 : 4LL * eta_cap); L.eta_val = take(big ? 0 : 8LL * eta_cap);
     L.red_d = take(8LL * 2 * NW); L.red_i = take(4LL * 4 * NW + 64);
     L.stage = o; L.total = o;
     return L;
@@ -71,34 +76,46 @@ struct FtClock {
     }
 };
 
-struct FtCtx {
-    double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;
+template <bool kBig>
+struct FtCtxT {
+    static constexpr bool big = kBig;
+    typedef typename std::conditional<kBig, int32_t, unsigned short>::type perm_t;
+    double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;      // (big: sp, eta_val, eta_idx and the permutations are global)
     int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
     signed char* tslot;
-    const unsigned short *irp, *icp, *rp;              // original row -> pivot, basis position -> pivot, pivot -> original row
+    const perm_t *irp, *icp, *rp;                      // original row -> pivot, basis position -> pivot, pivot -> original row
     char* stage;
     int m, tcap, ldt, t, eta_used, eta_cap, journal_n;
     FtClock clk;
 };
 
-__device__ __forceinline__ void ft_bind(FtCtx& c, char* lds, const FtState& st) {
-    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap);
-    c.x = (double*)(lds + L.x); c.sp = (double*)(lds + L.sp); c.pi = (double*)(lds + L.pi); c.TC = (double*)(lds + L.tc);
-    c.irp = (const unsigned short*)(lds + L.perm); c.icp = c.irp + st.m; c.rp = c.icp + st.m;
+template <class Ctx>
+__device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, const FtState& st) {
+    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::big, st.fused_x != 0);
+    c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.TC = (double*)(lds + L.tc);
+    if constexpr (Ctx::big) {
+        c.sp = st.sp_work; c.irp = st.inv_rowperm; c.icp = st.inv_colperm; c.rp = lu.rowperm;
+        c.eta_idx = st.eta_idx; c.eta_val = st.eta_val;
+    } else {
+        c.sp = (double*)(lds + L.sp);
+        c.irp = (const unsigned short*)(lds + L.perm); c.icp = c.irp + st.m; c.rp = c.icp + st.m;
+        c.eta_idx = (int*)(lds + L.eta_idx); c.eta_val = (double*)(lds + L.eta_val);
+    }
     c.dots = (double*)(lds + L.dots); c.zt = (double*)(lds + L.zt); c.uv = (double*)(lds + L.uv); c.ct = (double*)(lds + L.ct);
     c.slot_pivot = (int*)(lds + L.slot_pivot); c.slot_prev = (int*)(lds + L.slot_prev); c.slot_live = (int*)(lds + L.slot_live);
     c.slot_next = (int*)(lds + L.slot_next); c.eta_off = (int*)(lds + L.eta_off); c.spk_off = (int*)(lds + L.spk_off);
-    c.tslot = (signed char*)(lds + L.tslot); c.eta_idx = (int*)(lds + L.eta_idx); c.eta_val = (double*)(lds + L.eta_val);
+    c.tslot = (signed char*)(lds + L.tslot);
     c.red_d = (double*)(lds + L.red_d); c.red_i = (int*)(lds + L.red_i); c.stage = lds + L.stage;
     c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap; c.journal_n = 0;
     c.clk.start(nullptr);
 }
 
 // global state -> LDS (ends with a barrier)
-__device__ __forceinline__ void ft_load(FtCtx& c, const DeviceLU& lu, const FtState& st, const double* minus_pi) {
+template <class Ctx>
+__device__ __forceinline__ void ft_load(Ctx& c, const DeviceLU& lu, const FtState& st, const double* minus_pi) {
     const int tid = threadIdx.x;
     c.t = st.hdr[0]; c.eta_used = st.hdr[1];
-    {   // the permutations as 16-bit copies: every pivot needs a few entries of each, a global round trip apiece otherwise
+    if constexpr (!Ctx::big) {   // the permutations as 16-bit copies: every pivot needs a few entries of each, a global round trip apiece otherwise
         unsigned short* w = const_cast<unsigned short*>(c.irp);
         for (int k = tid; k < c.m; k += NT) {
             w[k] = (unsigned short)st.inv_rowperm[k]; w[c.m + k] = (unsigned short)st.inv_colperm[k];
@@ -112,7 +129,7 @@ __device__ __forceinline__ void ft_load(FtCtx& c, const DeviceLU& lu, const FtSt
     }
     for (int i = tid; i < c.tcap * (NW + 1); i += NT) { c.eta_off[i] = st.eta_off[i]; c.spk_off[i] = st.spk_off[i]; }
     for (int k = tid; k < c.m; k += NT) c.tslot[k] = (signed char)st.tslot[k];
-    for (int e = tid; e < c.eta_used; e += NT) { c.eta_idx[e] = st.eta_idx[e]; c.eta_val[e] = st.eta_val[e]; }
+    if constexpr (!Ctx::big) for (int e = tid; e < c.eta_used; e += NT) { c.eta_idx[e] = st.eta_idx[e]; c.eta_val[e] = st.eta_val[e]; }
     if (minus_pi) for (int i = tid; i < c.m; i += NT) c.pi[i] = minus_pi[i];
     __syncthreads();
     for (int s = tid; s < c.t; s += NT) { const int pv = c.slot_prev[s]; if (pv >= 0) c.slot_next[pv] = s; }
@@ -120,7 +137,8 @@ __device__ __forceinline__ void ft_load(FtCtx& c, const DeviceLU& lu, const FtSt
 }
 
 // LDS -> global state (what an update may have changed)
-__device__ __forceinline__ void ft_store(const FtCtx& c, const FtState& st, double* minus_pi, int need_refactor) {
+template <class Ctx>
+__device__ __forceinline__ void ft_store(const Ctx& c, const FtState& st, double* minus_pi, int need_refactor) {
     const int tid = threadIdx.x;
     __syncthreads();
     for (int i = tid; i < c.tcap * c.ldt; i += NT) st.TC[i] = c.TC[i];
@@ -129,7 +147,7 @@ __device__ __forceinline__ void ft_store(const FtCtx& c, const FtState& st, doub
     }
     for (int i = tid; i < c.tcap * (NW + 1); i += NT) { st.eta_off[i] = c.eta_off[i]; st.spk_off[i] = c.spk_off[i]; }
     for (int k = tid; k < c.m; k += NT) st.tslot[k] = c.tslot[k];
-    for (int e = tid; e < c.eta_used; e += NT) { st.eta_idx[e] = c.eta_idx[e]; st.eta_val[e] = c.eta_val[e]; }
+    if constexpr (!Ctx::big) for (int e = tid; e < c.eta_used; e += NT) { st.eta_idx[e] = c.eta_idx[e]; st.eta_val[e] = c.eta_val[e]; }
     if (minus_pi) for (int i = tid; i < c.m; i += NT) minus_pi[i] = c.pi[i];
     if (tid == 0) { st.hdr[0] = c.t; st.hdr[1] = c.eta_used; st.hdr[2] = need_refactor; st.hdr[3] = c.journal_n; }
 }
@@ -211,18 +229,20 @@ __device__ __forceinline__ double sum8(double v) {
 }
 
 // `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
-__device__ __forceinline__ void sweep(const FtState& st, int which, FtCtx& c, int first_level = 0) {
+template <class Ctx>
+__device__ __forceinline__ void sweep(const FtState& st, int which, Ctx& c, int first_level = 0) {
     auto lap = [&]() { c.clk.lap(FT_STAGE); };
     int passes;
-    if (st.stage[which]) passes = ell_solve_pp<true, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
-    else passes = ell_solve_pp<false, NT>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    else passes = ell_solve_pp<false, NT, Ctx::big>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
     if (c.clk.on) { c.clk.passes[which] += passes; c.clk.sweeps[which] += 1; c.clk.total[which] += st.ell[which].n_passes; }
 }
 
 // ---- FTRAN: x = P a on entry (pivot-indexed); x = U^-1 R_t .. R_1 L^-1 (P a) on exit, the spike in sp -----------------
 // lower_upper/mod.rs:157-190
 // spike_only: stop once the spike (what an update needs) is formed, before the solve with U
-__device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool spike_only = false) {
+template <class Ctx>
+__device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, Ctx& c, bool spike_only = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     sweep(st, 0, c);
@@ -312,7 +332,8 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
 // ---- y' U = c' for the current U: c in x (pivot-indexed) on entry; y over the never-updated pivots in x, over the
 // slots in zt on exit (invert_upper_left, mod.rs:332-356, on the unrotated representation) ------------------------------
 // first_level: the sweep over U0' may start at this level (everything below is known to be zero)
-__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 0) {
+template <class Ctx>
+__device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& st, Ctx& c, bool do_sweep, int first_level = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     if (t > 0) {
@@ -377,7 +398,8 @@ __device__ __forceinline__ void ft_ut_solve(const DeviceLU& lu, const FtState& s
 }
 
 // ---- BTRAN: c (pivot-indexed, i.e. Q' c) in x on entry; w = P z with z' B = c' on exit (mod.rs:204-222) ------------------
-__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, FtCtx& c, bool do_sweep, int first_level = 0) {
+template <class Ctx>
+__device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, Ctx& c, bool do_sweep, int first_level = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     ft_ut_solve(lu, st, c, do_sweep, first_level);
@@ -437,8 +459,8 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
 // bucket w = pivots with k % NW == w, written by wavefront w at [base + off[w], base + off[w + 1]).  off (NW + 1 ints) is
 // left in `off_out` relative to off_base.  Returns the total (all threads).  Ends with a barrier.
 // `room`: entries the destination can still take; when the non-zeros do not fit nothing is written and -1 is returned.
-template <class IdxPtr, class ValPtr>
-__device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip, IdxPtr out_idx, ValPtr out_val, int out_base,
+template <class Ctx, class IdxPtr, class ValPtr>
+__device__ __forceinline__ int ft_compact(Ctx& c, const double* vec, int skip, IdxPtr out_idx, ValPtr out_val, int out_base,
                                           int* off_out, int off_base, int room) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_wave = (c.m - wave + NW - 1) / NW;           // pivots k = wave + NW * i, i < per_wave
@@ -476,7 +498,8 @@ __device__ __forceinline__ int ft_compact(FtCtx& c, const double* vec, int skip,
 
 // ---- the Forrest-Tomlin update (mod.rs:92-155) for the basis change in basis position `r`; the spike is in sp -------------
 // Returns false, with the update file untouched, when r does not fit the eta pool any more (refactorisation due).
-__device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st, FtCtx& c, int r) {
+template <class Ctx>
+__device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st, Ctx& c, int r) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
     const int p = c.icp[r];                            // the pivot whose column leaves (mod.rs:99-107)
@@ -565,7 +588,8 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
 }
 
 // x := P a for tableau column q (partially.rs:72-80, matrix_data.rs:308-348), pivot-indexed.  Ends with a barrier.
-__device__ __forceinline__ void ft_scatter_column(const FtState& st, const FtProblem& pb, FtCtx& c, int q) {
+template <class Ctx>
+__device__ __forceinline__ void ft_scatter_column(const FtState& st, const FtProblem& pb, Ctx& c, int q) {
     const int tid = threadIdx.x;
     const ColumnTable& ct = pb.ct;
     for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
@@ -613,7 +637,8 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
-__device__ __forceinline__ int block_min_int(FtCtx& c, int v) {
+template <class Ctx>
+__device__ __forceinline__ int block_min_int(Ctx& c, int v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_min_i32(v);
     __syncthreads();
@@ -625,7 +650,8 @@ __device__ __forceinline__ int block_min_int(FtCtx& c, int v) {
     return v;
 }
 
-__device__ __forceinline__ double block_min_double(FtCtx& c, double v) {
+template <class Ctx>
+__device__ __forceinline__ double block_min_double(Ctx& c, double v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_min_f64(v);
     __syncthreads();
@@ -637,8 +663,26 @@ __device__ __forceinline__ double block_min_double(FtCtx& c, double v) {
     return v;
 }
 
+// minimum of 64-bit tie keys (relp_device_common.h: tie_key) over the workgroup; only the RELP_RATIO_LARGEST_PIVOT rule
+// comes here, the reference's rule reduces 32-bit leaving columns (block_min_int)
+template <class Ctx>
+__device__ __forceinline__ tie_key_t block_min_key64(Ctx& c, tie_key_t v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const tie_key_t o = __shfl_down(v, off, 64); v = o < v ? o : v; }
+    tie_key_t* red = reinterpret_cast<tie_key_t*>(c.red_d);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    v = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v = red[w] < v ? red[w] : v;
+    return v;
+}
+
 // lexicographic minimum of (key, j) over the workgroup: the smallest key, then the lowest j among the threads that hold it
-__device__ __forceinline__ void block_min_key(FtCtx& c, double& key, int& kj) {
+template <class Ctx>
+__device__ __forceinline__ void block_min_key(Ctx& c, double& key, int& kj) {
     const double kmin = block_min_double(c, key);
     kj = block_min_int(c, key == kmin ? kj : 0x7fffffff);
     key = kmin;
@@ -647,12 +691,24 @@ __device__ __forceinline__ void block_min_key(FtCtx& c, double& key, int& kj) {
 // ------------------------------------------------------------------------------------------------------------------
 // The persistent pivot kernel
 // ------------------------------------------------------------------------------------------------------------------
+template <bool kBig>
 __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProblem pb, long long max_pivots) {
     extern __shared__ __align__(16) char lds[];
     PivotRecord* rec = pb.rec;
-    if (rec->outcome != DEV_RUNNING) return;
-    FtCtx c;
-    ft_bind(c, lds, st);
+    if (rec->outcome != DEV_RUNNING) {
+        // nothing to do; the report is still this launch's own (no basis change in the journal), never the previous one's
+        if (pb.mirror) {
+            if (threadIdx.x == 0) {
+                pb.mirror->rec = *rec;
+                pb.mirror->hdr[0] = st.hdr[0]; pb.mirror->hdr[1] = st.hdr[1]; pb.mirror->hdr[2] = st.hdr[2]; pb.mirror->hdr[3] = 0;
+            }
+            for (int i = threadIdx.x; i < st.m; i += NT) pb.mirror->basis[i] = pb.basis[i];
+        }
+        if (threadIdx.x == 0) st.hdr[3] = 0;
+        return;
+    }
+    FtCtxT<kBig> c;
+    ft_bind(c, lds, lu, st);
     c.clk.start(st.prof);
     ft_load(c, lu, st, pb.minus_pi);
     c.clk.lap(FT_LOAD_STORE);
@@ -884,14 +940,25 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         const double gmin = block_min_double(c, mn);
         if (gmin == INFINITY) { outcome = DEV_NO_ROW; break; }
         const double bound = gmin + pb.tol.tie * fmax(1.0, fabs(gmin));
-        int best_leave = 0x7fffffff;
-        if (t0 <= bound) best_leave = s0;
-        if (t1 <= bound) best_leave = min(best_leave, s1);
-        for (int i = tid + 2 * NT; i < m; i += NT) {
-            const double a = c.x[c.icp[i]];
-            if (row_ratio(a, pb.b[i], pb.tol) <= bound) best_leave = min(best_leave, pb.basis[i]);
+        if (pb.tol.ratio_rule == 0) {                  // the reference: lowest leaving column inside the band
+            int best_leave = 0x7fffffff;
+            if (t0 <= bound) best_leave = s0;
+            if (t1 <= bound) best_leave = min(best_leave, s1);
+            for (int i = tid + 2 * NT; i < m; i += NT) {
+                const double a = c.x[c.icp[i]];
+                if (row_ratio(a, pb.b[i], pb.tol) <= bound) best_leave = min(best_leave, pb.basis[i]);
+            }
+            leaving = block_min_int(c, best_leave);
+        } else {                                       // RELP_RATIO_LARGEST_PIVOT: pivot size first, then the column
+            tie_key_t best = kNoTieKey;
+            if (t0 <= bound) best = tie_key(a0, s0, 1);
+            if (t1 <= bound) { const tie_key_t k1 = tie_key(a1, s1, 1); best = k1 < best ? k1 : best; }
+            for (int i = tid + 2 * NT; i < m; i += NT) {
+                const double a = c.x[c.icp[i]];
+                if (row_ratio(a, pb.b[i], pb.tol) <= bound) { const tie_key_t k = tie_key(a, pb.basis[i], 1); best = k < best ? k : best; }
+            }
+            leaving = tie_key_leaving(block_min_key64(c, best));
         }
-        leaving = block_min_int(c, best_leave);
         // the row of the leaving column
         int rr = 0x7fffffff;
         if (h0 && s0 == leaving && t0 <= bound) rr = i0;
@@ -981,11 +1048,12 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
 }
 
 // ---- single steps (step-wise API, phase boundaries) ------------------------------------------------------------------
+template <bool kBig>
 __global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProblem pb, int column, const double* rhs,
                                                   double* alpha) {
     extern __shared__ __align__(16) char lds[];
-    FtCtx c;
-    ft_bind(c, lds, st);
+    FtCtxT<kBig> c;
+    ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     const int tid = threadIdx.x;
     if (rhs) {
@@ -998,10 +1066,11 @@ __global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProb
     for (int k = tid; k < c.m; k += NT) { alpha[lu.colperm[k]] = c.x[k]; st.spike[k] = c.sp[k]; }
 }
 
+template <bool kBig>
 __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProblem pb, int row, const double* rhs, double* rho) {
     extern __shared__ __align__(16) char lds[];
-    FtCtx c;
-    ft_bind(c, lds, st);
+    FtCtxT<kBig> c;
+    ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     const int tid = threadIdx.x;
     bool sweep_u = true;
@@ -1020,10 +1089,11 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
     for (int k = tid; k < c.m; k += NT) rho[lu.rowperm[k]] = c.x[k];
 }
 
+template <bool kBig>
 __global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtProblem pb) {
     extern __shared__ __align__(16) char lds[];
-    FtCtx c;
-    ft_bind(c, lds, st);
+    FtCtxT<kBig> c;
+    ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
     __syncthreads();
@@ -1041,34 +1111,47 @@ void ft_allow_lds(const void* fn, int bytes) {
 
 }  // namespace
 
-size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap) { return (size_t)ft_layout(m, tcap, eta_cap).total; }
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big, bool fused) {
+    return (size_t)ft_layout(m, tcap, eta_cap, big, fused).total;
+}
 int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg) { return schedule_lds_bytes(m, nnz, n_levels, n_seg); }
 
+// (st.big selects the instantiation: ft_layout, the index width of the images and where the spike, the permutations and the
+// eta pool live all follow from it)
+#define FT_LAUNCH(kernel, ...)                                                                                        \
+    do {                                                                                                              \
+        if (st.big) {                                                                                                 \
+            ft_allow_lds(reinterpret_cast<const void*>(kernel<true>), st.lds_bytes);                                  \
+            hipLaunchKernelGGL(kernel<true>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);                \
+        } else {                                                                                                      \
+            ft_allow_lds(reinterpret_cast<const void*>(kernel<false>), st.lds_bytes);                                 \
+            hipLaunchKernelGGL(kernel<false>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);               \
+        }                                                                                                             \
+    } while (0)
+
 void launch_ft_run(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int64_t max_pivots, hipStream_t s) {
-    ft_allow_lds(reinterpret_cast<const void*>(k_ft_run), st.lds_bytes);
-    hipLaunchKernelGGL(k_ft_run, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, (long long)max_pivots);
+    FT_LAUNCH(k_ft_run, lu, st, pb, (long long)max_pivots);
 }
 
 void launch_ft_ftran(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t column, const double* rhs, double* alpha,
                      hipStream_t s) {
-    ft_allow_lds(reinterpret_cast<const void*>(k_ft_ftran), st.lds_bytes);
-    hipLaunchKernelGGL(k_ft_ftran, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, column, rhs, alpha);
+    FT_LAUNCH(k_ft_ftran, lu, st, pb, column, rhs, alpha);
 }
 
 void launch_ft_btran(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t row, const double* rhs, double* rho,
                      hipStream_t s) {
-    ft_allow_lds(reinterpret_cast<const void*>(k_ft_btran), st.lds_bytes);
-    hipLaunchKernelGGL(k_ft_btran, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, row, rhs, rho);
+    FT_LAUNCH(k_ft_btran, lu, st, pb, row, rhs, rho);
 }
 
 // The basis changes the pivot kernel made while the host was factorising an earlier basis, applied to those fresh factors:
 // per change the spike of the entering column (L solve + the etas replayed so far) and the Forrest-Tomlin update of the
 // leaving position -- what Carry::bring_into_basis does minus everything that is not the factorisation (b, -pi, the basis
 // array are already current).
+template <bool kBig>
 __global__ __launch_bounds__(NT) void k_ft_replay(DeviceLU lu, FtState st, FtProblem pb, int count) {
     extern __shared__ __align__(16) char lds[];
-    FtCtx c;
-    ft_bind(c, lds, st);
+    FtCtxT<kBig> c;
+    ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     int need = 0;
     for (int i = 0; i < count; ++i) {
@@ -1083,13 +1166,11 @@ __global__ __launch_bounds__(NT) void k_ft_replay(DeviceLU lu, FtState st, FtPro
 }
 
 void launch_ft_replay(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t count, hipStream_t s) {
-    ft_allow_lds(reinterpret_cast<const void*>(k_ft_replay), st.lds_bytes);
-    hipLaunchKernelGGL(k_ft_replay, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb, (int)count);
+    FT_LAUNCH(k_ft_replay, lu, st, pb, (int)count);
 }
 
 void launch_ft_update(const DeviceLU& lu, const FtState& st, const FtProblem& pb, hipStream_t s) {
-    ft_allow_lds(reinterpret_cast<const void*>(k_ft_update), st.lds_bytes);
-    hipLaunchKernelGGL(k_ft_update, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, lu, st, pb);
+    FT_LAUNCH(k_ft_update, lu, st, pb);
 }
 
 }  // namespace relp

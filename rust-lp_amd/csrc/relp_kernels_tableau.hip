@@ -166,10 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_column(TableauView tv, Deferre
 __device__ __forceinline__ void tab_row_update_core(const TableauView& tv, const DeferredUpdate& du, const SelectPartials& sp,
                                                     const PivotRecord& R, int block, const double* s_wr, int p_old, int jt, int r,
                                                     int q, int leaving, double d_q, double alpha_r) {
-    __shared__ double s_wp[kMaxEta];                   // row r of the previous block's W (overlapped flush)
     const PivotRecord* rec = &R;
-    const int pp = (tv.pp && jt >= p_old) ? *tv.pp : 0;
-    if ((int)threadIdx.x < pp) s_wp[threadIdx.x] = tv.Wp[(int64_t)threadIdx.x * du.ld + r];
     const int c = tv.c_lo + block * kThreads + threadIdx.x;
     const double d_old = c < tv.c_hi ? tv.d[c] : 0.0;
     __syncthreads();
@@ -179,10 +176,8 @@ __device__ __forceinline__ void tab_row_update_core(const TableauView& tv, const
         double base;
         if (jt < p_old) base = tv.R0[(int64_t)jt * tv.ld_r + c];
         else {
-            // row r is new in this block: its row of the tableau the block started from (T0, plus the previous block's
-            // update while that is still being folded in)
+            // row r is new in this block: its row of the tableau the block started from
             base = tv.T0[(int64_t)c * tv.ld_t + r];
-            for (int j = 0; j < pp; ++j) base = fma(s_wp[j], tv.R0p[(int64_t)j * tv.ld_r + c], base);
             tv.R0[(int64_t)jt * tv.ld_r + c] = base;
         }
         double row = base;
@@ -442,15 +437,10 @@ __global__ void k_tab_apply_shadow(DeferredUpdate du, double* __restrict__ shado
 // of the record; a rank without a candidate sends key = +inf and stays RUNNING (another rank may have one).
 // `rmin` (single-GPU loop): the minimum ratio b_i / alpha_i over this workgroup's 256 rows, for
 // k_ratio_blocks.
-// `ticket` (single-GPU loop, optional): the ratio test runs in the LAST workgroup of this launch to finish instead of in a
-// launch of its own (k_ratio_blocks): every workgroup releases its rows of alpha and its block minimum (agent-scope fence)
-// and draws a ticket; the one that draws the last ticket acquires and does what k_ratio_blocks does.  One kernel boundary
-// and the record's round trip less per pivot.
 __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, DeferredUpdate du, SelectPartials sp,
                                                                 int count, double* alpha, double* msg,
                                                                 const double* b, Tolerances tol,
                                                                 double* rmin, PivotRecord* rec,
-                                                                const int32_t* basis_indices = nullptr, int32_t* ticket = nullptr,
                                                                 const double* shadow = nullptr, int32_t* shadow_meta = nullptr) {
     const int outcome = rec->outcome, p = rec->n_eta;          // one round trip for both ...
     // ... and for the shadow row of the previous pivot's fused update: the workgroup that owns the row folds it into W before
@@ -551,16 +541,12 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
             if (sp.rule == 1) rec->last_selected = bj;
         }
     }
-    __shared__ double s_vp[kMaxEta];                   // column q of the previous block's R0 (overlapped flush)
-    const int pp = tv.pp ? *tv.pp : 0;
     if ((int)threadIdx.x < p) s_vs[threadIdx.x] = tv.R0[(int64_t)threadIdx.x * tv.ld_r + cq];
-    if ((int)threadIdx.x < pp) s_vp[threadIdx.x] = tv.R0p[(int64_t)threadIdx.x * tv.ld_r + cq];
     const double t0 = i < tv.m ? tv.T0[(int64_t)cq * tv.ld_t + i] : 0.0;     // in flight together with the R0 column
     __syncthreads();
     double ratio = INFINITY;
     if (i < tv.m) {
         double a = t0;
-        for (int j = 0; j < pp; ++j) a = fma(tv.Wp[(int64_t)j * du.ld + i], s_vp[j], a);
         for (int j = 0; j < p; ++j) a = fma(du.W[(int64_t)j * du.ld + i], s_vs[j], a);
         alpha[i] = a;
         // the same expression as the ratio test's first pass (ratio_body), so min over the block minima is
@@ -574,16 +560,6 @@ __global__ __launch_bounds__(kThreads) void k_tab_select_column(TableauView tv, 
     if (lane == 0) s_k1[wave] = ratio;
     __syncthreads();
     if (threadIdx.x == 0) rmin[blockIdx.x] = fmin(fmin(s_k1[0], s_k1[1]), fmin(s_k1[2], s_k1[3]));
-    if (!ticket) return;
-    __shared__ int s_last;
-    __threadfence();                                   // release alpha[rows of this workgroup], rmin[blockIdx.x]
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                   // acquire what the other workgroups released
-    if (threadIdx.x == 0) *ticket = 0;                 // (the next pivot's launch starts behind this kernel)
-    ratio_blocks_body<kThreads>(alpha, b, basis_indices, tv.m, tol, du, rmin, (int)gridDim.x, p, rec);
 }
 
 // Ratio test from the per-block minima of k_tab_select_column (ratio_blocks_body): one workgroup.
@@ -709,11 +685,10 @@ __global__ void k_tab_update_vectors(int m, const double* __restrict__ alpha, do
 // Wavefront tile 64 columns x 64 rows (4 x 4 MFMA tiles, 8 operand loads per 16 MFMAs), workgroup
 // 128 x 128.
 template <int MT, int NT>
-__global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, DeferredUpdate du, const int32_t* p_dev,
-                                                        double* T_dst) {
+__global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, DeferredUpdate du, const int32_t* p_dev) {
     constexpr int kFlushMT = MT, kFlushNT = NT;
     const int p = *p_dev;
-    if (p == 0 && T_dst == tv.T0) return;            // (out of place: an empty block is still a copy)
+    if (p == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c_wave = tv.c_lo + blockIdx.x * (2 * 16 * MT) + (wave & 1) * (16 * MT);   // first T0 column of this wavefront
     const int i_wave = blockIdx.y * (2 * 16 * NT) + (wave >> 1) * (16 * NT);            // first T0 row
@@ -769,7 +744,7 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
             for (int g = 0; g < 4; ++g) {
                 const int c = c_wave + a * 16 + lk + 4 * g;
                 const int i = i_wave + b * 16 + lm;
-                if (c < tv.c_hi && i < tv.m) T_dst[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
             }
 }
 
@@ -780,14 +755,13 @@ __global__ __launch_bounds__(kThreads) void k_tab_flush(TableauView tv, Deferred
 // each wavefront fetches its own operands from L2 / Infinity Cache: 48 KB per 32 KB of T0 traffic
 // (4.7 GB per flush at 10k x 20k against 3.2 GB of HBM traffic); with a 256 x 128 tile it is 12 KB.
 template <int WC, int WR, int KC>
-__global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, DeferredUpdate du, const int32_t* p_dev,
-                                                                double* T_dst) {
+__global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, DeferredUpdate du, const int32_t* p_dev) {
     constexpr int MT = 4, NT = 2;                     // wavefront tile: 64 columns x 32 rows
     constexpr int TC = WC * 16 * MT, TR = WR * 16 * NT, NTHR = WC * WR * 64;
     constexpr int RA = KC * TC / 2 / NTHR, RB = KC * TR / 2 / NTHR;
     static_assert(RA * NTHR * 2 == KC * TC && RB * NTHR * 2 == KC * TR, "staging must divide evenly");
     const int p = *p_dev;
-    if (p == 0 && T_dst == tv.T0) return;            // (out of place: an empty block is still a copy)
+    if (p == 0) return;
     __shared__ __align__(16) double As[2][KC][TC];
     __shared__ __align__(16) double Bs[2][KC][TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -872,17 +846,8 @@ __global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, 
             for (int g = 0; g < 4; ++g) {
                 const int c = c_wave + a * 16 + lk + 4 * g;
                 const int i = i_wave + b * 16 + lm;
-                if (c < tv.c_hi && i < tv.m) T_dst[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
+                if (c < tv.c_hi && i < tv.m) tv.T0[(int64_t)c * tv.ld_t + i] = acc[a][b][g];
             }
-}
-
-// End of a block whose flush runs on another stream: remember its number of pivot rows for that flush and for the
-// pivots that overlap with it, and start the next block (k_flush_reset).
-__global__ void k_tab_block_rollover(DeferredUpdate du, PivotRecord* rec, int32_t* prev_p) {
-    const int p = rec->n_eta;
-    for (int j = threadIdx.x; j < p; j += blockDim.x) du.pos_of_row[du.S[j]] = -1;
-    __syncthreads();
-    if (threadIdx.x == 0) { *prev_p = p; rec->n_eta = 0; rec->n_eta_old = 0; rec->eta_target = 0; }
 }
 
 __global__ void k_tab_gather_columns(TableauView tv, const int32_t* __restrict__ cols, double* __restrict__ out) {
@@ -985,16 +950,15 @@ void launch_tab_update_w_vectors(const DeferredUpdate& du, int32_t m, const doub
 void launch_tab_select_column(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                               double* alpha, PivotRecord* rec, hipStream_t s) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       (double*)nullptr, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec, (const int32_t*)nullptr,
-                       (int32_t*)nullptr, (const double*)nullptr, (int32_t*)nullptr);
+                       (double*)nullptr, (const double*)nullptr, Tolerances{}, (double*)nullptr, rec, (const double*)nullptr,
+                       (int32_t*)nullptr);
 }
 
 void launch_tab_select_column_rmin(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t count,
                                    double* alpha, const double* b, Tolerances tol, double* rmin, PivotRecord* rec,
-                                   hipStream_t s, const int32_t* basis_indices, int32_t* ticket, const double* shadow,
-                                   int32_t* shadow_meta) {
+                                   hipStream_t s, const double* shadow, int32_t* shadow_meta) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, alpha,
-                       (double*)nullptr, b, tol, rmin, rec, basis_indices, ticket, shadow, shadow_meta);
+                       (double*)nullptr, b, tol, rmin, rec, shadow, shadow_meta);
 }
 
 void launch_tab_ratio_update_all(const TableauView& tv, const DeferredUpdate& du, SelectPartials sp, int32_t m,
@@ -1023,7 +987,7 @@ void launch_tab_select_column_msg(const TableauView& tv, const DeferredUpdate& d
                                   double* msg, const double* b, Tolerances tol, PivotRecord* rec, hipStream_t s,
                                   const double* shadow, int32_t* shadow_meta) {
     hipLaunchKernelGGL(k_tab_select_column, dim3(cdiv(tv.m, kThreads)), dim3(kThreads), 0, s, tv, du, sp, count, msg + 3,
-                       msg, b, tol, msg + 3 + tv.m, rec, (const int32_t*)nullptr, (int32_t*)nullptr, shadow, shadow_meta);
+                       msg, b, tol, msg + 3 + tv.m, rec, shadow, shadow_meta);
 }
 
 void launch_tab_select_candidate_ratio(const double* msgs, int32_t count, int64_t msg_len, int32_t m, double* alpha,
@@ -1049,28 +1013,22 @@ void launch_tab_update_all(const TableauView& tv, const DeferredUpdate& du, Sele
                        basis_indices, in_basis, trace, trace_cap, rec);
 }
 
-void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s, double* T_dst,
-                      const int32_t* p_dev) {
+void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const PivotRecord* rec, hipStream_t s) {
     if (tv.c_hi <= tv.c_lo) return;
     const int ncols = tv.c_hi - tv.c_lo;
-    if (!T_dst) T_dst = tv.T0;                        // in place
-    if (!p_dev) p_dev = &rec->n_eta;
+    const int32_t* p_dev = &rec->n_eta;
     if ((int64_t)ncols * tv.m >= (1 << 16)) {
         // LDS-staged operands: 8 wavefronts, 128 columns x 128 rows per workgroup, chunks of 16 pivots
         // (64 KB of LDS, <= 128 VGPRs: two workgroups per CU, so one streams its T0 tile while the
         // other one is in its MFMA loop)
         constexpr int WC = 2, WR = 4, KC = 16;
         dim3 grid(cdiv(tv.m, WR * 32), cdiv(ncols, WC * 64));
-        hipLaunchKernelGGL((k_tab_flush_lds<WC, WR, KC>), grid, dim3(WC * WR * 64), 0, s, tv, du, p_dev, T_dst);
+        hipLaunchKernelGGL((k_tab_flush_lds<WC, WR, KC>), grid, dim3(WC * WR * 64), 0, s, tv, du, p_dev);
         return;
     }
     constexpr int MT = 4, NT = 2;      // wavefront tile 64 columns x 32 rows, workgroup 128 x 64
     dim3 grid(cdiv(ncols, 2 * 16 * MT), cdiv(tv.m, 2 * 16 * NT));
-    hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, p_dev, T_dst);
-}
-
-void launch_tab_block_rollover(const DeferredUpdate& du, PivotRecord* rec, int32_t* prev_p, hipStream_t s) {
-    hipLaunchKernelGGL(k_tab_block_rollover, dim3(1), dim3(128), 0, s, du, rec, prev_p);
+    hipLaunchKernelGGL((k_tab_flush<MT, NT>), grid, dim3(kThreads), 0, s, tv, du, p_dev);
 }
 
 void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s) {

@@ -474,7 +474,7 @@ void fuse_levels(const TriangularSchedule& t, bool maskable, bool keep_trivial, 
     }
 }
 
-void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out) {
+void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wide) {
     const TriangularSchedule& t = f.s;
     const int32_t m = (int32_t)t.diag.size();
     const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
@@ -485,6 +485,11 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out) {
     std::vector<int32_t> lane_of(t.idx.size(), -1);      // entry -> its slot (entries in overflow lists: -1)
     constexpr int32_t kLanes = 256;                      // threads that walk the passes (relp_lu_device.h: ell_solve)
     struct Row { int32_t lg, k; };
+    auto n_slots = [&]() { return wide ? out->sidx32.size() : out->sidx.size(); };
+    auto push_slot = [&](int32_t index, int32_t lg) {
+        if (wide) out->sidx32.push_back((uint32_t)index | ((uint32_t)lg << kEllLgShiftWide));
+        else out->sidx.push_back((uint16_t)(index | (lg << kEllLgShift)));
+    };
     for (int32_t l = 0; l < nlev; ++l) {
         out->lvl_pass[l] = (int32_t)out->passes.size();
         std::vector<Row> rows;
@@ -498,22 +503,25 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out) {
         std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.lg > b.lg; });
         const size_t first_pass = out->passes.size();
         for (size_t i = 0; i < rows.size();) {
-            EllPassHost ps{(int32_t)out->sidx.size(), 0, 0, l};
+            EllPassHost ps{(int32_t)n_slots(), 0, 0, l};
             int32_t pos = 0, max_lg = 0, ovf = 0;
             while (i < rows.size() && pos + (1 << rows[i].lg) <= kLanes) {
                 const int32_t k = rows[i].k, lg = rows[i].lg, w = 1 << lg, n = t.ptr[k + 1] - t.ptr[k];
                 out->rdiag[k] = 1.0 / t.diag[k];
-                out->sidx.push_back((uint16_t)(k | (lg << kEllLgShift)));    // the row's own unknown: -(-1) x[k]
+                push_slot(k, lg);                               // the row's own unknown: -(-1) x[k]
                 out->sval.push_back(-1.0);
                 for (int32_t j = 1; j < w; ++j) {
                     const bool has = j - 1 < n;
-                    if (has) lane_of[t.ptr[k] + j - 1] = (int32_t)out->sidx.size();
-                    out->sidx.push_back((uint16_t)((has ? t.idx[t.ptr[k] + j - 1] : 0) | (lg << kEllLgShift)));
+                    if (has) lane_of[t.ptr[k] + j - 1] = (int32_t)n_slots();
+                    push_slot(has ? t.idx[t.ptr[k] + j - 1] : 0, lg);
                     out->sval.push_back(has ? t.val[t.ptr[k] + j - 1] : 0.0);
                 }
-                out->rovf[2 * (size_t)k] = (int32_t)out->oidx.size();
-                for (int32_t e = t.ptr[k] + w - 1; e < t.ptr[k + 1]; ++e) { out->oidx.push_back((uint16_t)t.idx[e]); out->oval.push_back(t.val[e]); ovf = 1; }
-                out->rovf[2 * (size_t)k + 1] = (int32_t)out->oidx.size();
+                out->rovf[2 * (size_t)k] = (int32_t)out->oval.size();
+                for (int32_t e = t.ptr[k] + w - 1; e < t.ptr[k + 1]; ++e) {
+                    if (wide) out->oidx32.push_back((uint32_t)t.idx[e]); else out->oidx.push_back((uint16_t)t.idx[e]);
+                    out->oval.push_back(t.val[e]); ovf = 1;
+                }
+                out->rovf[2 * (size_t)k + 1] = (int32_t)out->oval.size();
                 max_lg = std::max(max_lg, lg);
                 pos += w;
                 ++i;
@@ -525,7 +533,7 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out) {
         if (out->passes.size() > first_pass) out->passes.back().info |= 1 << 8;
     }
     out->lvl_pass[nlev] = (int32_t)out->passes.size();
-    if (out->oidx.empty()) out->rovf.clear();            // no row has more than 63 entries: the ranges are never read
+    if (out->oval.empty()) out->rovf.clear();            // no row has more than 63 entries: the ranges are never read
     if (!f.via_ptr.empty()) {                            // (substituted entries never overflow: fuse_levels caps rows at 63)
         out->via_ptr = f.via_ptr;
         out->via_pos.resize(f.via_ent.size());

@@ -73,6 +73,7 @@ void fuse_levels(const TriangularSchedule& t, bool maskable, bool keep_trivial, 
 // ranges, no row descriptors.  Entries beyond the 63rd of a row live in an overflow list (rare).  Padding slots are (0, 0.0).
 struct EllPassHost { int32_t lane0, lanes, info, level; };     // info: max lg | (last pass of its level) << 8 | (has overflow rows) << 9
 constexpr int32_t kEllLgShift = 13;      // sidx = index | lg << 13: indices up to 2 m + 1 (right-hand-side copies) need m <= 4095
+constexpr int32_t kEllLgShiftWide = 24;  // sidx32 = index | lg << 24: the images of larger bases
 struct EllPacked {
     std::vector<EllPassHost> passes;
     std::vector<int32_t> lvl_pass;       // level -> first pass (n_levels + 1)
@@ -80,10 +81,13 @@ struct EllPacked {
     std::vector<double> sval, oval;
     std::vector<int32_t> rovf;           // 2 m: overflow entries [begin, end) by pivot; empty when no row overflows
     std::vector<uint16_t> sidx, oidx;    // sidx: index | lg << kEllLgShift
+    std::vector<uint32_t> sidx32, oidx32;    // `wide` packing instead: index | lg << kEllLgShiftWide (sidx / oidx stay empty)
+    size_t lanes() const { return sidx.empty() ? sidx32.size() : sidx.size(); }
+    size_t overflow() const { return oidx.empty() ? oidx32.size() : oidx.size(); }
     std::vector<int32_t> via_ptr, via_pos;   // maskable schedules: CSR by pivot of positions in sval to zero when the pivot is masked
 };
 // keep_trivial: also pack the rows without entries whose diagonal is 1 (needed when rows can be masked later: U, U')
-void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out);
+void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wide = false);
 
 // Factors given literally (P = Q = I), the way the reference's tests build a `LUDecomposition { lower_triangular,
 // upper_triangular, .. }` (lower_upper/mod.rs:44-52): L column-major, unit diagonal implied, entries (row > column);

@@ -276,16 +276,25 @@ __device__ __forceinline__ double ell_reduce(double sum, int lg) {
 }
 
 constexpr int kEllIdxMask = (1 << kEllLg) - 1;
+// The slot index array comes in two widths: 16 bits (index | lg << 13: m <= 4,095 with right-hand-side copies) and, for the
+// larger bases whose work vectors no longer fit the LDS next to everything else (FtState::big), 32 bits (index | lg << 24).
+template <bool kWide> struct EllIdx;
+template <> struct EllIdx<false> { typedef uint16_t type; static constexpr int shift = kEllLg, mask = kEllIdxMask; };
+template <> struct EllIdx<true> { typedef uint32_t type; static constexpr int shift = kEllLgWide, mask = (1 << kEllLgWide) - 1; };
 
 // Image -> LDS (one contiguous copy), right-hand side -> its copy behind x (fused schedules); ends with a barrier when
 // anything was written.  Returns the pointers of the image the solve should read.
+template <bool kWide = false>
 struct EllImage {
+    typedef typename EllIdx<kWide>::type idx_t;
     const EllPass* passes; const int32_t* lvl_pass; const double* rdiag; const double* sval; const double* oval;
-    const int32_t* rovf; const uint16_t* sidx; const uint16_t* oidx;
+    const int32_t* rovf; const idx_t* sidx; const idx_t* oidx;
 };
-template <bool kStage, int NT>
-__device__ __forceinline__ EllImage ell_stage(const EllSchedule& s, char* base, double* x) {
-    EllImage im{s.passes, s.lvl_pass, s.rdiag, s.sval, s.oval, s.rovf, s.sidx, s.oidx};
+template <bool kStage, int NT, bool kWide = false>
+__device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char* base, double* x) {
+    typedef typename EllIdx<kWide>::type idx_t;
+    EllImage<kWide> im{s.passes, s.lvl_pass, s.rdiag, s.sval, s.oval, s.rovf, reinterpret_cast<const idx_t*>(s.sidx),
+                       reinterpret_cast<const idx_t*>(s.oidx)};
     const int tid = threadIdx.x;
     if (s.rhs_base) for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i];
     if (kStage) {
@@ -310,8 +319,8 @@ __device__ __forceinline__ EllImage ell_stage(const EllSchedule& s, char* base, 
         im.sval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_lanes);
         im.oval = reinterpret_cast<const double*>(q); q += lu_up16(8LL * s.n_ovf);
         im.rovf = reinterpret_cast<const int32_t*>(q); q += lu_up16(s.n_ovf > 0 ? 8LL * s.m : 0);
-        im.sidx = reinterpret_cast<const uint16_t*>(q); q += lu_up16(2LL * s.n_lanes);
-        im.oidx = reinterpret_cast<const uint16_t*>(q);
+        im.sidx = reinterpret_cast<const idx_t*>(q); q += lu_up16((int64_t)sizeof(idx_t) * s.n_lanes);
+        im.oidx = reinterpret_cast<const idx_t*>(q);
     }
     if (kStage || s.rhs_base) __syncthreads();
     return im;
@@ -324,7 +333,7 @@ __device__ __forceinline__ EllImage ell_stage(const EllSchedule& s, char* base, 
 // Per pass a lane issues: x[idx] (this pass), rdiag (next pass), its slot of the pass after next, one pass header.
 template <bool kStage, int NT, int NTW, class Lap = NoLap>
 __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
-    const EllImage im = ell_stage<kStage, NT>(s, base, x);
+    const EllImage<false> im = ell_stage<kStage, NT>(s, base, x);
     const EllPass* passes = im.passes; const double* rdiag = im.rdiag;
     const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
     const uint16_t* sidx = im.sidx; const uint16_t* oidx = im.oidx;
@@ -388,12 +397,14 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
 // of its next pass: the bookkeeping that was half of a pass's clocks in ell_solve above overlaps with the other set's pass.
 // Every wavefront joins the barrier that ends a level, whoever owned its last pass; two passes of one level may run at the
 // same time (they are independent).
-template <bool kStage, int NT, class Lap = NoLap>
+template <bool kStage, int NT, bool kWide = false, class Lap = NoLap>
 __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
     static_assert(NT == 512, "two sets of 256 lanes");
-    const EllImage im = ell_stage<kStage, NT>(s, base, x);
+    typedef typename EllIdx<kWide>::type idx_t;
+    constexpr int kEllLg = EllIdx<kWide>::shift, kEllIdxMask = EllIdx<kWide>::mask;       // (shadow the 16-bit constants)
+    const EllImage<kWide> im = ell_stage<kStage, NT, kWide>(s, base, x);
     const double* rdiag = im.rdiag; const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
-    const uint16_t* sidx = im.sidx; const uint16_t* oidx = im.oidx;
+    const idx_t* sidx = im.sidx; const idx_t* oidx = im.oidx;
     lap();
     const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
     const int p0 = __builtin_amdgcn_readfirstlane(im.lvl_pass[fl]), p1 = s.n_passes;

@@ -36,6 +36,8 @@ OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded",
 KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
                 "apply_w", "update_w", "flush", "ft_run"]
 ENGINE_REVISED, ENGINE_TABLEAU, ENGINE_LU = 0, 1, 2   # relp_engine_kind_t
+RATIO_REFERENCE, RATIO_LARGEST_PIVOT = 0, 1           # relp_ratio_rule_t (f64 safeguard; 0 = tableau/mod.rs:229-239)
+ARTIFICIAL_REFERENCE, ARTIFICIAL_TEXTBOOK = 0, 1      # relp_artificial_removal_t (0 = phase_one.rs:223-260 literally)
 # relp_status_t
 E_ARG, E_HIP, E_ZERO_PIVOT, E_SINGULAR, E_STATE, E_UNSUPPORTED, E_ALLOC = -1, -2, -3, -4, -5, -6, -7
 FORMAT_CSC, FORMAT_DENSE = 0, 1
@@ -61,7 +63,8 @@ class Config(C.Structure):
                 ("tol_tie", C.c_double), ("tol_feas", C.c_double),
                 ("poll_interval", C.c_int32), ("trace_capacity", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
-                ("update_block", C.c_int32), ("engine", C.c_int32)]
+                ("update_block", C.c_int32), ("engine", C.c_int32),
+                ("ratio_rule", C.c_int32), ("artificial_removal", C.c_int32)]
 
 
 # every symbol include/relp_engine.h declares (tests/test_abi.py checks the export list against the header)
@@ -86,6 +89,7 @@ _SIGNATURES = {
     "relp_flush": (C.c_int, [C.c_void_p]),
     "relp_update_block": (C.c_int32, [C.c_void_p]),
     "relp_lu_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_lu_lookahead_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_lu_phase_cycles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_basis_inverse_row": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "relp_should_refactor": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -355,7 +359,11 @@ class Tableau:
         out = (C.c_int64 * 8)()
         self._ck(self._lib.relp_lu_stats(self._h, out))
         keys = ("refactorisations", "m", "nnz_l", "nnz_u", "levels_l", "levels_u", "levels_ut", "levels_lt")
-        return dict(zip(keys, (int(v) for v in out)))
+        stats = dict(zip(keys, (int(v) for v in out)))
+        la = (C.c_int64 * 4)()
+        self._ck(self._lib.relp_lu_lookahead_stats(self._h, la))
+        stats.update(lookahead_installs=int(la[0]), replayed_changes=int(la[1]), lookahead=int(la[2]), fuse_lanes=int(la[3]))
+        return stats
 
     # -- BasisInverse surface (carry/mod.rs:68-157) ---------------------------------------------
     def basis_inverse_row(self, row: int) -> np.ndarray:

@@ -89,16 +89,21 @@ static void solve_plain(const TriangularSchedule& s, std::vector<double>& x, con
 static void solve_ell(const EllPacked& e, int m, int rhs_base, std::vector<double> x_in, std::vector<double>* out) {
     std::vector<double> x((size_t)2 * m + 2, 0.0);
     for (int i = 0; i < m; ++i) { x[i] = x_in[i]; x[rhs_base + i] = x_in[i]; }
+    // both packings: 16-bit slots (index | lg << 13) and the 32-bit ones of large bases (index | lg << 24)
+    const bool wide = e.sidx.empty() && !e.sidx32.empty();
+    const int shift = wide ? kEllLgShiftWide : kEllLgShift;
+    auto slot = [&](int at) { return wide ? (int)e.sidx32[at] : (int)e.sidx[at]; };
     for (const EllPassHost& ps : e.passes) {
         std::vector<std::pair<int, double>> stores;
         for (int lane = 0; lane < ps.lanes;) {
-            const int iv = e.sidx[ps.lane0 + lane], lg = iv >> kEllLgShift, k = iv & ((1 << kEllLgShift) - 1);
+            const int iv = slot(ps.lane0 + lane), lg = iv >> shift, k = iv & ((1 << shift) - 1);
             double sum = 0.0;
             for (int j = 0; j < (1 << lg); ++j) {
-                const int jv = e.sidx[ps.lane0 + lane + j] & ((1 << kEllLgShift) - 1);
+                const int jv = slot(ps.lane0 + lane + j) & ((1 << shift) - 1);
                 sum += -e.sval[ps.lane0 + lane + j] * x[jv];
             }
-            if (!e.rovf.empty()) for (int o = e.rovf[2 * k]; o < e.rovf[2 * k + 1]; ++o) sum += -e.oval[o] * x[e.oidx[o]];
+            if (!e.rovf.empty())
+                for (int o = e.rovf[2 * k]; o < e.rovf[2 * k + 1]; ++o) sum += -e.oval[o] * x[wide ? (int)e.oidx32[o] : (int)e.oidx[o]];
             stores.emplace_back(k, sum * e.rdiag[k]);
             lane += 1 << lg;
         }
@@ -148,6 +153,15 @@ static void check_matrix(const char* name, int m, const Cols& cols_in, std::mt19
             solve_plain(*sch[k], want);
             solve_ell(e, m, fs.rhs_base, b, &got);
             CHECK(max_diff(got, want) <= 1e-9, "%s %s cap %d: packed solve differs by %.3e", name, nm[k], cap, max_diff(got, want));
+            {   // the 32-bit packing of large bases: same passes, same slots, same result bit for bit
+                EllPacked w;
+                ell_pack(fs, maskable, &w, true);
+                std::vector<double> got_w;
+                solve_ell(w, m, fs.rhs_base, b, &got_w);
+                CHECK(w.sidx.empty() && w.lanes() == e.lanes() && w.overflow() == e.overflow() && w.passes.size() == e.passes.size(),
+                      "%s %s cap %d: wide packing has another shape", name, nm[k], cap);
+                CHECK(got_w == got, "%s %s cap %d: wide packing solves differently", name, nm[k], cap);
+            }
             CHECK(fs.s.level_ptr.size() <= sch[k]->level_ptr.size(), "%s %s: more groups than levels", name, nm[k]);
             for (const EllPassHost& ps : e.passes) CHECK(ps.lanes <= 256 && ps.lanes > 0, "%s %s: pass of %d lanes", name, nm[k], ps.lanes);
             if (!maskable || m < 2) continue;

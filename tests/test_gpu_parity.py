@@ -1224,26 +1224,6 @@ def test_unicamp_files_on_every_engine(name, objective):
         assert abs(t.objective_function_value() + float(gf.fixed_cost) - objective) <= 1e-9 * max(1.0, abs(objective))
 
 
-@pytest.mark.parametrize("path,fixed", [("netlib/SC205.SIF", True), ("netlib/BOEING2.SIF", True), ("burkardt/adlittle.mps", False)])
-def test_overlapped_flush_walks_the_same_pivots(path, fixed, monkeypatch):
-    """The opt-in overlapped flush of the tableau engine (RELP_FLUSH_OVERLAP=1: a block is folded into the second tableau
-    buffer on another stream while the first pivots of the next block run against the old buffer plus the block's own
-    (W, R0)): same pivot sequence as the f64 oracle through both phases, incl. the flushes of empty blocks behind the end of a
-    phase and the re-tabulation inside the loop.  (Not the default: DESIGN.md 5.2 has the measurement.)"""
-    from lp_files import load
-    monkeypatch.setenv("RELP_FLUSH_OVERLAP", "1")
-    monkeypatch.setenv("RELP_FLUSH_OVERLAP_PIVOTS", "3")
-    gf, ex, md, emd = load(path, fixed=fixed)
-    ref = relp_f64.OracleF64(md)
-    assert ref.run() == "optimal"
-    t = engine.Tableau(md, trace_capacity=1 << 15, engine=engine.ENGINE_TABLEAU, update_block=8)
-    assert t.solve_relaxation() == engine.OPTIMAL
-    assert t.trace() == ref.trace
-    ident, basic, min_b = t.check_basis()
-    assert ident <= 1e-9
-    t.close()
-
-
 @pytest.mark.parametrize("path,fixed,objective,tol", FILES)
 def test_reference_problem_files_on_the_lu_engine_with_lookahead_refactorisation(path, fixed, objective, tol):
     """The LU engine at a refactorisation interval of 24 (from 24 on the pivot kernel is relaunched on the old factors while
@@ -1260,8 +1240,33 @@ def test_reference_problem_files_on_the_lu_engine_with_lookahead_refactorisation
     got = t.objective_function_value() + float(gf.fixed_cost)
     assert abs(got - objective) < max(tol, 1e-9 * abs(objective))
     if len(ref.trace) > 40:
-        assert t.lu_stats()["refactorisations"] >= 2
+        stats = t.lu_stats()
+        assert stats["refactorisations"] >= 2
+        # the look-ahead path itself ran: factorisations installed beside the running kernel, journal entries replayed
+        assert stats["lookahead"] == 8 and stats["lookahead_installs"] >= 1
+        if len(ref.trace) > 200:
+            assert stats["replayed_changes"] >= 1
     t.close()
+
+
+@pytest.mark.parametrize("path,fixed", [("netlib/SHARE1B.SIF", True), ("netlib/BOEING2.SIF", True), ("netlib/SC205.SIF", True)])
+def test_lookahead_refactorisation_on_and_off_walk_the_same_pivots(path, fixed, monkeypatch):
+    """RELP_LU_LOOKAHEAD is read when the engine is created: 0 = every refactorisation synchronous, 8 = prepared beside the
+    running kernel and completed by a replay of the journal.  Same pivot sequence and the same objective to rounding."""
+    from lp_files import load
+    gf, ex, md, emd = load(path, fixed=fixed)
+    out = {}
+    for la in (0, 8):
+        monkeypatch.setenv("RELP_LU_LOOKAHEAD", str(la))
+        t = engine.Tableau(md, trace_capacity=1 << 15, engine=engine.ENGINE_LU, update_block=24)
+        assert t.solve_relaxation() == engine.OPTIMAL
+        stats = t.lu_stats()
+        assert stats["lookahead"] == la
+        assert (stats["lookahead_installs"] > 0) == (la > 0)
+        out[la] = (t.trace(), t.objective_function_value())
+        t.close()
+    assert out[0][0] == out[8][0]
+    assert abs(out[0][1] - out[8][1]) <= 1e-9 * max(1.0, abs(out[0][1]))
 
 
 def test_two_launch_pivot_equals_three_launch_pivot_bit_for_bit(monkeypatch):
