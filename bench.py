@@ -35,6 +35,7 @@ Every N also reports "c4" (10,000 x 50,000, the shape whose flush is large enoug
 """
 import argparse
 import json
+import math
 import os
 import shutil
 import statistics
@@ -57,6 +58,19 @@ CPU_BUDGET_S = 20.0        # cpu_baseline: bounded sample (10-30 s of CPU work)
 # Pure helpers (no GPU, no torch): window plan, algorithmic bytes, JSON assembly.  tests/test_bench_json.py
 # feeds these with profile dictionaries for K in {1, 20, 64, 200}.
 # ------------------------------------------------------------------------------------------------------------
+def coprime_stride(stride, block):
+    """The per-pivot kernels of every `stride`-th pivot are bracketed by HIP events.  A stride that shares a factor with the
+    update block samples the same few positions of a block over and over (64 on 64: always its first pivot, where PRICE runs
+    on cold caches and the tableau engine's per-pivot kernels carry no pending updates): the next stride co-prime with the block
+    walks through every position p = 0 .. K - 1."""
+    stride = max(int(stride), 1)
+    if block <= 1:
+        return stride
+    while math.gcd(stride, block) != 1:
+        stride += 1
+    return stride
+
+
 def window_steps(requested, block):
     """Pivots per timed window: at least `requested`, at least 4 update blocks, a whole number of blocks."""
     requested = max(int(requested), 1)
@@ -164,7 +178,8 @@ def section(res, workload, m, n, world, kind):
     out = {"value": steps / med, "unit": "iterations/s", "steps": steps, "windows": len(res["window_s"]),
            "ms_per_step": ms_per_step, "window_ms": [round(w * 1e3, 4) for w in res["window_s"]],
            "update_block": res["block"], "kernels": kernels, "roofline": roof,
-           "pivot_roofline": pivot_roofline(alg, ms_per_step), "objective_after_run": res.get("objective")}
+           "pivot_roofline": pivot_roofline(alg, ms_per_step), "objective_after_run": res.get("objective"),
+           "kernel_event_stride": res.get("event_stride")}
     return out
 
 
@@ -199,7 +214,7 @@ def assemble(args_ns, world, primary_kind, primary, secondary=None, c2=None, c4=
         "timing": {"steps_requested": args_ns.steps, "windows": primary["windows"], "window_ms": primary["window_ms"],
                    "statistic": "median window; every window is a whole number of update blocks and starts right after a flush"},
         "roofline": roofline, "kernels": primary["kernels"],
-        "kernel_event_stride": None if args_ns.no_kernel_events else args_ns.event_stride,
+        "kernel_event_stride": primary.get("kernel_event_stride"),
         "objective_after_run": primary.get("objective_after_run"),
         "reference_iteration_algorithmic_bytes": 8.0 * m * n + 24.0 * m * m,
     }
@@ -341,6 +356,143 @@ def sparse_path(events, with_cpu):
     return out
 
 
+def _load_fixture(rel, fixed):
+    """tests/golden/mps/<rel> through the build's MPS reader, presolve and standardisation -> (general form, MatrixData)."""
+    from rust_lp_amd import general_form, mps
+    path = os.path.join(ROOT, "tests", "golden", "mps", rel)
+    if not os.path.exists(path):
+        return None, None
+    gf = general_form.GeneralForm.from_mps(mps.import_file(path, fixed))
+    return gf, gf.to_matrix_data(gf.derive_matrix_data_exact())
+
+
+def _timed_run(md, gf, kind, max_pivots=1 << 40, **cfg):
+    """One engine on one LP: whole solve (or the first `max_pivots` pivots), wall clock around relp_run."""
+    from rust_lp_amd import engine
+    reinv = cfg.pop("reinversion_interval", None)
+    t = engine.Tableau(md, engine=kind, **cfg)
+    if reinv is not None and kind != engine.ENGINE_LU:
+        t.set_reinversion_interval(reinv)
+    t0 = time.perf_counter()
+    total, oc = 0, engine.RUNNING
+    while total < max_pivots:
+        done, oc = t.run(max_pivots - total)
+        total += done
+        if oc not in (engine.RUNNING, engine.PHASE_ONE_DONE) or done == 0:
+            break
+    dt = time.perf_counter() - t0
+    res = {"outcome": engine.OUTCOME_NAMES.get(oc), "pivots": total, "value": total / dt if dt > 0 else None,
+           "unit": "iterations/s", "seconds": round(dt, 4), "degenerate_pivots": t.degenerate_pivots(),
+           "objective": t.objective_function_value() + float(gf.fixed_cost), "rows": t.nr_rows(), "columns": t.nr_columns()}
+    return t, res
+
+
+ENGINE_LABELS = {"lu": 2, "revised": 0, "tableau": 1}
+
+
+def config_one(with_cpu):
+    """BASELINE.json configs[0]: tests/burkardt adlittle.mps.  The exact (rational) path on the host -- oracle/relp_exact.py,
+    the restatement of `Carry<RationalBig, BasisInverseRows>` the reference's own test runs (tests/burkardt/test.rs:34-54) --
+    beside the f64 GPU engines, whose pivot sequence must equal the exact one."""
+    from rust_lp_amd import engine
+    gf, md = _load_fixture("burkardt/adlittle.mps", False)
+    if md is None:
+        return None
+    out = {"workload": f"burkardt adlittle.mps after presolve: {md.nr_rows} rows, {md.nr_columns} columns; two phases to optimality",
+           "reference_objective": "24975305659811992079614961229/120651674036153428931840"}
+    exact_trace = None
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from fractions import Fraction
+        from oracle import relp_exact as ox
+        from lp_files import exact_solve, load
+        gfx, ex, mdx, emd = load("burkardt/adlittle.mps")
+        tr = []
+        c0 = time.perf_counter()
+        status, obj, _ = exact_solve(gfx, emd, ox.BasisInverseRows, trace=tr.append)
+        cdt = time.perf_counter() - c0
+        exact_trace = [(e["phase"], e["entering"], e["row"], e["leaving"]) for e in tr]
+        out["exact_cpu"] = {"value": len(tr) / cdt, "unit": "iterations/s", "cores": 1, "kind": "port", "pivots": len(tr),
+                            "seconds": round(cdt, 3), "objective_is_the_reference_pin":
+                            obj == Fraction(24975305659811992079614961229, 120651674036153428931840),
+                            "sample": "whole solve, oracle/relp_exact.py (fractions.Fraction restatement of the reference's exact path)"}
+    for label, kind in ENGINE_LABELS.items():
+        t, res = _timed_run(md, gf, kind, trace_capacity=4096, update_block={"lu": 11, "tableau": 32}.get(label, -1))
+        if exact_trace is not None:
+            res["trace_identical_to_exact"] = t.trace() == exact_trace
+        t.close()
+        out[label] = res
+    return out
+
+
+def config_five():
+    """BASELINE.json configs[4]: MIPLIB LP relaxations.  50v-10 to optimality (the reference's active test, tests/miplib/test.rs:4)
+    and the degenerate stress acc-tight4 (`#[ignore]`d there as too expensive): the first 100,000 pivots per engine, with the
+    number of degenerate pivots (ratio exactly 0) SURVEY.md 8d asks for."""
+    out = {}
+    gf, md = _load_fixture("miplib/50v-10.mps", False)
+    if md is not None:
+        sec = {"workload": f"MIPLIB 50v-10 relaxation after presolve: {md.nr_rows} rows, {md.nr_columns} columns; to optimality",
+               "reference_objective": 2879.065687}
+        for label, kind in ENGINE_LABELS.items():
+            t, res = _timed_run(md, gf, kind)
+            t.close()
+            sec[label] = res
+        out["50v-10"] = sec
+    gf, md = _load_fixture("miplib/acc-tight4.mps", False)
+    if md is not None:
+        sec = {"workload": f"MIPLIB acc-tight4 relaxation after presolve: {md.nr_rows} rows, {md.nr_columns} columns; first 100,000 "
+                           "pivots (phase 1 needs more than 400,000)"}
+        for label, kind in ENGINE_LABELS.items():
+            t, res = _timed_run(md, gf, kind, max_pivots=100000 if label != "revised" else 30000)
+            t.close()
+            sec[label] = res
+        out["acc-tight4"] = sec
+    return out
+
+
+def sparse_large():
+    """The LU engine beyond one CU's LDS-resident work vectors (the persistent kernel's second layout: x and -pi in LDS, spike,
+    permutations and eta pool in L2): the reference's big Netlib files -- which it `#[ignore]`s as too expensive -- next to
+    the dense engines on the same LP.  GREENBEA / GREENBEB / 80BAU3B run with the f64 safeguards their pins need
+    (tests/test_gpu_big_pins.py), DFL001 for its first 40,000 pivots."""
+    from rust_lp_amd import engine
+    cases = [("GREENBEA", -0.72555248129845987457557870574845e8, dict(ratio_rule=1, artificial_removal=1), 1 << 40),
+             ("GREENBEB", -0.43022602612065867539213672544432e7, dict(ratio_rule=1, artificial_removal=1), 1 << 40),
+             ("80BAU3B", 9.872241924e+05, dict(artificial_removal=1), 1 << 40),
+             ("DFL001", None, dict(ratio_rule=1, artificial_removal=1), 40000)]
+    out = {}
+    for name, pin, cfg, budget in cases:
+        gf, md = _load_fixture(f"netlib/{name}.SIF", True)
+        if md is None:
+            continue
+        sec = {"workload": f"Netlib {name} after presolve: {md.nr_rows} rows, {md.nr_columns} columns"
+                           + ("" if budget >= 1 << 40 else f"; first {budget} pivots"),
+               "reference_pin": pin, "config": cfg}
+        for label, kind in ENGINE_LABELS.items():
+            extra = dict(cfg)
+            if label != "lu":                   # (as tests/test_gpu_big_pins.py: an f64 inverse / tableau that is only ever updated
+                extra["reinversion_interval"] = 200 if name == "80BAU3B" else 1000     # does not survive these files)
+            if label == "tableau":
+                extra["update_block"] = 32
+            t, res = _timed_run(md, gf, kind, max_pivots=budget, **extra)
+            if label == "lu":
+                st = t.lu_stats()
+                res["last_factor"] = {k: st[k] for k in ("nnz_l", "nnz_u", "levels_l", "levels_u")}
+                res["refactorisations"] = st["refactorisations"]
+                try:
+                    ph = t.lu_phase_cycles()
+                    res["pivot_kernel_clocks_per_pivot"] = round(sum(ph.values()) / max(res["pivots"], 1))
+                except engine.RelpError:
+                    res["pivot_kernel_clocks_per_pivot"] = None       # product-form fallback: no persistent kernel
+            if pin is not None and res["outcome"] == "optimal":
+                res["pin_error"] = res["objective"] - pin
+            t.close()
+            sec[label] = res
+        out[name] = sec
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU as a fresh child process (nothing in
@@ -370,6 +522,8 @@ def main():
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-path (LU engine, Netlib 25FV47) section")
     ap.add_argument("--no-c2", action="store_true", help="skip the configs[1] (dense 2,000 x 2,000) section")
     ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] (dense 10,000 x 50,000) section")
+    ap.add_argument("--no-c1", action="store_true", help="skip the configs[0] (adlittle, exact CPU path beside the f64 engines) section")
+    ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (MIPLIB relaxations, degenerate pivot counts) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=64,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
@@ -464,8 +618,9 @@ def main():
             assert done == W and oc == engine.RUNNING, "LP ended inside the warm-up"
         flush()                                        # the first window starts with an empty update block
         if events:
-            per_pivot = 12 * (WINDOWS * steps // max(args.event_stride, 1) + 1)
-            t.profile_enable(True, per_pivot + 4 * WINDOWS * (steps // max(block, 1) + 1) + 64, args.event_stride)
+            stride = coprime_stride(args.event_stride, block)
+            per_pivot = 12 * (WINDOWS * steps // stride + 1)
+            t.profile_enable(True, per_pivot + 4 * WINDOWS * (steps // max(block, 1) + 1) + 64, stride)
         windows = []
         for _ in range(WINDOWS):
             if sharded:
@@ -488,7 +643,8 @@ def main():
         t.close()
         del A
         torch.cuda.empty_cache()
-        res = {"steps": steps, "window_s": windows, "prof": prof, "block": block, "objective": obj}
+        res = {"steps": steps, "window_s": windows, "prof": prof, "block": block, "objective": obj,
+               "event_stride": stride if events else None}
         return section(res, workload, m, n, world, kind)
 
     primary = measure(primary_kind, args.workload)
@@ -506,6 +662,10 @@ def main():
         c4 = dict(measure("tableau", "c4"), workload=f"c4: synthetic dense LP {m4}x{n4} f64, dense tableau, "
                                                       + ("single GPU" if world == 1 else f"stored columns sharded x{world}"))
     sparse = sparse_path(events, not args.no_cpu_baseline) if solo and not args.no_sparse else None
+    if sparse is not None:
+        sparse["large"] = sparse_large()
+    c1 = config_one(not args.no_cpu_baseline) if solo and not args.no_c1 else None
+    c5 = config_five() if solo and not args.no_c5 else None
 
     if rank == 0:
         cpu = None
@@ -513,6 +673,10 @@ def main():
             m, n, seed = WORKLOADS[args.workload]
             cpu = cpu_baseline(m, n, seed, W)
         out = assemble(args, world, primary_kind, primary, secondary, c2, c4, sparse, cpu, loop_kind.get(primary_kind))
+        if c1 is not None:
+            out["c1"] = c1
+        if c5 is not None:
+            out["c5"] = c5
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if sharded:

@@ -102,7 +102,8 @@ typedef struct {
     /* basis-inverse maintenance: 0 = rank-1 update of the explicit inverse at every pivot
      * (basis_inverse_rows.rs:131-142 literally); K > 0 = deferred: the explicit inverse is kept as
      * (I + W S') B0inv and the K most recent pivots are folded in by one m x K x m GEMM ("flush");
-     * -1 = automatic (64 when m >= 4096, else 0).  Results are the same up to f64 rounding. */
+     * -1 = automatic (64 when m >= 4096, else 0; the dense tableau engine, which always works in blocks: 96 when
+     * m >= 4096, else 64).  Results are the same up to f64 rounding. */
     int32_t update_block;
     /* relp_engine_kind_t: which device representation maintains the basis inverse */
     int32_t engine;
@@ -213,6 +214,19 @@ relp_status_t relp_lu_stats(const relp_engine_t *h, int64_t *out8);
  * installed, basis changes replayed onto them, the look-ahead length in effect (RELP_LU_LOOKAHEAD, 0 = off), the lane
  * budget of a fused group of levels (RELP_FUSE_LANES) }; both switches are read when the engine is created. */
 relp_status_t relp_lu_lookahead_stats(const relp_engine_t *h, int64_t *out4);
+/* RELP_ENGINE_LU: refactorise ON THE DEVICE (LUDecomposition::invert -> decomposition/mod.rs:27-138 with the Markowitz
+ * pivoting of decomposition/pivoting.rs:45-81): singleton rows / columns peeled in parallel rounds, the bump eliminated on
+ * a dense working copy by one workgroup, L and U read off afterwards -- no basis download, no search on the host.  Off by
+ * default (the host factorisation behind the look-ahead is faster at Netlib sizes); RELP_LU_DEVICE_FACTOR=1
+ * switches it on at create.  A bump beyond the working copy (RELP_LUF_BUMP_CAP, 2,048) is factorised on the host.
+ * stats: out[6] = { enabled, device factorisations, fallbacks to the host, microseconds spent in the kernel so far,
+ * bump size and number of peeled singleton pivots of the last factorisation }. */
+relp_status_t relp_lu_set_device_factorisation(relp_engine_t *h, int32_t on);
+relp_status_t relp_lu_device_factorisation_stats(const relp_engine_t *h, int64_t *out6);
+/* max |P B Q - L U| over all entries for the factors in use and the current basis (decomposition/mod.rs:301-491 asserts
+ * the factors themselves; pivot orders differ, the identity is what they have in common).  Dense arithmetic on the host:
+ * m <= 1,024, else *out = -1. */
+relp_status_t relp_lu_factor_residual(relp_engine_t *h, double *out);
 
 /* RELP_ENGINE_LU in Forrest-Tomlin mode: shader clocks spent per phase of the pivot inside the persistent kernel since create
  * (thread 0): out[16] = { PRICE, entering-column scatter, L solve, eta file forward, spike push, U solve, ratio test, b update,

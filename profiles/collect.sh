@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $REPO/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-kernel-events --no-sparse --no-c2 --no-c4 ${BENCH_ARGS:-}"
+CMD="python3 $REPO/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-kernel-events --no-sparse --no-c2 --no-c4 --no-c1 --no-c5 ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace exit=$?"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/pmc_fetch.log" 2>&1

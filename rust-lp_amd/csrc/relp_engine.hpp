@@ -54,6 +54,10 @@ class Engine {
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
     relp_status_t lu_lookahead_stats(int64_t* out4) const;
+    relp_status_t luf_stats(int64_t* out6) const;
+    relp_status_t lu_set_device_factorisation(bool on);
+    relp_status_t lu_factor_residual(double* out);
+    relp_status_t lu_basis_columns(std::vector<std::vector<std::pair<int32_t, double>>>& cols);
     relp_status_t lu_phase_cycles(int64_t* out16);
     relp_status_t lu_download_basis();
     relp_status_t lu_factor_downloaded_basis();
@@ -256,7 +260,18 @@ class Engine {
     char* d_ft_buf_ = nullptr;
     int32_t* h_ft_hdr_ = nullptr;                         // pinned copy of fts_.hdr
     int32_t ft_tcap_ = 0, ft_eta_cap_ = 0;
-    bool ft_big_ = false, ft_fused_ = true;              // layout of the persistent kernel (relp_kernels_ft.hip: ft_layout)
+    // the refactorisation on the device (relp_engine_luf.cpp, relp_lu_factor_core.h): RELP_LU_DEVICE_FACTOR=1 or
+    // relp_lu_set_device_factorisation; a bump beyond the dense working copy falls back to lu_factor on the host
+    struct LufState;
+    LufState* luf_ = nullptr;
+    bool luf_enabled_ = false;
+    int64_t luf_runs_ = 0, luf_fallbacks_ = 0; double luf_kernel_us_ = 0.0; int32_t luf_last_bump_ = 0, luf_last_peeled_ = 0;
+    relp_status_t luf_prepare();
+    relp_status_t lu_factor_on_device(int32_t* device_status);
+    void luf_release();
+    void luf_mark_dirty();
+    bool hyper_forced_ = false; int32_t hyper_probe_in_[4] = {0, 0, 0, 0};    // adaptive hyper-sparse starts (ft_read_report)
+    bool ft_big_ = false; int32_t ft_rhs_cap_ = 0;        // layout of the persistent kernel (relp_kernels_ft.hip: ft_layout)
     int64_t ft_zero_bytes_ = 0, ft_ones_bytes_ = 0;       // the two regions of the state buffer a refactorisation resets
     bool ft_need_refactor_ = false;
     relp_status_t ft_plan_and_alloc();

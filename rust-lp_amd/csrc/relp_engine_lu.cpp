@@ -69,10 +69,9 @@ relp_status_t Engine::lu_download_basis() {
     return RELP_OK;
 }
 
-// P B Q = L U on the host for the basis in h_basis_ (hlu_ is overwritten)
-relp_status_t Engine::lu_factor_downloaded_basis() {
+// the columns of the basis in h_basis_ from the host copy of the matrix (the LU engine never holds A densely)
+relp_status_t Engine::lu_basis_columns(std::vector<std::vector<std::pair<int32_t, double>>>& cols) {
     const int32_t* const basis = h_basis_;
-    std::vector<std::vector<std::pair<int32_t, double>>>& cols = basis_cols_;     // (kept: no 790 allocations per refactorisation)
     cols.resize(m_);
     for (int32_t i = 0; i < m_; ++i) {
         const int32_t j = basis[i];
@@ -94,6 +93,14 @@ relp_status_t Engine::lu_factor_downloaded_basis() {
             if (vrow1_h_[v] >= 0) c.emplace_back(vrow1_h_[v], 1.0);
         }
     }
+    return RELP_OK;
+}
+
+// P B Q = L U on the host for the basis in h_basis_ (hlu_ is overwritten)
+relp_status_t Engine::lu_factor_downloaded_basis() {
+    std::vector<std::vector<std::pair<int32_t, double>>>& cols = basis_cols_;     // (kept: no 790 allocations per refactorisation)
+    const relp_status_t cst = lu_basis_columns(cols);
+    if (cst) return cst;
     if (const char* dump = std::getenv("RELP_DUMP_BASIS")) {
         if (lu_refactors_ == 100) {                        // one mid-solve basis as text: m, then per column "n i v i v ..."
             if (FILE* f = std::fopen(dump, "w")) {
@@ -123,10 +130,18 @@ void Engine::lu_refactor_clock(std::chrono::steady_clock::time_point tb, std::ch
 // columns, P B Q = L U on the host, schedules to the device, W := empty.  Synchronises the stream.
 relp_status_t Engine::lu_refactor() {
     const auto tb = std::chrono::steady_clock::now();
-    relp_status_t st = lu_download_basis();
-    if (st) return st;
+    relp_status_t st = RELP_OK;
+    bool on_device = false;
+    if (luf_enabled_) {                                    // P B Q = L U by the device kernel: no basis download, no host search
+        int32_t dev = 0;
+        st = lu_factor_on_device(&dev);
+        if (st == RELP_OK) on_device = true;
+        else if (st != RELP_E_UNSUPPORTED) return st;
+        else ++luf_fallbacks_;
+    }
+    if (!on_device && (st = lu_download_basis())) return st;
     const auto t0 = std::chrono::steady_clock::now();
-    if ((st = lu_factor_downloaded_basis())) return st;
+    if (!on_device && (st = lu_factor_downloaded_basis())) return st;
     const auto t1 = std::chrono::steady_clock::now();
     if ((st = lu_upload_factors())) return st;
     if (ft_) { if ((st = ft_reset())) return st; }
@@ -234,7 +249,8 @@ relp_status_t Engine::lu_upload_factors() {
     // (relp_lu.hpp: fuse_levels), packed "ELL by pass", one contiguous image each (headers | lvl_pass | rdiag | sval | oval |
     // rovf | sidx | oidx); rows of U and U' without entries are kept, an update may mask them
     EllPacked ell[4];
-    size_t o_ell[4] = {0, 0, 0, 0}, o_via_ptr[4] = {0, 0, 0, 0}, o_via_pos[4] = {0, 0, 0, 0};
+    size_t o_ell[4] = {0, 0, 0, 0}, o_via_ptr[4] = {0, 0, 0, 0}, o_via_pos[4] = {0, 0, 0, 0}, o_triv[4] = {0, 0, 0, 0},
+           o_reach[4] = {0, 0, 0, 0}, o_rhs[4] = {0, 0, 0, 0};
     int32_t rhs_base[4] = {0, 0, 0, 0};
     std::vector<int32_t> lev_ub(m_, 0);
     for (int32_t l = 0; l + 1 < (int32_t)hlu_.Ub.level_ptr.size(); ++l)
@@ -242,18 +258,29 @@ relp_status_t Engine::lu_upload_factors() {
     static_assert(kEllLgShift == kEllLg, "host packing and device decoding of sidx");
     if (ft_) {
         const int32_t fuse_cap = lu_fuse_lanes_env_;       // (RELP_FUSE_LANES, read at create)
-        // (fused schedules read a copy of the right-hand side behind x: 2 m + 1 words of LDS and of index space)
-        const int32_t cap = ft_big_ ? (ft_fused_ ? fuse_cap : 0) : (2 * (int64_t)m_ + 1 < (1 << kEllLgShift) ? fuse_cap : 0);
+        // (fused schedules read copies of some right-hand sides behind x: ft_rhs_cap_ words of LDS, and of index space)
+        const int32_t cap = ft_rhs_cap_ > 0 ? fuse_cap : 0;
+        const int64_t index_room = ft_big_ ? (int64_t(1) << kEllLgShiftWide) : (int64_t(1) << kEllLgShift);
+        bool uses_rhs[4] = {false, false, false, false};
         // fusion and packing of the four schedules are independent: U on this thread, U' and L + L' on two helpers (the
         // refactorisation runs beside the pivot kernel, and what the host takes longer than the kernel's look-ahead the
         // device waits)
         auto prepare = [&](int k) {
             const bool maskable = k == 1 || k == 2;
             FusedSchedule fs;
+            // (big layout: right-hand-side copies compacted, rows without entries as a list when that saves two passes or more;
+            // all-in-LDS layout: a copy per pivot by one LDS loop and every row a slot, as measured fastest on 25FV47)
+            const int32_t triv_min = ft_big_ ? 512 : 0x7fffffff;
             fuse_levels(*sch[k], maskable, maskable, cap, &fs);
-            ell_pack(fs, maskable, &ell[k], ft_big_);
+            ell_pack(fs, maskable, &ell[k], ft_big_, ft_big_, triv_min);
+            if (ft_big_ && ((int64_t)ell[k].rhs_src.size() > ft_rhs_cap_ || (int64_t)m_ + 1 + (int64_t)ell[k].rhs_src.size() > index_room)) {
+                fuse_levels(*sch[k], maskable, maskable, 0, &fs);      // more copies than the layout has room for: level by level
+                ell_pack(fs, maskable, &ell[k], ft_big_, ft_big_, triv_min);
+            }
+            uses_rhs[k] = false;
+            for (int32_t v : fs.s.idx) if (v >= fs.rhs_base) { uses_rhs[k] = true; break; }
             if (k == 2) lev_ub = fs.start_after;
-            for (int32_t v : fs.s.idx) if (v >= fs.rhs_base) { rhs_base[k] = fs.rhs_base; break; }
+            if (uses_rhs[k]) rhs_base[k] = fs.rhs_base;
         };
         if (m_ >= 256) {
             host_pool_.run(0, [&] { prepare(2); });
@@ -279,6 +306,11 @@ relp_status_t Engine::lu_upload_factors() {
         for (int k = 1; k <= 2; ++k) {
             o_via_ptr[k] = put(ell[k].via_ptr.data(), sizeof(int32_t) * ell[k].via_ptr.size());
             o_via_pos[k] = put(ell[k].via_pos.data(), sizeof(int32_t) * ell[k].via_pos.size());
+        }
+        for (int k = 0; k < 4; ++k) {
+            o_rhs[k] = put(ell[k].rhs_src.data(), sizeof(int32_t) * ell[k].rhs_src.size());
+            o_triv[k] = put(ell[k].triv.data(), sizeof(int32_t) * ell[k].triv.size());
+            o_reach[k] = put(ell[k].reach.data(), sizeof(int32_t) * ell[k].reach.size());
         }
     }
     const size_t o_lub = put(lev_ub.data(), sizeof(int32_t) * m_);
@@ -368,7 +400,7 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
         fts_.pinfo = reinterpret_cast<const FtPivotInfo*>(d_lu_buf_ + o_pinfo);
         // what is left of the CU's LDS after the work vectors stages one schedule image at a time
-        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_fused_);
+        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_rhs_cap_);
         const int64_t idx_bytes = ft_big_ ? 4 : 2;
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
         int64_t need = 0;
@@ -391,7 +423,12 @@ relp_status_t Engine::lu_upload_factors() {
             const int64_t total = q - q0;
             d.n_passes = (int32_t)np; d.n_levels = (int32_t)nlv - 1; d.m = m_; d.n_lanes = (int32_t)nln; d.n_ovf = (int32_t)nov;
             d.bytes = (int32_t)total;
-            d.rhs_base = rhs_base[k]; d.pad_ = 0;
+            d.rhs_base = rhs_base[k];
+            d.n_triv = (int32_t)e.triv.size();
+            d.triv = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_triv[k]);
+            d.reach = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_reach[k]);
+            d.rhs_src = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rhs[k]);
+            d.n_rhs = ft_big_ ? (int32_t)e.rhs_src.size() : -1; d.pad_ = 0;
             const bool has_via = !e.via_ptr.empty();
             d.via_ptr = has_via ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_via_ptr[k]) : nullptr;
             d.via_pos = has_via ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_via_pos[k]) : nullptr;
@@ -412,41 +449,49 @@ relp_status_t Engine::lu_upload_factors() {
 // Forrest-Tomlin mode (relp_kernels_ft.hip)
 // ------------------------------------------------------------------------------------------------
 relp_status_t Engine::ft_plan_and_alloc() {
-    ft_ = false; ft_big_ = false; ft_fused_ = true;
+    ft_ = false; ft_big_ = false; ft_rhs_cap_ = 0;
     if (m_ > kFtMaxRows) return RELP_OK;
     // The dense tail of U (tcap x tcap in LDS) is as large as the refactorisation interval asks for, not larger: what it does
     // not take stages the triangular factors, and an image that does not fit is solved from L2 at several times the cost.
     // Default interval 48: with a refactorisation at ~0.7 ms and ~1,100 clocks per pending update and pivot, the optimum is
     // flat between 40 and 64, and 48 x 49 doubles leave 14 KB more for the images than 64 x 65.
     const int32_t want = cfg_.update_block < 0 ? 48 : std::max(1, std::min(cfg_.update_block, kFtMaxSlots));
-    // Two layouts (relp_kernels_ft.hip: ft_layout).  "All in LDS": x with its right-hand-side copy, spike, -pi, permutations,
-    // eta pool -- 63 bytes per row.  "big": x, -pi and the slot tables only (17 bytes per row, 25 with the right-hand-side
-    // copy), the rest read from L2; slot indices of the images 32 bits wide.  The first is taken while it leaves the dense
+    // Two layouts (relp_kernels_ft.hip: ft_layout).  "All in LDS": x with m right-hand-side copies, spike, -pi, permutations,
+    // eta pool -- 63 bytes per row.  "big": x, -pi and the slot tables only (17 bytes per row + 8 per right-hand-side copy the
+    // fused schedules may use: as many as fit, a schedule that needs more is packed level by level), the rest read from L2;
+    // slot indices of the images 32 bits wide.  The first is taken while it leaves the dense
     // tail the interval asks for AND >= kFtMinStage bytes to stage the factor images (an image that is not staged is solved
     // from L2 at several times the cost); RELP_FT_BIG = 0 / 1 forces one of them.
     const int64_t eta_cap = std::max<int64_t>((int64_t)2 * m_ + 64, 1024);   // (one eta never exceeds m entries)
     constexpr int64_t kFtMinStage = 64 * 1024;
+    (void)kFtMinStage;
     const char* big_env = std::getenv("RELP_FT_BIG");
     const int force_big = big_env ? std::atoi(big_env) : -1;
-    auto plan = [&](bool big, bool fused, int64_t min_stage) {
+    auto plan = [&](bool big, int32_t rhs_cap, int64_t min_stage, int32_t min_tcap = 16) {
         for (int32_t tcap : {64, 48, 32, 16}) {
             if (tcap != 16 && tcap - 16 >= want) continue;              // a smaller tail serves the interval
+            if (tcap < std::min(want, min_tcap)) return false;          // (a refactorisation every 16 pivots is the last resort)
             if (tcap < want && min_stage > 4096) return false;          // (only the last resort shortens the interval)
-            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap, big, fused) + min_stage <= kFtLdsBudget) {
-                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_big_ = big; ft_fused_ = fused; ft_ = true;
+            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap, big, rhs_cap) + min_stage <= kFtLdsBudget) {
+                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_big_ = big; ft_rhs_cap_ = rhs_cap; ft_ = true;
                 return true;
             }
         }
         return false;
     };
-    if (force_big != 1 && plan(false, true, force_big == 0 ? 4096 : kFtMinStage)) {}
-    else if (force_big != 0 && (plan(true, true, kFtMinStage) || plan(true, true, 16 * 1024) || plan(true, false, 4096))) {}
-    else if (force_big != 1) plan(false, true, 4096);
+    // (16-bit slot indices: m + 1 + copies < 8,192)
+    const int32_t small_rhs = (int32_t)std::max<int64_t>(0, std::min<int64_t>(m_, (int64_t(1) << kEllLgShift) - 2 - m_));
+    // (measured on GREENBEB, m = 2,228: all-in-LDS with a 32-slot tail and nothing staged 209,000 clocks per pivot, big with a
+    // 48-slot tail and 78 KB of staging 235,000 -- what the big layout reads from L2 costs more than staging saves; so the
+    // all-in-LDS layout is taken whenever it fits at all)
+    if (force_big != 1 && small_rhs > 0 && plan(false, small_rhs, 4096, force_big == 0 ? 16 : 32)) {}
+    else if (force_big != 0 && (plan(true, m_, kFtMinStage) || plan(true, std::min(m_, 2048), 32 * 1024) ||
+                                plan(true, std::min(m_, 1024), 8 * 1024) || plan(true, 0, 4096))) {}
     if (!ft_) return RELP_OK;
     if (std::getenv("RELP_DEBUG"))
-        std::fprintf(stderr, "[relp] persistent pivot kernel: m %d, layout %s%s, dense tail %d, LDS base %zu bytes\n", m_,
-                     ft_big_ ? "big" : "all-in-LDS", ft_fused_ ? "" : " (no fused levels)", ft_tcap_,
-                     ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_fused_));
+        std::fprintf(stderr, "[relp] persistent pivot kernel: m %d, layout %s, %d right-hand-side copies, dense tail %d, LDS base %zu bytes\n",
+                     m_, ft_big_ ? "big" : "all-in-LDS", ft_rhs_cap_, ft_tcap_,
+                     ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_rhs_cap_));
     const int64_t tc = ft_tcap_, ldt = tc + 1, m = m_, nwp = kFtWaves + 1;
     std::vector<char> dummy;
     int64_t o = 0;
@@ -488,7 +533,12 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spk_val = reinterpret_cast<double*>(d_ft_buf_ + o_sv);
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
     fts_.sp_work = reinterpret_cast<double*>(d_ft_buf_ + o_spw);
-    fts_.big = ft_big_ ? 1 : 0; fts_.fused_x = ft_fused_ ? 1 : 0;
+    fts_.big = ft_big_ ? 1 : 0; fts_.rhs_cap = ft_rhs_cap_;
+    {   // hyper-sparse starts: L and L' by default (U' starts from the leaving pivot's level anyway; on U the spike reaches the first groups: measured 31.4 of 31.4 passes on 25FV47, not worth the reduction); RELP_FT_HYPER = bit mask
+        const char* e = std::getenv("RELP_FT_HYPER");
+        fts_.hyper = e ? std::atoi(e) : 0x9;
+        hyper_forced_ = e != nullptr;
+    }
     fts_.prof = reinterpret_cast<long long*>(d_ft_buf_ + o_prof);
     fts_.journal = reinterpret_cast<int32_t*>(d_ft_buf_ + o_journal);
     // refactor when this many updates are pending (lower_upper/mod.rs:199-202 refactors when updates.len() > 10, i.e.
@@ -576,6 +626,19 @@ relp_status_t Engine::ft_read_report(bool* have_basis) {
     HIP_TRY(hipStreamSynchronize(stream_));
     *h_rec_ = h_mirror_->rec;
     std::memcpy(h_ft_hdr_, h_mirror_->hdr, 4 * sizeof(int32_t));
+    // Hyper-sparse starts pay when they skip more passes than the scan for the first group costs (~1,500 clocks = 2 passes):
+    // a schedule whose sweeps saved less in this launch starts at the front in the next ones, and is probed again later.
+    if (!hyper_forced_ && ft_big_) {
+        for (int k : {0, 3}) {
+            const int32_t sw = h_mirror_->sweeps[k];
+            if (sw <= 0) continue;
+            if ((fts_.hyper >> k) & 1) {
+                if ((double)(h_mirror_->whole[k] - h_mirror_->walked[k]) < 2.0 * sw) { fts_.hyper &= ~(1 << k); hyper_probe_in_[k] = 64; }
+            } else if (--hyper_probe_in_[k] <= 0) {
+                fts_.hyper |= 1 << k;
+            }
+        }
+    }
     since_flush_ = h_ft_hdr_[0];
     ft_need_refactor_ = h_ft_hdr_[2] != 0;
     if (have_basis) {
@@ -608,7 +671,8 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     struct Tick { int64_t& t; ~Tick() { ++t; } };
     // Look-ahead refactorisation (lu_refactor_lookahead): the kernel returns `la` updates before the file is full, and fills
     // the rest while the host factorises.  On for refactorisation intervals from 24 on; RELP_LU_LOOKAHEAD = 0 switches it off.
-    const int32_t la_env = lu_lookahead_env_;              // (RELP_LU_LOOKAHEAD, read at create)
+    const int32_t la_env = luf_enabled_ ? 0 : lu_lookahead_env_;     // (RELP_LU_LOOKAHEAD, read at create; the device
+                                                                     // factorisation is synchronous on the engine's stream)
     const int32_t la = (fts_.max_updates >= 24 && la_env > 0) ? std::min(la_env, fts_.max_updates / 3) : 0;
     bool have_basis = false;                               // h_basis_ holds the basis as the last launch left it
     while (h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters) {

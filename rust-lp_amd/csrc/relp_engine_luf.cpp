@@ -1,0 +1,206 @@
+// relp_engine_luf.cpp -- Engine: the refactorisation of the LU engine ON THE DEVICE (relp_lu_factor_core.h).
+// What stays on the host is what is static: the row-major copy of the provider matrix the kernel enumerates basis rows
+// from (built at create, after a row removal and at the phase switch), and the buffers.
+#include "relp_engine_internal.hpp"
+#include "relp_lu_factor_core.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+namespace relp {
+
+struct Engine::LufState {
+    char* d_buf = nullptr;
+    LufMatrix M{}; LufWork W{}; LufOut O{};
+    int32_t cap = 0, nb_cap = 0;
+    bool dirty = true;
+    int32_t key[4] = {-1, -1, -1, -1};                         // (m, artificial columns, phase, wrapped artificials) the tables were built for
+    std::vector<int32_t> h_int; std::vector<double> h_dbl;       // download staging
+    ~LufState() { if (d_buf) (void)hipFree(d_buf); }
+};
+
+void Engine::luf_release() { delete luf_; luf_ = nullptr; }
+void Engine::luf_mark_dirty() { if (luf_) luf_->dirty = true; }
+
+// static tables + workspace for the current shape of the problem (rows may have been removed, the phase may have changed)
+relp_status_t Engine::luf_prepare() {
+    if (!luf_) luf_ = new LufState();
+    LufState& S = *luf_;
+    if (S.d_buf) { HIP_TRY(hipFree(S.d_buf)); S.d_buf = nullptr; }
+    const int32_t m = m_, nprov = nr_normal_ + nr_virtual_, na = nr_artificial_;
+    // row-major copy of the provider columns (structural incl. bound rows, virtual), in column order
+    std::vector<int32_t> rcount(m + 1, 0);
+    auto each = [&](auto f) {
+        for (int32_t p = 0; p < nr_normal_; ++p) {
+            for (int64_t e = hc_ptr_[p]; e < hc_ptr_[p + 1]; ++e) f(hc_idx_[e], p, hc_val_[e]);
+            if (bound_row_h_[p] >= 0) f(bound_row_h_[p], p, 1.0);
+        }
+        for (int32_t v = 0; v < nr_virtual_; ++v) {
+            if (vrow0_h_[v] >= 0) f(vrow0_h_[v], nr_normal_ + v, (double)vsign_h_[v]);
+            if (vrow1_h_[v] >= 0) f(vrow1_h_[v], nr_normal_ + v, 1.0);
+        }
+    };
+    int64_t nnz = 0;
+    each([&](int32_t i, int32_t, double) { ++rcount[i + 1]; ++nnz; });
+    for (int32_t i = 0; i < m; ++i) rcount[i + 1] += rcount[i];
+    std::vector<int32_t> rcol((size_t)nnz), fill(rcount.begin(), rcount.end() - 1), art_of_row(m, -1);
+    std::vector<double> rval((size_t)nnz);
+    each([&](int32_t i, int32_t p, double v) { const int32_t o = fill[i]++; rcol[o] = p; rval[o] = v; });
+    for (int32_t a = 0; a < na; ++a) art_of_row[column_to_row_[a]] = a;
+    // sizes: the bump is eliminated on a dense working copy of at most nb_cap x nb_cap (a larger bump falls back to the host)
+    const char* cap_env = std::getenv("RELP_LUF_BUMP_CAP");
+    S.nb_cap = std::min<int32_t>(m, cap_env ? std::max(16, std::atoi(cap_env)) : 2048);
+    S.cap = (int32_t)std::min<int64_t>(INT32_MAX / 2, nnz + (int64_t)wrapped_na_ + na + 2 * (int64_t)m + (int64_t)S.nb_cap * S.nb_cap / 2 + 1024);
+    const int32_t nt = luf_threads();
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += round_up(std::max<int64_t>(bytes, 16), 16); return at; };
+    const int64_t o_rptr = take(4 * ((int64_t)m + 1)), o_rcol = take(4 * nnz), o_rval = take(8 * nnz), o_art = take(4 * (int64_t)m),
+                  o_wr = take(4 * (int64_t)std::max<int32_t>(wrapped_na_, 1));
+    const int64_t o_posp = take(4 * ((int64_t)nprov + 1)), o_posa = take(4 * ((int64_t)na + 1));
+    int64_t o_m[13];
+    for (auto& v : o_m) v = take(4 * (int64_t)m);       // wrow_pos rcount ccount claim claim2 list list2 piv brow bcol lrow lcol (+1 spare)
+    const int64_t o_part = take(4 * ((int64_t)nt + 2));
+    int64_t o_nb[8];
+    for (auto& v : o_nb) v = take(4 * (int64_t)S.nb_cap);     // brc bcc ract cact bstep_row bstep_col I J
+    const int64_t o_fmul = take(8 * (int64_t)S.nb_cap), o_red = take(8 * 80), o_D = take(8 * (int64_t)S.nb_cap * S.nb_cap), o_sc = take(64);
+    const int64_t o_status = take(32), o_rowperm = take(4 * (int64_t)m), o_colperm = take(4 * (int64_t)m), o_rstep = take(4 * (int64_t)m),
+                  o_cstep = take(4 * (int64_t)m), o_diag = take(8 * (int64_t)m);
+    int64_t o_tp[4], o_ti[4], o_tv[4];
+    for (int q = 0; q < 4; ++q) { o_tp[q] = take(4 * ((int64_t)m + 1)); o_ti[q] = take(4 * (int64_t)S.cap); o_tv[q] = take(8 * (int64_t)S.cap); }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_buf), (size_t)o));
+    HIP_TRY(hipMemset(S.d_buf, 0, (size_t)o));
+    char* const B = S.d_buf;
+    HIP_TRY(hipMemcpy(B + o_rptr, rcount.data(), 4 * ((size_t)m + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        HIP_TRY(hipMemcpy(B + o_rcol, rcol.data(), 4 * (size_t)nnz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(B + o_rval, rval.data(), 8 * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(B + o_art, art_of_row.data(), 4 * (size_t)m, hipMemcpyHostToDevice));
+    if (wrapped_na_ > 0) HIP_TRY(hipMemcpy(B + o_wr, column_to_row_.data(), 4 * (size_t)wrapped_na_, hipMemcpyHostToDevice));
+    auto I32 = [&](int64_t at) { return reinterpret_cast<int32_t*>(B + at); };
+    auto F64 = [&](int64_t at) { return reinterpret_cast<double*>(B + at); };
+    S.M = LufMatrix{};
+    S.M.m = m; S.M.na = na; S.M.n_provider = nprov;
+    S.M.csc = csc(); S.M.ct = table();
+    S.M.rptr = I32(o_rptr); S.M.rcol = I32(o_rcol); S.M.rval = F64(o_rval); S.M.art_of_row = I32(o_art);
+    S.M.wrapped_na = wrapped_na_; S.M.wrapped_row = I32(o_wr);
+    LufWork& W = S.W;
+    W.pos_p = I32(o_posp); W.pos_a = I32(o_posa);
+    W.wrow_pos = I32(o_m[0]); W.rcount = I32(o_m[1]); W.ccount = I32(o_m[2]); W.claim = I32(o_m[3]); W.claim2 = I32(o_m[4]);
+    W.list = I32(o_m[5]); W.list2 = I32(o_m[6]); W.piv = I32(o_m[7]); W.brow = I32(o_m[8]); W.bcol = I32(o_m[9]);
+    W.lrow = I32(o_m[10]); W.lcol = I32(o_m[11]); W.part = I32(o_part);
+    W.brc = I32(o_nb[0]); W.bcc = I32(o_nb[1]); W.ract = I32(o_nb[2]); W.cact = I32(o_nb[3]); W.bstep_row = I32(o_nb[4]);
+    W.bstep_col = I32(o_nb[5]); W.I = I32(o_nb[6]); W.J = I32(o_nb[7]);
+    W.fmul = F64(o_fmul); W.red = reinterpret_cast<unsigned long long*>(B + o_red); W.D = F64(o_D); W.nb_cap = S.nb_cap;
+    W.scalars = I32(o_sc);
+    LufOut& O = S.O;
+    O.status = I32(o_status); O.rowperm = I32(o_rowperm); O.colperm = I32(o_colperm); O.row_step = I32(o_rstep); O.col_step = I32(o_cstep);
+    O.diag = F64(o_diag);
+    LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
+    for (int q = 0; q < 4; ++q) { tri[q]->ptr = I32(o_tp[q]); tri[q]->idx = I32(o_ti[q]); tri[q]->val = F64(o_tv[q]); }
+    O.cap = S.cap;
+    S.dirty = false;
+    S.key[0] = m_; S.key[1] = nr_artificial_; S.key[2] = phase_; S.key[3] = wrapped_na_;
+    return RELP_OK;
+}
+
+// P B Q = L U of the basis in d_basis_ by the device kernel; the factors come back as the four triangular views and are given
+// their level schedules here (relp_lu.cpp: schedule_from_rows), like after lu_factor.  RELP_E_UNSUPPORTED: the bump exceeds the
+// dense working copy (the caller factorises on the host instead).
+relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
+    if (!luf_ || luf_->dirty || luf_->key[0] != m_ || luf_->key[1] != nr_artificial_ || luf_->key[2] != phase_ || luf_->key[3] != wrapped_na_) {
+        const relp_status_t st = luf_prepare();            // (a row removal or the phase switch renumbers rows / columns)
+        if (st) return st;
+    }
+    LufState& S = *luf_;
+    const auto t0 = std::chrono::steady_clock::now();
+    S.M.csc = csc(); S.M.ct = table();                  // (pointers may have been re-allocated)
+    launch_lu_factor(S.M, d_basis_, S.W, S.O, stream_);
+    int32_t status[8] = {0};
+    HIP_TRY(hipMemcpyAsync(status, S.O.status, sizeof status, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    luf_kernel_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    ++luf_runs_;
+    luf_last_bump_ = status[1]; luf_last_peeled_ = status[2];
+    if (device_status) *device_status = status[0];
+    if (status[0] == LUF_SINGULAR) return fail(RELP_E_SINGULAR, "singular basis (device factorisation)");
+    if (status[0] != LUF_OK) return RELP_E_UNSUPPORTED;      // bump too large / no room: not an error, the host takes over
+    const int32_t m = m_, nl = status[3], nu = status[4];
+    // download: permutations, diagonal, the four views
+    hlu_ = LUFactors{};
+    hlu_.m = m;
+    hlu_.rowperm.resize(m); hlu_.colperm.resize(m);
+    std::vector<double> diag(m), ones(m, 1.0);
+    HIP_TRY(hipMemcpyAsync(hlu_.rowperm.data(), S.O.rowperm, 4 * (size_t)m, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(hlu_.colperm.data(), S.O.colperm, 4 * (size_t)m, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(diag.data(), S.O.diag, 8 * (size_t)m, hipMemcpyDeviceToHost, stream_));
+    TriangularSchedule* sch[4] = {&hlu_.Lf, &hlu_.Uf, &hlu_.Ub, &hlu_.Lb};
+    const LufTriangle* tri[4] = {&S.O.Lf, &S.O.Uf, &S.O.Ub, &S.O.Lb};
+    const int32_t cnt[4] = {nl, nu, nu, nl};
+    for (int q = 0; q < 4; ++q) {
+        sch[q]->ptr.resize(m + 1); sch[q]->idx.resize(cnt[q]); sch[q]->val.resize(cnt[q]);
+        HIP_TRY(hipMemcpyAsync(sch[q]->ptr.data(), tri[q]->ptr, 4 * ((size_t)m + 1), hipMemcpyDeviceToHost, stream_));
+        if (cnt[q]) {
+            HIP_TRY(hipMemcpyAsync(sch[q]->idx.data(), tri[q]->idx, 4 * (size_t)cnt[q], hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(sch[q]->val.data(), tri[q]->val, 8 * (size_t)cnt[q], hipMemcpyDeviceToHost, stream_));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(stream_));
+    lu_levels_from_rows(m, ones, true, &hlu_.Lf);
+    lu_levels_from_rows(m, diag, false, &hlu_.Uf);
+    lu_levels_from_rows(m, diag, true, &hlu_.Ub);
+    lu_levels_from_rows(m, ones, false, &hlu_.Lb);
+    hlu_.nnz_l = nl; hlu_.nnz_u = (int64_t)nu + m;
+    return RELP_OK;
+}
+
+relp_status_t Engine::lu_set_device_factorisation(bool on) {
+    if (!lu_) return fail(RELP_E_UNSUPPORTED, "the device factorisation belongs to the LU engine");
+    luf_enabled_ = on;
+    return RELP_OK;
+}
+
+relp_status_t Engine::luf_stats(int64_t* out6) const {
+    if (!lu_) return RELP_E_STATE;
+    out6[0] = luf_enabled_ ? 1 : 0; out6[1] = luf_runs_; out6[2] = luf_fallbacks_; out6[3] = (int64_t)luf_kernel_us_;
+    out6[4] = luf_last_bump_; out6[5] = luf_last_peeled_;
+    return RELP_OK;
+}
+
+}  // namespace relp
+
+namespace relp {
+
+// max |P B Q - L U| over all entries, for the factors currently installed (whoever computed them) and the basis they were
+// computed for; dense arithmetic on the host, so only for m <= 1,024 (tests: the reference's factorisation cases of
+// decomposition/mod.rs:301-491 through the ABI).  *out = -1 when m is larger.
+relp_status_t Engine::lu_factor_residual(double* out) {
+    if (!lu_) return fail(RELP_E_UNSUPPORTED, "the LU engine's factors");
+    *out = -1.0;
+    const int32_t m = m_;
+    if (m > 1024 || hlu_.m != m) return RELP_OK;
+    relp_status_t st = lu_download_basis();
+    if (st) return st;
+    std::vector<std::vector<std::pair<int32_t, double>>> cols;
+    if ((st = lu_basis_columns(cols))) return st;
+    std::vector<double> a((size_t)m * m, 0.0), L((size_t)m * m, 0.0), U((size_t)m * m, 0.0);
+    for (int32_t c = 0; c < m; ++c) for (auto& e : cols[c]) a[(size_t)e.first * m + c] += e.second;
+    for (int32_t k = 0; k < m; ++k) {
+        L[(size_t)k * m + k] = 1.0; U[(size_t)k * m + k] = hlu_.Uf.diag[k];
+        for (int32_t e = hlu_.Lf.ptr[k]; e < hlu_.Lf.ptr[k + 1]; ++e) L[(size_t)k * m + hlu_.Lf.idx[e]] = hlu_.Lf.val[e];
+        for (int32_t e = hlu_.Uf.ptr[k]; e < hlu_.Uf.ptr[k + 1]; ++e) U[(size_t)k * m + hlu_.Uf.idx[e]] = hlu_.Uf.val[e];
+    }
+    double worst = 0.0;
+    for (int32_t k = 0; k < m; ++k)
+        for (int32_t l = 0; l < m; ++l) {
+            double s = 0.0;
+            for (int32_t q = 0; q <= std::min(k, l); ++q) s += L[(size_t)k * m + q] * U[(size_t)q * m + l];
+            worst = std::max(worst, std::fabs(s - a[(size_t)hlu_.rowperm[k] * m + hlu_.colperm[l]]));
+        }
+    *out = worst;
+    return RELP_OK;
+}
+
+}  // namespace relp

@@ -127,7 +127,11 @@ struct EllSchedule {
     int32_t n_passes, n_levels, m, n_lanes, n_ovf;
     int32_t bytes;               // size of the image
     int32_t rhs_base;            // m + 1 when some entry reads the right-hand-side copy, else 0 (no copy is made)
-    int32_t pad_;
+    int32_t n_triv;              // rows without entries of U / U' (relp_lu.hpp: EllPacked::triv): x[k] *= rdiag[k] before the passes
+    const int32_t* triv;         // n_triv pivots (global, not part of the staged image)
+    const int32_t* reach;        // m: first group in which x[p] matters (EllPacked::reach) -> where a sweep may start
+    const int32_t* rhs_src;      // n_rhs: slot index rhs_base + i reads the right-hand side of pivot rhs_src[i] (EllPacked::rhs_src)
+    int32_t n_rhs, pad_;
 };
 // Column indices at or above this value are artificial variables that survived phase 1 (see
 // Engine::switch_to_phase_two): INT32_MAX - (na - 1 - a).  They have no flag, no cost and no column.
@@ -183,8 +187,10 @@ struct FtState {
                                            // launch, hdr[3] of them: what k_ft_replay applies to freshly computed factors
     double*  spike;          // m: the spike of the last FTRAN (step-wise API: consumed by the next update)
     double*  sp_work;        // m: the spike inside the kernels when it does not live in LDS (big)
+    int32_t  hyper;          // bit k: sweep k (L, U, U', L') starts at the first group its right-hand side reaches (RELP_FT_HYPER)
+    int32_t  pad2_;
     int32_t  big;            // 1: spike, permutations and eta pool in global memory, 32-bit slot indices (relp_kernels_ft.hip: ft_layout)
-    int32_t  fused_x;        // x holds the right-hand-side copy of the fused schedules (2 m + 1 words instead of m + 1)
+    int32_t  rhs_cap;        // words behind x[m] for the right-hand-side copies of the fused schedules (0: levels are not fused)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
     int32_t  stage_bytes;
     int32_t  lds_bytes;      // dynamic LDS of every FT kernel
@@ -215,6 +221,8 @@ struct PriceEll {
 struct FtMirror {
     PivotRecord rec;
     int32_t hdr[4];
+    int32_t walked[4], whole[4]; // this launch: passes walked / passes of the whole schedule, summed over its sweeps of L, U, U', L'
+    int32_t sweeps[4];           // (the host switches the hyper-sparse start of a schedule off while it saves less than it costs)
     int32_t basis[1];            // m entries
 };
 struct FtProblem {           // what the persistent kernel needs besides the factors
@@ -442,7 +450,7 @@ void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double
 
 // ---- Forrest-Tomlin engine (relp_kernels_ft.hip) ---------------------------------------------------------------
 // bytes of dynamic LDS the FT kernels need besides the staging area
-size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big = false, bool fused = true);
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big, int32_t rhs_cap);
 // LDS bytes a schedule needs to be staged (relp_lu_device.h: schedule_lds_bytes)
 int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg);
 // up to `max_pivots` whole pivots (PRICE -> FTRAN -> RATIO -> FT update -> BTRAN -> b, -pi, basis) in ONE launch of one

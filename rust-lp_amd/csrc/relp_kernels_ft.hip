@@ -28,15 +28,15 @@ struct FtLayout {
     int64_t x, sp, pi, perm, tc, dots, zt, uv, ct, slot_pivot, slot_prev, slot_live, slot_next, eta_off, spk_off, tslot, eta_idx,
         eta_val, red_d, red_i, stage, total;
 };
-// `big` (FtState::big, m beyond ~2,400 rows): only what a pass of a solve touches stays in LDS -- x (with the right-hand-side
-// copy of the fused schedules when `fused`), -pi (PRICE gathers from it), the slot tables and the dense tail; the spike, the
+// `big` (FtState::big, m beyond ~2,400 rows): only what a pass of a solve touches stays in LDS -- x (with `rhs_cap` words for
+// the right-hand-side copies of the fused schedules), -pi (PRICE gathers from it), the slot tables and the dense tail; the spike, the
 // permutations and the eta pool, each read a few times per pivot, are read from global memory (L2).
-__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap, bool big = false, bool fused = true) {
+__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap, bool big, int rhs_cap) {
     FtLayout L;
     int64_t o = 0;
     const int ldt = tcap + 1;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
-    L.x = take(8LL * ((big && !fused ? m : 2 * m) + 1));       // x[m]: scratch word of ell_solve; x[m + 1 ..]: rhs copy
+    L.x = take(8LL * (m + 1 + rhs_cap));           // x[m]: scratch word of ell_solve; x[m + 1 ..]: right-hand-side copies
     L.sp = take(big ? 0 : 8LL * m); L.pi = take(8LL * m);
     L.perm = take(big ? 0 : 2LL * 3 * m);            // inv_rowperm | inv_colperm | rowperm as 16-bit indices
     L.tc = take(8LL * tcap * ldt);
@@ -91,7 +91,7 @@ struct FtCtxT {
 
 template <class Ctx>
 __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, const FtState& st) {
-    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::big, st.fused_x != 0);
+    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::big, st.rhs_cap);
     c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.TC = (double*)(lds + L.tc);
     if constexpr (Ctx::big) {
         c.sp = st.sp_work; c.irp = st.inv_rowperm; c.icp = st.inv_colperm; c.rp = lu.rowperm;
@@ -229,9 +229,32 @@ __device__ __forceinline__ double sum8(double v) {
 }
 
 // `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
+template <class Ctx> __device__ __forceinline__ int block_min_int(Ctx& c, int v);
+
+// Hyper-sparse start of a sweep (the reference's solves only touch what they reach: lower_upper/mod.rs:236-271, 359-374 walk a
+// BTreeMap of non-zeros): the first group of the schedule in which a non-zero of x matters (EllSchedule::reach).  One
+// coalesced pass over reach (its loads do not depend on x), one block reduction.  x must be complete (behind a barrier).
 template <class Ctx>
-__device__ __forceinline__ void sweep(const FtState& st, int which, Ctx& c, int first_level = 0) {
+__device__ __forceinline__ int ft_first_group(Ctx& c, const int32_t* __restrict__ reach) {
+    int g = 0x7fffffff;
+    for (int k0 = threadIdx.x; k0 < c.m; k0 += 4 * NT) {
+        int r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = reach[min(k0 + u * NT, c.m - 1)];
+        asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k0 + u * NT < c.m && c.x[k0 + u * NT] != 0.0) g = min(g, r[u]);
+    }
+    return block_min_int(c, g);
+}
+
+// `hyper`: derive the first level from the non-zeros of x (st.hyper selects the schedules for which that pays)
+template <class Ctx>
+__device__ __forceinline__ void sweep(const FtState& st, int which, Ctx& c, int first_level = 0, bool hyper = false) {
     auto lap = [&]() { c.clk.lap(FT_STAGE); };
+    if constexpr (Ctx::big) {                          // (big layout only, see ell_stage)
+        if (hyper && ((st.hyper >> which) & 1)) first_level = max(first_level, ft_first_group(c, st.ell[which].reach));
+    }
     int passes;
     if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
     else passes = ell_solve_pp<false, NT, Ctx::big>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
@@ -245,7 +268,7 @@ template <class Ctx>
 __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, Ctx& c, bool spike_only = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = c.t;
-    sweep(st, 0, c);
+    sweep(st, 0, c, 0, true);
     c.clk.lap(FT_L);
     if (t > 0) {
         // eta.apply_right for every update (eta_file.rs:72-109): w[p_s] -= r_s . w.  The sparse parts read entries no
@@ -321,7 +344,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
         __syncthreads();
     }
     c.clk.lap(FT_PUSH);
-    sweep(st, 1, c);
+    sweep(st, 1, c);                                   // (no hyper-sparse start: the spike reaches the first groups of U, measured)
     if (t > 0) {
         if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.zt[tid];
         __syncthreads();
@@ -451,7 +474,7 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
         __syncthreads();
     }
     c.clk.lap(FT_BT_CHAIN);
-    sweep(st, 3, c);
+    sweep(st, 3, c, 0, true);
     c.clk.lap(FT_LT);
 }
 
@@ -701,6 +724,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             if (threadIdx.x == 0) {
                 pb.mirror->rec = *rec;
                 pb.mirror->hdr[0] = st.hdr[0]; pb.mirror->hdr[1] = st.hdr[1]; pb.mirror->hdr[2] = st.hdr[2]; pb.mirror->hdr[3] = 0;
+                for (int k = 0; k < 4; ++k) { pb.mirror->walked[k] = 0; pb.mirror->whole[k] = 0; pb.mirror->sweeps[k] = 0; }
             }
             for (int i = threadIdx.x; i < st.m; i += NT) pb.mirror->basis[i] = pb.basis[i];
         }
@@ -1042,6 +1066,12 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (tid == 0) {
             pb.mirror->rec = *rec;
             pb.mirror->hdr[0] = c.t; pb.mirror->hdr[1] = c.eta_used; pb.mirror->hdr[2] = need_refactor; pb.mirror->hdr[3] = c.journal_n;
+            if constexpr (kBig) {
+                for (int k = 0; k < 4; ++k) {
+                    pb.mirror->walked[k] = (int32_t)c.clk.passes[k]; pb.mirror->whole[k] = (int32_t)c.clk.total[k];
+                    pb.mirror->sweeps[k] = (int32_t)c.clk.sweeps[k];
+                }
+            }
         }
         for (int i = tid; i < m; i += NT) pb.mirror->basis[i] = pb.basis[i];
     }
@@ -1111,8 +1141,8 @@ void ft_allow_lds(const void* fn, int bytes) {
 
 }  // namespace
 
-size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big, bool fused) {
-    return (size_t)ft_layout(m, tcap, eta_cap, big, fused).total;
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big, int32_t rhs_cap) {
+    return (size_t)ft_layout(m, tcap, eta_cap, big, rhs_cap).total;
 }
 int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg) { return schedule_lds_bytes(m, nnz, n_levels, n_seg); }
 

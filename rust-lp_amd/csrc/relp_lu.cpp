@@ -103,6 +103,10 @@ struct ListArena {
 
 }  // namespace
 
+void lu_levels_from_rows(int32_t m, const std::vector<double>& diag, bool ascending, TriangularSchedule* s) {
+    finish_schedule(m, diag, ascending, s);
+}
+
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err) {
     // active submatrix, row major: entries (column, value) of row i at rc / rv [rows.beg[i], + rows.len[i]); colrows: the rows
@@ -474,7 +478,7 @@ void fuse_levels(const TriangularSchedule& t, bool maskable, bool keep_trivial, 
     }
 }
 
-void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wide) {
+void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wide, bool compact_rhs, int32_t triv_min) {
     const TriangularSchedule& t = f.s;
     const int32_t m = (int32_t)t.diag.size();
     const int32_t nlev = (int32_t)t.level_ptr.size() - 1;
@@ -485,6 +489,21 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wi
     std::vector<int32_t> lane_of(t.idx.size(), -1);      // entry -> its slot (entries in overflow lists: -1)
     constexpr int32_t kLanes = 256;                      // threads that walk the passes (relp_lu_device.h: ell_solve)
     struct Row { int32_t lg, k; };
+    // compact the right-hand-side copies: pivots that are read through their copy, ascending -> rhs_base + rank
+    std::vector<int32_t> rhs_id;
+    int32_t n_trivial = 0;
+    if (keep_trivial) for (int32_t k = 0; k < m; ++k) if (t.ptr[k + 1] == t.ptr[k]) ++n_trivial;
+    const bool list_trivial = keep_trivial && n_trivial >= triv_min;
+    if (f.rhs_base > 0 && compact_rhs) {
+        std::vector<char> used((size_t)m, 0);
+        bool any = false;
+        for (int32_t v : t.idx) if (v >= f.rhs_base) { used[v - f.rhs_base] = 1; any = true; }
+        if (any) {
+            rhs_id.assign((size_t)m, -1);
+            for (int32_t j = 0; j < m; ++j) if (used[j]) { rhs_id[j] = (int32_t)out->rhs_src.size(); out->rhs_src.push_back(j); }
+        }
+    }
+    auto slot_index = [&](int32_t v) { return (!rhs_id.empty() && v >= f.rhs_base) ? f.rhs_base + rhs_id[v - f.rhs_base] : v; };
     auto n_slots = [&]() { return wide ? out->sidx32.size() : out->sidx.size(); };
     auto push_slot = [&](int32_t index, int32_t lg) {
         if (wide) out->sidx32.push_back((uint32_t)index | ((uint32_t)lg << kEllLgShiftWide));
@@ -496,6 +515,11 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wi
         for (int32_t i = t.level_ptr[l]; i < t.level_ptr[l + 1]; ++i) {
             const int32_t k = t.level_rows[i], n = t.ptr[k + 1] - t.ptr[k];
             if (n == 0 && !keep_trivial && t.diag[k] == 1.0) continue;
+            if (n == 0 && list_trivial) {                // (such a row has no dependency: it sits in the first level)
+                out->rdiag[k] = 1.0 / t.diag[k];
+                out->triv.push_back(k);
+                continue;
+            }
             int32_t lg = 0;
             while ((1 << lg) < n + 1 && lg < 6) ++lg;
             rows.push_back(Row{lg, k});
@@ -513,12 +537,12 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wi
                 for (int32_t j = 1; j < w; ++j) {
                     const bool has = j - 1 < n;
                     if (has) lane_of[t.ptr[k] + j - 1] = (int32_t)n_slots();
-                    push_slot(has ? t.idx[t.ptr[k] + j - 1] : 0, lg);
+                    push_slot(has ? slot_index(t.idx[t.ptr[k] + j - 1]) : 0, lg);
                     out->sval.push_back(has ? t.val[t.ptr[k] + j - 1] : 0.0);
                 }
                 out->rovf[2 * (size_t)k] = (int32_t)out->oval.size();
                 for (int32_t e = t.ptr[k] + w - 1; e < t.ptr[k + 1]; ++e) {
-                    if (wide) out->oidx32.push_back((uint32_t)t.idx[e]); else out->oidx.push_back((uint16_t)t.idx[e]);
+                    if (wide) out->oidx32.push_back((uint32_t)slot_index(t.idx[e])); else out->oidx.push_back((uint16_t)slot_index(t.idx[e]));
                     out->oval.push_back(t.val[e]); ovf = 1;
                 }
                 out->rovf[2 * (size_t)k + 1] = (int32_t)out->oval.size();
@@ -533,6 +557,17 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wi
         if (out->passes.size() > first_pass) out->passes.back().info |= 1 << 8;
     }
     out->lvl_pass[nlev] = (int32_t)out->passes.size();
+    out->reach.assign((size_t)m, 0x7fffffff);
+    for (int32_t l = 0; l < nlev; ++l)
+        for (int32_t i = t.level_ptr[l]; i < t.level_ptr[l + 1]; ++i) {
+            const int32_t k = t.level_rows[i], n = t.ptr[k + 1] - t.ptr[k];
+            if (n == 0 && (list_trivial || (!keep_trivial && t.diag[k] == 1.0))) continue;   // (unit rows that are left out, or rows of the `triv` loop)
+            out->reach[k] = std::min(out->reach[k], l);
+            for (int32_t e = t.ptr[k]; e < t.ptr[k + 1]; ++e) {
+                const int32_t p = t.idx[e] >= f.rhs_base && f.rhs_base > 0 ? t.idx[e] - f.rhs_base : t.idx[e];
+                out->reach[p] = std::min(out->reach[p], l);
+            }
+        }
     if (out->oval.empty()) out->rovf.clear();            // no row has more than 63 entries: the ranges are never read
     if (!f.via_ptr.empty()) {                            // (substituted entries never overflow: fuse_levels caps rows at 63)
         out->via_ptr = f.via_ptr;

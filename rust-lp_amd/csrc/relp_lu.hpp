@@ -44,6 +44,10 @@ struct LUFactors {
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err);
 
+// Levels for a schedule whose rows (ptr / idx / val) are given, e.g. by the device factorisation (relp_lu_factor_core.h):
+// fills diag, level_ptr, level_rows.  ascending: the dependencies of a row have smaller indices.
+void lu_levels_from_rows(int32_t m, const std::vector<double>& diag, bool ascending, TriangularSchedule* s);
+
 // Level fusion by local inversion.  A basis factor of an LP has dozens of levels of a handful of rows each, and on the device a
 // level costs a fixed ~800 clocks whatever it holds, so consecutive levels are merged into GROUPS that one
 // pass solves: a row r of the group that depends on a row j of the same group gets j's equation substituted,
@@ -85,9 +89,22 @@ struct EllPacked {
     size_t lanes() const { return sidx.empty() ? sidx32.size() : sidx.size(); }
     size_t overflow() const { return oidx.empty() ? oidx32.size() : oidx.size(); }
     std::vector<int32_t> via_ptr, via_pos;   // maskable schedules: CSR by pivot of positions in sval to zero when the pivot is masked
+    // keep_trivial schedules (U, U'): the rows without entries are not packed as slots -- one lane each, they were a dozen
+    // passes of a near-diagonal factor -- but listed here: x[k] *= rdiag[k], one loop in front of the passes
+    std::vector<int32_t> triv;
+    // The right-hand-side copies the fused rows read, compacted: slot index rhs_base + i means b[rhs_src[i]] (fuse_levels
+    // writes rhs_base + pivot; only the pivots some row was substituted through need a copy -- a few hundred of thousands)
+    std::vector<int32_t> rhs_src;
+    // by pivot p: the first group (level of the fused schedule) in which x[p] matters -- p's own row if it is packed, and every
+    // row that reads x[p] or its right-hand-side copy; 0x7fffffff = none.  A sweep whose right-hand side is zero wherever
+    // reach[p] < g may start at group g (hyper-sparse start).
+    std::vector<int32_t> reach;
 };
 // keep_trivial: also pack the rows without entries whose diagonal is 1 (needed when rows can be masked later: U, U')
-void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wide = false);
+// wide: 32-bit slots.  compact_rhs: number the right-hand-side copies consecutively (rhs_src) instead of rhs_base + pivot.
+// triv_min: rows without entries are listed in `triv` when there are at least this many of them, else packed as slots.
+void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wide = false, bool compact_rhs = false,
+              int32_t triv_min = 0x7fffffff);
 
 // Factors given literally (P = Q = I), the way the reference's tests build a `LUDecomposition { lower_triangular,
 // upper_triangular, .. }` (lower_upper/mod.rs:44-52): L column-major, unit diagonal implied, entries (row > column);

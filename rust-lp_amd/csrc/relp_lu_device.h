@@ -296,7 +296,13 @@ __device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char*
     EllImage<kWide> im{s.passes, s.lvl_pass, s.rdiag, s.sval, s.oval, s.rovf, reinterpret_cast<const idx_t*>(s.sidx),
                        reinterpret_cast<const idx_t*>(s.oidx)};
     const int tid = threadIdx.x;
-    if (s.rhs_base) for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i];
+    // (the wide images belong to the big layout: right-hand-side copies compacted; the all-in-LDS layout keeps a copy per
+    // pivot, one LDS loop.  Everything the big layout adds is compiled out of the other instantiation: the persistent
+    // kernel sits at 256 VGPRs with spills, and a few more live values cost 5 % of a 25FV47 pivot)
+    if (s.rhs_base) {
+        if constexpr (kWide) { for (int i = tid; i < s.n_rhs; i += NT) x[s.rhs_base + i] = x[s.rhs_src[i]]; }
+        else { for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i]; }
+    }
     if (kStage) {
         const int n16 = s.bytes / 16;
         typedef int v4i __attribute__((ext_vector_type(4)));            // (an array of HIP's int4 struct ends up in scratch)
@@ -405,6 +411,21 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
     const EllImage<kWide> im = ell_stage<kStage, NT, kWide>(s, base, x);
     const double* rdiag = im.rdiag; const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
     const idx_t* sidx = im.sidx; const idx_t* oidx = im.oidx;
+    if constexpr (kWide) if (s.n_triv > 0) {           // the rows without entries (U, U'): nothing to wait for, no passes
+        for (int i0 = threadIdx.x; i0 < s.n_triv; i0 += 4 * NT) {
+            int k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = s.triv[min(i0 + u * NT, s.n_triv - 1)];
+            // (only where x is not zero: the right-hand sides are sparse, and 1 / diagonal of an image that is not staged is a
+            // dependent round trip to L2)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double v = x[k[u]];
+                if (i0 + u * NT < s.n_triv && v != 0.0) x[k[u]] = v * rdiag[k[u]];
+            }
+        }
+        __syncthreads();
+    }
     lap();
     const int fl = first_level < 0 ? 0 : (first_level > s.n_levels ? s.n_levels : first_level);
     const int p0 = __builtin_amdgcn_readfirstlane(im.lvl_pass[fl]), p1 = s.n_passes;

@@ -90,6 +90,9 @@ _SIGNATURES = {
     "relp_update_block": (C.c_int32, [C.c_void_p]),
     "relp_lu_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_lu_lookahead_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_lu_set_device_factorisation": (C.c_int, [C.c_void_p, C.c_int32]),
+    "relp_lu_device_factorisation_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_lu_factor_residual": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "relp_lu_phase_cycles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_basis_inverse_row": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "relp_should_refactor": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -364,6 +367,22 @@ class Tableau:
         self._ck(self._lib.relp_lu_lookahead_stats(self._h, la))
         stats.update(lookahead_installs=int(la[0]), replayed_changes=int(la[1]), lookahead=int(la[2]), fuse_lanes=int(la[3]))
         return stats
+
+    def lu_set_device_factorisation(self, on: bool) -> None:
+        """Refactorise on the device from now on (relp_lu_set_device_factorisation; LUDecomposition::invert)."""
+        self._ck(self._lib.relp_lu_set_device_factorisation(self._h, 1 if on else 0))
+
+    def lu_factor_residual(self) -> float:
+        """max |P B Q - L U| for the factors in use (relp_lu_factor_residual)."""
+        out = C.c_double()
+        self._ck(self._lib.relp_lu_factor_residual(self._h, C.byref(out)))
+        return out.value
+
+    def lu_device_factorisation_stats(self) -> dict:
+        out = (C.c_int64 * 6)()
+        self._ck(self._lib.relp_lu_device_factorisation_stats(self._h, out))
+        keys = ("enabled", "device_factorisations", "host_fallbacks", "kernel_us", "last_bump", "last_peeled")
+        return dict(zip(keys, (int(v) for v in out)))
 
     # -- BasisInverse surface (carry/mod.rs:68-157) ---------------------------------------------
     def basis_inverse_row(self, row: int) -> np.ndarray:

@@ -56,7 +56,7 @@ static void run(const char* name, const TriangularSchedule& t, bool maskable, in
     s.sidx = (const uint16_t*)q; q += up16(2 * e.sidx.size()); s.oidx = (const uint16_t*)q; q += up16(2 * e.oidx.size());
     s.n_passes = (int)e.passes.size(); s.n_levels = (int)e.lvl_pass.size() - 1;
     for (int v : fs.s.idx) if (v >= fs.rhs_base) { s.rhs_base = fs.rhs_base; break; }
-    s.m = m; s.n_lanes = (int)e.sidx.size(); s.n_ovf = (int)e.oidx.size();
+    s.m = m; s.n_lanes = (int)e.sidx.size(); s.n_ovf = (int)e.oidx.size(); s.n_triv = 0; s.triv = nullptr; s.reach = nullptr;
     s.bytes = (int)(q - d);
     long long* out; double* xg; (void)hipMalloc(&out, 64); (void)hipMalloc(&xg, 8 * m);
     const size_t lds = (size_t)up16(8 * (2 * m + 1)) + s.bytes;

@@ -1,0 +1,303 @@
+// The device-side LU factorisation (rust-lp_amd/csrc/relp_lu_factor_core.h) compiled for the HOST: the
+// very code the kernel k_lu_factor runs, with its parallel loops as plain loops.  Checked on the reference's factorisation
+// cases (decomposition/mod.rs:301-491) and on seeded LP-like bases -- with structural, slack, bound and artificial columns --
+// against P B Q = L U, against dense solves and against the host factorisation lu_factor.  No GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "relp_lu.hpp"
+#include "relp_lu_factor_core.h"
+
+using namespace relp;
+using Cols = std::vector<std::vector<std::pair<int32_t, double>>>;
+
+static int g_checks = 0, g_failed = 0;
+#define CHECK(cond, ...) do { ++g_checks; if (!(cond)) { ++g_failed; std::printf("FAILED %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+// A provider in the engine's terms: structural columns (CSC over the constraint rows) with optional bound rows, virtual
+// (slack) columns, artificial columns; and a basis = m column ids.
+struct Provider {
+    int32_t mc = 0, m = 0, na = 0, nn = 0, nv = 0;
+    std::vector<int64_t> cptr; std::vector<int32_t> cidx; std::vector<double> cval;
+    std::vector<int32_t> bound_row, vrow0, vrow1, vsign, column_to_row;
+    std::vector<double> cost;
+    // row-major copy of the provider columns
+    std::vector<int32_t> rptr, rcol, art_of_row; std::vector<double> rval;
+    std::vector<int32_t> wrapped_row;
+
+    std::vector<std::pair<int32_t, double>> column_of(int32_t j) const {      // one column as (row, value) pairs
+        std::vector<std::pair<int32_t, double>> c;
+        if (j < na) { c.emplace_back(column_to_row[j], 1.0); return c; }
+        const int32_t p = j - na;
+        if (p < nn) {
+            for (int64_t e = cptr[p]; e < cptr[p + 1]; ++e) c.emplace_back(cidx[e], cval[e]);
+            if (bound_row[p] >= 0) c.emplace_back(bound_row[p], 1.0);
+        } else {
+            const int32_t v = p - nn;
+            if (vrow0[v] >= 0) c.emplace_back(vrow0[v], (double)vsign[v]);
+            if (vrow1[v] >= 0) c.emplace_back(vrow1[v], 1.0);
+        }
+        return c;
+    }
+    void finish() {
+        std::vector<std::vector<std::pair<int32_t, double>>> rows(m);
+        for (int32_t p = 0; p < nn + nv; ++p) { const auto col = column_of(na + p); for (auto& e : col) rows[e.first].emplace_back(p, e.second); }
+        rptr.assign(m + 1, 0);
+        for (int32_t i = 0; i < m; ++i) { rptr[i + 1] = rptr[i] + (int32_t)rows[i].size(); for (auto& e : rows[i]) { rcol.push_back(e.first); rval.push_back(e.second); } }
+        art_of_row.assign(m, -1);
+        for (int32_t a = 0; a < na; ++a) art_of_row[column_to_row[a]] = a;
+        cost.assign(std::max(nn, 1), 0.0);
+    }
+    LufMatrix view() const {
+        LufMatrix M{};
+        M.m = m; M.na = na; M.n_provider = nn + nv;
+        M.csc = DeviceCSC{cptr.data(), cidx.data(), cval.data()};
+        M.ct = ColumnTable{na, nn, nv, mc, column_to_row.data(), bound_row.data(), vrow0.data(), vrow1.data(), vsign.data(), cost.data()};
+        M.rptr = rptr.data(); M.rcol = rcol.data(); M.rval = rval.data(); M.art_of_row = art_of_row.data();
+        M.wrapped_na = 0; M.wrapped_row = wrapped_row.data();
+        return M;
+    }
+};
+
+struct Buffers {
+    std::vector<int32_t> ints; std::vector<double> dbl; std::vector<unsigned long long> red;
+    LufWork W{}; LufOut O{};
+    void setup(const Provider& P, int32_t nb_cap, int32_t cap) {
+        const int32_t m = P.m;
+        auto need = (size_t)(P.nn + P.nv) + P.na + 16 * (size_t)m + 8 * (size_t)nb_cap + 128 + 8 * (size_t)(m + 1) + 4 * (size_t)cap + 64;
+        ints.assign(need, 0); dbl.assign((size_t)nb_cap * nb_cap + nb_cap + m + 4 * (size_t)cap + 16, 0.0); red.assign(80, 0);
+        int32_t* ip = ints.data(); double* dp = dbl.data();
+        auto ti = [&](size_t n) { int32_t* r = ip; ip += n; return r; };
+        auto td = [&](size_t n) { double* r = dp; dp += n; return r; };
+        W.pos_p = ti(P.nn + P.nv + 1); W.pos_a = ti(P.na + 1); W.wrow_pos = ti(m); W.rcount = ti(m); W.ccount = ti(m);
+        W.claim = ti(m); W.claim2 = ti(m); W.list = ti(m); W.list2 = ti(m); W.piv = ti(m); W.part = ti(66);
+        W.brow = ti(m); W.bcol = ti(m); W.lrow = ti(m); W.lcol = ti(m);
+        W.brc = ti(nb_cap); W.bcc = ti(nb_cap); W.ract = ti(nb_cap); W.cact = ti(nb_cap); W.bstep_row = ti(nb_cap); W.bstep_col = ti(nb_cap);
+        W.I = ti(nb_cap); W.J = ti(nb_cap); W.fmul = td(nb_cap); W.red = red.data(); W.D = td((size_t)nb_cap * nb_cap); W.nb_cap = nb_cap;
+        W.scalars = ti(16);
+        O.status = ti(8); O.rowperm = ti(m); O.colperm = ti(m); O.row_step = ti(m); O.col_step = ti(m); O.diag = td(m);
+        LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
+        for (auto* t : tri) { t->ptr = ti(m + 1); t->idx = ti(cap); t->val = td(cap); }
+        O.cap = cap;
+    }
+};
+
+static std::vector<double> dense_basis(const Provider& P, const std::vector<int32_t>& basis) {
+    std::vector<double> a((size_t)P.m * P.m, 0.0);
+    for (int32_t c = 0; c < P.m; ++c) { const auto col = P.column_of(basis[c]); for (auto& e : col) a[(size_t)e.first * P.m + c] += e.second; }
+    return a;
+}
+
+// x = B^-1 a through the device factors (forward with the rows of L, backward with the rows of U)
+static std::vector<double> ftran(const LufOut& O, int32_t m, const std::vector<double>& a) {
+    std::vector<double> y(m), x(m);
+    for (int32_t k = 0; k < m; ++k) { double s = a[O.rowperm[k]]; for (int32_t e = O.Lf.ptr[k]; e < O.Lf.ptr[k + 1]; ++e) s -= O.Lf.val[e] * y[O.Lf.idx[e]]; y[k] = s; }
+    for (int32_t k = m - 1; k >= 0; --k) { double s = y[k]; for (int32_t e = O.Uf.ptr[k]; e < O.Uf.ptr[k + 1]; ++e) s -= O.Uf.val[e] * y[O.Uf.idx[e]]; y[k] = s / O.diag[k]; }
+    for (int32_t k = 0; k < m; ++k) x[O.colperm[k]] = y[k];
+    return x;
+}
+// z' = c' B^-1 through the column views (U' forward, L' backward)
+static std::vector<double> btran(const LufOut& O, int32_t m, const std::vector<double>& c) {
+    std::vector<double> t(m), z(m);
+    for (int32_t k = 0; k < m; ++k) { double s = c[O.colperm[k]]; for (int32_t e = O.Ub.ptr[k]; e < O.Ub.ptr[k + 1]; ++e) s -= O.Ub.val[e] * t[O.Ub.idx[e]]; t[k] = s / O.diag[k]; }
+    for (int32_t k = m - 1; k >= 0; --k) { double s = t[k]; for (int32_t e = O.Lb.ptr[k]; e < O.Lb.ptr[k + 1]; ++e) s -= O.Lb.val[e] * t[O.Lb.idx[e]]; t[k] = s; }
+    for (int32_t k = 0; k < m; ++k) z[O.rowperm[k]] = t[k];
+    return z;
+}
+
+static std::vector<double> dense_solve(int m, std::vector<double> a, std::vector<double> b, bool transposed) {
+    if (transposed) for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) std::swap(a[(size_t)i * m + j], a[(size_t)j * m + i]);
+    for (int k = 0; k < m; ++k) {
+        int p = k;
+        for (int i = k + 1; i < m; ++i) if (std::fabs(a[(size_t)i * m + k]) > std::fabs(a[(size_t)p * m + k])) p = i;
+        if (p != k) { for (int j = 0; j < m; ++j) std::swap(a[(size_t)k * m + j], a[(size_t)p * m + j]); std::swap(b[k], b[p]); }
+        for (int i = k + 1; i < m; ++i) {
+            const double f = a[(size_t)i * m + k] / a[(size_t)k * m + k];
+            if (f == 0.0) continue;
+            for (int j = k; j < m; ++j) a[(size_t)i * m + j] -= f * a[(size_t)k * m + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = m - 1; k >= 0; --k) { double s = b[k]; for (int j = k + 1; j < m; ++j) s -= a[(size_t)k * m + j] * b[j]; b[k] = s / a[(size_t)k * m + k]; }
+    return b;
+}
+
+static double max_rel(const std::vector<double>& a, const std::vector<double>& b) {
+    double d = 0.0, n = 1.0;
+    for (size_t i = 0; i < a.size(); ++i) { d = std::max(d, std::fabs(a[i] - b[i])); n = std::max(n, std::fabs(b[i])); }
+    return d / n;
+}
+
+// factorise `basis` of provider P with the device code and check it every way there is
+static void check(const char* name, const Provider& P, const std::vector<int32_t>& basis, std::mt19937_64& rng, bool expect_singular = false) {
+    const int32_t m = P.m;
+    Buffers B;
+    size_t nnz = 0;
+    for (int32_t c = 0; c < m; ++c) nnz += P.column_of(basis[c]).size();
+    B.setup(P, m, (int32_t)(nnz + (size_t)m * m + 16));
+    const LufMatrix M = P.view();
+    luf_factor(M, basis.data(), B.W, B.O);
+    Cols cols(m);
+    for (int32_t c = 0; c < m; ++c) { cols[c] = P.column_of(basis[c]); std::sort(cols[c].begin(), cols[c].end()); }
+    LUFactors hf; std::string err;
+    const bool host_ok = lu_factor(m, cols, &hf, &err);
+    if (expect_singular) { CHECK(B.O.status[0] == LUF_SINGULAR && !host_ok, "%s: a singular basis passed (status %d)", name, B.O.status[0]); return; }
+    if (!host_ok) return;                                 // (a random basis may be singular: nothing to compare with)
+    CHECK(B.O.status[0] == LUF_OK, "%s: status %d (bump %d, peeled %d)", name, B.O.status[0], B.O.status[1], B.O.status[2]);
+    if (B.O.status[0] != LUF_OK) return;
+    const LufOut& O = B.O;
+    // permutations are permutations, the inverses agree
+    std::vector<int> seen_r(m, 0), seen_c(m, 0);
+    for (int32_t k = 0; k < m; ++k) { ++seen_r[O.rowperm[k]]; ++seen_c[O.colperm[k]]; CHECK(O.row_step[O.rowperm[k]] == k && O.col_step[O.colperm[k]] == k, "%s: step %d", name, k); }
+    for (int32_t i = 0; i < m; ++i) CHECK(seen_r[i] == 1 && seen_c[i] == 1, "%s: not a permutation at %d", name, i);
+    // P B Q = L U, entry by entry
+    const std::vector<double> a = dense_basis(P, basis);
+    std::vector<double> L((size_t)m * m, 0.0), U((size_t)m * m, 0.0);
+    for (int32_t k = 0; k < m; ++k) {
+        L[(size_t)k * m + k] = 1.0; U[(size_t)k * m + k] = O.diag[k];
+        for (int32_t e = O.Lf.ptr[k]; e < O.Lf.ptr[k + 1]; ++e) { CHECK(O.Lf.idx[e] < k, "%s: L entry above the diagonal", name); L[(size_t)k * m + O.Lf.idx[e]] = O.Lf.val[e]; }
+        for (int32_t e = O.Uf.ptr[k]; e < O.Uf.ptr[k + 1]; ++e) { CHECK(O.Uf.idx[e] > k, "%s: U entry below the diagonal", name); U[(size_t)k * m + O.Uf.idx[e]] = O.Uf.val[e]; }
+    }
+    double worst = 0.0, scale = 1.0;
+    for (int32_t k = 0; k < m; ++k)
+        for (int32_t l = 0; l < m; ++l) {
+            double s = 0.0;
+            for (int32_t q = 0; q <= std::min(k, l); ++q) s += L[(size_t)k * m + q] * U[(size_t)q * m + l];
+            const double want = a[(size_t)O.rowperm[k] * m + O.colperm[l]];
+            worst = std::max(worst, std::fabs(s - want)); scale = std::max(scale, std::fabs(want));
+        }
+    CHECK(worst <= 1e-12 * scale * std::max(1, m), "%s: |P B Q - L U| = %.3e", name, worst);
+    // the column views hold the same entries as the row views
+    {
+        std::vector<double> Lc((size_t)m * m, 0.0), Uc((size_t)m * m, 0.0);
+        for (int32_t l = 0; l < m; ++l) {
+            for (int32_t e = O.Lb.ptr[l]; e < O.Lb.ptr[l + 1]; ++e) Lc[(size_t)O.Lb.idx[e] * m + l] = O.Lb.val[e];
+            for (int32_t e = O.Ub.ptr[l]; e < O.Ub.ptr[l + 1]; ++e) Uc[(size_t)O.Ub.idx[e] * m + l] = O.Ub.val[e];
+        }
+        bool same = true;
+        for (int32_t k = 0; k < m && same; ++k)
+            for (int32_t l = 0; l < m; ++l) {
+                if (k > l && Lc[(size_t)k * m + l] != L[(size_t)k * m + l]) same = false;
+                if (k < l && Uc[(size_t)k * m + l] != U[(size_t)k * m + l]) same = false;
+            }
+        CHECK(same, "%s: row and column views differ", name);
+        CHECK(O.Lf.ptr[m] == O.Lb.ptr[m] && O.Uf.ptr[m] == O.Ub.ptr[m] && O.status[3] == O.Lf.ptr[m] && O.status[4] == O.Uf.ptr[m], "%s: entry counts", name);
+    }
+    // FTRAN / BTRAN: against dense elimination and against the host factorisation
+    std::vector<double> rhs(m), xh, zh;
+    for (auto& v : rhs) v = (double)((int)(rng() % 19) - 9);
+    const std::vector<double> x = ftran(O, m, rhs), z = btran(O, m, rhs);
+    CHECK(max_rel(x, dense_solve(m, a, rhs, false)) <= 1e-9, "%s: FTRAN differs from the dense solve by %.3e", name, max_rel(x, dense_solve(m, a, rhs, false)));
+    CHECK(max_rel(z, dense_solve(m, a, rhs, true)) <= 1e-9, "%s: BTRAN differs from the dense solve by %.3e", name, max_rel(z, dense_solve(m, a, rhs, true)));
+    lu_ftran_host(hf, rhs, &xh); lu_btran_host(hf, rhs, &zh);
+    CHECK(max_rel(x, xh) <= 1e-9 && max_rel(z, zh) <= 1e-9, "%s: solves differ from lu_factor's by %.3e / %.3e", name, max_rel(x, xh), max_rel(z, zh));
+    // no more fill than the host factorisation by a wide margin (both pivot for sparsity)
+    CHECK(O.Lf.ptr[m] + O.Uf.ptr[m] <= 3 * (hf.nnz_l + hf.nnz_u) + 4 * m, "%s: %d + %d entries against the host's %lld + %lld", name, O.Lf.ptr[m], O.Uf.ptr[m],
+          (long long)hf.nnz_l, (long long)hf.nnz_u);
+}
+
+// a provider that is just the given square matrix as structural columns; basis = all of them
+static Provider square(int m, const Cols& cols) {
+    Provider P;
+    P.mc = P.m = m; P.nn = m;
+    P.cptr.assign(1, 0);
+    for (auto c : cols) { std::sort(c.begin(), c.end()); for (auto& e : c) { P.cidx.push_back(e.first); P.cval.push_back(e.second); } P.cptr.push_back((int64_t)P.cidx.size()); }
+    P.bound_row.assign(m, -1);
+    P.finish();
+    return P;
+}
+static void check_square(const char* name, int m, const Cols& cols, std::mt19937_64& rng, bool singular = false) {
+    const Provider P = square(m, cols);
+    std::vector<int32_t> basis(m);
+    for (int c = 0; c < m; ++c) basis[c] = c;
+    check(name, P, basis, rng, singular);
+}
+
+int main() {
+    std::mt19937_64 rng(20250611);
+    // the reference's factorisation cases (decomposition/mod.rs:301-491), column by column
+    check_square("identity 2", 2, {{{0, 1.0}}, {{1, 1.0}}}, rng);
+    check_square("identity 3", 3, {{{0, 1.0}}, {{1, 1.0}}, {{2, 1.0}}}, rng);
+    check_square("offdiagonal upper", 2, {{{0, 1.0}}, {{0, 1.0}, {1, 1.0}}}, rng);
+    check_square("offdiagonal lower", 2, {{{0, 1.0}, {1, 1.0}}, {{1, 1.0}}}, rng);
+    check_square("offdiagonal swapped", 2, {{{0, 1.0}, {1, 1.0}}, {{0, 1.0}}}, rng);
+    check_square("wikipedia 1", 2, {{{0, 4.0}, {1, 6.0}}, {{0, 3.0}, {1, 3.0}}}, rng);
+    check_square("wikipedia 2", 2, {{{0, -1.0}, {1, 1.0}}, {{0, 1.5}, {1, -1.0}}}, rng);
+    check_square("elble-sahinidis U", 5, {{{0, 11.0}}, {{0, 12.0}, {1, 22.0}}, {{0, 13.0}, {1, 23.0}, {2, 33.0}},
+                                          {{0, 14.0}, {1, 24.0}, {2, 34.0}, {3, 44.0}}, {{0, 15.0}, {1, 25.0}, {2, 35.0}, {3, 45.0}, {4, 55.0}}}, rng);
+    check_square("dense 3", 3, {{{0, 2.0}, {1, 1.0}, {2, 4.0}}, {{0, 1.0}, {1, 3.0}, {2, 1.0}}, {{0, 5.0}, {1, 1.0}, {2, 2.0}}}, rng);
+    check_square("singular", 2, {{{0, 1.0}, {1, 2.0}}, {{0, 2.0}, {1, 4.0}}}, rng, true);
+    // LP-like random bases (the generator of test_lu_host.cpp): a permuted diagonal, a sparse bump, dense columns, chains
+    for (int trial = 0; trial < 80; ++trial) {
+        const int m = 2 + (int)(rng() % (trial < 50 ? 40 : 300));
+        Cols cols(m);
+        for (int j = 0; j < m; ++j) {
+            std::vector<int> rows_{(int)(((long long)j * 7 + 3) % m)};
+            if (m % 7 == 0) rows_.push_back(j);
+            const int extra = (int)(rng() % 4);
+            for (int e = 0; e < extra; ++e) rows_.push_back((int)(rng() % m));
+            if (rng() % 5 == 0 && j > 0) rows_.push_back((int)(((long long)(j - 1) * 7 + 3) % m));
+            if (rng() % 50 == 0) for (int e = 0; e < 70 && e < m; ++e) rows_.push_back((int)(rng() % m));
+            std::sort(rows_.begin(), rows_.end());
+            rows_.erase(std::unique(rows_.begin(), rows_.end()), rows_.end());
+            for (int r : rows_) { const int q = (int)(rng() % 9) - 4; cols[j].emplace_back(r, q == 0 ? 1.0 : (rng() % 3 == 0 ? q * 0.5 : (double)q)); }
+        }
+        char nm[64];
+        std::snprintf(nm, sizeof nm, "random %d (m = %d)", trial, m);
+        check_square(nm, m, cols, rng);
+    }
+    // providers with every kind of column: mc constraint rows, bound rows, slacks of both signs, artificial columns; random bases
+    for (int trial = 0; trial < 60; ++trial) {
+        Provider P;
+        P.mc = 3 + (int)(rng() % 30);
+        P.nn = 2 + (int)(rng() % 40);
+        std::vector<int32_t> bounded;
+        P.bound_row.assign(P.nn, -1);
+        for (int p = 0; p < P.nn; ++p) if (rng() % 3 == 0) { P.bound_row[p] = P.mc + (int)bounded.size(); bounded.push_back(p); }
+        P.m = P.mc + (int)bounded.size();
+        P.cptr.assign(1, 0);
+        for (int p = 0; p < P.nn; ++p) {
+            std::vector<int> rows_;
+            const int n = 1 + (int)(rng() % 4);
+            for (int e = 0; e < n; ++e) rows_.push_back((int)(rng() % P.mc));
+            std::sort(rows_.begin(), rows_.end()); rows_.erase(std::unique(rows_.begin(), rows_.end()), rows_.end());
+            for (int r : rows_) { P.cidx.push_back(r); P.cval.push_back((double)((int)(rng() % 7) + 1) * (rng() % 2 ? 1.0 : -0.5)); }
+            P.cptr.push_back((int64_t)P.cidx.size());
+        }
+        // one slack per constraint row (sign by row), one bound slack per bound row
+        for (int i = 0; i < P.mc; ++i) { P.vrow0.push_back(i); P.vrow1.push_back(-1); P.vsign.push_back(i % 3 == 0 ? -1 : 1); }
+        for (size_t k = 0; k < bounded.size(); ++k) { P.vrow0.push_back(P.mc + (int)k); P.vrow1.push_back(-1); P.vsign.push_back(1); }
+        P.nv = (int)P.vrow0.size();
+        // artificial columns on the rows whose slack is negative
+        for (int i = 0; i < P.mc; ++i) if (i % 3 == 0) P.column_to_row.push_back(i);
+        P.na = (int)P.column_to_row.size();
+        P.finish();
+        // a basis: start from slacks / artificials (nonsingular), then swap in structural columns while it stays nonsingular
+        std::vector<int32_t> basis(P.m);
+        {
+            int a = 0;
+            for (int i = 0; i < P.mc; ++i) basis[i] = (i % 3 == 0) ? a++ : P.na + P.nn + i;
+            for (size_t k = 0; k < bounded.size(); ++k) basis[P.mc + k] = P.na + P.nn + P.mc + (int)k;
+        }
+        for (int swaps = 0; swaps < P.m; ++swaps) {
+            const int pos = (int)(rng() % P.m), cand = P.na + (int)(rng() % P.nn);
+            if (std::find(basis.begin(), basis.end(), cand) != basis.end()) continue;
+            std::vector<int32_t> trial_basis = basis;
+            trial_basis[pos] = cand;
+            Cols cols(P.m);
+            for (int c = 0; c < P.m; ++c) { cols[c] = P.column_of(trial_basis[c]); std::sort(cols[c].begin(), cols[c].end()); }
+            LUFactors f; std::string err;
+            if (lu_factor(P.m, cols, &f, &err)) basis = trial_basis;
+        }
+        char nm[64];
+        std::snprintf(nm, sizeof nm, "provider %d (m = %d, %d structural, %d artificial)", trial, P.m, P.nn, P.na);
+        check(nm, P, basis, rng);
+    }
+    std::printf("test_lu_device_model: %d checks, %d failed\n", g_checks, g_failed);
+    return g_failed ? 1 : 0;
+}

@@ -21,7 +21,7 @@ def test_driver_command_emits_one_complete_json_line():
     assert out["metric"] == "simplex iterations/sec" and out["unit"] == "iterations/s" and out["n_gpus"] == 1
     assert out["value"] > 1000 and out["higher_is_better"] is True and out["dtype"] == "f64" and out["vs_baseline"] is None
     block = out["config"]["update_block"]
-    assert block == 64 and out["steps"] % block == 0 and out["steps"] >= 4 * block and out["timing"]["steps_requested"] == 20
+    assert block == 96 and out["steps"] % block == 0 and out["steps"] >= 4 * block and out["timing"]["steps_requested"] == 20
     assert out["timing"]["windows"] == 5 and len(out["timing"]["window_ms"]) == 5
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
     roof = out["roofline"]
@@ -40,3 +40,53 @@ def test_driver_command_emits_one_complete_json_line():
     assert sp["reference_cadence_update_block_11"]["outcome"] == "optimal"
     for other in ("explicit_inverse_engine", "tableau_engine"):
         assert sp[other]["outcome"] == "optimal" and abs(sp[other]["objective"] - 5.5018459e+03) < 1e-4
+    # BASELINE configs[0] and configs[4] in the line (missing 6), and the LU engine beyond 2,400 / 4,096 rows
+    c1 = out["c1"]
+    assert c1["exact_cpu"]["objective_is_the_reference_pin"] is True and c1["exact_cpu"]["pivots"] > 100
+    for label in ("lu", "revised", "tableau"):
+        assert c1[label]["outcome"] == "optimal" and c1[label]["trace_identical_to_exact"] is True
+        assert abs(c1[label]["objective"] - 24975305659811992079614961229 / 120651674036153428931840) < 1e-6
+    c5 = out["c5"]
+    for label in ("lu", "revised", "tableau"):
+        assert c5["50v-10"][label]["outcome"] == "optimal" and abs(c5["50v-10"][label]["objective"] - 2879.065687) < 1e-3
+        assert c5["50v-10"][label]["degenerate_pivots"] > 0
+        assert c5["acc-tight4"][label]["pivots"] >= 30000 and c5["acc-tight4"][label]["degenerate_pivots"] > 0
+    large = sp["large"]
+    for name, tol in (("GREENBEA", 1.0), ("GREENBEB", 10.0), ("80BAU3B", 1e-3)):
+        for label in ("lu", "revised", "tableau"):
+            assert large[name][label]["outcome"] == "optimal" and abs(large[name][label]["pin_error"]) < tol, (name, label)
+    assert large["80BAU3B"]["lu"]["pivot_kernel_clocks_per_pivot"] and large["DFL001"]["lu"]["pivot_kernel_clocks_per_pivot"]
+    stride = out["kernel_event_stride"]
+    assert stride % block != 0                                            # (no aliasing with the block)
+
+
+def _one_line(p):
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_multi_rank_command_rehearsed_with_two_ranks_on_one_gpu():
+    """The driver's N = 2 path, `python bench.py --gpus 2 ...`, as a fresh child process (it starts torch.distributed.run
+    itself): RELP_BENCH_REHEARSE=1 puts both ranks on this box's one GPU and lets gloo carry the exchange (RCCL refuses two
+    ranks on one device); launcher, rank wiring, sharded engines, barrier + max-over-ranks timing and the JSON assembly are the
+    ones an 8-GPU node runs.  No scaling curve has been measured anywhere yet: this checks the path, not a speed."""
+    env = dict(os.environ, RELP_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"]
+    out = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500))
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 10       # (gloo on the host carries every exchange)
+    assert "sharded x2" in out["config"]["parallelism"] and "shard_loop" in out["config"]
+    assert out["roofline"]["kernel"] == "k_tab_flush_lds" and out["roofline"]["frac"] > 0
+    assert out["c4"]["value"] > 10 and "sharded x2" in out["c4"]["workload"]
+    assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
+
+
+def test_sharded_loop_over_rccl_with_one_rank():
+    """`--force-sharded` at N = 1: the native multi-GPU loop (relp_shard_run) with RCCL itself -- ncclCommInitRank from the id
+    torch.distributed broadcasts, ncclAllGather between the kernels on the engine's stream -- on a communicator of one rank."""
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--force-sharded", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
+    out = _one_line(subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500))
+    assert out["n_gpus"] == 1 and out["value"] > 1000
+    assert "native" in out["config"]["shard_loop"] and out["c4"]["value"] > 1000
+    assert out["roofline"]["kernel"] == "k_tab_flush_lds"

@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import math
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -124,3 +126,15 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_as_a_child(monkeypatch):
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "20"]
+
+
+@pytest.mark.parametrize("block", [0, 1, 11, 32, 48, 64, 96, 128])
+@pytest.mark.parametrize("stride", [1, 16, 64, 96])
+def test_event_stride_never_aliases_with_the_update_block(stride, block):
+    """stride 64 on block 64 bracketed the first pivot of every block only.  The sampled positions of a block
+    must cover all of 0 .. K - 1."""
+    got = bench.coprime_stride(stride, block)
+    assert got >= stride
+    if block > 1:
+        assert got % block != 0 and math.gcd(got, block) == 1
+        assert {(k * got) % block for k in range(block)} == set(range(block))

@@ -33,6 +33,17 @@ def test_host_lu_factorisation_fusion_and_packing():
     assert " 0 failed" in res.stdout
 
 
+def test_device_lu_factorisation_as_a_host_model():
+    """tests/cpp/test_lu_device_model.cpp (no GPU): the device-side LU factorisation (relp_lu_factor_core.h)
+    compiled for the host -- the code the kernel k_lu_factor runs, its parallel loops serial -- on the reference's
+    factorisation cases (decomposition/mod.rs:301-491), LP-like random bases and providers with slack, bound and artificial
+    columns: P B Q = L U, row and column views, FTRAN / BTRAN against dense solves and against lu_factor."""
+    subprocess.check_call(["make", "-C", CPP, "test_lu_device_model"], stdout=subprocess.DEVNULL)
+    res = subprocess.run([os.path.join(CPP, "test_lu_device_model")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert " 0 failed" in res.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_host_tests_pass_on_the_gpu():
     if not os.access(BINARY, os.X_OK):

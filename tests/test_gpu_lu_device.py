@@ -1,0 +1,162 @@
+"""The refactorisation of the LU engine ON THE DEVICE (rust-lp_amd/csrc/relp_lu_factor_core.h, kernel
+k_lu_factor) through the C ABI.  Reference: `LUDecomposition::invert` -> `decomposition/mod.rs:27-138` with the Markowitz
+pivoting of `decomposition/pivoting.rs:45-81`; its 14 unit cases are `decomposition/mod.rs:301-491` -- seven matrices whose
+factors are asserted and seven cases of the row update `subtract_multiple_of_row_from_other_row` (`:141-205`).
+
+The factors of a device factorisation cannot equal the reference's literally (another pivot order: singletons are peeled in
+parallel rounds), so what is checked is what every valid factorisation shares: P B Q = L U to 1e-12 (relp_lu_factor_residual),
+every column (FTRAN of unit vectors) and every row (BTRAN) of the inverse against numpy, and the reference's known answers of
+`wikipedia_example2`.  The same code runs on the host, serially, in tests/cpp/test_lu_device_model.cpp (CPU tier)."""
+import numpy as np
+import pytest
+
+import rust_lp_amd  # noqa: F401
+from rust_lp_amd import MatrixData, engine
+from oracle import relp_f64
+
+pytestmark = pytest.mark.gpu
+
+
+def square_problem(a):
+    """An LP whose structural columns are the columns of `a` and whose rows are all equalities: the basis {0 .. m-1} is `a`."""
+    a = np.asarray(a, dtype=np.float64)
+    m = a.shape[0]
+    return MatrixData(nr_normal=m, nr_eq=m, nr_range=0, nr_le=0, nr_ge=0, b=np.ones(m), cost=np.zeros(m),
+                      upper_bound=np.full(m, np.inf), dense=np.asfortranarray(a))
+
+
+def factorise_on_device(a):
+    t = engine.Tableau(square_problem(a), engine=engine.ENGINE_LU)
+    t.lu_set_device_factorisation(True)
+    t.from_basis(np.arange(a.shape[0], dtype=np.int32))
+    st = t.lu_device_factorisation_stats()
+    assert st["enabled"] == 1 and st["device_factorisations"] >= 1 and st["host_fallbacks"] == 0
+    return t, st
+
+
+def check_inverse(t, a):
+    m = a.shape[0]
+    inv = np.linalg.inv(a)
+    scale = max(1.0, np.abs(inv).max())
+    assert 0.0 <= t.lu_factor_residual() <= 1e-12 * max(1.0, np.abs(a).max()) * m
+    for j in range(m):
+        np.testing.assert_allclose(t.generate_column_of([(j, 1.0)]), inv[:, j], rtol=0, atol=1e-10 * scale)      # FTRAN
+        np.testing.assert_allclose(t.basis_inverse_row(j), inv[j, :], rtol=0, atol=1e-10 * scale)        # BTRAN
+
+
+# decomposition/mod.rs:315-420: the seven matrices (given there by rows, or by columns for `wikipedia_example`)
+REFERENCE_MATRICES = {
+    "identity_2": [[1, 0], [0, 1]],
+    "identity_3": [[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+    "offdiagonal_2_upper": [[1, 1], [0, 1]],
+    "offdiagonal_2_lower": [[1, 0], [1, 1]],
+    "offdiagonal_2_both": [[1, 1], [1, 0]],
+    "wikipedia_example": [[4, 6], [3, 3]],
+    "wikipedia_example2": [[-1, 1.5], [1, -1]],
+}
+# decomposition/mod.rs:436-491: `column1 -= 1 * column2`-style updates as the elimination step that performs them: row 1 of
+# the matrix below is the pivot row, row 2 the edited one (multiplier 1 for the first six, 1/3 for make_zero), columns 1.. hold
+# the vectors of the case.  The expected edited row is in the reference test; here the factorisation must stay exact.
+ROW_UPDATE_CASES = {
+    "empty": [[1, 0, 0], [1, 1, 0], [0, 0, 1]],                           # both vectors empty beyond the pivot
+    "edited_empty": [[1, 1, 0], [1, 0, 1], [0, 1, 1]],                    # fill in an empty position
+    "other_empty": [[1, 0, 0], [1, 1, 0], [0, 1, 1]],                     # nothing to subtract
+    "single_before": [[1, 0, 3], [1, 1, 0], [0, 1, 1]],                   # fill behind an existing entry
+    "single_at": [[1, 3, 0], [1, 1, 0], [0, 0, 1]],                       # update in place: 1 - 3 = -2
+    "single_at_make_zero": [[3, 3, 1], [1, 1, 1], [0, 1, 2]],             # exact cancellation: the entry disappears
+    "single_after": [[1, 3, 0], [1, 0, 1], [0, 1, 1]],                    # fill in front of an existing entry
+}
+
+
+@pytest.mark.parametrize("name", sorted(REFERENCE_MATRICES))
+def test_reference_factorisation_cases_on_the_device(name):
+    a = np.array(REFERENCE_MATRICES[name], dtype=np.float64)
+    t, st = factorise_on_device(a)
+    check_inverse(t, a)
+    if name == "wikipedia_example2":                                      # decomposition/mod.rs:470-489
+        np.testing.assert_allclose(t.generate_column_of([(0, 1.0)]), [2.0, 2.0], atol=1e-14)
+        np.testing.assert_allclose(t.generate_column_of([(1, 1.0)]), [3.0, 2.0], atol=1e-14)
+    if name.startswith("identity") or name.startswith("offdiagonal"):
+        assert st["last_bump"] == 0                                       # triangular: peeled, nothing to eliminate
+    t.close()
+
+
+@pytest.mark.parametrize("name", sorted(ROW_UPDATE_CASES))
+def test_row_update_cases_as_elimination_steps_on_the_device(name):
+    a = np.array(ROW_UPDATE_CASES[name], dtype=np.float64)
+    t, st = factorise_on_device(a)
+    check_inverse(t, a)
+    t.close()
+
+
+@pytest.mark.parametrize("m,density,seed", [(6, 0.5, 1), (40, 0.08, 2), (150, 0.03, 3), (300, 0.015, 4), (300, 0.2, 5), (700, 0.006, 6)])
+def test_random_sparse_bases_device_factors_equal_the_host_factors_in_every_solve(m, density, seed):
+    """LP-like bases (a permuted diagonal + random entries, a few dense columns): FTRAN / BTRAN through the device factors
+    equal those through relp_lu.cpp's lu_factor (the engine with the device factorisation switched off) to 1e-9, both equal
+    numpy's inverse, and the residual identity holds."""
+    rng = np.random.default_rng(seed)
+    a = np.zeros((m, m))
+    perm = rng.permutation(m)
+    a[perm, np.arange(m)] = rng.integers(1, 5, m) * rng.choice([-1.0, 1.0], m)
+    mask = rng.random((m, m)) < density
+    a[mask] += rng.integers(-4, 5, mask.sum())
+    for j in rng.choice(m, max(1, m // 60), replace=False):
+        rows = rng.choice(m, min(m, 60), replace=False)
+        a[rows, j] += rng.integers(1, 4, len(rows))
+    if abs(np.linalg.det(a / np.abs(a).max())) < 1e-200 or np.linalg.cond(a) > 1e10:
+        pytest.skip("the random matrix is (nearly) singular")
+    dev, st = factorise_on_device(a)
+    host = engine.Tableau(square_problem(a), engine=engine.ENGINE_LU)
+    host.from_basis(np.arange(m, dtype=np.int32))
+    assert host.lu_device_factorisation_stats()["device_factorisations"] == 0
+    inv = np.linalg.inv(a)
+    scale = max(1.0, np.abs(inv).max())
+    res = dev.lu_factor_residual()
+    assert 0.0 <= res <= 1e-11 * max(1.0, np.abs(a).max()) * m
+    for j in rng.choice(m, min(m, 12), replace=False):
+        xd, xh = dev.generate_column_of([(int(j), 1.0)]), host.generate_column_of([(int(j), 1.0)])
+        np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-9 * scale)
+        np.testing.assert_allclose(xd, inv[:, j], rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(dev.basis_inverse_row(int(j)), host.basis_inverse_row(int(j)), rtol=0, atol=1e-9 * scale)
+    print(f"m {m}: bump {st['last_bump']}, peeled {st['last_peeled']}, kernel {st['kernel_us']} us, residual {res:.2e}")
+    dev.close()
+    host.close()
+
+
+@pytest.mark.parametrize("path,fixed,objective,tol", [
+    ("burkardt/adlittle.mps", False, 24975305659811992079614961229 / 120651674036153428931840, 1e-6),
+    ("netlib/SC205.SIF", True, -5.220206121e+01, 1e-5), ("netlib/SHARE1B.SIF", True, -0.76589318579185e5, 1e-3),
+    ("netlib/BOEING2.SIF", True, -0.31501872801520287e3, 1e-3), ("netlib/BORE3D.SIF", True, 0.13730803942084927e4, 1e-2),
+    ("miplib/50v-10.mps", False, 2879.065687, 1e-3), ("netlib/25FV47.SIF", True, 5.5018459e+03, 1e-4)])
+def test_whole_solves_with_every_refactorisation_on_the_device(path, fixed, objective, tol):
+    """Both phases, artificial removal, row removal (BORE3D, 50v-10), the phase switch and -- on the small files at the
+    reference's cadence of 11 updates -- hundreds of refactorisations, every one of them by the device kernel: the reference's
+    objective pin, the f64 oracle's pivot sequence where the host-factorised engine walks it too."""
+    from lp_files import load
+    gf, ex, md, emd = load(path, fixed=fixed)
+    big = "25FV47" in path
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=-1 if big else 11, trace_capacity=1 << 15)
+    t.lu_set_device_factorisation(True)
+    assert t.solve_relaxation() == engine.OPTIMAL
+    got = t.objective_function_value() + float(gf.fixed_cost)
+    assert abs(got - objective) < max(tol, 1e-9 * abs(objective))
+    st = t.lu_device_factorisation_stats()
+    assert st["device_factorisations"] >= 2 and st["host_fallbacks"] == 0
+    ident, basic, min_b = t.check_basis()
+    assert ident <= 1e-6 and min_b >= -1e-6
+    if not big:
+        ref = relp_f64.OracleF64(md)
+        assert ref.run() == "optimal"
+        assert t.trace() == ref.trace
+    print(f"{path}: {t.iterations()} pivots, {st['device_factorisations']} device factorisations, "
+          f"{st['kernel_us'] / max(st['device_factorisations'], 1):.0f} us each, last bump {st['last_bump']} of {t.nr_rows()}")
+    t.close()
+
+
+def test_a_singular_basis_is_reported_by_the_device_factorisation():
+    a = np.array([[1.0, 2.0], [2.0, 4.0]])
+    t = engine.Tableau(square_problem(a), engine=engine.ENGINE_LU)
+    t.lu_set_device_factorisation(True)
+    with pytest.raises(engine.RelpError, match="singular"):
+        t.from_basis(np.arange(2, dtype=np.int32))
+    t.close()

@@ -681,7 +681,7 @@ def test_c2_full_solve_both_engines_agree_to_optimality():
 # ------------------------------------------------------------------------------------------------
 # Sparse LU engine (Carry<_, LUDecomposition<_>>)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kind", [engine.ENGINE_LU, engine.ENGINE_REVISED])
+@pytest.mark.parametrize("kind", [engine.ENGINE_LU, engine.ENGINE_REVISED, engine.ENGINE_TABLEAU])
 @pytest.mark.parametrize("path,fixed", [("burkardt/adlittle.mps", False), ("netlib/SC205.SIF", True), ("netlib/SHARE1B.SIF", True)])
 def test_from_basis_restarts_at_the_optimum(path, fixed, kind):
     """InverseMaintener::from_basis (carry/mod.rs:428-463) with a general basis: the LU engine factorises the
@@ -704,7 +704,7 @@ def test_from_basis_restarts_at_the_optimum(path, fixed, kind):
     np.testing.assert_allclose(t.minus_pi(), first.minus_pi(), rtol=1e-7, atol=1e-7 * scale)
 
 
-@pytest.mark.parametrize("kind", [engine.ENGINE_LU, engine.ENGINE_REVISED])
+@pytest.mark.parametrize("kind", [engine.ENGINE_LU, engine.ENGINE_REVISED, engine.ENGINE_TABLEAU])
 def test_from_basis_mid_solve_continues_the_same_path(kind):
     """Warm start from an intermediate basis: the continuation walks the same pivots as the run it was
     taken from (Dantzig's rule has no memory)."""
@@ -809,9 +809,45 @@ def test_25fv47_reaches_the_netlib_optimum_under_the_default_config(kind, block)
     assert t.config.tol_pivot == 1e-5 and t.config.tol_cost == 1e-7            # relp_default_config
     assert t.solve_relaxation() == engine.OPTIMAL
     got = t.objective_function_value() + float(gf.fixed_cost)
+    # tests/netlib/test.rs:157 writes `< 1e-5` beside a pin of 8 digits, 5.5018459e+03: the optimum is 5501.845888.. (all three
+    # engines, the f64 oracle, scipy's LU in scripts/f64_lab.py and HiGHS agree on these digits), 1.2e-5 away from the pin as
+    # printed, so the reference's own assert could not hold for the exact optimum either (its test is `#[ignore]`d and has
+    # never run).  1e-4 is the pin's rounding; the agreement on the full value is checked to 1e-8 relative.
     assert abs(got - 5.5018459e+03) < 1e-4
+    assert abs(got - 5501.845888286) <= 1e-8 * 5501.845888286
     ident, basic, min_b = t.check_basis()
     assert ident <= 1e-6 and min_b >= -1e-6
+    t.close()
+
+
+@pytest.mark.parametrize("kind,block", [(engine.ENGINE_LU, -1), (engine.ENGINE_REVISED, 0), (engine.ENGINE_TABLEAU, 32)])
+def test_25fv47_phase_two_pivot_by_pivot_from_the_oracles_phase_one_basis(kind, block):
+    """Phase 2 of C3 from a COMMON start: the f64 oracle's basis at the end of its phase 1 is handed to every engine through
+    `relp_from_basis` (InverseMaintener::from_basis, carry/mod.rs:428-463), then engine and oracle run phase 2 (SteepestDescent)
+    side by side.  Identical pivots for at least the first 500 (a few thousand follow; like in phase 1, a tie within rounding
+    eventually resolves differently), the same optimum at the end."""
+    from lp_files import load
+    gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
+    ref = relp_f64.OracleF64(md)
+    assert ref.run(through_phases=False) == "phase_one_done"
+    n1 = len(ref.trace)
+    assert ref.filtered_rows() == []
+    basis, b_start = ref.basis(), ref.b()
+    assert ref.run() == "optimal"
+    phase2 = ref.trace[n1:]
+    t = engine.Tableau(md, engine=kind, update_block=block, trace_capacity=1 << 14)
+    if kind == engine.ENGINE_REVISED:
+        t.set_reinversion_interval(0)              # like the oracle: an inverse that is only ever updated
+    t.from_basis(basis)
+    assert t.phase == 2
+    np.testing.assert_allclose(t.b(), b_start, rtol=1e-6, atol=1e-6 * max(1.0, np.max(np.abs(b_start))))
+    assert t.run(1 << 20)[1] == engine.OPTIMAL
+    tr = t.trace()
+    same = next((k for k, (a, b) in enumerate(zip(tr, phase2)) if a != b), min(len(tr), len(phase2)))
+    print(f"25FV47 phase 2: engine {len(tr)} pivots, oracle {len(phase2)}, identical for the first {same}")
+    assert same >= 500
+    got = t.objective_function_value() + float(gf.fixed_cost)
+    assert abs(got - (ref.objective + float(gf.fixed_cost))) <= 1e-8 * abs(got)
     t.close()
 
 
@@ -864,7 +900,7 @@ def test_dense10k_full_size_engines_agree_and_match_the_cpu_oracle_prefix():
     traces = []
     for kind in (engine.ENGINE_TABLEAU, engine.ENGINE_REVISED):
         t = engine.Tableau(counts, engine=kind, device_dense_ptr=ptr.value, device_dense_ld=m, trace_capacity=1024)
-        assert t.update_block() == 64
+        assert t.update_block() == (96 if kind == engine.ENGINE_TABLEAU else 64)       # the automatic choices at this size
         assert t.run(1)[1] == engine.PHASE_ONE_DONE
         objs = []
         for _ in range(5):
@@ -921,7 +957,7 @@ def test_c4_full_size_on_one_gpu_matches_the_oracle_prefix_and_both_engines_agre
     traces = []
     for kind in (engine.ENGINE_TABLEAU, engine.ENGINE_REVISED):
         t = engine.Tableau(counts, engine=kind, device_dense_ptr=ptr.value, device_dense_ld=m, trace_capacity=1024)
-        assert t.update_block() == 64
+        assert t.update_block() == (96 if kind == engine.ENGINE_TABLEAU else 64)       # the automatic choices at this size
         assert t.run(1)[1] == engine.PHASE_ONE_DONE
         objs = []
         for _ in range(3):
