@@ -102,8 +102,8 @@ typedef struct {
     /* basis-inverse maintenance: 0 = rank-1 update of the explicit inverse at every pivot
      * (basis_inverse_rows.rs:131-142 literally); K > 0 = deferred: the explicit inverse is kept as
      * (I + W S') B0inv and the K most recent pivots are folded in by one m x K x m GEMM ("flush");
-     * -1 = automatic (64 when m >= 4096, else 0; the dense tableau engine, which always works in blocks: 96 when
-     * m >= 4096, else 64).  Results are the same up to f64 rounding. */
+     * -1 = automatic (64 when m >= 4096, else 0; the dense tableau engine, which always works in blocks: 64, and 96 for
+     * tableaus of 40,000 columns or more with m >= 4096).  Results are the same up to f64 rounding. */
     int32_t update_block;
     /* relp_engine_kind_t: which device representation maintains the basis inverse */
     int32_t engine;

@@ -17,6 +17,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$OUT/pmc_fetch" -- $CMD > "
 echo "pmc fetch exit=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d "$OUT/pmc_write" -- $CMD > "$OUT/pmc_write.log" 2>&1
 echo "pmc write exit=$?"
+# (SKIP_EXTRA=1: only the three passes above -- the c2 / c4 collections that fill roofline.traffic for those workloads;
+# summarize.py then takes the calibration factors from the main collection's cal_* directories passed as CAL_FROM)
+if [ "${SKIP_EXTRA:-0}" = "1" ]; then find "$OUT" -name '*.csv' -size +8M -delete; exit 0; fi
 # 3. calibration of FETCH_SIZE / WRITE_SIZE for the flush kernel's access pattern (8 bytes per lane along a column of a
 #    column-major tile): scripts/microbench/tile_rmw.hip walks the same tiles with a known byte count
 #    (MI355X_MICROARCH.md section HBM: "calibrate on a known byte count in your own access pattern")

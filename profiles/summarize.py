@@ -56,9 +56,10 @@ def main():
     write = per_kernel(newest(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
     # calibration of the counters for 8-byte-per-lane tile accesses: k_tile<true> in place moves 8 m n bytes each way
     cal_f = cal_w = None
+    cal_src = os.path.join(ROOT, "gpurun_out", f"prof_{sys.argv[3]}") if len(sys.argv) > 3 else src     # calibration of another collection
     try:
-        cf = per_kernel(newest(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
-        cw = per_kernel(newest(os.path.join(src, "cal_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+        cf = per_kernel(newest(os.path.join(cal_src, "cal_fetch", "*", "*_counter_collection.csv"))[0], "Counter_Value")
+        cw = per_kernel(newest(os.path.join(cal_src, "cal_write", "*", "*_counter_collection.csv"))[0], "Counter_Value")
         known = 8.0 * 10000 * 20000
         cal_f = known / (cf["k_tile"]["value"] * 1024.0)
         cal_w = known / (cw["k_tile"]["value"] * 1024.0)

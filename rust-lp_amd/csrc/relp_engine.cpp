@@ -291,6 +291,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
             const char* fl = std::getenv("RELP_FUSE_LANES");
             const char* df = std::getenv("RELP_LU_DEVICE_FACTOR");
             luf_enabled_ = df && std::atoi(df) != 0;
+            luf_download_ = df && std::atoi(df) == 2;
             lu_lookahead_env_ = la ? std::atoi(la) : 8;
             lu_fuse_lanes_env_ = fl ? std::atoi(fl) : 256;
         }
@@ -299,9 +300,11 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     }
     if (tableau_) {
         if (block_ == 0) block_ = 64;                  // the tableau is always maintained in blocks
-        // automatic choice for large tableaus: 96 pivots per flush (measured at 10,000 x 10,000 / x 50,000: +3 % / +7 % pivots
-        // per second over 64 -- the flush is amortised over more pivots while its own time grows by less; flat from 80 to 112)
-        if (cfg_.update_block < 0 && m_ >= 4096) block_ = 96;
+        // automatic choice for wide tableaus: 96 pivots per flush where the flush dominates the pivot.  Measured: 10,000 x
+        // 50,000 (60,000 stored columns) 19,600 it/s against 18,600 with 64; at 10,000 x 10,000 (20,000 stored columns) the gain is
+        // within the noise of the windows (+0.8 %) while the flush kernel leaves its best operating point (0.58 instead of 0.61
+        // of HBM peak: more arithmetic per byte), so 64 stays there.
+        if (cfg_.update_block < 0 && m_ >= 4096 && n_alloc_ >= 40000) block_ = 96;
         n_store_ = n_alloc_;
         tab_na_ = nr_artificial_;
         const int64_t n_owned = std::max(sc_hi_ - sc_lo_, 1);

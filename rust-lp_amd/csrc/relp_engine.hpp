@@ -268,6 +268,10 @@ class Engine {
     int64_t luf_runs_ = 0, luf_fallbacks_ = 0; double luf_kernel_us_ = 0.0; int32_t luf_last_bump_ = 0, luf_last_peeled_ = 0;
     relp_status_t luf_prepare();
     relp_status_t lu_factor_on_device(int32_t* device_status);
+    relp_status_t luf_download_factors();
+    relp_status_t lu_host_factors();
+    bool luf_is_resident() const;
+    bool luf_download_ = false;                          // RELP_LU_DEVICE_FACTOR=2: download the factors, schedule on the host
     void luf_release();
     void luf_mark_dirty();
     bool hyper_forced_ = false; int32_t hyper_probe_in_[4] = {0, 0, 0, 0};    // adaptive hyper-sparse starts (ft_read_report)

@@ -235,6 +235,7 @@ relp_status_t Engine::lu_get_upper(int64_t* col_ptr, int32_t* row_idx, double* v
     FtHostView v;
     relp_status_t st = ft_download(fts_, stream_, &v, &err_);
     if (st) return st;
+    if ((st = lu_host_factors())) return st;               // (after a device-resident factorisation the rows are fetched now)
     const std::vector<int32_t> pos = v.positions_before(v.t);
     std::vector<std::vector<std::pair<int32_t, double>>> cols(m_);
     const int nwp = kFtWaves + 1;

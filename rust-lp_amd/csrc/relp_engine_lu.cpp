@@ -143,7 +143,8 @@ relp_status_t Engine::lu_refactor() {
     const auto t0 = std::chrono::steady_clock::now();
     if (!on_device && (st = lu_factor_downloaded_basis())) return st;
     const auto t1 = std::chrono::steady_clock::now();
-    if ((st = lu_upload_factors())) return st;
+    // (a device-resident factorisation has installed its schedules where the kernels built them: nothing to pack or upload)
+    if (!(on_device && luf_is_resident()) && (st = lu_upload_factors())) return st;
     if (ft_) { if ((st = ft_reset())) return st; }
     else launch_flush_reset(deferred(), d_rec_, stream_);
     HIP_TRY(hipStreamSynchronize(stream_));

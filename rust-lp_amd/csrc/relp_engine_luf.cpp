@@ -3,6 +3,7 @@
 // from (built at create, after a row removal and at the phase switch), and the buffers.
 #include "relp_engine_internal.hpp"
 #include "relp_lu_factor_core.h"
+#include "relp_lu_schedule_core.h"
 
 #include <algorithm>
 #include <chrono>
@@ -17,7 +18,10 @@ struct Engine::LufState {
     int32_t cap = 0, nb_cap = 0;
     bool dirty = true;
     int32_t key[4] = {-1, -1, -1, -1};                         // (m, artificial columns, phase, wrapped artificials) the tables were built for
-    std::vector<int32_t> h_int; std::vector<double> h_dbl;       // download staging
+    LufSchedWork SW{}; LufSchedIn sin[4]; LufSchedOut sout[4];   // the schedules (relp_lu_schedule_core.h)
+    FtPivotInfo* pinfo = nullptr;
+    int64_t img_cap = 0;
+    bool resident = false;                                       // hlu_ does not hold the rows of the factors in use (they are on the device)
     ~LufState() { if (d_buf) (void)hipFree(d_buf); }
 };
 
@@ -69,6 +73,20 @@ relp_status_t Engine::luf_prepare() {
                   o_cstep = take(4 * (int64_t)m), o_diag = take(8 * (int64_t)m);
     int64_t o_tp[4], o_ti[4], o_tv[4];
     for (int q = 0; q < 4; ++q) { o_tp[q] = take(4 * ((int64_t)m + 1)); o_ti[q] = take(4 * (int64_t)S.cap); o_tv[q] = take(8 * (int64_t)S.cap); }
+    // the schedules: work arrays, one image arena per schedule, lists and descriptors
+    const int32_t nlev_cap = m + 1;
+    int64_t o_sm[4];
+    for (auto& v : o_sm) v = take(4 * (int64_t)m);       // lev lg loff list
+    int64_t o_sl[3];
+    for (auto& v : o_sl) v = take(4 * ((int64_t)nlev_cap + 2));
+    const int64_t o_ovf = take(4 * ((int64_t)m + 1)), o_hist = take(64), o_spart = take(4 * ((int64_t)nt + 2)), o_flag = take(16);
+    S.img_cap = 64 + 40 * ((int64_t)S.cap + 2 * (int64_t)m + 64) + 16 * ((int64_t)m + 8);
+    int64_t o_img[4], o_desc[4], o_triv[4], o_reach[4], o_lof[4];
+    for (int q = 0; q < 4; ++q) {
+        o_img[q] = take(S.img_cap); o_desc[q] = take(4 * LUF_D_WORDS); o_triv[q] = take(4 * (int64_t)m); o_reach[q] = take(4 * (int64_t)m);
+        o_lof[q] = take(4 * (int64_t)m);
+    }
+    const int64_t o_pinfo = take((int64_t)sizeof(FtPivotInfo) * m);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_buf), (size_t)o));
     HIP_TRY(hipMemset(S.d_buf, 0, (size_t)o));
     char* const B = S.d_buf;
@@ -101,25 +119,45 @@ relp_status_t Engine::luf_prepare() {
     LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
     for (int q = 0; q < 4; ++q) { tri[q]->ptr = I32(o_tp[q]); tri[q]->idx = I32(o_ti[q]); tri[q]->val = F64(o_tv[q]); }
     O.cap = S.cap;
+    S.SW = LufSchedWork{};
+    S.SW.lev = I32(o_sm[0]); S.SW.lg = I32(o_sm[1]); S.SW.loff = I32(o_sm[2]); S.SW.list = I32(o_sm[3]);
+    S.SW.lvl_lanes = I32(o_sl[0]); S.SW.lvl_pass0 = I32(o_sl[1]); S.SW.lvl_lane0 = I32(o_sl[2]);
+    S.SW.ovf_off = I32(o_ovf); S.SW.hist = I32(o_hist); S.SW.part = I32(o_spart); S.SW.flag = I32(o_flag); S.SW.nlev_cap = nlev_cap;
+    {
+        const bool wide = ft_big_;
+        const LufTriangle* tri4[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
+        const int32_t asc[4] = {1, 0, 1, 0};
+        for (int q = 0; q < 4; ++q) {
+            const bool maskable = q == 1 || q == 2;
+            S.sin[q] = LufSchedIn{m, tri4[q]->ptr, tri4[q]->idx, tri4[q]->val, maskable ? O.diag : nullptr, asc[q], maskable ? 1 : 0,
+                                  wide ? 1 : 0, wide ? 512 : 0x7fffffff};
+            S.sout[q] = LufSchedOut{B + o_img[q], S.img_cap, I32(o_desc[q]), I32(o_triv[q]), I32(o_reach[q]), I32(o_lof[q])};
+        }
+    }
+    S.pinfo = reinterpret_cast<FtPivotInfo*>(B + o_pinfo);
     S.dirty = false;
     S.key[0] = m_; S.key[1] = nr_artificial_; S.key[2] = phase_; S.key[3] = wrapped_na_;
     return RELP_OK;
 }
 
-// P B Q = L U of the basis in d_basis_ by the device kernel; the factors come back as the four triangular views and are given
-// their level schedules here (relp_lu.cpp: schedule_from_rows), like after lu_factor.  RELP_E_UNSUPPORTED: the bump exceeds the
-// dense working copy (the caller factorises on the host instead).
+// P B Q = L U of the basis in d_basis_ by the device kernel.  `resident`: the second kernel also builds the four solve
+// schedules on the device and they are installed where they are (persistent pivot kernel only) -- no factor leaves the device;
+// otherwise the factors are downloaded and scheduled like lu_factor's (the product-form fallback of very large bases).
+// RELP_E_UNSUPPORTED: the bump exceeds the dense working copy, or an arena is too small (the caller factorises on the host).
 relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     if (!luf_ || luf_->dirty || luf_->key[0] != m_ || luf_->key[1] != nr_artificial_ || luf_->key[2] != phase_ || luf_->key[3] != wrapped_na_) {
         const relp_status_t st = luf_prepare();            // (a row removal or the phase switch renumbers rows / columns)
         if (st) return st;
     }
     LufState& S = *luf_;
+    const bool resident = ft_ && !luf_download_;
     const auto t0 = std::chrono::steady_clock::now();
     S.M.csc = csc(); S.M.ct = table();                  // (pointers may have been re-allocated)
     launch_lu_factor(S.M, d_basis_, S.W, S.O, stream_);
-    int32_t status[8] = {0};
+    if (resident) launch_lu_schedules(S.sin, S.sout, S.SW, S.W, S.O.status, S.pinfo, stream_);
+    int32_t status[8] = {0}, desc[4][LUF_D_WORDS] = {};
     HIP_TRY(hipMemcpyAsync(status, S.O.status, sizeof status, hipMemcpyDeviceToHost, stream_));
+    if (resident) for (int q = 0; q < 4; ++q) HIP_TRY(hipMemcpyAsync(desc[q], S.sout[q].desc, sizeof desc[q], hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     luf_kernel_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     ++luf_runs_;
@@ -127,10 +165,51 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     if (device_status) *device_status = status[0];
     if (status[0] == LUF_SINGULAR) return fail(RELP_E_SINGULAR, "singular basis (device factorisation)");
     if (status[0] != LUF_OK) return RELP_E_UNSUPPORTED;      // bump too large / no room: not an error, the host takes over
+    if (resident) for (int q = 0; q < 4; ++q) if (desc[q][LUF_D_STATUS] != LUF_OK) return RELP_E_UNSUPPORTED;
     const int32_t m = m_, nl = status[3], nu = status[4];
-    // download: permutations, diagonal, the four views
     hlu_ = LUFactors{};
-    hlu_.m = m;
+    hlu_.m = m; hlu_.nnz_l = nl; hlu_.nnz_u = (int64_t)nu + m;
+    S.resident = resident;
+    if (!resident) return luf_download_factors();
+    // install the factors where they are
+    dlu_ = DeviceLU{};
+    dlu_.m = m; dlu_.rowperm = S.O.rowperm; dlu_.colperm = S.O.colperm;
+    dlu_.Uf.idx = S.O.Uf.idx; dlu_.Uf.val = S.O.Uf.val; dlu_.Uf.nnz = nu;
+    TriangularSchedule* hs[4] = {&hlu_.Lf, &hlu_.Uf, &hlu_.Ub, &hlu_.Lb};
+    DeviceSchedule* ds[4] = {&dlu_.Lf, &dlu_.Uf, &dlu_.Ub, &dlu_.Lb};
+    fts_.m = m;
+    fts_.inv_rowperm = S.O.row_step; fts_.inv_colperm = S.O.col_step; fts_.task_uf = S.O.row_step; fts_.task_ub = S.O.row_step;
+    fts_.lev_ub = S.sout[2].level_of; fts_.pinfo = S.pinfo;
+    const int64_t base = (int64_t)ft_lds_base_bytes(m, ft_tcap_, ft_eta_cap_, ft_big_, ft_rhs_cap_);
+    fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
+    int64_t need = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int32_t* d = desc[q];
+        const LufImageLayout L = luf_image_layout(m, d[LUF_D_PASSES], d[LUF_D_LEVELS], d[LUF_D_LANES], d[LUF_D_OVF], ft_big_);
+        char* const img = S.sout[q].image;
+        EllSchedule& e = fts_.ell[q];
+        e = EllSchedule{};
+        e.passes = reinterpret_cast<const EllPass*>(img + L.passes); e.lvl_pass = reinterpret_cast<const int32_t*>(img + L.lvl_pass);
+        e.rdiag = reinterpret_cast<double*>(img + L.rdiag); e.sval = reinterpret_cast<double*>(img + L.sval);
+        e.oval = reinterpret_cast<const double*>(img + L.oval); e.rovf = reinterpret_cast<const int32_t*>(img + L.rovf);
+        e.sidx = reinterpret_cast<const uint16_t*>(img + L.sidx); e.oidx = reinterpret_cast<const uint16_t*>(img + L.oidx);
+        e.via_ptr = nullptr; e.via_pos = nullptr;
+        e.n_passes = d[LUF_D_PASSES]; e.n_levels = d[LUF_D_LEVELS]; e.m = m; e.n_lanes = d[LUF_D_LANES]; e.n_ovf = d[LUF_D_OVF];
+        e.bytes = d[LUF_D_BYTES]; e.rhs_base = 0;
+        e.n_triv = d[LUF_D_TRIV]; e.triv = S.sout[q].triv; e.reach = S.sout[q].reach; e.rhs_src = nullptr; e.n_rhs = ft_big_ ? 0 : -1;
+        fts_.stage[q] = e.bytes <= fts_.stage_bytes ? 1 : 0;
+        if (fts_.stage[q]) need = std::max<int64_t>(need, e.bytes);
+        ds[q]->n_levels = d[LUF_D_LEVELS];
+        hs[q]->level_ptr.assign((size_t)d[LUF_D_LEVELS] + 1, 0);     // (lu_stats reports the level counts)
+    }
+    fts_.lds_bytes = (int32_t)(base + need);
+    return RELP_OK;
+}
+
+// the factors of the last device factorisation -> hlu_ with level schedules, like after lu_factor (relp_lu.cpp)
+relp_status_t Engine::luf_download_factors() {
+    LufState& S = *luf_;
+    const int32_t m = m_, nl = (int32_t)hlu_.nnz_l, nu = (int32_t)(hlu_.nnz_u - m);
     hlu_.rowperm.resize(m); hlu_.colperm.resize(m);
     std::vector<double> diag(m), ones(m, 1.0);
     HIP_TRY(hipMemcpyAsync(hlu_.rowperm.data(), S.O.rowperm, 4 * (size_t)m, hipMemcpyDeviceToHost, stream_));
@@ -152,9 +231,17 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     lu_levels_from_rows(m, diag, false, &hlu_.Uf);
     lu_levels_from_rows(m, diag, true, &hlu_.Ub);
     lu_levels_from_rows(m, ones, false, &hlu_.Lb);
-    hlu_.nnz_l = nl; hlu_.nnz_u = (int64_t)nu + m;
     return RELP_OK;
 }
+
+// hlu_ as the host needs it for inspection (relp_lu_get_upper, relp_lu_factor_residual): after a device-resident
+// factorisation the rows are still on the device
+relp_status_t Engine::lu_host_factors() {
+    if (luf_ && luf_->resident && hlu_.Lf.ptr.empty()) return luf_download_factors();
+    return RELP_OK;
+}
+
+bool Engine::luf_is_resident() const { return luf_ && luf_->resident; }
 
 relp_status_t Engine::lu_set_device_factorisation(bool on) {
     if (!lu_) return fail(RELP_E_UNSUPPORTED, "the device factorisation belongs to the LU engine");
@@ -181,8 +268,9 @@ relp_status_t Engine::lu_factor_residual(double* out) {
     *out = -1.0;
     const int32_t m = m_;
     if (m > 1024 || hlu_.m != m) return RELP_OK;
-    relp_status_t st = lu_download_basis();
+    relp_status_t st = lu_host_factors();
     if (st) return st;
+    if ((st = lu_download_basis())) return st;
     std::vector<std::vector<std::pair<int32_t, double>>> cols;
     if ((st = lu_basis_columns(cols))) return st;
     std::vector<double> a((size_t)m * m, 0.0), L((size_t)m * m, 0.0), U((size_t)m * m, 0.0);

@@ -76,6 +76,9 @@ LUF_FN void luf_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
 LUF_FN int32_t luf_cas(int32_t* p, int32_t expect, int32_t v) { return atomicCAS(p, expect, v); }
 LUF_FN void luf_min64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
 LUF_FN void luf_max64(unsigned long long* p, unsigned long long v) { atomicMax(p, v); }
+LUF_FN void luf_max32(int32_t* p, int32_t v) { atomicMax(p, v); }
+LUF_FN void luf_min32(int32_t* p, int32_t v) { atomicMin(p, v); }
+LUF_FN void luf_or(int32_t* p, int32_t v) { atomicOr(p, v); }
 LUF_FN int32_t luf_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 LUF_FN void luf_st(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 LUF_FN unsigned long long luf_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -91,6 +94,9 @@ LUF_FN void luf_add(int32_t* p, int32_t v) { *p += v; }
 LUF_FN int32_t luf_cas(int32_t* p, int32_t expect, int32_t v) { const int32_t o = *p; if (o == expect) *p = v; return o; }
 LUF_FN void luf_min64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
 LUF_FN void luf_max64(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
+LUF_FN void luf_max32(int32_t* p, int32_t v) { if (v > *p) *p = v; }
+LUF_FN void luf_min32(int32_t* p, int32_t v) { if (v < *p) *p = v; }
+LUF_FN void luf_or(int32_t* p, int32_t v) { *p |= v; }
 LUF_FN int32_t luf_ld(const int32_t* p) { return *p; }
 LUF_FN void luf_st(int32_t* p, int32_t v) { *p = v; }
 LUF_FN unsigned long long luf_ld64(const unsigned long long* p) { return *p; }
@@ -129,31 +135,63 @@ LUF_FN void luf_row_entries(const LufMatrix& M, const LufWork& W, int32_t i, F f
     if (W.wrow_pos[i] >= 0) f(W.wrow_pos[i], 1.0);
 }
 
+#if defined(RELP_LUF_DEVICE)
+// exclusive prefix sum of one value per thread over the workgroup (<= 1,024 threads); *total = the sum.  Two barriers.
+LUF_FN int32_t luf_block_exscan(int32_t v, int32_t* total) {
+    __shared__ int32_t s_wave[17];
+    const int lane = LUF_TID & 63, wave = LUF_TID >> 6, nw = (LUF_NT + 63) >> 6;
+    int32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    __syncthreads();                                   // (s_wave may still be read by the previous call)
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int32_t before = 0, all = 0;
+    for (int w = 0; w < nw; ++w) { const int32_t c = s_wave[w]; if (w < wave) before += c; all += c; }
+    *total = all;
+    return before + inc - v;
+}
+#endif
+
 // Ordered compaction: out = { i in [0, n) : pred(i) } ascending; returns the count (uniform).  Every thread owns a contiguous
 // chunk, so the order does not depend on the execution.
 template <class P>
 LUF_FN int32_t luf_select(int32_t n, P pred, int32_t* out, const LufWork& W) {
-    const int32_t nt = LUF_NT, chunk = (n + nt - 1) / nt;
+    (void)W;
 #if defined(RELP_LUF_DEVICE)
-    {
-        const int32_t t = LUF_TID, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
-        int32_t cnt = 0;
-        for (int32_t i = lo; i < hi; ++i) cnt += pred(i) ? 1 : 0;
-        W.part[t] = cnt;
-        __syncthreads();
-        if (t == 0) { int32_t run = 0; for (int32_t u = 0; u < nt; ++u) { const int32_t c = W.part[u]; W.part[u] = run; run += c; } W.part[nt] = run; }
-        __syncthreads();
-        int32_t at = W.part[t];
-        for (int32_t i = lo; i < hi; ++i) if (pred(i)) out[at++] = i;
-        const int32_t total = W.part[nt];
-        __syncthreads();
-        return total;
-    }
+    const int32_t nt = LUF_NT, chunk = (n + nt - 1) / nt;
+    const int32_t t = LUF_TID, lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    int32_t cnt = 0;
+    for (int32_t i = lo; i < hi; ++i) cnt += pred(i) ? 1 : 0;
+    int32_t total = 0;
+    int32_t at = luf_block_exscan(cnt, &total);
+    for (int32_t i = lo; i < hi; ++i) if (pred(i)) out[at++] = i;
+    __syncthreads();
+    return total;
 #else
-    (void)chunk;
     int32_t at = 0;
     for (int32_t i = 0; i < n; ++i) if (pred(i)) out[at++] = i;
     return at;
+#endif
+}
+
+// counts a[1 .. n] -> offsets: a[0] = 0, a[k + 1] = a[1] + .. + a[k + 1]; returns the total (uniform).  In place.
+LUF_FN int32_t luf_offsets_from_counts(int32_t* a, int32_t n) {
+#if defined(RELP_LUF_DEVICE)
+    const int32_t nt = LUF_NT, chunk = (n + nt - 1) / nt;
+    const int32_t t = LUF_TID, lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    int32_t sum = 0;
+    for (int32_t i = lo; i < hi; ++i) sum += a[i + 1];
+    int32_t total = 0;
+    int32_t run = luf_block_exscan(sum, &total);
+    for (int32_t i = lo; i < hi; ++i) { run += a[i + 1]; a[i + 1] = run; }
+    if (t == 0) a[0] = 0;
+    __syncthreads();
+    return total;
+#else
+    a[0] = 0;
+    for (int32_t i = 0; i < n; ++i) a[i + 1] += a[i];
+    return a[n];
 #endif
 }
 
@@ -370,16 +408,12 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
             if (!pass) { O.Lb.ptr[kk + 1] = nl; O.Ub.ptr[kk + 1] = nu; }
         } PAR_END
         if (!pass) {
+            int32_t* const ptrs[4] = {O.Lf.ptr, O.Uf.ptr, O.Ub.ptr, O.Lb.ptr};
+            int32_t tot[4];
+            for (int q = 0; q < 4; ++q) tot[q] = luf_offsets_from_counts(ptrs[q], m);
             LUF_SINGLE {
-                LufTriangle* tri[4] = {const_cast<LufTriangle*>(&O.Lf), const_cast<LufTriangle*>(&O.Uf), const_cast<LufTriangle*>(&O.Ub),
-                                       const_cast<LufTriangle*>(&O.Lb)};
-                for (int q = 0; q < 4; ++q) {
-                    int32_t run = 0;
-                    tri[q]->ptr[0] = 0;
-                    for (int32_t kk = 0; kk < m; ++kk) { run += tri[q]->ptr[kk + 1]; tri[q]->ptr[kk + 1] = run; }
-                    if (run > O.cap) O.status[0] = LUF_NO_ROOM;
-                }
-                O.status[3] = O.Lf.ptr[m]; O.status[4] = O.Uf.ptr[m];
+                for (int q = 0; q < 4; ++q) if (tot[q] > O.cap) O.status[0] = LUF_NO_ROOM;
+                O.status[3] = tot[0]; O.status[4] = tot[1];
             } PAR_END
             if (O.status[0] != LUF_OK) return;
         }

@@ -12,6 +12,7 @@
 
 #include "relp_lu.hpp"
 #include "relp_lu_factor_core.h"
+#include "relp_lu_schedule_core.h"
 
 using namespace relp;
 using Cols = std::vector<std::vector<std::pair<int32_t, double>>>;
@@ -133,6 +134,8 @@ static double max_rel(const std::vector<double>& a, const std::vector<double>& b
     return d / n;
 }
 
+static void check_schedules(const char* name, const LufOut& O, const LufWork& W, int32_t m, std::mt19937_64& rng);
+
 // factorise `basis` of provider P with the device code and check it every way there is
 static void check(const char* name, const Provider& P, const std::vector<int32_t>& basis, std::mt19937_64& rng, bool expect_singular = false) {
     const int32_t m = P.m;
@@ -196,9 +199,91 @@ static void check(const char* name, const Provider& P, const std::vector<int32_t
     CHECK(max_rel(z, dense_solve(m, a, rhs, true)) <= 1e-9, "%s: BTRAN differs from the dense solve by %.3e", name, max_rel(z, dense_solve(m, a, rhs, true)));
     lu_ftran_host(hf, rhs, &xh); lu_btran_host(hf, rhs, &zh);
     CHECK(max_rel(x, xh) <= 1e-9 && max_rel(z, zh) <= 1e-9, "%s: solves differ from lu_factor's by %.3e / %.3e", name, max_rel(x, xh), max_rel(z, zh));
+    check_schedules(name, O, B.W, m, rng);
     // no more fill than the host factorisation by a wide margin (both pivot for sparsity)
     CHECK(O.Lf.ptr[m] + O.Uf.ptr[m] <= 3 * (hf.nnz_l + hf.nnz_u) + 4 * m, "%s: %d + %d entries against the host's %lld + %lld", name, O.Lf.ptr[m], O.Uf.ptr[m],
           (long long)hf.nnz_l, (long long)hf.nnz_u);
+}
+
+// ---- the device-side schedule builder (relp_lu_schedule_core.h) on the factors above ------------------------------------------
+static void plain_solve(const LufTriangle& T, const double* diag, bool ascending, int32_t m, std::vector<double>& x) {
+    for (int32_t q = 0; q < m; ++q) {
+        const int32_t k = ascending ? q : m - 1 - q;
+        double s = x[k];
+        for (int32_t e = T.ptr[k]; e < T.ptr[k + 1]; ++e) s -= T.val[e] * x[T.idx[e]];
+        x[k] = diag ? s / diag[k] : s;
+    }
+}
+// executes an image the way ell_solve_pp does: rows without entries first, then pass by pass from group `first`
+static void image_solve(const char* img, const int32_t* desc, int32_t m, bool wide, const int32_t* triv, std::vector<double>& x, int first) {
+    const LufImageLayout L = luf_image_layout(m, desc[LUF_D_PASSES], desc[LUF_D_LEVELS], desc[LUF_D_LANES], desc[LUF_D_OVF], wide);
+    const EllPass* passes = reinterpret_cast<const EllPass*>(img + L.passes);
+    const double* rdiag = reinterpret_cast<const double*>(img + L.rdiag);
+    const double* sval = reinterpret_cast<const double*>(img + L.sval);
+    const double* oval = reinterpret_cast<const double*>(img + L.oval);
+    const int32_t* rovf = reinterpret_cast<const int32_t*>(img + L.rovf);
+    const int shift = wide ? kEllLgWide : kEllLg;
+    auto sidx = [&](int64_t at) { return wide ? (int)reinterpret_cast<const uint32_t*>(img + L.sidx)[at] : (int)reinterpret_cast<const uint16_t*>(img + L.sidx)[at]; };
+    auto oidx = [&](int64_t at) { return wide ? (int)reinterpret_cast<const uint32_t*>(img + L.oidx)[at] : (int)reinterpret_cast<const uint16_t*>(img + L.oidx)[at]; };
+    for (int32_t i = 0; i < desc[LUF_D_TRIV]; ++i) x[triv[i]] *= rdiag[triv[i]];
+    for (int32_t p = 0; p < desc[LUF_D_PASSES]; ++p) {
+        const EllPass& ps = passes[p];
+        if (ps.level < first) continue;
+        std::vector<std::pair<int, double>> stores;
+        for (int lane = 0; lane < ps.lanes;) {
+            const int iv = sidx(ps.lane0 + lane), lg = iv >> shift, k = iv & ((1 << shift) - 1);
+            double sum = 0.0;
+            for (int j = 0; j < (1 << lg); ++j) sum += -sval[ps.lane0 + lane + j] * x[sidx(ps.lane0 + lane + j) & ((1 << shift) - 1)];
+            if (desc[LUF_D_OVF] > 0) for (int o = rovf[2 * k]; o < rovf[2 * k + 1]; ++o) sum += -oval[o] * x[oidx(o)];
+            stores.emplace_back(k, sum * rdiag[k]);
+            lane += 1 << lg;
+        }
+        for (auto& st : stores) x[st.first] = st.second;
+    }
+}
+
+static void check_schedules(const char* name, const LufOut& O, const LufWork& W, int32_t m, std::mt19937_64& rng) {
+    const LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
+    const bool asc[4] = {true, false, true, false};
+    const char* nm[4] = {"L", "U", "U'", "L'"};
+    for (int q = 0; q < 4; ++q)
+        for (int variant = 0; variant < 3; ++variant) {
+            const bool wide = variant > 0, maskable = q == 1 || q == 2;
+            if (!wide && m + 1 >= (1 << kEllLg)) continue;
+            LufSchedIn T{m, tri[q]->ptr, tri[q]->idx, tri[q]->val, maskable ? O.diag : nullptr, asc[q] ? 1 : 0, maskable ? 1 : 0, wide ? 1 : 0,
+                         variant == 2 ? 3 : 0x7fffffff};
+            std::vector<int32_t> wi(8 * (size_t)m + 3 * ((size_t)m + 2) + 256, 0), oi(3 * (size_t)m + LUF_D_WORDS, 0);
+            int32_t* ip = wi.data();
+            auto ti = [&](size_t n) { int32_t* r = ip; ip += n; return r; };
+            LufSchedWork S{};
+            S.lev = ti(m); S.lg = ti(m); S.loff = ti(m); S.list = ti(m); S.nlev_cap = m + 1;
+            S.lvl_lanes = ti(m + 2); S.lvl_pass0 = ti(m + 2); S.lvl_lane0 = ti(m + 2); S.ovf_off = ti(m + 1); S.hist = ti(8); S.part = ti(66); S.flag = ti(4);
+            const int64_t cap = 64 + 40 * ((int64_t)tri[q]->ptr[m] + 2 * m + 64) + 16 * ((int64_t)m + 8);
+            std::vector<char> image((size_t)cap, 0);
+            LufSchedOut SO{image.data(), cap, oi.data(), oi.data() + LUF_D_WORDS, oi.data() + LUF_D_WORDS + m, oi.data() + LUF_D_WORDS + 2 * m};
+            luf_build_schedule(T, S, SO, W);
+            CHECK(SO.desc[LUF_D_STATUS] == LUF_OK, "%s %s: schedule status %d", name, nm[q], SO.desc[LUF_D_STATUS]);
+            if (SO.desc[LUF_D_STATUS] != LUF_OK) continue;
+            std::vector<double> b(m), want, got;
+            for (auto& v : b) v = (rng() % 3 == 0) ? (double)((int)(rng() % 13) - 6) : 0.0;
+            want = b; got = b;
+            plain_solve(*tri[q], T.diag, asc[q], m, want);
+            image_solve(image.data(), SO.desc, m, wide, SO.triv, got, 0);
+            CHECK(max_rel(got, want) <= 1e-9, "%s %s variant %d: image solve differs by %.3e", name, nm[q], variant, max_rel(got, want));
+            // levels are levels: every entry of a row lives in an earlier level
+            bool ok = true;
+            for (int32_t k = 0; k < m && ok; ++k) for (int32_t e = tri[q]->ptr[k]; e < tri[q]->ptr[k + 1]; ++e) if (SO.level_of[tri[q]->idx[e]] >= SO.level_of[k]) ok = false;
+            CHECK(ok, "%s %s: an entry in the same or a later level", name, nm[q]);
+            // hyper-sparse start from the reach array
+            std::vector<double> bs(m, 0.0);
+            for (int t = 0; t < 3; ++t) bs[rng() % m] = (double)((int)(rng() % 9) + 1);
+            int g0 = 0x7fffffff;
+            for (int32_t i = 0; i < m; ++i) if (bs[i] != 0.0) g0 = std::min(g0, SO.reach[i]);
+            want = bs; got = bs;
+            plain_solve(*tri[q], T.diag, asc[q], m, want);
+            image_solve(image.data(), SO.desc, m, wide, SO.triv, got, g0);
+            CHECK(max_rel(got, want) <= 1e-9, "%s %s variant %d: sweep from group %d differs by %.3e", name, nm[q], variant, g0, max_rel(got, want));
+        }
 }
 
 // a provider that is just the given square matrix as structural columns; basis = all of them

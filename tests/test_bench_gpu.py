@@ -21,7 +21,7 @@ def test_driver_command_emits_one_complete_json_line():
     assert out["metric"] == "simplex iterations/sec" and out["unit"] == "iterations/s" and out["n_gpus"] == 1
     assert out["value"] > 1000 and out["higher_is_better"] is True and out["dtype"] == "f64" and out["vs_baseline"] is None
     block = out["config"]["update_block"]
-    assert block == 96 and out["steps"] % block == 0 and out["steps"] >= 4 * block and out["timing"]["steps_requested"] == 20
+    assert block == 64 and out["c4"]["update_block"] == 96 and out["steps"] % block == 0 and out["steps"] >= 4 * block and out["timing"]["steps_requested"] == 20
     assert out["timing"]["windows"] == 5 and len(out["timing"]["window_ms"]) == 5
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
     roof = out["roofline"]
