@@ -276,6 +276,7 @@ class Engine {
     void luf_mark_dirty();
     bool hyper_forced_ = false; int32_t hyper_probe_in_[4] = {0, 0, 0, 0};    // adaptive hyper-sparse starts (ft_read_report)
     bool ft_big_ = false; int32_t ft_rhs_cap_ = 0;        // layout of the persistent kernel (relp_kernels_ft.hip: ft_layout)
+    int32_t ft_tier_ = 0;                                 // 0 all in LDS, 1 big (ft_big_), 2 no per-row array in LDS (ft_big_ too)
     int64_t ft_zero_bytes_ = 0, ft_ones_bytes_ = 0;       // the two regions of the state buffer a refactorisation resets
     bool ft_need_refactor_ = false;
     relp_status_t ft_plan_and_alloc();

@@ -401,7 +401,7 @@ relp_status_t Engine::lu_upload_factors() {
         fts_.lev_ub = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_lub);
         fts_.pinfo = reinterpret_cast<const FtPivotInfo*>(d_lu_buf_ + o_pinfo);
         // what is left of the CU's LDS after the work vectors stages one schedule image at a time
-        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_rhs_cap_);
+        const int64_t base = (int64_t)ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_tier_, ft_rhs_cap_);
         const int64_t idx_bytes = ft_big_ ? 4 : 2;
         fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
         int64_t need = 0;
@@ -450,7 +450,7 @@ relp_status_t Engine::lu_upload_factors() {
 // Forrest-Tomlin mode (relp_kernels_ft.hip)
 // ------------------------------------------------------------------------------------------------
 relp_status_t Engine::ft_plan_and_alloc() {
-    ft_ = false; ft_big_ = false; ft_rhs_cap_ = 0;
+    ft_ = false; ft_big_ = false; ft_tier_ = 0; ft_rhs_cap_ = 0;
     if (m_ > kFtMaxRows) return RELP_OK;
     // The dense tail of U (tcap x tcap in LDS) is as large as the refactorisation interval asks for, not larger: what it does
     // not take stages the triangular factors, and an image that does not fit is solved from L2 at several times the cost.
@@ -468,13 +468,13 @@ relp_status_t Engine::ft_plan_and_alloc() {
     (void)kFtMinStage;
     const char* big_env = std::getenv("RELP_FT_BIG");
     const int force_big = big_env ? std::atoi(big_env) : -1;
-    auto plan = [&](bool big, int32_t rhs_cap, int64_t min_stage, int32_t min_tcap = 16) {
+    auto plan = [&](int32_t tier, int32_t rhs_cap, int64_t min_stage, int32_t min_tcap = 16) {
         for (int32_t tcap : {64, 48, 32, 16}) {
             if (tcap != 16 && tcap - 16 >= want) continue;              // a smaller tail serves the interval
             if (tcap < std::min(want, min_tcap)) return false;          // (a refactorisation every 16 pivots is the last resort)
             if (tcap < want && min_stage > 4096) return false;          // (only the last resort shortens the interval)
-            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap, big, rhs_cap) + min_stage <= kFtLdsBudget) {
-                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_big_ = big; ft_rhs_cap_ = rhs_cap; ft_ = true;
+            if ((int64_t)ft_lds_base_bytes(m_, tcap, (int32_t)eta_cap, tier, rhs_cap) + min_stage <= kFtLdsBudget) {
+                ft_tcap_ = tcap; ft_eta_cap_ = (int32_t)eta_cap; ft_tier_ = tier; ft_big_ = tier >= 1; ft_rhs_cap_ = rhs_cap; ft_ = true;
                 return true;
             }
         }
@@ -485,14 +485,20 @@ relp_status_t Engine::ft_plan_and_alloc() {
     // (measured on GREENBEB, m = 2,228: all-in-LDS with a 32-slot tail and nothing staged 209,000 clocks per pivot, big with a
     // 48-slot tail and 78 KB of staging 235,000 -- what the big layout reads from L2 costs more than staging saves; so the
     // all-in-LDS layout is taken whenever it fits at all)
-    if (force_big != 1 && small_rhs > 0 && plan(false, small_rhs, 4096, force_big == 0 ? 16 : 32)) {}
-    else if (force_big != 0 && (plan(true, m_, kFtMinStage) || plan(true, std::min(m_, 2048), 32 * 1024) ||
-                                plan(true, std::min(m_, 1024), 8 * 1024) || plan(true, 0, 4096))) {}
+    // Layout 2 (nothing per row in LDS, x and -pi in L2) takes whatever the other two cannot hold: any m, every right-hand-side
+    // copy the fused schedules ask for, the whole LDS minus the dense tail as the staging area.  RELP_FT_BIG = 2 forces it.
+    // (the 16-bit row indices of the PRICE copy end at 32,767; the slot indices of the images at 2^24)
+    const bool fits_tier1 = m_ < kPriceLongFlag;
+    const bool fits_tier2 = 2 * (int64_t)m_ + 2 <= (int64_t(1) << kEllLgShiftWide);
+    if (force_big < 1 && m_ < kPriceLongFlag && small_rhs > 0 && plan(0, small_rhs, 4096, force_big == 0 ? 16 : 32)) {}
+    else if (force_big != 0 && force_big != 2 && fits_tier1 &&
+             (plan(1, m_, kFtMinStage) || plan(1, std::min(m_, 2048), 32 * 1024) || plan(1, std::min(m_, 1024), 8 * 1024) || plan(1, 0, 4096))) {}
+    else if (force_big != 0 && force_big != 1 && fits_tier2 && plan(2, m_, kFtMinStage)) {}
     if (!ft_) return RELP_OK;
     if (std::getenv("RELP_DEBUG"))
         std::fprintf(stderr, "[relp] persistent pivot kernel: m %d, layout %s, %d right-hand-side copies, dense tail %d, LDS base %zu bytes\n",
-                     m_, ft_big_ ? "big" : "all-in-LDS", ft_rhs_cap_, ft_tcap_,
-                     ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_big_, ft_rhs_cap_));
+                     m_, ft_tier_ >= 2 ? "nothing per row in LDS" : ft_big_ ? "big" : "all-in-LDS", ft_rhs_cap_, ft_tcap_,
+                     ft_lds_base_bytes(m_, ft_tcap_, ft_eta_cap_, ft_tier_, ft_rhs_cap_));
     const int64_t tc = ft_tcap_, ldt = tc + 1, m = m_, nwp = kFtWaves + 1;
     std::vector<char> dummy;
     int64_t o = 0;
@@ -501,7 +507,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_lv = take(4 * tc), o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp),
                   o_so = take(4 * tc * nwp), o_pv = take(4 * tc), o_ts = take(4 * m), o_ei = take(4 * (int64_t)ft_eta_cap_),
                   o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32),
-                  o_journal = take(8 * tc), o_spw = take(8 * m);
+                  o_journal = take(8 * tc), o_spw = take(8 * m), o_xw = take(ft_tier_ >= 2 ? 8 * (m + 1 + ft_rhs_cap_) : 0);
     ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
@@ -534,7 +540,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spk_val = reinterpret_cast<double*>(d_ft_buf_ + o_sv);
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
     fts_.sp_work = reinterpret_cast<double*>(d_ft_buf_ + o_spw);
-    fts_.big = ft_big_ ? 1 : 0; fts_.rhs_cap = ft_rhs_cap_;
+    fts_.x_work = ft_tier_ >= 2 ? reinterpret_cast<double*>(d_ft_buf_ + o_xw) : nullptr;
+    fts_.big = ft_tier_; fts_.rhs_cap = ft_rhs_cap_;
     {   // hyper-sparse starts: L and L' by default (U' starts from the leaving pivot's level anyway; on U the spike reaches the first groups: measured 31.4 of 31.4 passes on 25FV47, not worth the reduction); RELP_FT_HYPER = bit mask
         const char* e = std::getenv("RELP_FT_HYPER");
         fts_.hyper = e ? std::atoi(e) : 0x9;
@@ -587,6 +594,20 @@ relp_status_t Engine::ft_build_price_ell() {
     std::vector<uint16_t> long_of((size_t)ns, 0xFFFF);
     if (longs.size() < 0xFFFF) for (size_t i = 0; i < longs.size(); ++i) long_of[longs[i]] = (uint16_t)i;
     const size_t o_lof = put(long_of.data(), long_of.size() * 2);
+    size_t o_idx32 = 0, o_lidx32 = 0;
+    if (ft_tier_ >= 2) {                                   // the same two tables with 32-bit row indices (bit 31 = long column)
+        std::vector<uint32_t> w(idx.size(), 0), lw(lidx.size(), 0);
+        for (int32_t p = 0; p < nr_normal_; ++p) {
+            const int64_t n = hc_ptr_[p + 1] - hc_ptr_[p];
+            for (int64_t k = 0; k < std::min<int64_t>(n, kPriceSlots); ++k) w[(size_t)k * ns + p] = (uint32_t)hc_idx_[hc_ptr_[p] + k];
+            if (n > kPriceSlots) w[p] |= kPriceLongFlag32;
+        }
+        for (size_t i = 0; i < longs.size(); ++i) {
+            const int32_t p = longs[i];
+            for (int64_t k = 0; k < hc_ptr_[p + 1] - hc_ptr_[p]; ++k) lw[(size_t)k * nl + i] = (uint32_t)hc_idx_[hc_ptr_[p] + k];
+        }
+        o_idx32 = put(w.data(), w.size() * 4); o_lidx32 = put(lw.data(), lw.size() * 4);
+    }
     if (d_pe_buf_) { HIP_TRY(hipFree(d_pe_buf_)); d_pe_buf_ = nullptr; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pe_buf_), buf.size()));
     HIP_TRY(hipMemcpy(d_pe_buf_, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -597,6 +618,8 @@ relp_status_t Engine::ft_build_price_ell() {
     pe_.long_cols = reinterpret_cast<const int32_t*>(d_pe_buf_ + o_long);
     pe_.very_long = reinterpret_cast<const int32_t*>(d_pe_buf_ + o_vl);
     pe_.long_of = reinterpret_cast<const uint16_t*>(d_pe_buf_ + o_lof);
+    pe_.idx32 = ft_tier_ >= 2 ? reinterpret_cast<const uint32_t*>(d_pe_buf_ + o_idx32) : nullptr;
+    pe_.lidx32 = ft_tier_ >= 2 ? reinterpret_cast<const uint32_t*>(d_pe_buf_ + o_lidx32) : nullptr;
     pe_.n_long = (int32_t)longs.size(); pe_.n_very_long = (int32_t)very_long.size();
     return RELP_OK;
 }

@@ -145,6 +145,9 @@ relp_status_t Engine::luf_prepare() {
 // otherwise the factors are downloaded and scheduled like lu_factor's (the product-form fallback of very large bases).
 // RELP_E_UNSUPPORTED: the bump exceeds the dense working copy, or an arena is too small (the caller factorises on the host).
 relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
+    // (the device factorisation packs its images for layouts 0 and 1 and keeps its working sets in one workgroup's LDS:
+    // beyond their row range the host factorises)
+    if (ft_tier_ >= 2) return RELP_E_UNSUPPORTED;
     if (!luf_ || luf_->dirty || luf_->key[0] != m_ || luf_->key[1] != nr_artificial_ || luf_->key[2] != phase_ || luf_->key[3] != wrapped_na_) {
         const relp_status_t st = luf_prepare();            // (a row removal or the phase switch renumbers rows / columns)
         if (st) return st;
@@ -180,7 +183,7 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     fts_.m = m;
     fts_.inv_rowperm = S.O.row_step; fts_.inv_colperm = S.O.col_step; fts_.task_uf = S.O.row_step; fts_.task_ub = S.O.row_step;
     fts_.lev_ub = S.sout[2].level_of; fts_.pinfo = S.pinfo;
-    const int64_t base = (int64_t)ft_lds_base_bytes(m, ft_tcap_, ft_eta_cap_, ft_big_, ft_rhs_cap_);
+    const int64_t base = (int64_t)ft_lds_base_bytes(m, ft_tcap_, ft_eta_cap_, ft_tier_, ft_rhs_cap_);
     fts_.stage_bytes = (int32_t)std::max<int64_t>(0, kFtLdsBudget - base);
     int64_t need = 0;
     for (int q = 0; q < 4; ++q) {

@@ -154,7 +154,7 @@ struct DeviceCSC { const int64_t* col_ptr; const int32_t* row_idx; const double*
 static constexpr int kFtThreads = 512;                 // the persistent pivot workgroup: 8 wavefronts
 static constexpr int kFtWaves = kFtThreads / 64;       // sparse lists are bucketed by (pivot % kFtWaves): one wavefront per bucket
 static constexpr int kFtMaxSlots = 64;                 // one lane of a wavefront per slot in the chains over TC
-static constexpr int kFtMaxRows = 16384;               // x, -pi and the slot tables must fit one CU's LDS (ft_layout decides)
+static constexpr int kFtMaxRows = 1 << 20;             // (layout 2 keeps no per-row array in LDS; the spike pool is tcap x m pairs)
 static constexpr int kFtLdsBudget = 156 * 1024;        // of the CU's 160 KB
 // Everything the Forrest-Tomlin update needs to know about the leaving pivot p, together in one cache line segment (it was
 // five dependent global round trips: task -> row header -> entries, via_ptr -> via_pos, twice).
@@ -189,7 +189,10 @@ struct FtState {
     double*  sp_work;        // m: the spike inside the kernels when it does not live in LDS (big)
     int32_t  hyper;          // bit k: sweep k (L, U, U', L') starts at the first group its right-hand side reaches (RELP_FT_HYPER)
     int32_t  pad2_;
-    int32_t  big;            // 1: spike, permutations and eta pool in global memory, 32-bit slot indices (relp_kernels_ft.hip: ft_layout)
+    double*  x_work;         // m + 1 + rhs_cap: the work vector inside the kernels when it does not live in LDS (layout 2)
+    int32_t  big;            // layout (relp_kernels_ft.hip: ft_layout).  0: everything in LDS.  1: spike, permutations and eta pool in
+                             // global memory (L2), 32-bit slot indices.  2: x, -pi and the pivot -> slot table there as well (no per-row
+                             // array in LDS: any m), 32-bit row indices in the PRICE copy
     int32_t  rhs_cap;        // words behind x[m] for the right-hand-side copies of the fused schedules (0: levels are not fused)
     int32_t  stage[4];       // which of the four schedules (L, U, U', L') fit the LDS staging area
     int32_t  stage_bytes;
@@ -207,9 +210,11 @@ struct FtState {
 static constexpr int kPriceSlots = 8;
 static constexpr int kPriceLongSlots = 24;
 static constexpr int kPriceLongFlag = 0x8000;
+static constexpr uint32_t kPriceLongFlag32 = 0x80000000u;
 struct PriceEll {
     const uint16_t* idx; const double* val;            // kPriceSlots x nr_normal
     const uint16_t* lidx; const double* lval;          // kPriceLongSlots x n_long
+    const uint32_t* idx32; const uint32_t* lidx32;     // the two index arrays 32 bits wide (FtState::big == 2: rows beyond 32,767), else null
     const int32_t* long_cols;                          // n_long
     const int32_t* very_long;                          // n_very_long
     const uint16_t* long_of;                           // nr_normal: index of a column in tier B, 0xFFFF = not there
@@ -450,7 +455,7 @@ void launch_lu_btran_rows(const DeviceLU& lu, const DeferredUpdate& none, double
 
 // ---- Forrest-Tomlin engine (relp_kernels_ft.hip) ---------------------------------------------------------------
 // bytes of dynamic LDS the FT kernels need besides the staging area
-size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big, int32_t rhs_cap);
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, int32_t tier, int32_t rhs_cap);
 // LDS bytes a schedule needs to be staged (relp_lu_device.h: schedule_lds_bytes)
 int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg);
 // up to `max_pivots` whole pivots (PRICE -> FTRAN -> RATIO -> FT update -> BTRAN -> b, -pi, basis) in ONE launch of one

@@ -31,19 +31,22 @@ struct FtLayout {
 // `big` (FtState::big, m beyond ~2,400 rows): only what a pass of a solve touches stays in LDS -- x (with `rhs_cap` words for
 // the right-hand-side copies of the fused schedules), -pi (PRICE gathers from it), the slot tables and the dense tail; the spike, the
 // permutations and the eta pool, each read a few times per pivot, are read from global memory (L2).
-__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap, bool big, int rhs_cap) {
+// tier 2 (m beyond what 17 bytes per row leave of the LDS, ~9,000 rows): x, -pi and the pivot -> slot table are global too;
+// the LDS holds the dense tail, the slot tables and the staged factor image, nothing that grows with m.
+__host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap, int tier, int rhs_cap) {
     FtLayout L;
     int64_t o = 0;
     const int ldt = tcap + 1;
+    const bool big = tier >= 1, huge = tier >= 2;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += up16(bytes); return at; };
-    L.x = take(8LL * (m + 1 + rhs_cap));           // x[m]: scratch word of ell_solve; x[m + 1 ..]: right-hand-side copies
-    L.sp = take(big ? 0 : 8LL * m); L.pi = take(8LL * m);
+    L.x = take(huge ? 0 : 8LL * (m + 1 + rhs_cap));           // x[m]: scratch word of ell_solve; x[m + 1 ..]: right-hand-side copies
+    L.sp = take(big ? 0 : 8LL * m); L.pi = take(huge ? 0 : 8LL * m);
     L.perm = take(big ? 0 : 2LL * 3 * m);            // inv_rowperm | inv_colperm | rowperm as 16-bit indices
     L.tc = take(8LL * tcap * ldt);
     L.dots = take(8LL * tcap); L.zt = take(8LL * tcap); L.uv = take(8LL * tcap); L.ct = take(8LL * tcap);
     L.slot_pivot = take(4LL * tcap); L.slot_prev = take(4LL * tcap); L.slot_live = take(4LL * tcap); L.slot_next = take(4LL * tcap);
     L.eta_off = take(4LL * tcap * (NW + 1)); L.spk_off = take(4LL * tcap * (NW + 1));
-    L.tslot = take(m);
+    L.tslot = take(huge ? 0 : m);
     L.eta_idx = take(big ? 0 : 4LL * eta_cap); L.eta_val = take(big ? 0 : 8LL * eta_cap);
     L.red_d = take(8LL * 2 * NW); L.red_i = take(4LL * 4 * NW + 64);
     L.stage = o; L.total = o;
@@ -76,13 +79,15 @@ struct FtClock {
     }
 };
 
-template <bool kBig>
+template <int kTier>
 struct FtCtxT {
-    static constexpr bool big = kBig;
-    typedef typename std::conditional<kBig, int32_t, unsigned short>::type perm_t;
+    static constexpr int tier = kTier;
+    static constexpr bool big = kTier >= 1, huge = kTier >= 2;
+    typedef typename std::conditional<big, int32_t, unsigned short>::type perm_t;
+    typedef typename std::conditional<huge, int32_t, signed char>::type tslot_t;
     double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;      // (big: sp, eta_val, eta_idx and the permutations are global)
     int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
-    signed char* tslot;
+    tslot_t* tslot;
     const perm_t *irp, *icp, *rp;                      // original row -> pivot, basis position -> pivot, pivot -> original row
     char* stage;
     int m, tcap, ldt, t, eta_used, eta_cap, journal_n;
@@ -91,8 +96,10 @@ struct FtCtxT {
 
 template <class Ctx>
 __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, const FtState& st) {
-    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::big, st.rhs_cap);
-    c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.TC = (double*)(lds + L.tc);
+    const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::tier, st.rhs_cap);
+    if constexpr (Ctx::huge) { c.x = st.x_work; c.pi = nullptr; c.tslot = st.tslot; }      // (-pi: bound by ft_load to the engine's own vector)
+    else { c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.tslot = (signed char*)(lds + L.tslot); }
+    c.TC = (double*)(lds + L.tc);
     if constexpr (Ctx::big) {
         c.sp = st.sp_work; c.irp = st.inv_rowperm; c.icp = st.inv_colperm; c.rp = lu.rowperm;
         c.eta_idx = st.eta_idx; c.eta_val = st.eta_val;
@@ -104,7 +111,6 @@ __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, c
     c.dots = (double*)(lds + L.dots); c.zt = (double*)(lds + L.zt); c.uv = (double*)(lds + L.uv); c.ct = (double*)(lds + L.ct);
     c.slot_pivot = (int*)(lds + L.slot_pivot); c.slot_prev = (int*)(lds + L.slot_prev); c.slot_live = (int*)(lds + L.slot_live);
     c.slot_next = (int*)(lds + L.slot_next); c.eta_off = (int*)(lds + L.eta_off); c.spk_off = (int*)(lds + L.spk_off);
-    c.tslot = (signed char*)(lds + L.tslot);
     c.red_d = (double*)(lds + L.red_d); c.red_i = (int*)(lds + L.red_i); c.stage = lds + L.stage;
     c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap; c.journal_n = 0;
     c.clk.start(nullptr);
@@ -128,9 +134,10 @@ __device__ __forceinline__ void ft_load(Ctx& c, const DeviceLU& lu, const FtStat
         c.slot_next[s] = -1;
     }
     for (int i = tid; i < c.tcap * (NW + 1); i += NT) { c.eta_off[i] = st.eta_off[i]; c.spk_off[i] = st.spk_off[i]; }
-    for (int k = tid; k < c.m; k += NT) c.tslot[k] = (signed char)st.tslot[k];
+    if constexpr (!Ctx::huge) for (int k = tid; k < c.m; k += NT) c.tslot[k] = (signed char)st.tslot[k];
     if constexpr (!Ctx::big) for (int e = tid; e < c.eta_used; e += NT) { c.eta_idx[e] = st.eta_idx[e]; c.eta_val[e] = st.eta_val[e]; }
-    if (minus_pi) for (int i = tid; i < c.m; i += NT) c.pi[i] = minus_pi[i];
+    if constexpr (Ctx::huge) c.pi = const_cast<double*>(minus_pi);
+    else if (minus_pi) for (int i = tid; i < c.m; i += NT) c.pi[i] = minus_pi[i];
     __syncthreads();
     for (int s = tid; s < c.t; s += NT) { const int pv = c.slot_prev[s]; if (pv >= 0) c.slot_next[pv] = s; }
     __syncthreads();
@@ -146,9 +153,9 @@ __device__ __forceinline__ void ft_store(const Ctx& c, const FtState& st, double
         st.slot_pivot[s] = c.slot_pivot[s]; st.slot_prev[s] = c.slot_prev[s]; st.slot_live[s] = c.slot_live[s];
     }
     for (int i = tid; i < c.tcap * (NW + 1); i += NT) { st.eta_off[i] = c.eta_off[i]; st.spk_off[i] = c.spk_off[i]; }
-    for (int k = tid; k < c.m; k += NT) st.tslot[k] = c.tslot[k];
+    if constexpr (!Ctx::huge) for (int k = tid; k < c.m; k += NT) st.tslot[k] = c.tslot[k];
     if constexpr (!Ctx::big) for (int e = tid; e < c.eta_used; e += NT) { st.eta_idx[e] = c.eta_idx[e]; st.eta_val[e] = c.eta_val[e]; }
-    if (minus_pi) for (int i = tid; i < c.m; i += NT) minus_pi[i] = c.pi[i];
+    if constexpr (!Ctx::huge) if (minus_pi) for (int i = tid; i < c.m; i += NT) minus_pi[i] = c.pi[i];
     if (tid == 0) { st.hdr[0] = c.t; st.hdr[1] = c.eta_used; st.hdr[2] = need_refactor; st.hdr[3] = c.journal_n; }
 }
 
@@ -602,7 +609,7 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
     }
     // ... entries in the never-updated rows into the spike pool, bucketed
     ft_compact(c, c.sp, p, st.spk_idx + (int64_t)tn * c.m, st.spk_val + (int64_t)tn * c.m, 0, c.spk_off + tn * (NW + 1), 0, c.m);
-    if (tid == 0) c.tslot[p] = (signed char)tn;
+    if (tid == 0) c.tslot[p] = (typename Ctx::tslot_t)tn;
     c.eta_used += eta_n;
     c.t = tn + 1;
     __syncthreads();
@@ -714,7 +721,7 @@ __device__ __forceinline__ void block_min_key(Ctx& c, double& key, int& kj) {
 // ------------------------------------------------------------------------------------------------------------------
 // The persistent pivot kernel
 // ------------------------------------------------------------------------------------------------------------------
-template <bool kBig>
+template <int kTier>
 __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProblem pb, long long max_pivots) {
     extern __shared__ __align__(16) char lds[];
     PivotRecord* rec = pb.rec;
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (threadIdx.x == 0) st.hdr[3] = 0;
         return;
     }
-    FtCtxT<kBig> c;
+    FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     c.clk.start(st.prof);
     ft_load(c, lu, st, pb.minus_pi);
@@ -748,6 +755,10 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     double d_q = rec->d_q, alpha_r = rec->alpha_r, b_r = rec->b_r, key1 = rec->key1;
     PivotRecord fake;                                  // select_key reads rule memory through a record
     fake.last_selected = last_selected;
+    // (row indices of the PRICE copy: 16 bits, bit 15 = "long column"; 32 bits with bit 31 in layout 2)
+    constexpr int kLongFlag = kTier >= 2 ? (int)kPriceLongFlag32 : kPriceLongFlag, kLongMask = kTier >= 2 ? 0x7fffffff : kPriceLongFlag - 1;
+    auto pe_idx = [&](int i) -> int { if constexpr (kTier >= 2) return (int)pb.pe.idx32[i]; else return pb.pe.idx[i]; };
+    auto pe_lidx = [&](int i) -> int { if constexpr (kTier >= 2) return (int)pb.pe.lidx32[i]; else return pb.pe.lidx[i]; };
 
     for (long long it = 0; it < max_pivots; ++it) {
         if (need_refactor || c.t >= st.max_updates || c.t >= c.tcap) { if (!need_refactor) need_refactor = 1; break; }
@@ -789,12 +800,12 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
                         int ri[kPriceSlots];
                         double va[kPriceSlots], px[kPriceSlots];
 #pragma unroll
-                        for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pb.pe.idx[u * nstr + p]; va[u] = pb.pe.val[u * nstr + p]; }
+                        for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pe_idx(u * nstr + p); va[u] = pb.pe.val[u * nstr + p]; }
                         const int br = ct.bound_row[p];
                         const int li = pb.pe.long_of[p];
                         const double cp = costs ? costs[p] : 0.0;
-                        const bool is_long = (ri[0] & kPriceLongFlag) != 0;
-                        ri[0] &= kPriceLongFlag - 1;
+                        const bool is_long = (ri[0] & kLongFlag) != 0;
+                        ri[0] &= kLongMask;
 #pragma unroll
                         for (int u = 0; u < kPriceSlots; ++u) px[u] = c.pi[ri[u]];
                         const double pb_r = c.pi[br >= 0 ? br : 0];
@@ -807,7 +818,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
                             int rj[kRest];
                             double vb[kRest], py[kRest];
 #pragma unroll
-                            for (int u = 0; u < kRest; ++u) { rj[u] = pb.pe.lidx[(kPriceSlots + u) * nl + li]; vb[u] = pb.pe.lval[(kPriceSlots + u) * nl + li]; }
+                            for (int u = 0; u < kRest; ++u) { rj[u] = pe_lidx((kPriceSlots + u) * nl + li); vb[u] = pb.pe.lval[(kPriceSlots + u) * nl + li]; }
 #pragma unroll
                             for (int u = 0; u < kRest; ++u) py[u] = c.pi[rj[u]];
 #pragma unroll
@@ -841,12 +852,12 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             int ri[kPriceSlots];
             double va[kPriceSlots], px[kPriceSlots];
 #pragma unroll
-            for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pb.pe.idx[u * nstr + p]; va[u] = pb.pe.val[u * nstr + p]; }
+            for (int u = 0; u < kPriceSlots; ++u) { ri[u] = pe_idx(u * nstr + p); va[u] = pb.pe.val[u * nstr + p]; }
             const int br = ct.bound_row[p];
             const int basic = pb.in_basis[na + p];
             const double cp = costs ? costs[p] : 0.0;
-            const bool is_long = (ri[0] & kPriceLongFlag) != 0;    // more than kPriceSlots entries: priced below
-            ri[0] &= kPriceLongFlag - 1;
+            const bool is_long = (ri[0] & kLongFlag) != 0;    // more than kPriceSlots entries: priced below
+            ri[0] &= kLongMask;
 #pragma unroll
             for (int u = 0; u < kPriceSlots; ++u) px[u] = c.pi[ri[u]];
             const double pb_r = c.pi[br >= 0 ? br : 0];
@@ -863,7 +874,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             int ri[kPriceLongSlots];
             double va[kPriceLongSlots], px[kPriceLongSlots];
 #pragma unroll
-            for (int u = 0; u < kPriceLongSlots; ++u) { ri[u] = pb.pe.lidx[u * nl + i]; va[u] = pb.pe.lval[u * nl + i]; }
+            for (int u = 0; u < kPriceLongSlots; ++u) { ri[u] = pe_lidx(u * nl + i); va[u] = pb.pe.lval[u * nl + i]; }
             const int br = ct.bound_row[p];
             const int basic = pb.in_basis[na + p];
             const double cp = costs ? costs[p] : 0.0;
@@ -1066,7 +1077,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (tid == 0) {
             pb.mirror->rec = *rec;
             pb.mirror->hdr[0] = c.t; pb.mirror->hdr[1] = c.eta_used; pb.mirror->hdr[2] = need_refactor; pb.mirror->hdr[3] = c.journal_n;
-            if constexpr (kBig) {
+            if constexpr (kTier >= 1) {
                 for (int k = 0; k < 4; ++k) {
                     pb.mirror->walked[k] = (int32_t)c.clk.passes[k]; pb.mirror->whole[k] = (int32_t)c.clk.total[k];
                     pb.mirror->sweeps[k] = (int32_t)c.clk.sweeps[k];
@@ -1078,11 +1089,11 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
 }
 
 // ---- single steps (step-wise API, phase boundaries) ------------------------------------------------------------------
-template <bool kBig>
+template <int kTier>
 __global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProblem pb, int column, const double* rhs,
                                                   double* alpha) {
     extern __shared__ __align__(16) char lds[];
-    FtCtxT<kBig> c;
+    FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     const int tid = threadIdx.x;
@@ -1096,10 +1107,10 @@ __global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProb
     for (int k = tid; k < c.m; k += NT) { alpha[lu.colperm[k]] = c.x[k]; st.spike[k] = c.sp[k]; }
 }
 
-template <bool kBig>
+template <int kTier>
 __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProblem pb, int row, const double* rhs, double* rho) {
     extern __shared__ __align__(16) char lds[];
-    FtCtxT<kBig> c;
+    FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     const int tid = threadIdx.x;
@@ -1119,10 +1130,10 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
     for (int k = tid; k < c.m; k += NT) rho[lu.rowperm[k]] = c.x[k];
 }
 
-template <bool kBig>
+template <int kTier>
 __global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtProblem pb) {
     extern __shared__ __align__(16) char lds[];
-    FtCtxT<kBig> c;
+    FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
@@ -1141,8 +1152,8 @@ void ft_allow_lds(const void* fn, int bytes) {
 
 }  // namespace
 
-size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, bool big, int32_t rhs_cap) {
-    return (size_t)ft_layout(m, tcap, eta_cap, big, rhs_cap).total;
+size_t ft_lds_base_bytes(int32_t m, int32_t tcap, int32_t eta_cap, int32_t tier, int32_t rhs_cap) {
+    return (size_t)ft_layout(m, tcap, eta_cap, tier, rhs_cap).total;
 }
 int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_t n_seg) { return schedule_lds_bytes(m, nnz, n_levels, n_seg); }
 
@@ -1150,12 +1161,15 @@ int64_t ft_schedule_stage_bytes(int32_t m, int64_t nnz, int32_t n_levels, int32_
 // eta pool live all follow from it)
 #define FT_LAUNCH(kernel, ...)                                                                                        \
     do {                                                                                                              \
-        if (st.big) {                                                                                                 \
-            ft_allow_lds(reinterpret_cast<const void*>(kernel<true>), st.lds_bytes);                                  \
-            hipLaunchKernelGGL(kernel<true>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);                \
+        if (st.big >= 2) {                                                                                            \
+            ft_allow_lds(reinterpret_cast<const void*>(kernel<2>), st.lds_bytes);                                     \
+            hipLaunchKernelGGL(kernel<2>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);                   \
+        } else if (st.big) {                                                                                          \
+            ft_allow_lds(reinterpret_cast<const void*>(kernel<1>), st.lds_bytes);                                     \
+            hipLaunchKernelGGL(kernel<1>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);                   \
         } else {                                                                                                      \
-            ft_allow_lds(reinterpret_cast<const void*>(kernel<false>), st.lds_bytes);                                 \
-            hipLaunchKernelGGL(kernel<false>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);               \
+            ft_allow_lds(reinterpret_cast<const void*>(kernel<0>), st.lds_bytes);                                     \
+            hipLaunchKernelGGL(kernel<0>, dim3(1), dim3(NT), (size_t)st.lds_bytes, s, __VA_ARGS__);                   \
         }                                                                                                             \
     } while (0)
 
@@ -1177,10 +1191,10 @@ void launch_ft_btran(const DeviceLU& lu, const FtState& st, const FtProblem& pb,
 // per change the spike of the entering column (L solve + the etas replayed so far) and the Forrest-Tomlin update of the
 // leaving position -- what Carry::bring_into_basis does minus everything that is not the factorisation (b, -pi, the basis
 // array are already current).
-template <bool kBig>
+template <int kTier>
 __global__ __launch_bounds__(NT) void k_ft_replay(DeviceLU lu, FtState st, FtProblem pb, int count) {
     extern __shared__ __align__(16) char lds[];
-    FtCtxT<kBig> c;
+    FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
     int need = 0;
