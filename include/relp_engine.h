@@ -214,6 +214,12 @@ relp_status_t relp_lu_stats(const relp_engine_t *h, int64_t *out8);
  * installed, basis changes replayed onto them, the look-ahead length in effect (RELP_LU_LOOKAHEAD, 0 = off), the lane
  * budget of a fused group of levels (RELP_FUSE_LANES) }; both switches are read when the engine is created. */
 relp_status_t relp_lu_lookahead_stats(const relp_engine_t *h, int64_t *out4);
+/* RELP_ENGINE_LU: how the pivot loop runs.  out[4] = { persistent pivot kernel in use (0: the product-form fallback, one launch
+ * per step), its layout (0: work vectors, eta file and permutations in one CU's LDS; 1: x, -pi and the slot tables in LDS, the
+ * rest in L2; 2: nothing per row in LDS, any m), slots of the dense tail of U (= the longest refactorisation interval), PRICE as
+ * a grid launch per pivot (Dantzig's rule over >= 32,768 columns in layout 2; RELP_FT_GRID_PRICE) }.  RELP_FT_BIG = 0 / 1 / 2
+ * forces a layout at create; a layout that does not fit falls through to the next one. */
+relp_status_t relp_lu_kernel_layout(const relp_engine_t *h, int32_t *out4);
 /* RELP_ENGINE_LU: refactorise ON THE DEVICE (LUDecomposition::invert -> decomposition/mod.rs:27-138 with the Markowitz
  * pivoting of decomposition/pivoting.rs:45-81): singleton rows / columns peeled in parallel rounds, the bump eliminated on
  * a dense working copy by one workgroup, L and U read off afterwards -- no basis download, no search on the host.  Off by

@@ -72,6 +72,7 @@ int64_t relp_reinversions(const relp_engine_t* h) { return h ? H(h).reinversions
 int32_t relp_update_block(const relp_engine_t* h) { return h ? H(h).update_block() : -1; }
 relp_status_t relp_lu_stats(const relp_engine_t* h, int64_t* out8) { return (h && out8) ? H(h).lu_stats(out8) : RELP_E_ARG; }
 relp_status_t relp_lu_lookahead_stats(const relp_engine_t* h, int64_t* out4) { return (h && out4) ? H(h).lu_lookahead_stats(out4) : RELP_E_ARG; }
+relp_status_t relp_lu_kernel_layout(const relp_engine_t* h, int32_t* out4) { return (h && out4) ? H(h).lu_kernel_layout(out4) : RELP_E_ARG; }
 relp_status_t relp_lu_set_device_factorisation(relp_engine_t* h, int32_t on) { return h ? H(h).lu_set_device_factorisation(on != 0) : RELP_E_ARG; }
 relp_status_t relp_lu_factor_residual(relp_engine_t* h, double* out) { return (h && out) ? H(h).lu_factor_residual(out) : RELP_E_ARG; }
 relp_status_t relp_lu_device_factorisation_stats(const relp_engine_t* h, int64_t* out6) { return (h && out6) ? H(h).luf_stats(out6) : RELP_E_ARG; }

@@ -1,6 +1,7 @@
 // relp_device_common.h -- device helpers shared by the three kernel files (constants, wavefront and
 // workgroup reductions, the PRICE key, the ratio-test body).  Included by relp_kernels_*.hip only.
 #pragma once
+#include <algorithm>
 #include "relp_kernels.h"
 
 #include <math.h>
@@ -442,5 +443,8 @@ __device__ __forceinline__ void ratio_blocks_pick(const double* alpha, const dou
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// Blocks of 256 threads for a grid-stride loop over `total` elements.  (A HIP launch takes at most 2^32 - 1 threads: a tableau
+// of 64,000 x 256,000 has four times as many elements, and a launch beyond the limit fails without running.)
+static inline int element_blocks(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, int64_t(1) << 22); }
 
 }  // namespace relp

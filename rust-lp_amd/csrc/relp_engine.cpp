@@ -396,6 +396,9 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
     relp_status_t st = upload_rec();
     if (st) return st;
     HIP_TRY(hipDeviceSynchronize());   // hipMemset on the null stream vs. our non-blocking stream
+    // (a refused launch -- e.g. more than 2^32 - 1 threads -- returns nothing by itself: without this the engine would start
+    // from a tableau that was never built)
+    if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "a kernel launch of the set-up failed");
     if (lu_ && (st = lu_refactor())) return st;
     return RELP_OK;
 }

@@ -54,6 +54,7 @@ class Engine {
     int32_t update_block() const { return block_; }
     relp_status_t lu_stats(int64_t* out8) const;
     relp_status_t lu_lookahead_stats(int64_t* out4) const;
+    relp_status_t lu_kernel_layout(int32_t* out4) const;
     relp_status_t luf_stats(int64_t* out6) const;
     relp_status_t lu_set_device_factorisation(bool on);
     relp_status_t lu_factor_residual(double* out);
@@ -276,6 +277,7 @@ class Engine {
     void luf_mark_dirty();
     bool hyper_forced_ = false; int32_t hyper_probe_in_[4] = {0, 0, 0, 0};    // adaptive hyper-sparse starts (ft_read_report)
     bool ft_big_ = false; int32_t ft_rhs_cap_ = 0;        // layout of the persistent kernel (relp_kernels_ft.hip: ft_layout)
+    bool ft_grid_price_ = false;                          // Dantzig PRICE as a grid launch per pivot (run_ft): layout 2 with very many columns
     int32_t ft_tier_ = 0;                                 // 0 all in LDS, 1 big (ft_big_), 2 no per-row array in LDS (ft_big_ too)
     int64_t ft_zero_bytes_ = 0, ft_ones_bytes_ = 0;       // the two regions of the state buffer a refactorisation resets
     bool ft_need_refactor_ = false;
@@ -283,6 +285,7 @@ class Engine {
     relp_status_t ft_reset();
     relp_status_t ft_read_hdr();
     FtProblem ft_problem(int rule) const;
+    void ft_enqueue_pivots(const FtState& go, int rule, int64_t left);
     char* d_pe_buf_ = nullptr; PriceEll pe_{};            // PRICE copy of the structural columns (relp_kernels.h: PriceEll)
     relp_status_t ft_build_price_ell();
     relp_status_t run_ft(int64_t max_iters, int64_t* done, int32_t* outcome);

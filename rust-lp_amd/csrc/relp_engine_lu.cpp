@@ -169,7 +169,7 @@ relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget, bool have_
     go.max_updates = std::max(go.max_updates, std::min(cfg_.update_block < 0 ? ft_tcap_ : cfg_.update_block, ft_tcap_));
     prof_tick_ = 0;
     prof_begin(RELP_K_FT_RUN);
-    launch_ft_run(dlu_, go, ft_problem(rule), budget, stream_);
+    ft_enqueue_pivots(go, rule, budget);
     prof_end();
     const auto t0 = std::chrono::steady_clock::now();
     // the current factors stay valid (and in use) until the new ones are installed
@@ -507,7 +507,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
     const int64_t o_hdr = take(16), o_sp = take(4 * tc), o_lv = take(4 * tc), o_tc = take(8 * tc * ldt), o_eo = take(4 * tc * nwp),
                   o_so = take(4 * tc * nwp), o_pv = take(4 * tc), o_ts = take(4 * m), o_ei = take(4 * (int64_t)ft_eta_cap_),
                   o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32),
-                  o_journal = take(8 * tc), o_spw = take(8 * m), o_xw = take(ft_tier_ >= 2 ? 8 * (m + 1 + ft_rhs_cap_) : 0);
+                  o_journal = take(8 * tc), o_spw = take(8 * m), o_xw = take(ft_tier_ >= 2 ? 8 * (m + 1 + ft_rhs_cap_) : 0),
+                  o_cm = take(ft_tier_ >= 2 ? 8 * ((m + 63) / 64 + 1) : 0);
     ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
@@ -541,6 +542,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
     fts_.sp_work = reinterpret_cast<double*>(d_ft_buf_ + o_spw);
     fts_.x_work = ft_tier_ >= 2 ? reinterpret_cast<double*>(d_ft_buf_ + o_xw) : nullptr;
+    fts_.chunk_mask = ft_tier_ >= 2 ? reinterpret_cast<unsigned long long*>(d_ft_buf_ + o_cm) : nullptr;
     fts_.big = ft_tier_; fts_.rhs_cap = ft_rhs_cap_;
     {   // hyper-sparse starts: L and L' by default (U' starts from the leaving pivot's level anyway; on U the spike reaches the first groups: measured 31.4 of 31.4 passes on 25FV47, not worth the reduction); RELP_FT_HYPER = bit mask
         const char* e = std::getenv("RELP_FT_HYPER");
@@ -553,6 +555,10 @@ relp_status_t Engine::ft_plan_and_alloc() {
     // relp_config_t.update_block = 11 reproduces the reference's cadence)
     fts_.max_updates = cfg_.update_block < 0 ? ft_tcap_ : std::max(1, std::min(cfg_.update_block, ft_tcap_));
     block_ = fts_.max_updates;
+    {   // RELP_FT_GRID_PRICE = 0 / 1 forces the choice (any layout: -pi is current in global memory between launches)
+        const char* e = std::getenv("RELP_FT_GRID_PRICE");
+        ft_grid_price_ = e ? std::atoi(e) != 0 : (ft_tier_ >= 2 && nr_columns() >= 32768);
+    }
     return ft_build_price_ell();
 }
 
@@ -673,6 +679,41 @@ relp_status_t Engine::ft_read_report(bool* have_basis) {
     return RELP_OK;
 }
 
+// Pivots of the persistent kernel on `go`: one launch that runs until something stops it, or -- Dantzig's rule over very many
+// columns (ft_grid_price_) -- PRICE as a grid launch (every CU instead of one) followed by ONE pivot of the persistent kernel with
+// the column the grid chose, as many times as the update file has room, enqueued without a synchronisation (a launch whose
+// record says "decided" returns at once), plus one launch that only marks the refactorisation due.  The launches of a batch
+// share the journal (hdr[3]) and honour each other's "refactorisation due" (hdr[2]); only the last one writes the host mirror.
+void Engine::ft_enqueue_pivots(const FtState& go, int rule, int64_t left) {
+    if (!(ft_grid_price_ && rule == RELP_RULE_STEEPEST_DESCENT)) {
+        launch_ft_run(dlu_, go, ft_problem(rule), left, stream_);
+        return;
+    }
+    const int64_t room = std::max<int64_t>((int64_t)go.max_updates - since_flush_, 0);
+    const int64_t batch = std::min<int64_t>(left, room + 1);
+    (void)hipMemsetAsync(fts_.hdr + 2, 0, 2 * sizeof(int32_t), stream_);
+    FtProblem pb = ft_problem(rule);
+    pb.external_price = 1;
+    const ColumnTable ct = table();
+    SelectPartials sp;
+    sp.k1 = d_part_k1_; sp.j = d_part_j_; sp.in_basis = d_in_basis_; sp.tol_cost = cfg_.tol_cost; sp.rule = rule;
+    const int nb_struct = price_csc_blocks(0, nr_normal_), nb_virt = price_virtual_blocks(ct);
+    sp.n = nr_columns(); sp.offset = 0; sp.nb_struct = nb_struct; sp.tol_tie = cfg_.tol_tie; sp.p_lo = 0; sp.cols_per_slot = 256;
+    for (int64_t k = 0; k < batch; ++k) {
+        if (nb_struct > 0 && nb_virt > 0) {
+            launch_price_csc_all(csc(), ct, d_minus_pi_, d_d_, nr_normal_, phase_, sp, nb_virt, d_rec_, stream_);
+        } else {
+            launch_price_csc(csc(), ct, d_minus_pi_, d_d_, 0, nr_normal_, phase_, sp, d_rec_, stream_);
+            SelectPartials spv = sp;
+            spv.offset = nb_struct;
+            launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
+        }
+        launch_select_partials_csc(sp, nb_struct + nb_virt, d_d_, csc(), ct, m_, d_aq_, d_rec_, stream_);
+        pb.mirror = k + 1 == batch ? d_mirror_ : nullptr;
+        launch_ft_run(dlu_, go, pb, 1, stream_);
+    }
+}
+
 FtProblem Engine::ft_problem(int rule) const {
     FtProblem pb{};
     pb.csc = csc(); pb.ct = table(); pb.pe = pe_;
@@ -719,7 +760,8 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
         prof_begin(RELP_K_FT_RUN);
         FtState go = fts_;
         go.max_updates = fts_.max_updates - la;
-        launch_ft_run(dlu_, go, ft_problem(rule), max_iters - (h_rec_->iterations - start), stream_);
+        const int64_t left = max_iters - (h_rec_->iterations - start);
+        ft_enqueue_pivots(go, rule, left);
         prof_end();
         if ((st = ft_read_report(&have_basis))) return st;
         if (!ft_need_refactor_ && h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters)
@@ -759,6 +801,12 @@ relp_status_t Engine::lu_stats(int64_t* out8) const {
     out8[0] = lu_refactors_; out8[1] = hlu_.m; out8[2] = hlu_.nnz_l; out8[3] = hlu_.nnz_u;
     out8[4] = (int64_t)hlu_.Lf.level_ptr.size() - 1; out8[5] = (int64_t)hlu_.Uf.level_ptr.size() - 1;
     out8[6] = (int64_t)hlu_.Ub.level_ptr.size() - 1; out8[7] = (int64_t)hlu_.Lb.level_ptr.size() - 1;
+    return RELP_OK;
+}
+
+relp_status_t Engine::lu_kernel_layout(int32_t* out4) const {
+    if (!lu_) return RELP_E_STATE;
+    out4[0] = ft_ ? 1 : 0; out4[1] = ft_ ? ft_tier_ : -1; out4[2] = ft_ ? ft_tcap_ : 0; out4[3] = (ft_ && ft_grid_price_) ? 1 : 0;
     return RELP_OK;
 }
 

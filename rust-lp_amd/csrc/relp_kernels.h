@@ -190,6 +190,7 @@ struct FtState {
     int32_t  hyper;          // bit k: sweep k (L, U, U', L') starts at the first group its right-hand side reaches (RELP_FT_HYPER)
     int32_t  pad2_;
     double*  x_work;         // m + 1 + rhs_cap: the work vector inside the kernels when it does not live in LDS (layout 2)
+    unsigned long long* chunk_mask;    // ceil(m / 64) words of scratch (layout 2: ft_compact)
     int32_t  big;            // layout (relp_kernels_ft.hip: ft_layout).  0: everything in LDS.  1: spike, permutations and eta pool in
                              // global memory (L2), 32-bit slot indices.  2: x, -pi and the pivot -> slot table there as well (no per-row
                              // array in LDS: any m), 32-bit row indices in the PRICE copy
@@ -237,7 +238,8 @@ struct FtProblem {           // what the persistent kernel needs besides the fac
     PivotRecord* rec;
     FtMirror* mirror;        // or null
     Tolerances tol;
-    int32_t rule, n, phase, pad_;
+    int32_t rule, n, phase;
+    int32_t external_price;  // 1: PRICE ran as a grid launch (k_price_csc + k_select_partials): the entering column is in the record
 };
 
 // ---- launchers (all asynchronous on `s`) -------------------------------------------------------

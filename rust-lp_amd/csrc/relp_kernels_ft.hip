@@ -85,6 +85,9 @@ struct FtCtxT {
     static constexpr bool big = kTier >= 1, huge = kTier >= 2;
     typedef typename std::conditional<big, int32_t, unsigned short>::type perm_t;
     typedef typename std::conditional<huge, int32_t, signed char>::type tslot_t;
+    // the wavefront that owns pivot k in the bucketed lists (eta pool, spike pool): see ft_compact
+    static __device__ __forceinline__ int bucket_of(int k) { return huge ? (k >> 6) % NW : k % NW; }
+    unsigned long long* chunk_mask;                    // (layout 2) ceil(m / 64) ballots, scratch of ft_compact
     double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;      // (big: sp, eta_val, eta_idx and the permutations are global)
     int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
     tslot_t* tslot;
@@ -97,7 +100,7 @@ struct FtCtxT {
 template <class Ctx>
 __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, const FtState& st) {
     const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::tier, st.rhs_cap);
-    if constexpr (Ctx::huge) { c.x = st.x_work; c.pi = nullptr; c.tslot = st.tslot; }      // (-pi: bound by ft_load to the engine's own vector)
+    if constexpr (Ctx::huge) { c.x = st.x_work; c.pi = nullptr; c.tslot = st.tslot; c.chunk_mask = st.chunk_mask; }      // (-pi: bound by ft_load to the engine's own vector)
     else { c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.tslot = (signed char*)(lds + L.tslot); }
     c.TC = (double*)(lds + L.tc);
     if constexpr (Ctx::big) {
@@ -286,6 +289,20 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
             double sum = 0.0;
             if (s < t) {
                 const int e0 = c.eta_off[s * (NW + 1)], e1 = c.eta_off[s * (NW + 1) + NW];
+                if constexpr (Ctx::huge) {             // (pool and x in L2: four entries requested before the first is used)
+                    for (int e = e0 + l; e < e1; e += 4 * G) {
+                        int k[4];
+                        double v[4], xv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int ee = min(e + u * G, e1 - 1); k[u] = c.eta_idx[ee]; v[u] = c.eta_val[ee]; }
+                        asm volatile("" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) xv[u] = c.x[k[u]];
+                        asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) sum = fma(e + u * G < e1 ? v[u] : 0.0, xv[u], sum);
+                    }
+                } else
                 for (int e = e0 + l; e < e1; e += G) sum = fma(c.eta_val[e], c.x[c.eta_idx[e]], sum);
             }
             sum = group_sum(sum, G);
@@ -308,6 +325,16 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
         __syncthreads();
     }
     c.clk.lap(FT_ETA_FWD);
+    if constexpr (Ctx::huge) {                         // the spike (mod.rs:176); L2 to L2, four requests at a time
+        for (int k0 = tid; k0 < c.m; k0 += 4 * NT) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = c.x[min(k0 + u * NT, c.m - 1)];
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (k0 + u * NT < c.m) c.sp[k0 + u * NT] = v[u];
+        }
+    } else
     for (int k = tid; k < c.m; k += NT) c.sp[k] = c.x[k];          // the spike (mod.rs:176)
     if (spike_only) { __syncthreads(); return; }
     if (t > 0) {
@@ -489,10 +516,69 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
 // bucket w = pivots with k % NW == w, written by wavefront w at [base + off[w], base + off[w + 1]).  off (NW + 1 ints) is
 // left in `off_out` relative to off_base.  Returns the total (all threads).  Ends with a barrier.
 // `room`: entries the destination can still take; when the non-zeros do not fit nothing is written and -1 is returned.
+// Layout 2 (vec and the slot table in L2): bucket w = the 64-pivot chunks w, w + NW, .. (Ctx::bucket_of), so a wavefront reads
+// whole cache lines; four chunks are requested before the first is looked at; the first pass leaves every chunk's ballot in
+// `chunk_mask` and the second touches the chunks that hold anything only (an eta row or a spike has a few hundred non-zeros
+// among tens of thousands of pivots).
 template <class Ctx, class IdxPtr, class ValPtr>
 __device__ __forceinline__ int ft_compact(Ctx& c, const double* vec, int skip, IdxPtr out_idx, ValPtr out_val, int out_base,
                                           int* off_out, int off_base, int room) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (Ctx::huge) {
+        const int n_chunks = (c.m + 63) >> 6;
+        const int mine_chunks = (n_chunks - wave + NW - 1) / NW;       // chunks wave + NW * i, i < mine_chunks
+        unsigned long long* masks = c.chunk_mask;
+        int cnt = 0;
+        for (int i0 = 0; i0 < mine_chunks; i0 += 4) {
+            int ts[4];
+            double vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(((wave + NW * min(i0 + u, mine_chunks - 1)) << 6) + lane, c.m - 1);
+                ts[u] = c.tslot[k]; vv[u] = vec[k];
+            }
+            asm volatile("" : "+v"(ts[0]), "+v"(ts[1]), "+v"(ts[2]), "+v"(ts[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = wave + NW * (i0 + u), k = (ch << 6) + lane;
+                const bool on = i0 + u < mine_chunks && k < c.m && k != skip && ts[u] < 0 && vv[u] != 0.0;
+                const unsigned long long mask = __ballot(on);
+                if (i0 + u < mine_chunks && lane == 0) masks[ch] = mask;
+                cnt += __popcll(mask);
+            }
+        }
+        if (lane == 0) c.red_i[wave] = cnt;
+        __syncthreads();
+        int mine = 0, total = 0;
+        for (int w = 0; w < NW; ++w) { const int v = c.red_i[w]; if (w < wave) mine += v; total += v; }
+        if (total > room) { __syncthreads(); return -1; }
+        if (tid <= NW) {
+            int o = 0;
+            for (int w = 0; w < tid; ++w) o += c.red_i[w];
+            off_out[tid] = off_base + o;
+        }
+        int pos = out_base + mine;
+        for (int i0 = 0; i0 < mine_chunks && cnt > 0; i0 += 64) {      // (a wavefront reads 64 of its own masks at a time)
+            const int i = i0 + lane;
+            const unsigned long long mk = i < mine_chunks ? masks[wave + NW * i] : 0ull;
+            unsigned long long any = __ballot(mk != 0ull);
+            while (any) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)any) - 1);
+                any &= any - 1;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)mk, src), hi = __builtin_amdgcn_readlane((unsigned)(mk >> 32), src);
+                const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+                const int k = ((wave + NW * (i0 + src)) << 6) + lane;
+                if ((mask >> lane) & 1ull) {
+                    const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
+                    out_idx[at] = k;
+                    out_val[at] = vec[k];
+                }
+                pos += __popcll(mask);
+            }
+        }
+        __syncthreads();
+        return total;
+    }
     const int per_wave = (c.m - wave + NW - 1) / NW;           // pivots k = wave + NW * i, i < per_wave
     int cnt = 0;
     for (int i0 = 0; i0 < per_wave; i0 += 64) {
@@ -545,7 +631,7 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
             if (c.tslot[l] < 0) { c.x[l] = lu.Uf.val[e]; any = 1; }
         }
         // entries of row p in the spike columns of the live slots: only the bucket p % NW of each list can hold them
-        const int bucket = p % NW;
+        const int bucket = Ctx::bucket_of(p);
         for (int s = wave; s < t; s += NW) {
             if (!c.slot_live[s]) continue;
             const int base = s * c.m;
@@ -751,6 +837,10 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     long long iterations = rec->iterations;
     int degenerate = rec->degenerate;
     int outcome = DEV_RUNNING, need_refactor = st.hdr[2] >= 2 ? 2 : 0;       // (2: a replay failed, the factors are unusable)
+    // (a launch of the one-pivot-per-launch loop must not pivot on factors an earlier launch of its batch declared due: the host
+    // looks at the header after the batch only.  The persistent loop is relaunched on purpose with hdr[2] == 1: look-ahead.)
+    if (pb.external_price && st.hdr[2]) need_refactor = st.hdr[2];
+    if (pb.external_price) c.journal_n = st.hdr[3];                     // (one journal per batch)
     int q = rec->q, r = rec->r, leaving = rec->leaving;
     double d_q = rec->d_q, alpha_r = rec->alpha_r, b_r = rec->b_r, key1 = rec->key1;
     PivotRecord fake;                                  // select_key reads rule memory through a record
@@ -763,6 +853,9 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     for (long long it = 0; it < max_pivots; ++it) {
         if (need_refactor || c.t >= st.max_updates || c.t >= c.tcap) { if (!need_refactor) need_refactor = 1; break; }
         // ---- PRICE (pivot_rule.rs:38-126 over tableau/mod.rs:102-108): d_j = c_j + (-pi) . a_j, thread per column ----------
+        // (external_price: this launch makes one pivot with the column a grid-wide PRICE chose -- Engine::run_ft, Dantzig's rule
+        // over very many columns, where one workgroup pricing all of them was 70 % of the pivot)
+        if (!pb.external_price) {
         fake.last_selected = last_selected;
         double key = INFINITY, kv = 0.0;
         int kj = 0x7fffffff;
@@ -943,6 +1036,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         __syncthreads();
         q = kj; key1 = key; d_q = c.red_d[NW];
         if (rule == 1) last_selected = q;
+        }
 #ifdef PRICE_DIAG
         c.clk.lap(FT_SCATTER);
 #else
@@ -955,6 +1049,72 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         ft_ftran(lu, st, c);
 
         // ---- RATIO TEST (tableau/mod.rs:221-247; two passes as relp_device_common.h ratio_body) ------------------------
+        double br;
+        if constexpr (kTier >= 2) {
+        // Layout 2: alpha = x[icp[.]] is two dependent round trips to L2 per row, so every pass requests four rows before it
+        // looks at the first; the first pass leaves alpha in pb.alpha (each thread re-reads its own rows from there,
+        // coalesced); the pass over the tie band finds the leaving column AND its row.
+        double mn = INFINITY;
+        for (int j0 = tid; j0 < m; j0 += 4 * NT) {
+            int pp[4];
+            double bb[4], aa[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(j0 + u * NT, m - 1); pp[u] = c.icp[i]; bb[u] = pb.b[i]; }
+            asm volatile("" : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(pp[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) aa[u] = c.x[pp[u]];
+            asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u * NT < m) { pb.alpha[j0 + u * NT] = aa[u]; mn = fmin(mn, row_ratio(aa[u], bb[u], pb.tol)); }
+        }
+        const double gmin = block_min_double(c, mn);
+        if (gmin == INFINITY) { outcome = DEV_NO_ROW; break; }
+        const double bound = gmin + pb.tol.tie * fmax(1.0, fabs(gmin));
+        int best_leave = 0x7fffffff, rr = 0x7fffffff;
+        tie_key_t best = kNoTieKey;
+        const bool by_column = pb.tol.ratio_rule == 0;
+        for (int j0 = tid; j0 < m; j0 += 4 * NT) {
+            double bb[4], aa[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(j0 + u * NT, m - 1); aa[u] = pb.alpha[i]; bb[u] = pb.b[i]; }
+            asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = j0 + u * NT;
+                if (i < m && row_ratio(aa[u], bb[u], pb.tol) <= bound) {
+                    const int sc = pb.basis[i];
+                    if (by_column) { if (sc < best_leave) { best_leave = sc; rr = i; } }
+                    else { const tie_key_t k = tie_key(aa[u], sc, 1); if (k < best) { best = k; best_leave = sc; rr = i; } }
+                }
+            }
+        }
+        if (by_column) leaving = block_min_int(c, best_leave);
+        else {
+            const tie_key_t kmin = block_min_key64(c, best);
+            leaving = tie_key_leaving(kmin);
+            if (best != kmin) best_leave = 0x7fffffff;
+        }
+        r = block_min_int(c, best_leave == leaving ? rr : 0x7fffffff);       // (a column is basic in one row)
+        if (best_leave == leaving && rr == r) { c.red_d[NW] = pb.alpha[r]; c.red_d[NW + 1] = pb.b[r]; }
+        __syncthreads();
+        alpha_r = c.red_d[NW];
+        b_r = c.red_d[NW + 1];
+        c.clk.lap(FT_RATIO);
+        br = b_r / alpha_r;
+        for (int j0 = tid; j0 < m; j0 += 4 * NT) {
+            double bb[4], aa[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(j0 + u * NT, m - 1); aa[u] = pb.alpha[i]; bb[u] = pb.b[i]; }
+            asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = j0 + u * NT;
+                if (i < m) { if (i == r) pb.b[i] = br; else if (aa[u] != 0.0) pb.b[i] = fma(-aa[u], br, bb[u]); }
+            }
+        }
+        __syncthreads();
+        } else {
         // Rows tid and tid + NT of this thread stay in registers through the three passes and the update of b (one round of
         // global loads for m <= 2 NT); rows beyond that take the generic loops.
         const int i0 = tid, i1 = tid + NT;
@@ -1009,7 +1169,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         c.clk.lap(FT_RATIO);
 
         // ---- b (carry/mod.rs:283-313) while alpha is still in x -----------------------------------------------------
-        const double br = b_r / alpha_r;
+        br = b_r / alpha_r;
         if (h0) { if (i0 == r) pb.b[i0] = br; else if (a0 != 0.0) pb.b[i0] = fma(-a0, br, b0); }
         if (h1) { if (i1 == r) pb.b[i1] = br; else if (a1 != 0.0) pb.b[i1] = fma(-a1, br, b1); }
         for (int i = tid + 2 * NT; i < m; i += NT) {
@@ -1020,6 +1180,7 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             }
         }
         __syncthreads();
+        }
 
         c.clk.lap(FT_B);
         // ---- basis inverse: the Forrest-Tomlin update, then row r of the new inverse (mod.rs:92-155, 204-222) --------------
@@ -1042,6 +1203,23 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             need_refactor = 1;
         }
         // ---- -pi, -obj, basis (carry/mod.rs:326-333, 549-570) ----------------------------------------------------------
+        if constexpr (kTier >= 2) {                     // (four rows requested at a time; -pi changes where rho is not zero only)
+            for (int k0 = tid; k0 < m; k0 += 4 * NT) {
+                int ii[4];
+                double xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int k = min(k0 + u * NT, m - 1); ii[u] = c.rp[k]; xv[u] = c.x[k]; }
+                asm volatile("" : "+v"(ii[0]), "+v"(ii[1]), "+v"(ii[2]), "+v"(ii[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u * NT < m) {
+                        const double rho = xv[u] * rho_scale;
+                        pb.rho[ii[u]] = rho;
+                        if (rho != 0.0) c.pi[ii[u]] = fma(-d_q, rho, c.pi[ii[u]]);
+                    }
+                }
+            }
+        } else
         for (int k = tid; k < m; k += NT) {
             const int i = c.rp[k];
             const double rho = c.x[k] * rho_scale;

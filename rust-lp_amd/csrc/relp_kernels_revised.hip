@@ -741,11 +741,11 @@ __global__ void k_weighted_column_sums(const double* __restrict__ Binv, int64_t 
 
 // rows [row_lo, row_hi) of the identity, stored locally starting at row 0
 __global__ void k_set_identity(double* __restrict__ Binv, int64_t ld_b, int row_lo, int row_hi) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)(row_hi - row_lo) * ld_b;
-    if (idx >= total) return;
-    const int64_t i = idx / ld_b, j = idx % ld_b;
-    Binv[idx] = (row_lo + i == j) ? 1.0 : 0.0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx / ld_b, j = idx % ld_b;
+        Binv[idx] = (row_lo + i == j) ? 1.0 : 0.0;
+    }
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t stream, uint64_t idx) {
@@ -758,12 +758,12 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t stream, u
 // A[i, j] = (1 + x(0, (first_column + j) * m + i) % 999) / 1000   (rust-lp_amd/synthetic.py)
 __global__ void k_fill_dense(double* __restrict__ A, int64_t ld, int m, int n, uint64_t seed,
                              int64_t first_column) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)m * n;
-    if (idx >= total) return;
-    const int64_t j = idx / m, i = idx % m;
-    const uint64_t x = splitmix64(seed, 0, (uint64_t)((first_column + j) * m + i));
-    A[j * ld + i] = (double)(1 + x % 999) / 1000.0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = idx / m, i = idx % m;
+        const uint64_t x = splitmix64(seed, 0, (uint64_t)((first_column + j) * m + i));
+        A[j * ld + i] = (double)(1 + x % 999) / 1000.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1032,14 +1032,14 @@ void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, co
 void launch_set_identity(double* Binv, int64_t ld_b, int32_t row_lo, int32_t row_hi, hipStream_t s) {
     const int64_t total = (int64_t)(row_hi - row_lo) * ld_b;
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_set_identity, dim3(cdiv(total, 256)), dim3(256), 0, s, Binv, ld_b, row_lo, row_hi);
+    hipLaunchKernelGGL(k_set_identity, dim3(element_blocks(total)), dim3(256), 0, s, Binv, ld_b, row_lo, row_hi);
 }
 
 void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
                        hipStream_t s) {
     const int64_t total = (int64_t)m * n;
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_fill_dense, dim3(cdiv(total, 256)), dim3(256), 0, s, A, ld, m, n, seed, first_column);
+    hipLaunchKernelGGL(k_fill_dense, dim3(element_blocks(total)), dim3(256), 0, s, A, ld, m, n, seed, first_column);
 }
 
 void launch_apply_w(const DeferredUpdate& du, int32_t m, const double* v, double* alpha, const PivotRecord* rec,

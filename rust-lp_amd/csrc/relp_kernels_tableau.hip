@@ -13,25 +13,25 @@ namespace relp {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ void k_tab_build(TableauView tv, const double* __restrict__ A, int64_t ld_a, ColumnTable ct) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)tv.m * (tv.c_hi - tv.c_lo);
-    if (idx >= total) return;
-    const int c = tv.c_lo + (int)(idx / tv.m), i = (int)(idx % tv.m);
-    double v = 0.0;
-    if (c < ct.nr_artificial) {
-        v = (i == ct.column_to_row[c]) ? 1.0 : 0.0;
-    } else {
-        const int p = c - ct.nr_artificial;
-        if (p < ct.nr_normal) {
-            if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
-            else v = (i == ct.bound_row[p]) ? 1.0 : 0.0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = tv.c_lo + (int)(idx / tv.m), i = (int)(idx % tv.m);
+        double v = 0.0;
+        if (c < ct.nr_artificial) {
+            v = (i == ct.column_to_row[c]) ? 1.0 : 0.0;
         } else {
-            const int vv = p - ct.nr_normal;
-            if (i == ct.vrow0[vv]) v = (double)ct.vsign[vv];
-            else if (i == ct.vrow1[vv]) v = 1.0;
+            const int p = c - ct.nr_artificial;
+            if (p < ct.nr_normal) {
+                if (i < ct.nr_constraints) v = A[(int64_t)p * ld_a + i];
+                else v = (i == ct.bound_row[p]) ? 1.0 : 0.0;
+            } else {
+                const int vv = p - ct.nr_normal;
+                if (i == ct.vrow0[vv]) v = (double)ct.vsign[vv];
+                else if (i == ct.vrow1[vv]) v = 1.0;
+            }
         }
+        tv.T0[(int64_t)c * tv.ld_t + i] = v;
     }
-    tv.T0[(int64_t)c * tv.ld_t + i] = v;
 }
 
 // d[c] = cost[c] - w . T0[:,c]   (the PRICE multi-dot over the stored tableau, phase boundaries only)
@@ -851,11 +851,11 @@ __global__ __launch_bounds__(WC * WR * 64) void k_tab_flush_lds(TableauView tv, 
 }
 
 __global__ void k_tab_gather_columns(TableauView tv, const int32_t* __restrict__ cols, double* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)tv.m * tv.m;
-    if (idx >= total) return;
-    const int k = (int)(idx / tv.m), i = (int)(idx % tv.m);        // consecutive threads walk down a column of T0
-    out[(int64_t)i * tv.m + k] = tv.T0[(int64_t)cols[k] * tv.ld_t + i];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / tv.m), i = (int)(idx % tv.m);        // consecutive threads walk down a column of T0
+        out[(int64_t)i * tv.m + k] = tv.T0[(int64_t)cols[k] * tv.ld_t + i];
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void k_tab_row(TableauView tv, DeferredUpdate du, int row, double* __restrict__ out,
@@ -898,7 +898,7 @@ int32_t tab_scan_blocks(int32_t n_owned_columns) { return cdiv(n_owned_columns, 
 void launch_tab_build(const TableauView& tv, const double* A, int64_t ld_a, const ColumnTable& ct, hipStream_t s) {
     const int64_t total = (int64_t)tv.m * (tv.c_hi - tv.c_lo);
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_tab_build, dim3(cdiv(total, 256)), dim3(256), 0, s, tv, A, ld_a, ct);
+    hipLaunchKernelGGL(k_tab_build, dim3(element_blocks(total)), dim3(256), 0, s, tv, A, ld_a, ct);
 }
 
 void launch_tab_price_init(const TableauView& tv, const double* w, const double* cost_store, hipStream_t s) {
@@ -1033,7 +1033,7 @@ void launch_tab_flush(const TableauView& tv, const DeferredUpdate& du, const Piv
 
 void launch_tab_gather_columns(const TableauView& tv, const int32_t* cols, double* out, hipStream_t s) {
     const int64_t total = (int64_t)tv.m * tv.m;
-    hipLaunchKernelGGL(k_tab_gather_columns, dim3(cdiv(total, 256)), dim3(256), 0, s, tv, cols, out);
+    hipLaunchKernelGGL(k_tab_gather_columns, dim3(element_blocks(total)), dim3(256), 0, s, tv, cols, out);
 }
 
 void launch_tab_row(const TableauView& tv, const DeferredUpdate& du, int32_t row, double* out, const PivotRecord* rec,

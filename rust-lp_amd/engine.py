@@ -90,6 +90,7 @@ _SIGNATURES = {
     "relp_update_block": (C.c_int32, [C.c_void_p]),
     "relp_lu_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_lu_lookahead_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "relp_lu_kernel_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "relp_lu_set_device_factorisation": (C.c_int, [C.c_void_p, C.c_int32]),
     "relp_lu_device_factorisation_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_lu_factor_residual": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
@@ -367,6 +368,13 @@ class Tableau:
         self._ck(self._lib.relp_lu_lookahead_stats(self._h, la))
         stats.update(lookahead_installs=int(la[0]), replayed_changes=int(la[1]), lookahead=int(la[2]), fuse_lanes=int(la[3]))
         return stats
+
+    def lu_kernel_layout(self) -> dict:
+        """How the LU engine's pivot loop runs (relp_lu_kernel_layout): persistent kernel or product-form fallback, the
+        kernel's layout (0 all in LDS, 1 big, 2 nothing per row in LDS), dense-tail slots, grid PRICE."""
+        out = (C.c_int32 * 4)()
+        self._ck(self._lib.relp_lu_kernel_layout(self._h, out))
+        return {"persistent_kernel": bool(out[0]), "layout": int(out[1]), "tail_slots": int(out[2]), "grid_price": bool(out[3])}
 
     def lu_set_device_factorisation(self, on: bool) -> None:
         """Refactorise on the device from now on (relp_lu_set_device_factorisation; LUDecomposition::invert)."""

@@ -178,3 +178,60 @@ def mixed_lp(m: int, n: int, seed: int, nnz_per_col: int = 4, frac_eq: float = 0
     return {"m": m, "n": n, "nr_eq": n_eq, "nr_range": n_rg, "nr_le": n_le, "nr_ge": n_ge,
             "col_ptr": np.array(col_ptr, dtype=np.int64), "row_idx": np.array(row_idx, dtype=np.int32),
             "values": np.array(values, dtype=np.float64), "b": b.astype(np.float64), "c": c, "ub": ub, "ranges": ranges}
+
+
+def multicommodity_lp(nodes: int, arcs: int, commodities: int, seed: int, drop_one_node: bool = True) -> Dict[str, object]:
+    """Multi-commodity minimum-cost flow, the shape of the reference's KEN-* / PDS-* files (tests/netlib/problem_files):
+    per commodity k a node-arc incidence block (flow conservation, == rows), and one bundle capacity row (<=) per arc
+    coupling the commodities.  Column (k, a): +1 in row (k, tail_a), -1 in row (k, head_a), +1 in the capacity row of a.
+
+    Built around a feasible flow x0 >= 0 (phase 1 ends feasible) with strictly positive costs (phase 2 is bounded); all data
+    small integers.  Conservation rows are sign-flipped where needed so that b >= 0.  ``drop_one_node``: leave out the
+    conservation row of node 0 of every commodity (the rows of a block sum to zero: with it the LP is rank deficient and
+    the solve goes through the artificial-removal / row-removal path).
+    m = commodities * (nodes - drop) + arcs rows, n = commodities * arcs columns, 3 entries per column (2 for arcs at node 0).
+    Same dictionary layout as `sparse_lp`."""
+    V, E, K = nodes, arcs, commodities
+    e = np.arange(E, dtype=np.uint64)
+    tail = (splitmix64(seed, 11, e) % np.uint64(V)).astype(np.int64)
+    hop = 1 + (splitmix64(seed, 12, e) % np.uint64(V - 1)).astype(np.int64)
+    head = (tail + hop) % V                                             # never a loop
+    tail[:V] = np.arange(V)
+    head[:V] = (np.arange(V) + 1) % V                                   # a ring first: the graph is connected
+    ke = np.arange(K * E, dtype=np.uint64)
+    draw = (splitmix64(seed, 13, ke) % np.uint64(16)).astype(np.int64)
+    x0 = np.where(draw < 3, draw + 1, 0).reshape(K, E)                  # ~ 1 in 5 arcs carries flow
+    first = 0 if not drop_one_node else 1
+    nv = V - first
+    n_eq = K * nv
+    m = n_eq + E
+    # conservation right-hand sides and the sign of every conservation row
+    bal = np.zeros((K, V), dtype=np.int64)
+    for k in range(K):
+        np.add.at(bal[k], tail, x0[k])
+        np.subtract.at(bal[k], head, x0[k])
+    sign = np.where(bal < 0, -1, 1)
+    cap_slack = 1 + (splitmix64(seed, 14, e) % np.uint64(4)).astype(np.int64)
+    b = np.concatenate([(bal * sign)[:, first:].reshape(-1), x0.sum(axis=0) + cap_slack]).astype(np.float64)
+    # columns, commodity-major: rows sorted within a column
+    kk = np.repeat(np.arange(K), E)
+    tt, hh, aa = np.tile(tail, K), np.tile(head, K), np.tile(np.arange(E), K)
+    r_t = kk * nv + (tt - first)
+    r_h = kk * nv + (hh - first)
+    v_t = sign[kk, tt].astype(np.float64)
+    v_h = -sign[kk, hh].astype(np.float64)
+    keep_t, keep_h = tt >= first, hh >= first
+    rows3 = np.stack([np.where(keep_t, r_t, -1), np.where(keep_h, r_h, -1), n_eq + aa], axis=1)
+    vals3 = np.stack([v_t, v_h, np.ones(K * E)], axis=1)
+    order = np.argsort(np.where(rows3 < 0, np.iinfo(np.int64).max, rows3), axis=1, kind="stable")
+    rows3 = np.take_along_axis(rows3, order, axis=1)
+    vals3 = np.take_along_axis(vals3, order, axis=1)
+    present = rows3 >= 0
+    counts = present.sum(axis=1)
+    col_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    c = 1 + (splitmix64(seed, 15, ke) % np.uint64(20)).astype(np.int64)
+    return {
+        "m": int(m), "n": int(K * E), "nr_eq": int(n_eq), "nr_range": 0, "nr_le": int(E), "nr_ge": 0,
+        "col_ptr": col_ptr, "row_idx": rows3[present].astype(np.int32), "values": vals3[present].astype(np.float64),
+        "b": b, "c": c.astype(np.float64), "ub": np.full(K * E, np.inf),
+    }
