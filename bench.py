@@ -493,6 +493,54 @@ def sparse_large():
     return out
 
 
+def sparse_scale():
+    """Where the sparse engine is the engine to take: a multi-commodity flow LP of the KEN / PDS shape
+    (synthetic.multicommodity_lp: 12 commodities on 4,000 nodes / 16,000 arcs -> 63,988 rows x 255,988 columns, 3 entries per
+    column), far beyond what one CU's LDS holds per row.  The persistent pivot kernel runs in its third layout (x, -pi and the
+    slot table in L2; tests/test_gpu_lu_layout2.py); beside it the product-form loop the engine used to fall back to there
+    (RELP_FT_BIG=0 leaves no layout), the dense tableau engine (131 GB of tableau + 98 GB of dense A) and the explicit inverse
+    (33 GB rewritten at every pivot), each over its first pivots of phase 1 -- the same pivots on every engine."""
+    from rust_lp_amd import MatrixData, engine, synthetic
+    v, e, k = 4000, 16000, 12
+    md = MatrixData.from_sparse_dict(synthetic.multicommodity_lp(v, e, k, 7))
+
+    class NoFixedCost:
+        fixed_cost = 0.0
+    out = {"workload": f"synthetic.multicommodity_lp({v}, {e}, {k}, seed 7): {md.nr_rows} rows, {md.nr_columns} columns, "
+                       f"{len(md.values)} entries; FirstProfitableWithMemory, phase 1, first pivots"}
+    legs = [("lu", engine.ENGINE_LU, 20000, None), ("lu_product_form_fallback", engine.ENGINE_LU, 1000, "0"),
+            ("tableau", engine.ENGINE_TABLEAU, 5000, None), ("revised", engine.ENGINE_REVISED, 250, None)]
+    for label, kind, budget, force in legs:
+        if force is not None:
+            os.environ["RELP_FT_BIG"] = force
+        try:
+            t0 = time.perf_counter()
+            t, res = _timed_run(md, NoFixedCost, kind, max_pivots=budget, trace_capacity=1024)
+            res["create_and_run_seconds"] = round(time.perf_counter() - t0, 3)
+        finally:
+            if force is not None:
+                del os.environ["RELP_FT_BIG"]
+        res["first_pivots"] = [list(p) for p in t.trace()[:250]]
+        if kind == engine.ENGINE_LU:
+            res["kernel_layout"] = t.lu_kernel_layout()
+            st = t.lu_stats()
+            res["refactorisations"] = st["refactorisations"]
+            res["last_factor"] = {q: st[q] for q in ("nnz_l", "nnz_u", "levels_l", "levels_u")}
+            if res["kernel_layout"]["persistent_kernel"]:
+                ph = t.lu_phase_cycles()
+                tot = sum(ph.values())
+                res["pivot_kernel_clocks_per_pivot"] = round(tot / max(res["pivots"], 1))
+                res["pivot_kernel_phase_share"] = {q: round(c / max(tot, 1), 4) for q, c in ph.items()}
+        t.close()
+        out[label] = res
+    first = out["lu"].pop("first_pivots")
+    for label, _, _, _ in legs[1:]:
+        out[label]["first_250_pivots_equal_the_lu_engines"] = out[label].pop("first_pivots") == first
+    out["lu_over_fallback"] = round(out["lu"]["value"] / out["lu_product_form_fallback"]["value"], 2)
+    out["lu_over_tableau"] = round(out["lu"]["value"] / out["tableau"]["value"], 2)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU as a fresh child process (nothing in
@@ -523,6 +571,7 @@ def main():
     ap.add_argument("--no-c2", action="store_true", help="skip the configs[1] (dense 2,000 x 2,000) section")
     ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] (dense 10,000 x 50,000) section")
     ap.add_argument("--no-c1", action="store_true", help="skip the configs[0] (adlittle, exact CPU path beside the f64 engines) section")
+    ap.add_argument("--no-scale", action="store_true", help="skip the 63,988-row multi-commodity section (LU engine, third kernel layout)")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (MIPLIB relaxations, degenerate pivot counts) section")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=64,
@@ -664,6 +713,8 @@ def main():
     sparse = sparse_path(events, not args.no_cpu_baseline) if solo and not args.no_sparse else None
     if sparse is not None:
         sparse["large"] = sparse_large()
+        if not args.no_scale:
+            sparse["scale"] = sparse_scale()
     c1 = config_one(not args.no_cpu_baseline) if solo and not args.no_c1 else None
     c5 = config_five() if solo and not args.no_c5 else None
 

@@ -238,16 +238,33 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         if (md.matrix_memory != RELP_MEM_HOST) return fail(RELP_E_UNSUPPORTED, "CSC input must be in host memory");
         if (!md.col_ptr) return fail(RELP_E_ARG, "col_ptr missing");
         ld_a_ = round_up(std::max<int64_t>(mc_, 1), 2);
-        std::vector<double> dense((size_t)ld_a_ * std::max(n_local, 1), 0.0);
-        for (int32_t j = col_lo_; j < col_hi_; ++j)
-            for (int64_t p = md.col_ptr[j]; p < md.col_ptr[j + 1]; ++p) {
-                const int32_t i = md.row_idx[p];
-                if (i < 0 || i >= mc_) return fail(RELP_E_ARG, "row index out of range");
-                dense[(size_t)(j - col_lo_) * ld_a_ + i] = md.values[p];
-            }
-        HIP_TRY(dev_alloc(&dA_, (int64_t)dense.size()));
+        // the dense engines' copy of the owned columns, scattered on the device from the CSC arrays (never staged dense on the host)
+        const int64_t e0 = n_local > 0 ? md.col_ptr[col_lo_] : 0, e1 = n_local > 0 ? md.col_ptr[col_hi_] : 0;
+        for (int64_t p = e0; p < e1; ++p)
+            if (md.row_idx[p] < 0 || md.row_idx[p] >= mc_) return fail(RELP_E_ARG, "row index out of range");
+        const int64_t cells = ld_a_ * std::max(n_local, 1);
+        HIP_TRY(dev_alloc(&dA_, cells));
         owns_A_ = true;
-        HIP_TRY(hipMemcpy(dA_, dense.data(), dense.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(dA_, 0, (size_t)cells * sizeof(double)));
+        if (e1 > e0) {
+            int64_t* t_ptr = nullptr; int32_t* t_idx = nullptr; double* t_val = nullptr;
+            auto drop = [&]() { if (t_ptr) (void)hipFree(t_ptr); if (t_idx) (void)hipFree(t_idx); if (t_val) (void)hipFree(t_val); };
+            if (hipMalloc(reinterpret_cast<void**>(&t_ptr), sizeof(int64_t) * (size_t)(n_local + 1)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&t_idx), sizeof(int32_t) * (size_t)(e1 - e0)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&t_val), sizeof(double) * (size_t)(e1 - e0)) != hipSuccess) {
+                drop();
+                return fail(RELP_E_ALLOC, "staging the CSC arrays");
+            }
+            hipError_t err = hipMemcpy(t_ptr, md.col_ptr + col_lo_, sizeof(int64_t) * (size_t)(n_local + 1), hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy(t_idx, md.row_idx + e0, sizeof(int32_t) * (size_t)(e1 - e0), hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy(t_val, md.values + e0, sizeof(double) * (size_t)(e1 - e0), hipMemcpyHostToDevice);
+            if (err == hipSuccess) {
+                launch_csc_to_dense(t_ptr, t_idx, t_val, n_local, dA_, ld_a_, nullptr);
+                err = hipDeviceSynchronize();
+            }
+            drop();
+            if (err != hipSuccess) return fail(RELP_E_HIP, "dense copy of the CSC input");
+        }
     } else {
         return fail(RELP_E_ARG, "unknown matrix format");
     }

@@ -191,6 +191,7 @@ struct FtState {
     int32_t  pad2_;
     double*  x_work;         // m + 1 + rhs_cap: the work vector inside the kernels when it does not live in LDS (layout 2)
     unsigned long long* chunk_mask;    // ceil(m / 64) words of scratch (layout 2: ft_compact)
+    int32_t* nz_idx; double* nz_val;   // m each (layout 2): the non-zeros of the entering column as (row, alpha), RATIO and the update of b
     int32_t  big;            // layout (relp_kernels_ft.hip: ft_layout).  0: everything in LDS.  1: spike, permutations and eta pool in
                              // global memory (L2), 32-bit slot indices.  2: x, -pi and the pivot -> slot table there as well (no per-row
                              // array in LDS: any m), 32-bit row indices in the PRICE copy
@@ -305,6 +306,9 @@ void launch_weighted_column_sums(const double* Binv, int64_t ld_b, int32_t m, co
 void launch_set_identity(double* Binv_local, int64_t ld_b, int32_t row_lo, int32_t row_hi, hipStream_t s);
 void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,
                        hipStream_t s);
+// A (zeroed, column-major, ld) := the n_cols CSC columns whose pointers start at col_ptr[0] (row_idx / values hold their entries only)
+void launch_csc_to_dense(const int64_t* col_ptr, const int32_t* row_idx, const double* values, int32_t n_cols, double* A,
+                         int64_t ld, hipStream_t s);
 
 // deferred update (see DeferredUpdate)
 // alpha[i] = v[i] + sum_j W[i,j] v[S[j]] for every row

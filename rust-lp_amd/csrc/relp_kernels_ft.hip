@@ -266,8 +266,8 @@ __device__ __forceinline__ void sweep(const FtState& st, int which, Ctx& c, int 
         if (hyper && ((st.hyper >> which) & 1)) first_level = max(first_level, ft_first_group(c, st.ell[which].reach));
     }
     int passes;
-    if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
-    else passes = ell_solve_pp<false, NT, Ctx::big>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    else passes = ell_solve_pp<false, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
     if (c.clk.on) { c.clk.passes[which] += passes; c.clk.sweeps[which] += 1; c.clk.total[which] += st.ell[which].n_passes; }
 }
 
@@ -1051,44 +1051,59 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         // ---- RATIO TEST (tableau/mod.rs:221-247; two passes as relp_device_common.h ratio_body) ------------------------
         double br;
         if constexpr (kTier >= 2) {
-        // Layout 2: alpha = x[icp[.]] is two dependent round trips to L2 per row, so every pass requests four rows before it
-        // looks at the first; the first pass leaves alpha in pb.alpha (each thread re-reads its own rows from there,
-        // coalesced); the pass over the tie band finds the leaving column AND its row.
-        double mn = INFINITY;
-        for (int j0 = tid; j0 < m; j0 += 4 * NT) {
-            int pp[4];
-            double bb[4], aa[4];
+        // Layout 2: the solve leaves x pivot-indexed and mostly zero.  One coalesced pass over x scatters alpha (dense, for
+        // whoever reads it after the launch) and appends the non-zeros as (row, alpha) pairs to a list; the ratio test, the tie
+        // band, the leaving row and the update of b then touch the list only (tableau/mod.rs:221-247 walks the stored
+        // non-zeros of the column just the same).  Every reduction is order-free (minima), so the list's order does not matter.
+        if (tid == 0) c.red_i[2 * NW] = 0;
+        __syncthreads();
+        for (int k0 = tid; k0 < m; k0 += 4 * NT) {
+            int cp[4];
+            double xv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = min(j0 + u * NT, m - 1); pp[u] = c.icp[i]; bb[u] = pb.b[i]; }
-            asm volatile("" : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(pp[3]));
+            for (int u = 0; u < 4; ++u) { const int k = min(k0 + u * NT, m - 1); xv[u] = c.x[k]; cp[u] = lu.colperm[k]; }
+            asm volatile("" : "+v"(cp[0]), "+v"(cp[1]), "+v"(cp[2]), "+v"(cp[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
 #pragma unroll
-            for (int u = 0; u < 4; ++u) aa[u] = c.x[pp[u]];
-            asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]));
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j0 + u * NT < m) { pb.alpha[j0 + u * NT] = aa[u]; mn = fmin(mn, row_ratio(aa[u], bb[u], pb.tol)); }
+            for (int u = 0; u < 4; ++u) {
+                const bool in = k0 + u * NT < m;
+                if (in) pb.alpha[cp[u]] = xv[u];
+                const bool nz = in && xv[u] != 0.0;
+                const unsigned long long mask = __ballot(nz);
+                if (mask) {                            // (wave-uniform)
+                    int at = 0;
+                    if ((tid & 63) == 0) at = atomicAdd(&c.red_i[2 * NW], __popcll(mask));
+                    at = __builtin_amdgcn_readfirstlane(at);
+                    if (nz) {
+                        const int e = at + __popcll(mask & ((1ull << (tid & 63)) - 1ull));
+                        st.nz_idx[e] = cp[u]; st.nz_val[e] = xv[u];
+                    }
+                }
+            }
         }
+        __syncthreads();
+        const int nnz = c.red_i[2 * NW];
+        // (the first entry of every thread stays in registers: a column rarely has more than NT non-zeros)
+        const bool h0 = tid < nnz;
+        const int i0 = h0 ? st.nz_idx[tid] : 0;
+        const double a0 = h0 ? st.nz_val[tid] : 0.0;
+        const double b0 = h0 ? pb.b[i0] : 0.0;
+        double mn = h0 ? row_ratio(a0, b0, pb.tol) : INFINITY;
+        for (int e = tid + NT; e < nnz; e += NT) mn = fmin(mn, row_ratio(st.nz_val[e], pb.b[st.nz_idx[e]], pb.tol));
         const double gmin = block_min_double(c, mn);
         if (gmin == INFINITY) { outcome = DEV_NO_ROW; break; }
         const double bound = gmin + pb.tol.tie * fmax(1.0, fabs(gmin));
         int best_leave = 0x7fffffff, rr = 0x7fffffff;
         tie_key_t best = kNoTieKey;
         const bool by_column = pb.tol.ratio_rule == 0;
-        for (int j0 = tid; j0 < m; j0 += 4 * NT) {
-            double bb[4], aa[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = min(j0 + u * NT, m - 1); aa[u] = pb.alpha[i]; bb[u] = pb.b[i]; }
-            asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = j0 + u * NT;
-                if (i < m && row_ratio(aa[u], bb[u], pb.tol) <= bound) {
-                    const int sc = pb.basis[i];
-                    if (by_column) { if (sc < best_leave) { best_leave = sc; rr = i; } }
-                    else { const tie_key_t k = tie_key(aa[u], sc, 1); if (k < best) { best = k; best_leave = sc; rr = i; } }
-                }
+        auto candidate = [&](int i, double a, double bi) {
+            if (row_ratio(a, bi, pb.tol) <= bound) {
+                const int sc = pb.basis[i];
+                if (by_column) { if (sc < best_leave || (sc == best_leave && i < rr)) { best_leave = sc; rr = i; } }
+                else { const tie_key_t k = tie_key(a, sc, 1); if (k < best || (k == best && i < rr)) { best = k; best_leave = sc; rr = i; } }
             }
-        }
+        };
+        if (h0) candidate(i0, a0, b0);
+        for (int e = tid + NT; e < nnz; e += NT) { const int i = st.nz_idx[e]; candidate(i, st.nz_val[e], pb.b[i]); }
         if (by_column) leaving = block_min_int(c, best_leave);
         else {
             const tie_key_t kmin = block_min_key64(c, best);
@@ -1102,16 +1117,10 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         b_r = c.red_d[NW + 1];
         c.clk.lap(FT_RATIO);
         br = b_r / alpha_r;
-        for (int j0 = tid; j0 < m; j0 += 4 * NT) {
-            double bb[4], aa[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = min(j0 + u * NT, m - 1); aa[u] = pb.alpha[i]; bb[u] = pb.b[i]; }
-            asm volatile("" : "+v"(aa[0]), "+v"(aa[1]), "+v"(aa[2]), "+v"(aa[3]), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = j0 + u * NT;
-                if (i < m) { if (i == r) pb.b[i] = br; else if (aa[u] != 0.0) pb.b[i] = fma(-aa[u], br, bb[u]); }
-            }
+        if (h0) pb.b[i0] = i0 == r ? br : fma(-a0, br, b0);
+        for (int e = tid + NT; e < nnz; e += NT) {
+            const int i = st.nz_idx[e];
+            pb.b[i] = i == r ? br : fma(-st.nz_val[e], br, pb.b[i]);
         }
         __syncthreads();
         } else {

@@ -755,6 +755,17 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t stream, u
     return z ^ (z >> 31);
 }
 
+// dense column-major copy of n_cols CSC columns (entries [col_ptr[j] - col_ptr[0], ..) of row_idx / values) into a zeroed A:
+// the dense engines' own copy of a sparse input, built where it lives (a 64,000 x 192,000 LP is 98 GB dense: staging it on the
+// host took 30 s of the engine's creation).  A thread per column, entries in order: a repeated row index keeps its last value.
+__global__ void k_csc_to_dense(const int64_t* __restrict__ col_ptr, const int32_t* __restrict__ row_idx,
+                               const double* __restrict__ values, int n_cols, double* __restrict__ A, int64_t ld) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cols) return;
+    const int64_t base = col_ptr[0];
+    for (int64_t e = col_ptr[j] - base; e < col_ptr[j + 1] - base; ++e) A[(int64_t)j * ld + row_idx[e]] = values[e];
+}
+
 // A[i, j] = (1 + x(0, (first_column + j) * m + i) % 999) / 1000   (rust-lp_amd/synthetic.py)
 __global__ void k_fill_dense(double* __restrict__ A, int64_t ld, int m, int n, uint64_t seed,
                              int64_t first_column) {
@@ -1033,6 +1044,12 @@ void launch_set_identity(double* Binv, int64_t ld_b, int32_t row_lo, int32_t row
     const int64_t total = (int64_t)(row_hi - row_lo) * ld_b;
     if (total <= 0) return;
     hipLaunchKernelGGL(k_set_identity, dim3(element_blocks(total)), dim3(256), 0, s, Binv, ld_b, row_lo, row_hi);
+}
+
+void launch_csc_to_dense(const int64_t* col_ptr, const int32_t* row_idx, const double* values, int32_t n_cols, double* A,
+                         int64_t ld, hipStream_t s) {
+    if (n_cols <= 0) return;
+    hipLaunchKernelGGL(k_csc_to_dense, dim3(cdiv(n_cols, 256)), dim3(256), 0, s, col_ptr, row_idx, values, n_cols, A, ld);
 }
 
 void launch_fill_dense(double* A, int64_t ld, int32_t m, int32_t n, uint64_t seed, int64_t first_column,

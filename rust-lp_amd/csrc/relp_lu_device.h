@@ -290,7 +290,9 @@ struct EllImage {
     const EllPass* passes; const int32_t* lvl_pass; const double* rdiag; const double* sval; const double* oval;
     const int32_t* rovf; const idx_t* sidx; const idx_t* oidx;
 };
-template <bool kStage, int NT, bool kWide = false>
+// kL2: x lives in global memory (layout 2 of the persistent kernel): the copies are two dependent round trips each, requested
+// four at a time
+template <bool kStage, int NT, bool kWide = false, bool kL2 = false>
 __device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char* base, double* x) {
     typedef typename EllIdx<kWide>::type idx_t;
     EllImage<kWide> im{s.passes, s.lvl_pass, s.rdiag, s.sval, s.oval, s.rovf, reinterpret_cast<const idx_t*>(s.sidx),
@@ -300,7 +302,20 @@ __device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char*
     // pivot, one LDS loop.  Everything the big layout adds is compiled out of the other instantiation: the persistent
     // kernel sits at 256 VGPRs with spills, and a few more live values cost 5 % of a 25FV47 pivot)
     if (s.rhs_base) {
-        if constexpr (kWide) { for (int i = tid; i < s.n_rhs; i += NT) x[s.rhs_base + i] = x[s.rhs_src[i]]; }
+        if constexpr (kL2) {
+            for (int i0 = tid; i0 < s.n_rhs; i0 += 4 * NT) {
+                int src[4];
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) src[u] = s.rhs_src[min(i0 + u * NT, s.n_rhs - 1)];
+                asm volatile("" : "+v"(src[0]), "+v"(src[1]), "+v"(src[2]), "+v"(src[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = x[src[u]];
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (i0 + u * NT < s.n_rhs) x[s.rhs_base + i0 + u * NT] = v[u];
+            }
+        } else if constexpr (kWide) { for (int i = tid; i < s.n_rhs; i += NT) x[s.rhs_base + i] = x[s.rhs_src[i]]; }
         else { for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i]; }
     }
     if (kStage) {
@@ -403,12 +418,12 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
 // of its next pass: the bookkeeping that was half of a pass's clocks in ell_solve above overlaps with the other set's pass.
 // Every wavefront joins the barrier that ends a level, whoever owned its last pass; two passes of one level may run at the
 // same time (they are independent).
-template <bool kStage, int NT, bool kWide = false, class Lap = NoLap>
+template <bool kStage, int NT, bool kWide = false, class Lap = NoLap, bool kL2 = false>
 __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
     static_assert(NT == 512, "two sets of 256 lanes");
     typedef typename EllIdx<kWide>::type idx_t;
     constexpr int kEllLg = EllIdx<kWide>::shift, kEllIdxMask = EllIdx<kWide>::mask;       // (shadow the 16-bit constants)
-    const EllImage<kWide> im = ell_stage<kStage, NT, kWide>(s, base, x);
+    const EllImage<kWide> im = ell_stage<kStage, NT, kWide, kL2>(s, base, x);
     const double* rdiag = im.rdiag; const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
     const idx_t* sidx = im.sidx; const idx_t* oidx = im.oidx;
     if constexpr (kWide) if (s.n_triv > 0) {           // the rows without entries (U, U'): nothing to wait for, no passes

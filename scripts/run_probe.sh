@@ -1,5 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests/test_gpu_lu_layout2.py -m gpu -x -q --durations=10 > gpurun_out/layout2_tests.log 2>&1 || { tail -n 60 gpurun_out/layout2_tests.log; exit 1; }
-tail -n 18 gpurun_out/layout2_tests.log
+SECONDS=0; python bench.py > gpurun_out/bench_scale.json 2> gpurun_out/bench_scale.err || { tail -n 30 gpurun_out/bench_scale.err; exit 1; }
+echo "bench seconds $SECONDS"
+python scripts/show_scale.py gpurun_out/bench_scale.json
