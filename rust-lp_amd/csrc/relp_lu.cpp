@@ -517,7 +517,9 @@ void ell_pack(const FusedSchedule& f, bool keep_trivial, EllPacked* out, bool wi
             if (n == 0 && !keep_trivial && t.diag[k] == 1.0) continue;
             if (n == 0 && list_trivial) {                // (such a row has no dependency: it sits in the first level)
                 out->rdiag[k] = 1.0 / t.diag[k];
-                out->triv.push_back(k);
+                // (a unit diagonal leaves x[k] as it is; a pivot that is masked later is zeroed by the kernel before every
+                // sweep -- ft_ftran, ft_ut_solve -- so its row need not be visited for that either)
+                if (t.diag[k] != 1.0) out->triv.push_back(k);
                 continue;
             }
             int32_t lg = 0;

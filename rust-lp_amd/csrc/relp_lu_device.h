@@ -433,10 +433,20 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
             for (int u = 0; u < 4; ++u) k[u] = s.triv[min(i0 + u * NT, s.n_triv - 1)];
             // (only where x is not zero: the right-hand sides are sparse, and 1 / diagonal of an image that is not staged is a
             // dependent round trip to L2)
+            if constexpr (kL2) {                      // (x in L2: operand and 1 / diagonal of all four requested together)
+                asm volatile("" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]));
+                double v[4], rd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u] = x[k[u]]; rd[u] = rdiag[k[u]]; }
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(rd[0]), "+v"(rd[1]), "+v"(rd[2]), "+v"(rd[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (i0 + u * NT < s.n_triv && v[u] != 0.0) x[k[u]] = v[u] * rd[u];
+            } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double v = x[k[u]];
                 if (i0 + u * NT < s.n_triv && v != 0.0) x[k[u]] = v * rdiag[k[u]];
+            }
             }
         }
         __syncthreads();
