@@ -56,6 +56,14 @@ def test_driver_command_emits_one_complete_json_line():
         for label in ("lu", "revised", "tableau"):
             assert large[name][label]["outcome"] == "optimal" and abs(large[name][label]["pin_error"]) < tol, (name, label)
     assert large["80BAU3B"]["lu"]["pivot_kernel_clocks_per_pivot"] and large["DFL001"]["lu"]["pivot_kernel_clocks_per_pivot"]
+    # the LU engine beyond one CU's LDS: third kernel layout against the loop it used to fall back to and the dense engines
+    scale = sp["scale"]
+    assert scale["lu"]["kernel_layout"]["persistent_kernel"] and scale["lu"]["kernel_layout"]["layout"] == 2
+    assert not scale["lu_product_form_fallback"]["kernel_layout"]["persistent_kernel"]
+    for leg in ("lu_product_form_fallback", "tableau", "revised"):
+        assert scale[leg]["first_250_pivots_equal_the_lu_engines"] is True, leg
+    assert scale["lu"]["rows"] == 63988 and scale["lu"]["pivots"] == 20000 and scale["lu"]["value"] > 1000
+    assert scale["lu_over_fallback"] > 5 and scale["lu"]["pivot_kernel_clocks_per_pivot"] > 0
     stride = out["kernel_event_stride"]
     assert stride % block != 0                                            # (no aliasing with the block)
 
