@@ -310,6 +310,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
             luf_enabled_ = df && std::atoi(df) != 0;
             luf_download_ = df && std::atoi(df) == 2;
             lu_lookahead_env_ = la ? std::atoi(la) : 8;
+            lu_lookahead_set_ = la != nullptr;
             lu_fuse_lanes_env_ = fl ? std::atoi(fl) : 256;
         }
         relp_status_t fst = ft_plan_and_alloc();           // Forrest-Tomlin on the device when the LDS budget allows

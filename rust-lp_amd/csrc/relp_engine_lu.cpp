@@ -456,7 +456,7 @@ relp_status_t Engine::ft_plan_and_alloc() {
     // not take stages the triangular factors, and an image that does not fit is solved from L2 at several times the cost.
     // Default interval 48: with a refactorisation at ~0.7 ms and ~1,100 clocks per pending update and pivot, the optimum is
     // flat between 40 and 64, and 48 x 49 doubles leave 14 KB more for the images than 64 x 65.
-    const int32_t want = cfg_.update_block < 0 ? 48 : std::max(1, std::min(cfg_.update_block, kFtMaxSlots));
+    int32_t want = cfg_.update_block < 0 ? 48 : std::max(1, std::min(cfg_.update_block, kFtMaxSlots));
     // Two layouts (relp_kernels_ft.hip: ft_layout).  "All in LDS": x with m right-hand-side copies, spike, -pi, permutations,
     // eta pool -- 63 bytes per row.  "big": x, -pi and the slot tables only (17 bytes per row + 8 per right-hand-side copy the
     // fused schedules may use: as many as fit, a schedule that needs more is packed level by level), the rest read from L2;
@@ -493,7 +493,10 @@ relp_status_t Engine::ft_plan_and_alloc() {
     if (force_big < 1 && m_ < kPriceLongFlag && small_rhs > 0 && plan(0, small_rhs, 4096, force_big == 0 ? 16 : 32)) {}
     else if (force_big != 0 && force_big != 2 && fits_tier1 &&
              (plan(1, m_, kFtMinStage) || plan(1, std::min(m_, 2048), 32 * 1024) || plan(1, std::min(m_, 1024), 8 * 1024) || plan(1, 0, 4096))) {}
-    else if (force_big != 0 && force_big != 1 && fits_tier2 && plan(2, m_, kFtMinStage)) {}
+    // (layout 2 by default refactorises every 64 updates and lets the kernel make 16 of them while the host factorises: at
+    // 64,000 rows a refactorisation is 5 ms of host time against 0.35 ms per pivot, and a pending update costs a pivot whose
+    // per-row loops dominate next to nothing -- measured 2,670 it/s at 48 / 8, 2,870 at 64 / 8, 2,975 at 64 / 16)
+    else if (force_big != 0 && force_big != 1 && fits_tier2 && ((want = cfg_.update_block < 0 ? 64 : want), plan(2, m_, kFtMinStage))) {}
     if (!ft_) return RELP_OK;
     if (std::getenv("RELP_DEBUG"))
         std::fprintf(stderr, "[relp] persistent pivot kernel: m %d, layout %s, %d right-hand-side copies, dense tail %d, LDS base %zu bytes\n",
@@ -739,7 +742,7 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     struct Tick { int64_t& t; ~Tick() { ++t; } };
     // Look-ahead refactorisation (lu_refactor_lookahead): the kernel returns `la` updates before the file is full, and fills
     // the rest while the host factorises.  On for refactorisation intervals from 24 on; RELP_LU_LOOKAHEAD = 0 switches it off.
-    const int32_t la_env = luf_enabled_ ? 0 : lu_lookahead_env_;     // (RELP_LU_LOOKAHEAD, read at create; the device
+    const int32_t la_env = luf_enabled_ ? 0 : (ft_tier_ >= 2 && !lu_lookahead_set_) ? 16 : lu_lookahead_env_;     // (RELP_LU_LOOKAHEAD, read at create; the device
                                                                      // factorisation is synchronous on the engine's stream)
     const int32_t la = (fts_.max_updates >= 24 && la_env > 0) ? std::min(la_env, fts_.max_updates / 3) : 0;
     bool have_basis = false;                               // h_basis_ holds the basis as the last launch left it
@@ -815,7 +818,7 @@ relp_status_t Engine::lu_kernel_layout(int32_t* out4) const {
 
 relp_status_t Engine::lu_lookahead_stats(int64_t* out4) const {
     if (!lu_) return RELP_E_STATE;
-    out4[0] = lu_lookahead_installs_; out4[1] = lu_replayed_changes_; out4[2] = lu_lookahead_env_; out4[3] = lu_fuse_lanes_env_;
+    out4[0] = lu_lookahead_installs_; out4[1] = lu_replayed_changes_; out4[2] = (ft_tier_ >= 2 && !lu_lookahead_set_) ? 16 : lu_lookahead_env_; out4[3] = lu_fuse_lanes_env_;
     return RELP_OK;
 }
 

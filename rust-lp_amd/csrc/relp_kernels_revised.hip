@@ -166,21 +166,56 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
                 }
             }
         };
+        auto block_low = [&](int v) {                      // minimum over the workgroup, in every thread
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_down(v, off, 64));
+            __syncthreads();
+            if (lane == 0) s_j[wave] = v;
+            __syncthreads();
+            int low = s_j[0];
+            for (int w = 1; w < kSingleBlock / 64; ++w) low = min(low, s_j[w]);
+            return low;
+        };
         if (listed <= kListMax) {
             for (int i = 0; i < listed; ++i) scan_slot(s_list[i], threadIdx.x, kSingleBlock);
+            lowest = block_low(lowest);
         } else {
-            for (int t = threadIdx.x; t < count; t += kSingleBlock)
-                if (sp.k1[t] <= bound) scan_slot(t, 0, 1);
+            // Many slots inside the band (exact ties: integer costs at the first pivots of a phase).  A slot inside the band
+            // holds a column inside the band -- its own minimum -- and the slots are in column order, so the lowest index is
+            // in the FIRST such slot: artificial columns (the low end of the virtual slots) before the structural slots before
+            // the other virtual columns.  (One thread per slot walking its 256 columns was 58 us per pivot at 141,000 columns.)
+            const int n_virt = count - sp.nb_struct;
+            const int n_art_slots = min(n_virt, (ct.nr_artificial + kThreads - 1) / kThreads);
+            for (int v = threadIdx.x / kThreads; v < n_art_slots; v += kSingleBlock / kThreads) {
+                if (!(sp.k1[sp.nb_struct + v] <= bound)) continue;
+                const int j = v * kThreads + threadIdx.x % kThreads;
+                if (j < ct.nr_artificial) {
+                    const double dv = d[j];
+                    if (!sp.in_basis[j] && dv < -sp.tol_cost && dv <= bound && j < lowest) lowest = j;
+                }
+            }
+            lowest = n_art_slots > 0 ? block_low(lowest) : 0x7fffffff;
+            if (lowest == 0x7fffffff) {
+                int first = 0x7fffffff;
+                for (int t = threadIdx.x; t < sp.nb_struct; t += kSingleBlock) if (sp.k1[t] <= bound) { first = t; break; }
+                first = block_low(first);
+                if (first != 0x7fffffff) {
+                    scan_slot(first, threadIdx.x, kSingleBlock);
+                    lowest = block_low(lowest);
+                }
+            }
+            int after = sp.nb_struct - 1;                  // the virtual slots, ascending, until one yields a column
+            while (lowest == 0x7fffffff) {
+                int first = 0x7fffffff;
+                for (int t = after + 1 + threadIdx.x; t < count; t += kSingleBlock) if (sp.k1[t] <= bound) { first = t; break; }
+                first = block_low(first);
+                if (first == 0x7fffffff) break;
+                scan_slot(first, threadIdx.x, kSingleBlock);
+                lowest = block_low(lowest);
+                after = first;
+            }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_down(lowest, off, 64));
-        if (lane == 0) s_j[wave] = lowest;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int low = 0x7fffffff;
-            for (int w = 0; w < kSingleBlock / 64; ++w) low = min(low, s_j[w]);
-            bj = low;
-        }
+        if (threadIdx.x == 0) bj = lowest;
     }
     if (threadIdx.x == 0) {
         if (bj == 0x7fffffff) {

@@ -1,11 +1,10 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_lu_layout2.py -m gpu -x -q > gpurun_out/layout2_tests.log 2>&1 || { tail -n 60 gpurun_out/layout2_tests.log; exit 1; }
-tail -n 2 gpurun_out/layout2_tests.log
-for big in 1 2; do
-  RELP_FT_BIG=$big timeout -k 10 200 python scripts/lu_large.py netlib/DFL001.SIF 1 lu 30000 -1 1 1 > gpurun_out/dfl_big$big.log 2>&1 || true
-  tail -n 3 gpurun_out/dfl_big$big.log
-done
-RELP_DEBUG=1 timeout -k 10 200 python scripts/xl_probe.py mc:4000,16000,12 0 lu 20000 > gpurun_out/mc64k_lu3.log 2>&1 || true
-grep -v "schedule\|so far" gpurun_out/mc64k_lu3.log | tail -n 7
+timeout -k 10 1150 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_gpu.py > gpurun_out/gpu_tier.log 2>&1 || { tail -n 60 gpurun_out/gpu_tier.log; exit 1; }
+tail -n 3 gpurun_out/gpu_tier.log
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_scale_le -o le -- python3 scripts/xl_probe.py le:30000,90000 0 lu 6000 > gpurun_out/prof_scale_le.log 2>&1
+grep "pivots " gpurun_out/prof_scale_le.log | tail -n 2
+find gpurun_out/prof_scale_le -name "*kernel_trace.csv" -delete
+head -4 gpurun_out/prof_scale_le/le_kernel_stats.csv | cut -c1-120
