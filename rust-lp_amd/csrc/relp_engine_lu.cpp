@@ -250,6 +250,7 @@ relp_status_t Engine::lu_upload_factors() {
     // (relp_lu.hpp: fuse_levels), packed "ELL by pass", one contiguous image each (headers | lvl_pass | rdiag | sval | oval |
     // rovf | sidx | oidx); rows of U and U' without entries are kept, an update may mask them
     EllPacked ell[4];
+    size_t o_rpos[4] = {0, 0, 0, 0}, o_tbits[4] = {0, 0, 0, 0};
     size_t o_ell[4] = {0, 0, 0, 0}, o_via_ptr[4] = {0, 0, 0, 0}, o_via_pos[4] = {0, 0, 0, 0}, o_triv[4] = {0, 0, 0, 0},
            o_reach[4] = {0, 0, 0, 0}, o_rhs[4] = {0, 0, 0, 0};
     int32_t rhs_base[4] = {0, 0, 0, 0};
@@ -311,6 +312,14 @@ relp_status_t Engine::lu_upload_factors() {
         for (int k = 0; k < 4; ++k) {
             o_rhs[k] = put(ell[k].rhs_src.data(), sizeof(int32_t) * ell[k].rhs_src.size());
             o_triv[k] = put(ell[k].triv.data(), sizeof(int32_t) * ell[k].triv.size());
+            if (ft_tier_ >= 2) {                       // layout 2 walks the non-zeros of x: the inverse of rhs_src, `triv` as a bitmap
+                std::vector<int32_t> pos(m_, -1);
+                for (size_t i = 0; i < ell[k].rhs_src.size(); ++i) pos[ell[k].rhs_src[i]] = (int32_t)i;
+                std::vector<uint32_t> tb((size_t)(m_ + 31) / 32 + 1, 0u);
+                for (int32_t r : ell[k].triv) tb[(size_t)r >> 5] |= 1u << (r & 31);
+                o_rpos[k] = put(pos.data(), sizeof(int32_t) * pos.size());
+                o_tbits[k] = put(tb.data(), sizeof(uint32_t) * tb.size());
+            }
             o_reach[k] = put(ell[k].reach.data(), sizeof(int32_t) * ell[k].reach.size());
         }
     }
@@ -393,6 +402,11 @@ relp_status_t Engine::lu_upload_factors() {
     }
     HIP_TRY(hipStreamSynchronize(stream_));             // (the pinned buffer is rewritten by the next refactorisation)
     if (ft_) {
+        if (ft_tier_ >= 2 && fts_.m != m_) {           // rows were removed: the bitmaps saved between launches describe another m
+            const int32_t reset[4] = {-1, -1, 0, 0};
+            HIP_TRY(hipMemcpyAsync(fts_.nzc, reset, sizeof reset, hipMemcpyHostToDevice, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+        }
         fts_.m = m_;
         fts_.inv_rowperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_irp);
         fts_.inv_colperm = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_icp);
@@ -430,6 +444,8 @@ relp_status_t Engine::lu_upload_factors() {
             d.reach = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_reach[k]);
             d.rhs_src = reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rhs[k]);
             d.n_rhs = ft_big_ ? (int32_t)e.rhs_src.size() : -1; d.pad_ = 0;
+            d.rhs_pos = ft_tier_ >= 2 ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_rpos[k]) : nullptr;
+            d.triv_bits = ft_tier_ >= 2 ? reinterpret_cast<const uint32_t*>(d_lu_buf_ + o_tbits[k]) : nullptr;
             const bool has_via = !e.via_ptr.empty();
             d.via_ptr = has_via ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_via_ptr[k]) : nullptr;
             d.via_pos = has_via ? reinterpret_cast<const int32_t*>(d_lu_buf_ + o_via_pos[k]) : nullptr;
@@ -512,7 +528,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
                   o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32),
                   o_journal = take(8 * tc), o_spw = take(8 * m), o_xw = take(ft_tier_ >= 2 ? 8 * (m + 1 + ft_rhs_cap_) : 0),
                   o_cm = take(ft_tier_ >= 2 ? 8 * ((m + 63) / 64 + 1) : 0), o_nzi = take(ft_tier_ >= 2 ? 4 * m : 0),
-                  o_nzv = take(ft_tier_ >= 2 ? 8 * m : 0);
+                  o_nzv = take(ft_tier_ >= 2 ? 8 * m : 0), o_rhoi = take(ft_tier_ >= 2 ? 4 * m : 0), o_nzc = take(16),
+                  o_bits = take(ft_tier_ >= 2 ? kFtBitmapBytes + 1024 : 0);
     ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
     HIP_TRY(hipMemset(d_ft_buf_, 0, (size_t)o));
@@ -549,6 +566,13 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.chunk_mask = ft_tier_ >= 2 ? reinterpret_cast<unsigned long long*>(d_ft_buf_ + o_cm) : nullptr;
     fts_.nz_idx = ft_tier_ >= 2 ? reinterpret_cast<int32_t*>(d_ft_buf_ + o_nzi) : nullptr;
     fts_.nz_val = ft_tier_ >= 2 ? reinterpret_cast<double*>(d_ft_buf_ + o_nzv) : nullptr;
+    fts_.rho_idx = ft_tier_ >= 2 ? reinterpret_cast<int32_t*>(d_ft_buf_ + o_rhoi) : nullptr;
+    fts_.nzc = reinterpret_cast<int32_t*>(d_ft_buf_ + o_nzc);
+    fts_.bits_save = ft_tier_ >= 2 ? reinterpret_cast<uint32_t*>(d_ft_buf_ + o_bits) : nullptr;
+    {   // (pb.alpha / pb.rho unknown, no bitmaps saved yet)
+        const int32_t reset[4] = {-1, -1, 0, 0};
+        HIP_TRY(hipMemcpy(fts_.nzc, reset, sizeof reset, hipMemcpyHostToDevice));
+    }
     fts_.big = ft_tier_; fts_.rhs_cap = ft_rhs_cap_;
     {   // hyper-sparse starts: L and L' by default (U' starts from the leaving pivot's level anyway; on U the spike reaches the first groups: measured 31.4 of 31.4 passes on 25FV47, not worth the reduction); RELP_FT_HYPER = bit mask
         const char* e = std::getenv("RELP_FT_HYPER");
@@ -714,7 +738,7 @@ void Engine::ft_enqueue_pivots(const FtState& go, int rule, int64_t left) {
             spv.offset = nb_struct;
             launch_price_virtual_sel(ct, d_minus_pi_, d_d_, phase_, spv, d_rec_, stream_);
         }
-        launch_select_partials_csc(sp, nb_struct + nb_virt, d_d_, csc(), ct, m_, d_aq_, d_rec_, stream_);
+        launch_select_partials_csc(sp, nb_struct + nb_virt, d_d_, csc(), ct, m_, nullptr, d_rec_, stream_);
         pb.mirror = k + 1 == batch ? d_mirror_ : nullptr;
         launch_ft_run(dlu_, go, pb, 1, stream_);
     }
@@ -792,8 +816,10 @@ relp_status_t Engine::lu_phase_cycles(int64_t* out16) {
     HIP_TRY(hipStreamSynchronize(stream_));
     HIP_TRY(hipMemcpy(out16, fts_.prof, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (std::getenv("RELP_DEBUG")) {                       // passes walked per sweep of L, U, U', L' against the whole schedule
-        int64_t ex[12];
+        int64_t ex[16];
         HIP_TRY(hipMemcpy(ex, fts_.prof + 16, sizeof ex, hipMemcpyDeviceToHost));
+        if (ex[15]) std::fprintf(stderr, "[relp] non-zeros per pivot (layout 2): entering column %.1f, eta row %.1f, spike %.1f\n",
+                                 (double)ex[12] / ex[15], (double)ex[13] / ex[15], (double)ex[14] / ex[15]);
         static const char* nm[4] = {"L", "U", "U'", "L'"};
         for (int k = 0; k < 4; ++k)
             if (ex[4 + k]) std::fprintf(stderr, "[relp] %s: %lld sweeps, %.1f passes walked of %.1f on average\n", nm[k], (long long)ex[4 + k],

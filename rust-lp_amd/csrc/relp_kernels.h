@@ -132,6 +132,9 @@ struct EllSchedule {
     const int32_t* reach;        // m: first group in which x[p] matters (EllPacked::reach) -> where a sweep may start
     const int32_t* rhs_src;      // n_rhs: slot index rhs_base + i reads the right-hand side of pivot rhs_src[i] (EllPacked::rhs_src)
     int32_t n_rhs, pad_;
+    // layout 2 of the persistent kernel (x as a sparse vector: relp_kernels_ft.hip, "hs_"), else null:
+    const int32_t* rhs_pos;      // m: i with rhs_src[i] == pivot, or -1 (the inverse of rhs_src)
+    const uint32_t* triv_bits;   // m bits: pivot is in `triv`
 };
 // Column indices at or above this value are artificial variables that survived phase 1 (see
 // Engine::switch_to_phase_two): INT32_MAX - (na - 1 - a).  They have no flag, no cost and no column.
@@ -156,6 +159,14 @@ static constexpr int kFtWaves = kFtThreads / 64;       // sparse lists are bucke
 static constexpr int kFtMaxSlots = 64;                 // one lane of a wavefront per slot in the chains over TC
 static constexpr int kFtMaxRows = 1 << 20;             // (layout 2 keeps no per-row array in LDS; the spike pool is tcap x m pairs)
 static constexpr int kFtLdsBudget = 156 * 1024;        // of the CU's 160 KB
+// Layout 2 keeps "may be non-zero" bitmaps of x (with its right-hand-side copies) and of the spike in LDS, one bit per 2^shift
+// entries: the smallest shift with which both fit kFtBitmapBytes.
+static constexpr int kFtBitmapBytes = 40 * 1024;
+static inline __host__ __device__ int ft_bitmap_shift(int m, int rhs_cap) {
+    int s = 0;
+    while (((((long long)m + 1 + rhs_cap) >> s) + 64 + (((long long)m) >> s) + 64) / 8 > kFtBitmapBytes) ++s;
+    return s;
+}
 // Everything the Forrest-Tomlin update needs to know about the leaving pivot p, together in one cache line segment (it was
 // five dependent global round trips: task -> row header -> entries, via_ptr -> via_pos, twice).
 struct FtPivotInfo {
@@ -192,6 +203,10 @@ struct FtState {
     double*  x_work;         // m + 1 + rhs_cap: the work vector inside the kernels when it does not live in LDS (layout 2)
     unsigned long long* chunk_mask;    // ceil(m / 64) words of scratch (layout 2: ft_compact)
     int32_t* nz_idx; double* nz_val;   // m each (layout 2): the non-zeros of the entering column as (row, alpha), RATIO and the update of b
+    int32_t* rho_idx;                  // m (layout 2): the rows where the last pivot row rho is not zero
+    int32_t* nzc;                      // [0] entries of nz_idx that describe pb.alpha, [1] of rho_idx / pb.rho (-1: unknown, the
+                                       // vectors are rewritten densely), [2] bits_save holds the bitmaps of x and the spike
+    uint32_t* bits_save;               // the two LDS bitmaps between launches
     int32_t  big;            // layout (relp_kernels_ft.hip: ft_layout).  0: everything in LDS.  1: spike, permutations and eta pool in
                              // global memory (L2), 32-bit slot indices.  2: x, -pi and the pivot -> slot table there as well (no per-row
                              // array in LDS: any m), 32-bit row indices in the PRICE copy

@@ -26,7 +26,8 @@ __host__ __device__ inline int64_t up16(int64_t b) { return (b + 15) / 16 * 16; 
 // byte offsets of the dynamic LDS arrays
 struct FtLayout {
     int64_t x, sp, pi, perm, tc, dots, zt, uv, ct, slot_pivot, slot_prev, slot_live, slot_next, eta_off, spk_off, tslot, eta_idx,
-        eta_val, red_d, red_i, stage, total;
+        eta_val, red_d, red_i, bx, bsp, stage, total;
+    int bx_words, bsp_words, bit_shift;               // (layout 2) the bitmaps of x and of the spike, one bit per 2^bit_shift entries
 };
 // `big` (FtState::big, m beyond ~2,400 rows): only what a pass of a solve touches stays in LDS -- x (with `rhs_cap` words for
 // the right-hand-side copies of the fused schedules), -pi (PRICE gathers from it), the slot tables and the dense tail; the spike, the
@@ -49,6 +50,10 @@ __host__ __device__ inline FtLayout ft_layout(int m, int tcap, int eta_cap, int 
     L.tslot = take(huge ? 0 : m);
     L.eta_idx = take(big ? 0 : 4LL * eta_cap); L.eta_val = take(big ? 0 : 8LL * eta_cap);
     L.red_d = take(8LL * 2 * NW); L.red_i = take(4LL * 4 * NW + 64);
+    L.bit_shift = huge ? ft_bitmap_shift(m, rhs_cap) : 0;
+    L.bx_words = huge ? (int)(((((int64_t)m + 1 + rhs_cap) >> L.bit_shift) + 32) / 32) : 0;
+    L.bsp_words = huge ? (int)(((((int64_t)m) >> L.bit_shift) + 32) / 32) : 0;
+    L.bx = take(4LL * L.bx_words); L.bsp = take(4LL * L.bsp_words);
     L.stage = o; L.total = o;
     return L;
 }
@@ -62,19 +67,20 @@ enum FtPhase { FT_PRICE = 0, FT_SCATTER, FT_L, FT_ETA_FWD, FT_PUSH, FT_U, FT_RAT
 struct FtClock {
     long long acc[FT_PHASES]; long long last; bool on;
     long long passes[4], sweeps[4], total[4];        // per schedule: passes walked, sweeps, passes of the whole schedule
+    long long nnz[4];                                // non-zeros met: entering column alpha, eta row, spike, (pivots counted)
     __device__ __forceinline__ void start(const long long* out) {
         on = out != nullptr && threadIdx.x == 0;
         for (int k = 0; k < FT_PHASES; ++k) acc[k] = 0;
-        for (int k = 0; k < 4; ++k) { passes[k] = 0; sweeps[k] = 0; total[k] = 0; }
+        for (int k = 0; k < 4; ++k) { passes[k] = 0; sweeps[k] = 0; total[k] = 0; nnz[k] = 0; }
         last = on ? clock64() : 0;
     }
     __device__ __forceinline__ void lap(int phase) {            // phase is a constant at every call site: acc stays in registers
         if (on) { const long long now = clock64(); acc[phase] += now - last; last = now; }
     }
-    __device__ __forceinline__ void flush(long long* out) {
+    __device__ __forceinline__ void flush(long long* out, bool with_nnz) {
         if (on) {
             for (int k = 0; k < FT_PHASES; ++k) out[k] += acc[k];
-            for (int k = 0; k < 4; ++k) { out[16 + k] += passes[k]; out[20 + k] += sweeps[k]; out[24 + k] += total[k]; }
+            for (int k = 0; k < 4; ++k) { out[16 + k] += passes[k]; out[20 + k] += sweeps[k]; out[24 + k] += total[k]; if (with_nnz) out[28 + k] += nnz[k]; }
         }
     }
 };
@@ -88,6 +94,12 @@ struct FtCtxT {
     // the wavefront that owns pivot k in the bucketed lists (eta pool, spike pool): see ft_compact
     static __device__ __forceinline__ int bucket_of(int k) { return huge ? (k >> 6) % NW : k % NW; }
     unsigned long long* chunk_mask;                    // (layout 2) ceil(m / 64) ballots, scratch of ft_compact
+    // (layout 2) x and the spike as sparse vectors: dense arrays in L2 plus "may be non-zero" bitmaps in LDS, a bit per 2^gs
+    // entries.  Invariant: bit clear => the entries are 0.0 in memory.  Every store of a value that may be non-zero marks
+    // (hs_mark); every per-row loop walks the set bits (hs_for_each) -- an entering column of a 120,000-row multi-commodity
+    // LP has 13 non-zeros, its eta row 16, its spike 2.
+    uint32_t *bx, *bsp;
+    int gs, bx_words, bsp_words;
     double *x, *sp, *pi, *TC, *dots, *zt, *uv, *ct, *eta_val, *red_d;      // (big: sp, eta_val, eta_idx and the permutations are global)
     int *slot_pivot, *slot_prev, *slot_live, *slot_next, *eta_off, *spk_off, *eta_idx, *red_i;
     tslot_t* tslot;
@@ -100,7 +112,10 @@ struct FtCtxT {
 template <class Ctx>
 __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, const FtState& st) {
     const FtLayout L = ft_layout(st.m, st.tcap, st.eta_cap, Ctx::tier, st.rhs_cap);
-    if constexpr (Ctx::huge) { c.x = st.x_work; c.pi = nullptr; c.tslot = st.tslot; c.chunk_mask = st.chunk_mask; }      // (-pi: bound by ft_load to the engine's own vector)
+    if constexpr (Ctx::huge) {                         // (-pi: bound by ft_load to the engine's own vector)
+        c.x = st.x_work; c.pi = nullptr; c.tslot = st.tslot; c.chunk_mask = st.chunk_mask;
+        c.bx = (uint32_t*)(lds + L.bx); c.bsp = (uint32_t*)(lds + L.bsp); c.gs = L.bit_shift; c.bx_words = L.bx_words; c.bsp_words = L.bsp_words;
+    }
     else { c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.tslot = (signed char*)(lds + L.tslot); }
     c.TC = (double*)(lds + L.tc);
     if constexpr (Ctx::big) {
@@ -117,6 +132,87 @@ __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, c
     c.red_d = (double*)(lds + L.red_d); c.red_i = (int*)(lds + L.red_i); c.stage = lds + L.stage;
     c.m = st.m; c.tcap = st.tcap; c.ldt = st.ldt; c.eta_cap = st.eta_cap; c.journal_n = 0;
     c.clk.start(nullptr);
+}
+
+// ---- layout 2: sparse-vector helpers ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void hs_mark(uint32_t* bits, int gs, int k) { atomicOr(&bits[(k >> gs) >> 5], 1u << ((k >> gs) & 31)); }
+__device__ __forceinline__ bool hs_test(const uint32_t* bits, int gs, int k) { return (bits[(k >> gs) >> 5] >> ((k >> gs) & 31)) & 1u; }
+// f(k) for every entry k < n whose bit is set; a thread per word, its bits one after the other (the vectors hold a few dozen
+// non-zeros among 10^5 entries: most threads find nothing).  No barrier inside; the caller decides.
+template <class F>
+__device__ __forceinline__ void hs_for_each(const uint32_t* bits, int gs, int first, int n, F f) {
+    const int w0 = (first >> gs) >> 5, w1 = (((n - 1) >> gs) >> 5) + 1;
+    for (int w = w0 + (int)threadIdx.x; w < w1; w += NT) {
+        uint32_t word = bits[w];
+        while (word) {
+            const int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            const int k0 = ((w << 5) + b) << gs;
+            if (gs == 0) { if (k0 >= first && k0 < n) f(k0); }
+            else for (int k = max(k0, first); k < min(k0 + (1 << gs), n); ++k) f(k);
+        }
+    }
+}
+// vec := 0 wherever its bitmap says it may not be, bitmap := empty.  Barriers on both sides.
+__device__ __forceinline__ void hs_clear(double* vec, uint32_t* bits, int gs, int words, int n) {
+    __syncthreads();
+    hs_for_each(bits, gs, 0, n, [&](int k) { vec[k] = 0.0; });
+    __syncthreads();
+    for (int w = threadIdx.x; w < words; w += NT) bits[w] = 0u;
+    __syncthreads();
+}
+// Kernel entry: the bitmaps as the previous launch left them (FtState::bits_save), or -- unknown contents -- both vectors zeroed
+// densely.  Kernel exit: hs_leave(save = true) by the kernels that keep the invariant to the end.
+template <class Ctx>
+__device__ __forceinline__ void hs_enter(Ctx& c, const FtState& st) {
+    if constexpr (Ctx::huge) {
+        const int tid = threadIdx.x;
+        if (st.nzc[2] == 1) {
+            for (int w = tid; w < c.bx_words; w += NT) c.bx[w] = st.bits_save[w];
+            for (int w = tid; w < c.bsp_words; w += NT) c.bsp[w] = st.bits_save[c.bx_words + w];
+        } else {
+            for (int k = tid; k < c.m + 1 + st.rhs_cap; k += NT) c.x[k] = 0.0;
+            for (int k = tid; k < c.m; k += NT) c.sp[k] = 0.0;
+            for (int w = tid; w < c.bx_words; w += NT) c.bx[w] = 0u;
+            for (int w = tid; w < c.bsp_words; w += NT) c.bsp[w] = 0u;
+        }
+        __syncthreads();
+    }
+}
+template <class Ctx>
+__device__ __forceinline__ void hs_leave(Ctx& c, const FtState& st, bool save) {
+    if constexpr (Ctx::huge) {
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (save) {
+            for (int w = tid; w < c.bx_words; w += NT) st.bits_save[w] = c.bx[w];
+            for (int w = tid; w < c.bsp_words; w += NT) st.bits_save[c.bx_words + w] = c.bsp[w];
+        }
+        if (tid == 0) st.nzc[2] = save ? 1 : 0;
+    }
+}
+// x[k] := v (a value that may be non-zero)
+template <class Ctx>
+__device__ __forceinline__ void xset(Ctx& c, int k, double v) {
+    c.x[k] = v;
+    if constexpr (Ctx::huge) hs_mark(c.bx, c.gs, k);
+}
+// x[k] := value(k) for every k < m (a dense right-hand side of the step-wise API).  Ends with a barrier.
+template <class Ctx, class F>
+__device__ __forceinline__ void xfill(Ctx& c, const FtState& st, F value) {
+    if constexpr (Ctx::huge) {
+        hs_clear(c.x, c.bx, c.gs, c.bx_words, c.m + 1 + st.rhs_cap);
+        for (int k = threadIdx.x; k < c.m; k += NT) { const double v = value(k); if (v != 0.0) xset(c, k, v); }
+    } else {
+        for (int k = threadIdx.x; k < c.m; k += NT) c.x[k] = value(k);
+    }
+    __syncthreads();
+}
+// x := 0 (ends with a barrier)
+template <class Ctx>
+__device__ __forceinline__ void xzero(Ctx& c, const FtState& st) {
+    if constexpr (Ctx::huge) hs_clear(c.x, c.bx, c.gs, c.bx_words, c.m + 1 + st.rhs_cap);
+    else { for (int k = threadIdx.x; k < c.m; k += NT) c.x[k] = 0.0; __syncthreads(); }
 }
 
 // global state -> LDS (ends with a barrier)
@@ -247,6 +343,10 @@ template <class Ctx> __device__ __forceinline__ int block_min_int(Ctx& c, int v)
 template <class Ctx>
 __device__ __forceinline__ int ft_first_group(Ctx& c, const int32_t* __restrict__ reach) {
     int g = 0x7fffffff;
+    if constexpr (Ctx::huge) {
+        hs_for_each(c.bx, c.gs, 0, c.m, [&](int k) { if (c.x[k] != 0.0) g = min(g, reach[k]); });
+        return block_min_int(c, g);
+    }
     for (int k0 = threadIdx.x; k0 < c.m; k0 += 4 * NT) {
         int r[4];
 #pragma unroll
@@ -266,8 +366,11 @@ __device__ __forceinline__ void sweep(const FtState& st, int which, Ctx& c, int 
         if (hyper && ((st.hyper >> which) & 1)) first_level = max(first_level, ft_first_group(c, st.ell[which].reach));
     }
     int passes;
-    if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
-    else passes = ell_solve_pp<false, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap);
+    uint32_t* bx = nullptr;
+    int gs = 0;
+    if constexpr (Ctx::huge) { bx = c.bx; gs = c.gs; }
+    if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap, bx, gs, st.rhs_cap);
+    else passes = ell_solve_pp<false, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap, bx, gs, st.rhs_cap);
     if (c.clk.on) { c.clk.passes[which] += passes; c.clk.sweeps[which] += 1; c.clk.total[which] += st.ell[which].n_passes; }
 }
 
@@ -316,7 +419,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
             const int prev = in ? c.slot_prev[s] : -1, piv = in ? c.slot_pivot[s] : 0;
             const bool live = in && c.slot_live[s];
             const double val = tc_chain<true, true, true, false>(c.TC, c.ldt, t, s, (in && prev < 0) ? c.x[piv] : 0.0, in ? c.dots[s] : 0.0, 1.0, prev);
-            if (live) c.x[piv] = val;
+            if (live) xset(c, piv, val);
             // U z = w on the updated pivots: they are last in the order, so they are solved first (from the back)
             const double rdiag = in ? 1.0 / c.TC[s * c.ldt + s] : 1.0;
             const double z = tc_chain<false, true, false, true>(c.TC, c.ldt, t, s, live ? val : 0.0, 0.0, rdiag, -1);
@@ -325,15 +428,10 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
         __syncthreads();
     }
     c.clk.lap(FT_ETA_FWD);
-    if constexpr (Ctx::huge) {                         // the spike (mod.rs:176); L2 to L2, four requests at a time
-        for (int k0 = tid; k0 < c.m; k0 += 4 * NT) {
-            double v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = c.x[min(k0 + u * NT, c.m - 1)];
-            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (k0 + u * NT < c.m) c.sp[k0 + u * NT] = v[u];
-        }
+    if constexpr (Ctx::huge) {                         // the spike (mod.rs:176): the old one cleared, the non-zeros of x copied
+        hs_clear(c.sp, c.bsp, c.gs, c.bsp_words, c.m);
+        hs_for_each(c.bx, c.gs, 0, c.m, [&](int k) { c.sp[k] = c.x[k]; });
+        for (int w = tid; w < c.bsp_words; w += NT) c.bsp[w] = c.bx[w];
     } else
     for (int k = tid; k < c.m; k += NT) c.sp[k] = c.x[k];          // the spike (mod.rs:176)
     if (spike_only) { __syncthreads(); return; }
@@ -365,10 +463,10 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
                 more = mask != 0;
                 if (more) fetch();
                 const double z = lane_bcast(zreg, cs);
-                if (ck >= 0 && c.tslot[ck] < 0) c.x[ck] = fma(-cv, z, c.x[ck]);
+                if (ck >= 0 && c.tslot[ck] < 0) xset(c, ck, fma(-cv, z, c.x[ck]));
                 for (int e = ce0 + lane + 64; e < ce1; e += 64) {
                     const int k = st.spk_idx[cs * c.m + e];
-                    if (c.tslot[k] < 0) c.x[k] = fma(-st.spk_val[cs * c.m + e], z, c.x[k]);
+                    if (c.tslot[k] < 0) xset(c, k, fma(-st.spk_val[cs * c.m + e], z, c.x[k]));
                 }
                 wave_fence();
             }
@@ -380,7 +478,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
     c.clk.lap(FT_PUSH);
     sweep(st, 1, c);                                   // (no hyper-sparse start: the spike reaches the first groups of U, measured)
     if (t > 0) {
-        if (tid < t && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.zt[tid];
+        if (tid < t && c.slot_live[tid]) xset(c, c.slot_pivot[tid], c.zt[tid]);
         __syncthreads();
     }
     c.clk.lap(FT_U);
@@ -470,7 +568,7 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
             const double u = tc_chain<false, false, true, false>(c.TC, c.ldt, t, s, (in && nxt < 0) ? c.zt[s] : 0.0, 0.0, 1.0, nxt);
             if (in) {
                 c.uv[s] = u;
-                if (prev < 0) c.x[c.slot_pivot[s]] = u;          // the value every earlier eta (sparse part) and L' see
+                if (prev < 0) xset(c, c.slot_pivot[s], u);       // the value every earlier eta (sparse part) and L' see
             }
         }
         __syncthreads();
@@ -497,10 +595,10 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
                 more = mask != 0;
                 if (more) fetch();
                 const double u = lane_bcast(ureg, cs);
-                if (cj >= 0) c.x[cj] = fma(-cv, u, c.x[cj]);
+                if (cj >= 0) xset(c, cj, fma(-cv, u, c.x[cj]));
                 for (int e = ce0 + lane + 64; e < ce1; e += 64) {
                     const int j = c.eta_idx[e];
-                    c.x[j] = fma(-c.eta_val[e], u, c.x[j]);
+                    xset(c, j, fma(-c.eta_val[e], u, c.x[j]));
                 }
                 wave_fence();
             }
@@ -516,34 +614,37 @@ __device__ __forceinline__ void ft_btran(const DeviceLU& lu, const FtState& st, 
 // bucket w = pivots with k % NW == w, written by wavefront w at [base + off[w], base + off[w + 1]).  off (NW + 1 ints) is
 // left in `off_out` relative to off_base.  Returns the total (all threads).  Ends with a barrier.
 // `room`: entries the destination can still take; when the non-zeros do not fit nothing is written and -1 is returned.
-// Layout 2 (vec and the slot table in L2): bucket w = the 64-pivot chunks w, w + NW, .. (Ctx::bucket_of), so a wavefront reads
-// whole cache lines; four chunks are requested before the first is looked at; the first pass leaves every chunk's ballot in
-// `chunk_mask` and the second touches the chunks that hold anything only (an eta row or a spike has a few hundred non-zeros
-// among tens of thousands of pivots).
+// Layout 2 (vec and the slot table in L2; `bits` = the bitmap of vec): bucket w = the 64-pivot chunks w, w + NW, ..
+// (Ctx::bucket_of).  A wavefront looks up 64 of its chunks in the bitmap at a time (a lane per chunk) and visits those that
+// may hold anything: an eta row or a spike has a few dozen non-zeros among 10^5 pivots.  The first pass leaves every visited
+// chunk's ballot in `chunk_mask` for the second.
 template <class Ctx, class IdxPtr, class ValPtr>
-__device__ __forceinline__ int ft_compact(Ctx& c, const double* vec, int skip, IdxPtr out_idx, ValPtr out_val, int out_base,
-                                          int* off_out, int off_base, int room) {
+__device__ __forceinline__ int ft_compact(Ctx& c, const double* vec, const uint32_t* bits, int skip, IdxPtr out_idx, ValPtr out_val,
+                                          int out_base, int* off_out, int off_base, int room) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if constexpr (Ctx::huge) {
         const int n_chunks = (c.m + 63) >> 6;
         const int mine_chunks = (n_chunks - wave + NW - 1) / NW;       // chunks wave + NW * i, i < mine_chunks
         unsigned long long* masks = c.chunk_mask;
+        const int gs = c.gs;
+        auto chunk_may = [&](int ch) -> bool {                          // any bit of the chunk's 64 entries set?
+            const int fb = (ch << 6) >> gs;
+            if (gs == 0) return (bits[fb >> 5] | bits[(fb >> 5) + 1]) != 0u;
+            const int nb = 64 >> gs;                                    // (gs <= 5: the field lies inside one word)
+            return ((bits[fb >> 5] >> (fb & 31)) & ((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u))) != 0u;
+        };
         int cnt = 0;
-        for (int i0 = 0; i0 < mine_chunks; i0 += 4) {
-            int ts[4];
-            double vv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = min(((wave + NW * min(i0 + u, mine_chunks - 1)) << 6) + lane, c.m - 1);
-                ts[u] = c.tslot[k]; vv[u] = vec[k];
-            }
-            asm volatile("" : "+v"(ts[0]), "+v"(ts[1]), "+v"(ts[2]), "+v"(ts[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ch = wave + NW * (i0 + u), k = (ch << 6) + lane;
-                const bool on = i0 + u < mine_chunks && k < c.m && k != skip && ts[u] < 0 && vv[u] != 0.0;
+        for (int i0 = 0; i0 < mine_chunks; i0 += 64) {
+            const int i = i0 + lane;
+            unsigned long long todo = __ballot(i < mine_chunks && chunk_may(wave + NW * i));
+            while (todo) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                todo &= todo - 1;
+                const int ch = wave + NW * (i0 + src), k = (ch << 6) + lane;
+                bool on = k < c.m && k != skip && hs_test(bits, gs, k);
+                if (on) on = c.tslot[k] < 0 && vec[k] != 0.0;
                 const unsigned long long mask = __ballot(on);
-                if (i0 + u < mine_chunks && lane == 0) masks[ch] = mask;
+                if (lane == 0) masks[ch] = mask;
                 cnt += __popcll(mask);
             }
         }
@@ -558,16 +659,14 @@ __device__ __forceinline__ int ft_compact(Ctx& c, const double* vec, int skip, I
             off_out[tid] = off_base + o;
         }
         int pos = out_base + mine;
-        for (int i0 = 0; i0 < mine_chunks && cnt > 0; i0 += 64) {      // (a wavefront reads 64 of its own masks at a time)
+        for (int i0 = 0; i0 < mine_chunks && cnt > 0; i0 += 64) {
             const int i = i0 + lane;
-            const unsigned long long mk = i < mine_chunks ? masks[wave + NW * i] : 0ull;
-            unsigned long long any = __ballot(mk != 0ull);
-            while (any) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)any) - 1);
-                any &= any - 1;
-                const unsigned lo = __builtin_amdgcn_readlane((unsigned)mk, src), hi = __builtin_amdgcn_readlane((unsigned)(mk >> 32), src);
-                const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
-                const int k = ((wave + NW * (i0 + src)) << 6) + lane;
+            unsigned long long todo = __ballot(i < mine_chunks && chunk_may(wave + NW * i));
+            while (todo) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                todo &= todo - 1;
+                const int ch = wave + NW * (i0 + src), k = (ch << 6) + lane;
+                const unsigned long long mask = masks[ch];
                 if ((mask >> lane) & 1ull) {
                     const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
                     out_idx[at] = k;
@@ -622,13 +721,12 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
     const FtPivotInfo pin = st.pinfo[p];               // (one load; its entries and lists follow in a second round trip)
     const int s_old = c.tslot[p];
     // u_bar = row p of U right of the diagonal (mod.rs:110-121), scattered into x
-    for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
-    __syncthreads();
+    xzero(c, st);
     int any = 0;
     if (s_old < 0) {
         for (int e = pin.u_e0 + tid; e < pin.u_e1; e += NT) {
             const int l = lu.Uf.idx[e];
-            if (c.tslot[l] < 0) { c.x[l] = lu.Uf.val[e]; any = 1; }
+            if (c.tslot[l] < 0) { xset(c, l, lu.Uf.val[e]); any = 1; }
         }
         // entries of row p in the spike columns of the live slots: only the bucket p % NW of each list can hold them
         const int bucket = Ctx::bucket_of(p);
@@ -637,10 +735,10 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
             const int base = s * c.m;
             const int e0 = c.spk_off[s * (NW + 1) + bucket], e1 = c.spk_off[s * (NW + 1) + bucket + 1];
             for (int e = e0 + lane; e < e1; e += 64)
-                if (st.spk_idx[base + e] == p) c.x[c.slot_pivot[s]] = st.spk_val[base + e];
+                if (st.spk_idx[base + e] == p) xset(c, c.slot_pivot[s], st.spk_val[base + e]);
         }
     } else {
-        if (tid < t && tid > s_old && c.slot_live[tid]) c.x[c.slot_pivot[tid]] = c.TC[s_old * c.ldt + tid];
+        if (tid < t && tid > s_old && c.slot_live[tid]) xset(c, c.slot_pivot[tid], c.TC[s_old * c.ldt + tid]);
     }
     const bool do_sweep = __syncthreads_or(any) != 0;
     c.clk.lap(FT_UBAR);
@@ -650,8 +748,9 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
     const int tn = t;                                  // the new slot
     int eta_n = 0;
     if (do_sweep) {
-        eta_n = ft_compact(c, c.x, p, c.eta_idx, c.eta_val, c.eta_used, c.eta_off + tn * (NW + 1), c.eta_used, c.eta_cap - c.eta_used);
+        eta_n = ft_compact(c, c.x, c.bx, p, c.eta_idx, c.eta_val, c.eta_used, c.eta_off + tn * (NW + 1), c.eta_used, c.eta_cap - c.eta_used);
         if (eta_n < 0) return false;
+        if constexpr (Ctx::huge) if (c.clk.on) c.clk.nnz[1] += eta_n;
     } else {
         if (tid <= NW) c.eta_off[tn * (NW + 1) + tid] = c.eta_used;
         __syncthreads();
@@ -694,7 +793,8 @@ __device__ __forceinline__ bool ft_update(const DeviceLU& lu, const FtState& st,
         c.slot_pivot[tn] = p; c.slot_prev[tn] = s_old; c.slot_live[tn] = 1; c.slot_next[tn] = -1;
     }
     // ... entries in the never-updated rows into the spike pool, bucketed
-    ft_compact(c, c.sp, p, st.spk_idx + (int64_t)tn * c.m, st.spk_val + (int64_t)tn * c.m, 0, c.spk_off + tn * (NW + 1), 0, c.m);
+    const int spike_n = ft_compact(c, c.sp, c.bsp, p, st.spk_idx + (int64_t)tn * c.m, st.spk_val + (int64_t)tn * c.m, 0, c.spk_off + tn * (NW + 1), 0, c.m);
+    if constexpr (Ctx::huge) { if (c.clk.on) c.clk.nnz[2] += spike_n; } else (void)spike_n;
     if (tid == 0) c.tslot[p] = (typename Ctx::tslot_t)tn;
     c.eta_used += eta_n;
     c.t = tn + 1;
@@ -708,22 +808,21 @@ template <class Ctx>
 __device__ __forceinline__ void ft_scatter_column(const FtState& st, const FtProblem& pb, Ctx& c, int q) {
     const int tid = threadIdx.x;
     const ColumnTable& ct = pb.ct;
-    for (int k = tid; k < c.m; k += NT) c.x[k] = 0.0;
-    __syncthreads();
+    xzero(c, st);
     if (q < ct.nr_artificial) {
-        if (tid == 0) c.x[c.irp[ct.column_to_row[q]]] = 1.0;
+        if (tid == 0) xset(c, c.irp[ct.column_to_row[q]], 1.0);
     } else {
         const int p = q - ct.nr_artificial;
         if (p < ct.nr_normal) {
             const int64_t s0 = pb.csc.col_ptr[p], s1 = pb.csc.col_ptr[p + 1];
-            for (int64_t e = s0 + tid; e < s1; e += NT) c.x[c.irp[pb.csc.row_idx[e]]] = pb.csc.values[e];
+            for (int64_t e = s0 + tid; e < s1; e += NT) xset(c, c.irp[pb.csc.row_idx[e]], pb.csc.values[e]);
             const int br = ct.bound_row[p];
-            if (tid == 0 && br >= 0) c.x[c.irp[br]] = 1.0;
+            if (tid == 0 && br >= 0) xset(c, c.irp[br], 1.0);
         } else if (tid == 0) {
             const int v = p - ct.nr_normal;
             const int r0 = ct.vrow0[v], r1 = ct.vrow1[v];
-            if (r0 >= 0) c.x[c.irp[r0]] = (double)ct.vsign[v];
-            if (r1 >= 0) c.x[c.irp[r1]] = 1.0;
+            if (r0 >= 0) xset(c, c.irp[r0], (double)ct.vsign[v]);
+            if (r1 >= 0) xset(c, c.irp[r1], 1.0);
         }
     }
     __syncthreads();
@@ -828,6 +927,9 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     ft_bind(c, lds, lu, st);
     c.clk.start(st.prof);
     ft_load(c, lu, st, pb.minus_pi);
+    hs_enter(c, st);
+    int alpha_nnz = 0, rho_nnz = 0;                    // (layout 2) entries of nz_idx / rho_idx that describe pb.alpha / pb.rho
+    if constexpr (kTier >= 2) { alpha_nnz = st.nzc[0]; rho_nnz = st.nzc[1]; }
     c.clk.lap(FT_LOAD_STORE);
     const int tid = threadIdx.x;
     const ColumnTable& ct = pb.ct;
@@ -1055,33 +1157,25 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         // whoever reads it after the launch) and appends the non-zeros as (row, alpha) pairs to a list; the ratio test, the tie
         // band, the leaving row and the update of b then touch the list only (tableau/mod.rs:221-247 walks the stored
         // non-zeros of the column just the same).  Every reduction is order-free (minima), so the list's order does not matter.
+        // pb.alpha (dense, for whoever reads it after the launch): zeroed where the previous column was not -- its list is
+        // still there -- then the non-zeros of x, found through the bitmap, are scattered and listed
+        if (alpha_nnz < 0) { for (int i = tid; i < m; i += NT) pb.alpha[i] = 0.0; }
+        else for (int e = tid; e < alpha_nnz; e += NT) pb.alpha[st.nz_idx[e]] = 0.0;
         if (tid == 0) c.red_i[2 * NW] = 0;
         __syncthreads();
-        for (int k0 = tid; k0 < m; k0 += 4 * NT) {
-            int cp[4];
-            double xv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int k = min(k0 + u * NT, m - 1); xv[u] = c.x[k]; cp[u] = lu.colperm[k]; }
-            asm volatile("" : "+v"(cp[0]), "+v"(cp[1]), "+v"(cp[2]), "+v"(cp[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = k0 + u * NT < m;
-                if (in) pb.alpha[cp[u]] = xv[u];
-                const bool nz = in && xv[u] != 0.0;
-                const unsigned long long mask = __ballot(nz);
-                if (mask) {                            // (wave-uniform)
-                    int at = 0;
-                    if ((tid & 63) == 0) at = atomicAdd(&c.red_i[2 * NW], __popcll(mask));
-                    at = __builtin_amdgcn_readfirstlane(at);
-                    if (nz) {
-                        const int e = at + __popcll(mask & ((1ull << (tid & 63)) - 1ull));
-                        st.nz_idx[e] = cp[u]; st.nz_val[e] = xv[u];
-                    }
-                }
+        hs_for_each(c.bx, c.gs, 0, m, [&](int k) {
+            const double v = c.x[k];
+            if (v != 0.0) {
+                const int i = lu.colperm[k];
+                pb.alpha[i] = v;
+                const int e = atomicAdd(&c.red_i[2 * NW], 1);
+                st.nz_idx[e] = i; st.nz_val[e] = v;
             }
-        }
+        });
         __syncthreads();
         const int nnz = c.red_i[2 * NW];
+        alpha_nnz = nnz;
+        if (c.clk.on) { c.clk.nnz[0] += nnz; c.clk.nnz[3] += 1; }
         // (the first entry of every thread stays in registers: a column rarely has more than NT non-zeros)
         const bool h0 = tid < nnz;
         const int i0 = h0 ? st.nz_idx[tid] : 0;
@@ -1197,9 +1291,8 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         if (tid == 0 && c.journal_n < c.tcap) { st.journal[2 * c.journal_n] = r; st.journal[2 * c.journal_n + 1] = q; }
         c.journal_n += 1;
         const int pl = c.icp[r];
-        for (int k = tid; k < m; k += NT) c.x[k] = 0.0;
-        __syncthreads();
-        if (tid == 0) c.x[pl] = 1.0;
+        xzero(c, st);
+        if (tid == 0) xset(c, pl, 1.0);
         __syncthreads();
         double rho_scale = 1.0;
         if (updated) {
@@ -1212,22 +1305,22 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             need_refactor = 1;
         }
         // ---- -pi, -obj, basis (carry/mod.rs:326-333, 549-570) ----------------------------------------------------------
-        if constexpr (kTier >= 2) {                     // (four rows requested at a time; -pi changes where rho is not zero only)
-            for (int k0 = tid; k0 < m; k0 += 4 * NT) {
-                int ii[4];
-                double xv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int k = min(k0 + u * NT, m - 1); ii[u] = c.rp[k]; xv[u] = c.x[k]; }
-                asm volatile("" : "+v"(ii[0]), "+v"(ii[1]), "+v"(ii[2]), "+v"(ii[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (k0 + u * NT < m) {
-                        const double rho = xv[u] * rho_scale;
-                        pb.rho[ii[u]] = rho;
-                        if (rho != 0.0) c.pi[ii[u]] = fma(-d_q, rho, c.pi[ii[u]]);
-                    }
+        if constexpr (kTier >= 2) {                     // (pb.rho as pb.alpha above; -pi changes where rho is not zero only)
+            if (rho_nnz < 0) { for (int i = tid; i < m; i += NT) pb.rho[i] = 0.0; }
+            else for (int e = tid; e < rho_nnz; e += NT) pb.rho[st.rho_idx[e]] = 0.0;
+            if (tid == 0) c.red_i[2 * NW + 1] = 0;
+            __syncthreads();
+            hs_for_each(c.bx, c.gs, 0, m, [&](int k) {
+                const double rho = c.x[k] * rho_scale;
+                if (rho != 0.0) {
+                    const int i = c.rp[k];
+                    pb.rho[i] = rho;
+                    c.pi[i] = fma(-d_q, rho, c.pi[i]);
+                    st.rho_idx[atomicAdd(&c.red_i[2 * NW + 1], 1)] = i;
                 }
-            }
+            });
+            __syncthreads();
+            rho_nnz = c.red_i[2 * NW + 1];
         } else
         for (int k = tid; k < m; k += NT) {
             const int i = c.rp[k];
@@ -1253,8 +1346,10 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         c.clk.lap(FT_VECTORS);
     }
     ft_store(c, st, pb.minus_pi, need_refactor);
+    hs_leave(c, st, true);
+    if constexpr (kTier >= 2) if (tid == 0) { st.nzc[0] = alpha_nnz; st.nzc[1] = rho_nnz; }
     c.clk.lap(FT_LOAD_STORE);
-    c.clk.flush(st.prof);
+    c.clk.flush(st.prof, kTier >= 2);
     if (tid == 0) {
         rec->outcome = outcome; rec->q = q; rec->d_q = d_q; rec->r = r; rec->leaving = leaving; rec->alpha_r = alpha_r;
         rec->b_r = b_r; rec->minus_objective = minus_objective; rec->iterations = iterations;
@@ -1283,15 +1378,14 @@ __global__ __launch_bounds__(NT) void k_ft_ftran(DeviceLU lu, FtState st, FtProb
     FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
+    hs_enter(c, st);
     const int tid = threadIdx.x;
-    if (rhs) {
-        for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.rowperm[k]];
-        __syncthreads();
-    } else {
-        ft_scatter_column(st, pb, c, column == -2 ? pb.rec->q : column);
-    }
+    if (rhs) xfill(c, st, [&](int k) { return rhs[lu.rowperm[k]]; });
+    else ft_scatter_column(st, pb, c, column == -2 ? pb.rec->q : column);
     ft_ftran(lu, st, c);
     for (int k = tid; k < c.m; k += NT) { alpha[lu.colperm[k]] = c.x[k]; st.spike[k] = c.sp[k]; }
+    hs_leave(c, st, true);
+    if constexpr (kTier >= 2) if (tid == 0) st.nzc[0] = -1;             // (`alpha` may be the engine's own vector: its list is void)
 }
 
 template <int kTier>
@@ -1303,18 +1397,22 @@ __global__ __launch_bounds__(NT) void k_ft_btran(DeviceLU lu, FtState st, FtProb
     const int tid = threadIdx.x;
     bool sweep_u = true;
     int first = 0;
+    hs_enter(c, st);
     if (rhs) {
-        for (int k = tid; k < c.m; k += NT) c.x[k] = rhs[lu.colperm[k]];
+        xfill(c, st, [&](int k) { return rhs[lu.colperm[k]]; });
     } else {
         const int r = row == -2 ? pb.rec->r : row;
         const int p = st.inv_colperm[r];
-        for (int k = tid; k < c.m; k += NT) c.x[k] = k == p ? 1.0 : 0.0;
+        xzero(c, st);
+        if (tid == 0) xset(c, p, 1.0);
         sweep_u = c.tslot[p] < 0;                      // an updated pivot has no entry in U0 any more
         first = st.lev_ub[p];                          // e_p: nothing below the level of p's own row
     }
     __syncthreads();
     ft_btran(lu, st, c, sweep_u, first);
     for (int k = tid; k < c.m; k += NT) rho[lu.rowperm[k]] = c.x[k];
+    hs_leave(c, st, true);
+    if constexpr (kTier >= 2) if (tid == 0) st.nzc[1] = -1;             // (`rho` may be the engine's own vector)
 }
 
 template <int kTier>
@@ -1323,10 +1421,17 @@ __global__ __launch_bounds__(NT) void k_ft_update(DeviceLU lu, FtState st, FtPro
     FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
-    for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
+    hs_enter(c, st);
+    if constexpr (kTier >= 2) {
+        hs_clear(c.sp, c.bsp, c.gs, c.bsp_words, c.m);
+        for (int k = threadIdx.x; k < c.m; k += NT) { const double v = st.spike[k]; if (v != 0.0) { c.sp[k] = v; hs_mark(c.bsp, c.gs, k); } }
+    } else {
+        for (int k = threadIdx.x; k < c.m; k += NT) c.sp[k] = st.spike[k];
+    }
     __syncthreads();
     const bool updated = ft_update(lu, st, c, pb.rec->r);
     ft_store(c, st, nullptr, !updated ? 2 : (c.t >= st.max_updates || c.t >= c.tcap) ? 1 : 0);
+    hs_leave(c, st, true);
 }
 
 void ft_allow_lds(const void* fn, int bytes) {
@@ -1384,6 +1489,7 @@ __global__ __launch_bounds__(NT) void k_ft_replay(DeviceLU lu, FtState st, FtPro
     FtCtxT<kTier> c;
     ft_bind(c, lds, lu, st);
     ft_load(c, lu, st, nullptr);
+    hs_enter(c, st);
     int need = 0;
     for (int i = 0; i < count; ++i) {
         if (c.t >= c.tcap) { need = 2; break; }
@@ -1394,6 +1500,7 @@ __global__ __launch_bounds__(NT) void k_ft_replay(DeviceLU lu, FtState st, FtPro
     }
     if (!need && (c.t >= st.max_updates || c.t >= c.tcap)) need = 1;
     ft_store(c, st, nullptr, need);
+    hs_leave(c, st, true);
 }
 
 void launch_ft_replay(const DeviceLU& lu, const FtState& st, const FtProblem& pb, int32_t count, hipStream_t s) {

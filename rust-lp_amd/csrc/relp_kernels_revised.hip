@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kSingleBlock) void k_select_partials(SelectPartials
     }
     __syncthreads();
     const int q = s_q;
-    if (q < 0) return;
+    if (q < 0 || !aq) return;                          // (aq == null: the caller scatters the column itself -- the persistent LU kernel)
     // build the entering column (k_build_column)
     int kind = 0, p = 0, r0 = -1, r1 = -1;
     double sgn = 1.0;

@@ -292,8 +292,24 @@ struct EllImage {
 };
 // kL2: x lives in global memory (layout 2 of the persistent kernel): the copies are two dependent round trips each, requested
 // four at a time
+// (kL2 also: x is a sparse vector, `bx` its "may be non-zero" bitmap in LDS with a bit per 2^gs entries -- relp_kernels_ft.hip,
+// hs_*: only the copies of non-zero right-hand sides are made, the stale ones of an earlier sweep zeroed first)
+template <int NT, class F>
+__device__ __forceinline__ void ell_for_each_bit(const uint32_t* bits, int gs, int first, int n, F f) {
+    const int w0 = (first >> gs) >> 5, w1 = (((n - 1) >> gs) >> 5) + 1;
+    for (int w = w0 + (int)threadIdx.x; w < w1; w += NT) {
+        uint32_t word = bits[w];
+        while (word) {
+            const int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            const int k0 = ((w << 5) + b) << gs;
+            for (int k = max(k0, first); k < min(k0 + (1 << gs), n); ++k) f(k);
+        }
+    }
+}
 template <bool kStage, int NT, bool kWide = false, bool kL2 = false>
-__device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char* base, double* x) {
+__device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char* base, double* x, uint32_t* bx = nullptr, int gs = 0,
+                                                     int rhs_cap = 0) {
     typedef typename EllIdx<kWide>::type idx_t;
     EllImage<kWide> im{s.passes, s.lvl_pass, s.rdiag, s.sval, s.oval, s.rovf, reinterpret_cast<const idx_t*>(s.sidx),
                        reinterpret_cast<const idx_t*>(s.oidx)};
@@ -303,18 +319,18 @@ __device__ __forceinline__ EllImage<kWide> ell_stage(const EllSchedule& s, char*
     // kernel sits at 256 VGPRs with spills, and a few more live values cost 5 % of a 25FV47 pivot)
     if (s.rhs_base) {
         if constexpr (kL2) {
-            for (int i0 = tid; i0 < s.n_rhs; i0 += 4 * NT) {
-                int src[4];
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) src[u] = s.rhs_src[min(i0 + u * NT, s.n_rhs - 1)];
-                asm volatile("" : "+v"(src[0]), "+v"(src[1]), "+v"(src[2]), "+v"(src[3]));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = x[src[u]];
-                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) if (i0 + u * NT < s.n_rhs) x[s.rhs_base + i0 + u * NT] = v[u];
-            }
+            ell_for_each_bit<NT>(bx, gs, s.m + 1, s.m + 1 + rhs_cap, [&](int k) { x[k] = 0.0; });
+            __syncthreads();
+            ell_for_each_bit<NT>(bx, gs, 0, s.m, [&](int k) {
+                const int i = s.rhs_pos[k];
+                if (i >= 0) {
+                    const double v = x[k];
+                    if (v != 0.0) {
+                        x[s.rhs_base + i] = v;
+                        atomicOr(&bx[((s.rhs_base + i) >> gs) >> 5], 1u << (((s.rhs_base + i) >> gs) & 31));
+                    }
+                }
+            });
         } else if constexpr (kWide) { for (int i = tid; i < s.n_rhs; i += NT) x[s.rhs_base + i] = x[s.rhs_src[i]]; }
         else { for (int i = tid; i < s.m; i += NT) x[s.rhs_base + i] = x[i]; }
     }
@@ -419,13 +435,22 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
 // Every wavefront joins the barrier that ends a level, whoever owned its last pass; two passes of one level may run at the
 // same time (they are independent).
 template <bool kStage, int NT, bool kWide = false, class Lap = NoLap, bool kL2 = false>
-__device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap()) {
+__device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap(),
+                                            uint32_t* bx = nullptr, int gs = 0, int rhs_cap = 0) {
     static_assert(NT == 512, "two sets of 256 lanes");
     typedef typename EllIdx<kWide>::type idx_t;
     constexpr int kEllLg = EllIdx<kWide>::shift, kEllIdxMask = EllIdx<kWide>::mask;       // (shadow the 16-bit constants)
-    const EllImage<kWide> im = ell_stage<kStage, NT, kWide, kL2>(s, base, x);
+    const EllImage<kWide> im = ell_stage<kStage, NT, kWide, kL2>(s, base, x, bx, gs, rhs_cap);
     const double* rdiag = im.rdiag; const double* sval = im.sval; const double* oval = im.oval; const int32_t* rovf = im.rovf;
     const idx_t* sidx = im.sidx; const idx_t* oidx = im.oidx;
+    if constexpr (kL2) {                               // the rows without entries (U, U'), those of them x is not zero in
+        if (s.n_triv > 0) {
+            ell_for_each_bit<NT>(bx, gs, 0, s.m, [&](int k) {
+                if ((s.triv_bits[k >> 5] >> (k & 31)) & 1u) { const double v = x[k]; if (v != 0.0) x[k] = v * rdiag[k]; }
+            });
+            __syncthreads();
+        }
+    } else
     if constexpr (kWide) if (s.n_triv > 0) {           // the rows without entries (U, U'): nothing to wait for, no passes
         for (int i0 = threadIdx.x; i0 < s.n_triv; i0 += 4 * NT) {
             int k[4];
@@ -470,7 +495,17 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
         const int znn = hdr[p + 2].z;
         const int info = __builtin_amdgcn_readfirstlane(z);
         const bool mine = ((p - p0) & 1) == set;       // (uniform per wavefront)
-        if (mine) {
+        bool go = mine;
+        if constexpr (kL2) {
+            // x is a sparse vector: a wavefront none of whose operands may be non-zero would compute zeros over zeros.  (A row
+            // with overflow entries owns its wavefront and is always computed: those operands are not in the slots.)
+            if (mine) {
+                const int ci = m_iv & kEllIdxMask;
+                const bool may = lt < hm.y && ((bx[(ci >> gs) >> 5] >> ((ci >> gs) & 31)) & 1u);
+                go = (info & 0x200) || __ballot(may) != 0ull;
+            }
+        }
+        if (go) {
             const bool act = lt < hm.y;
             const int c_idx = m_iv & kEllIdxMask, lg = m_iv >> kEllLg;
             const double xv = x[c_idx];
@@ -487,6 +522,10 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
 #ifdef ELL_PRED_STORE
             if (lead) x[c_idx] = sum * m_diag;
 #else
+            if constexpr (kL2) {
+                const double res = sum * m_diag;
+                if (lead) { x[c_idx] = res; if (res != 0.0) atomicOr(&bx[(c_idx >> gs) >> 5], 1u << ((c_idx >> gs) & 31)); }
+            } else
             x[lead ? c_idx : dummy] = sum * m_diag;
 #endif
         }

@@ -1,10 +1,10 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 1150 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_gpu.py > gpurun_out/gpu_tier.log 2>&1 || { tail -n 60 gpurun_out/gpu_tier.log; exit 1; }
-tail -n 3 gpurun_out/gpu_tier.log
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_scale_le -o le -- python3 scripts/xl_probe.py le:30000,90000 0 lu 6000 > gpurun_out/prof_scale_le.log 2>&1
-grep "pivots " gpurun_out/prof_scale_le.log | tail -n 2
-find gpurun_out/prof_scale_le -name "*kernel_trace.csv" -delete
-head -4 gpurun_out/prof_scale_le/le_kernel_stats.csv | cut -c1-120
+RELP_FT_BIG=2 RELP_LU_LOOKAHEAD=8 timeout -k 10 900 python -m pytest tests/test_gpu_lu_update.py tests/test_gpu_parity.py tests/test_gpu_big_pins.py -m gpu -x -q > gpurun_out/tier2_tests.log 2>&1 || { tail -n 40 gpurun_out/tier2_tests.log; exit 1; }
+tail -n 2 gpurun_out/tier2_tests.log
+for spec in "mc:4000,16000,12 0" "mc:6000,24000,16 0" "30000 90000" "le:30000,90000 0"; do
+  set -- $spec
+  RELP_DEBUG=1 timeout -k 10 200 python scripts/xl_probe.py $1 $2 lu 20000 > gpurun_out/hs_probe.log 2>&1 || true
+  echo "$spec"; grep "20000 pivots\|non-zeros per pivot\|clocks/pivot\|passes walked" gpurun_out/hs_probe.log | cut -c1-400
+done
