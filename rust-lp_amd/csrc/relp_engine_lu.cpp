@@ -452,6 +452,11 @@ relp_status_t Engine::lu_upload_factors() {
             fts_.stage[k] = total <= fts_.stage_bytes ? 1 : 0;
             if (fts_.stage[k]) need = std::max(need, total);
         }
+        if (ft_tier_ >= 2)                                 // (layout 2 copies the pass headers of an image that is not staged: sweep())
+            for (int k = 0; k < 4; ++k) {
+                const int64_t hb = 16 * ((int64_t)fts_.ell[k].n_passes + kEllPadHeaders);
+                if (!fts_.stage[k] && hb <= fts_.stage_bytes) need = std::max(need, hb);
+            }
         fts_.lds_bytes = (int32_t)(base + need);
         if (std::getenv("RELP_DEBUG") && lu_refactors_ % 60 == 59)
             for (int k = 0; k < 4; ++k)

@@ -369,8 +369,10 @@ __device__ __forceinline__ void sweep(const FtState& st, int which, Ctx& c, int 
     uint32_t* bx = nullptr;
     int gs = 0;
     if constexpr (Ctx::huge) { bx = c.bx; gs = c.gs; }
+    // (layout 2: the pass headers of an image that is not staged are copied into the staging area when they fit)
+    int4* hdr_lds = 16LL * (st.ell[which].n_passes + kEllPadHeaders) <= st.stage_bytes ? reinterpret_cast<int4*>(c.stage) : nullptr;
     if (st.stage[which]) passes = ell_solve_pp<true, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap, bx, gs, st.rhs_cap);
-    else passes = ell_solve_pp<false, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap, bx, gs, st.rhs_cap);
+    else passes = ell_solve_pp<false, NT, Ctx::big, decltype(lap), Ctx::huge>(st.ell[which], c.stage, c.x, c.m, first_level, lap, bx, gs, st.rhs_cap, hdr_lds);
     if (c.clk.on) { c.clk.passes[which] += passes; c.clk.sweeps[which] += 1; c.clk.total[which] += st.ell[which].n_passes; }
 }
 

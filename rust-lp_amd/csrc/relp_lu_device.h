@@ -436,7 +436,7 @@ __device__ __forceinline__ void ell_solve(const EllSchedule& s, char* base, doub
 // same time (they are independent).
 template <bool kStage, int NT, bool kWide = false, class Lap = NoLap, bool kL2 = false>
 __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, double* x, int dummy, int first_level = 0, Lap lap = Lap(),
-                                            uint32_t* bx = nullptr, int gs = 0, int rhs_cap = 0) {
+                                            uint32_t* bx = nullptr, int gs = 0, int rhs_cap = 0, int4* hdr_lds = nullptr) {
     static_assert(NT == 512, "two sets of 256 lanes");
     typedef typename EllIdx<kWide>::type idx_t;
     constexpr int kEllLg = EllIdx<kWide>::shift, kEllIdxMask = EllIdx<kWide>::mask;       // (shadow the 16-bit constants)
@@ -484,6 +484,98 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
     const int4* hdr = reinterpret_cast<const int4*>(im.passes);
     const int mm = s.m;
     auto slot_of = [&](const int4& h) { const int top = h.y > 0 ? h.y - 1 : 0; return h.x + (lt < top ? lt : top); };
+    if constexpr (kL2) if (kStage || hdr_lds != nullptr) {
+        // x is a sparse vector (bitmap bx): a wavefront none of whose operands may be non-zero would compute zeros over zeros, and
+        // with a dozen non-zeros in 10^5 entries that is nearly every wavefront of nearly every pass (measured on a 64,000-row
+        // multi-commodity LP: 1.3 of 1,050 wavefront-passes per pivot have an operand that may be non-zero).  The loop is
+        // arranged around that case.  The pass headers sit in LDS (copied there unless the whole image is) and are read, like
+        // the bitmap, through LDS-typed pointers (a pointer that is global on one path and LDS on another is a flat access,
+        // which waits like a global one -- behind every slot word requested ahead).  Blocks of 2 kAhead passes, kAhead of them
+        // this wavefront's: at the start of a block everything the NEXT block needs is requested (its headers, then the slot
+        // words: an L2 round trip when the image is not staged) into the other of two register sets -- no register is copied
+        // while its load is in flight (a copy waits for it) -- and the level-end flags of this block are read in one go; what
+        // is left on the chain of a pass is one LDS read (the bit) and a ballot.  Value, 1 / diagonal and operand are fetched --
+        // together -- only by a wavefront that has something to compute.  (A row with overflow entries owns its wavefront and
+        // is always computed: those operands are not in the slots.)  What a pass of nothing still costs is its ~50
+        // instructions at this kernel's ~5 clocks each.
+        constexpr int kAhead = 4;
+        typedef int hs_v4i __attribute__((ext_vector_type(4)));
+        typedef const hs_v4i __attribute__((address_space(3)))* lds_hdr_t;
+        typedef const uint32_t __attribute__((address_space(3)))* lds_bits_t;
+        if constexpr (!kStage) {
+            const int n16 = s.n_passes + kEllPadHeaders;
+            for (int i = threadIdx.x; i < n16; i += NT) hdr_lds[i] = hdr[i];
+            __syncthreads();
+        }
+        const lds_hdr_t hdrL = kStage ? (lds_hdr_t)reinterpret_cast<const hs_v4i*>(im.passes) : (lds_hdr_t)reinterpret_cast<const hs_v4i*>(hdr_lds);
+        const lds_bits_t bxL = (lds_bits_t)bx;
+        auto hdr_at = [&](int p) -> hs_v4i { return hdrL[p]; };
+        auto slot_at = [&](const hs_v4i& h) { const int top = h[1] > 0 ? h[1] - 1 : 0; return h[0] + (lt < top ? lt : top); };
+        bool stored = false;                               // this wavefront has written x since the last barrier
+        auto prefetch = [&](int pb, int (&iqn)[kAhead], int (&yqn)[kAhead]) {
+            hs_v4i hh[kAhead];
+#pragma unroll
+            for (int d = 0; d < kAhead; ++d) hh[d] = hdr_at(min(pb + 2 * d + set, p1 - 1));
+#pragma unroll
+            for (int d = 0; d < kAhead; ++d) { yqn[d] = hh[d][1]; iqn[d] = sidx[slot_at(hh[d])]; }
+        };
+        auto block = [&](int pb, int (&iq)[kAhead], int (&yq)[kAhead], int (&iqn)[kAhead], int (&yqn)[kAhead]) {
+            int zq[2 * kAhead];
+#pragma unroll
+            for (int u = 0; u < 2 * kAhead; ++u) zq[u] = hdrL[min(pb + u, p1 - 1)][2];
+            prefetch(pb + 2 * kAhead, iqn, yqn);
+#pragma unroll
+            for (int u = 0; u < 2 * kAhead; ++u) {
+                const int p = pb + u;
+                if (p < p1) {                              // (uniform)
+                    const int info = __builtin_amdgcn_readfirstlane(zq[u]);
+                    if ((u & 1) == set) {
+                        const int m_iv = iq[u >> 1];
+                        const int c_idx = m_iv & kEllIdxMask, lg = m_iv >> kEllLg;
+                        const bool act = lt < yq[u >> 1];
+                        const bool may = act && ((bxL[(c_idx >> gs) >> 5] >> ((c_idx >> gs) & 31)) & 1u);
+                        if ((info & 0x200) || __ballot(may) != 0ull) {
+                            const double xv = x[c_idx];
+                            const double m_val = sval[slot_at(hdr_at(p))];
+                            const double m_diag = rdiag[min(c_idx, mm)];
+                            double sum = act ? -m_val * xv : 0.0;
+                            if ((info & 0x2ff) <= 3) sum = ell_reduce<3>(sum, lg);
+                            else {
+                                if ((info & 0x200) && act && lg == 6) {
+                                    const int k = __builtin_amdgcn_readfirstlane(c_idx);
+                                    for (int e = rovf[2 * k] + (lt & 63); e < rovf[2 * k + 1]; e += 64) sum = fma(-oval[e], x[oidx[e]], sum);
+                                }
+                                sum = ell_reduce<6>(sum, lg);
+                            }
+                            const double res = sum * m_diag;
+                            if (act && (lt & ((1 << lg) - 1)) == 0) {
+                                x[c_idx] = res;
+                                if (res != 0.0) atomicOr(&bx[(c_idx >> gs) >> 5], 1u << ((c_idx >> gs) & 31));
+                            }
+                            stored = true;
+                        }
+                    }
+                    if (info & 0x100) {
+                        // End of a level.  __syncthreads() would also wait for the slot words requested ahead (a release fence
+                        // drains every outstanding vector memory operation).  Only a wavefront that stored waits for its stores
+                        // (x) and LDS atomics (bitmap); all meet at the bare barrier.  (The wavefronts of a workgroup share the
+                        // CU's vector L1: nothing to invalidate.)
+                        if (stored) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stored = false; }
+                        asm volatile("s_barrier" ::: "memory");
+                    }
+                }
+            }
+        };
+        int iqa[kAhead], yqa[kAhead], iqb[kAhead], yqb[kAhead];
+        prefetch(p0, iqa, yqa);
+        for (int pb = p0; pb < p1; pb += 4 * kAhead) {
+            block(pb, iqa, yqa, iqb, yqb);
+            if (pb + 2 * kAhead < p1) block(pb + 2 * kAhead, iqb, yqb, iqa, yqa);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        return p1 - p0;
+    }
     // my next pass (header, slot, 1 / diagonal in registers) and the header of the one after it; `z` = info word of the
     // pass the loop is at, `zn` of the next one (both sets need every pass's level-end flag)
     int4 hm = hdr[p0 + set], hm2 = hdr[p0 + set + 2];
