@@ -1,6 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_final.json 2> gpurun_out/r03_bench_final.err || { tail -n 30 gpurun_out/r03_bench_final.err; exit 1; }
-python scripts/show_scale.py gpurun_out/r03_bench_final.json
-python scripts/show_bench.py gpurun_out/r03_bench_final.json 2>/dev/null | head -40 || true
+timeout -k 10 400 python -m pytest tests/test_gpu_lu_layout2.py -m gpu -x -q > gpurun_out/layout2_tests.log 2>&1 || { tail -n 60 gpurun_out/layout2_tests.log; exit 1; }
+tail -n 2 gpurun_out/layout2_tests.log

@@ -156,3 +156,38 @@ def test_tableau_beyond_2_to_the_32_elements():
     assert tr == r.trace()
     assert abs(obj - r.objective_function_value()) <= 1e-9 * abs(obj)
     r.close()
+
+
+@pytest.mark.parametrize("name", ["test_no_change", "test_from_identity_2", "test_from_5x5_identity_no_r", "test_from_4x4_identity",
+                                  "test_from_5x5_elble_sahinidis", "test_reference_cadence_refactors_after_the_eleventh_update"])
+def test_change_basis_known_answers_in_layout_2(name, monkeypatch):
+    """The reference's five `change_basis` cases (lower_upper/mod.rs:605-867) and the cadence test of tests/test_gpu_lu_update.py
+    once more with the persistent kernel forced into layout 2 (the step-wise kernels k_ft_ftran / k_ft_btran / k_ft_update keep
+    the sparse-vector invariant too)."""
+    import test_gpu_lu_update as base
+    monkeypatch.setenv("RELP_FT_BIG", "2")
+    getattr(base, name)()
+
+
+@pytest.mark.parametrize("m,seed", [(13, 3), (97, 5), (300, 6)])
+def test_random_replacement_sequences_in_layout_2(m, seed, monkeypatch):
+    import test_gpu_lu_update as base
+    monkeypatch.setenv("RELP_FT_BIG", "2")
+    base.test_random_replacement_sequences_against_a_dense_inverse(m, seed)
+
+
+def test_row_removal_and_both_phases_in_layout_2(monkeypatch):
+    """BORE3D (artificials left basic at zero level, redundant rows removed at the phase switch: the bitmaps saved between
+    launches describe another m afterwards) and 50v-10 (upper bounds, 1,647 bound rows) to their pins in layout 2."""
+    from lp_files import load
+    monkeypatch.setenv("RELP_FT_BIG", "2")
+    for path, fixed, pin, tol in (("netlib/BORE3D.SIF", True, 0.13730803942084927e4, 1e-2), ("miplib/50v-10.mps", False, 2879.065687, 1e-3)):
+        gf, ex, md, emd = load(path, fixed=fixed)
+        t = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=1 << 16)
+        assert t.lu_kernel_layout()["layout"] == 2
+        assert t.solve_relaxation() == engine.OPTIMAL
+        assert abs(t.objective_function_value() + float(gf.fixed_cost) - pin) < tol, path
+        ref = relp_f64.OracleF64(md)
+        assert ref.run() == "optimal"
+        same = sum(1 for a, b in zip(t.trace(), ref.trace) if a == b)
+        assert same >= min(len(ref.trace), 300), (path, same)
