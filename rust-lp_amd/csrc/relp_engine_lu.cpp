@@ -532,8 +532,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
                   o_so = take(4 * tc * nwp), o_pv = take(4 * tc), o_ts = take(4 * m), o_ei = take(4 * (int64_t)ft_eta_cap_),
                   o_ev = take(8 * (int64_t)ft_eta_cap_), o_si = take(4 * tc * m), o_sv = take(8 * tc * m), o_spike = take(8 * m), o_prof = take(8 * 32),
                   o_journal = take(8 * tc), o_spw = take(8 * m), o_xw = take(ft_tier_ >= 2 ? 8 * (m + 1 + ft_rhs_cap_) : 0),
-                  o_cm = take(ft_tier_ >= 2 ? 8 * ((m + 63) / 64 + 1) : 0), o_nzi = take(ft_tier_ >= 2 ? 4 * m : 0),
-                  o_nzv = take(ft_tier_ >= 2 ? 8 * m : 0), o_rhoi = take(ft_tier_ >= 2 ? 4 * m : 0), o_nzc = take(16),
+                  o_cm = take(ft_tier_ >= 1 ? 8 * ((m + 63) / 64 + 1) : 0), o_nzi = take(ft_tier_ >= 1 ? 4 * m : 0),
+                  o_nzv = take(ft_tier_ >= 1 ? 8 * m : 0), o_rhoi = take(ft_tier_ >= 2 ? 4 * m : 0), o_nzc = take(16),
                   o_bits = take(ft_tier_ >= 2 ? kFtBitmapBytes + 1024 : 0);
     ft_zero_bytes_ = o_pv - o_hdr; ft_ones_bytes_ = o_ei - o_pv;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ft_buf_), (size_t)o));
@@ -568,9 +568,9 @@ relp_status_t Engine::ft_plan_and_alloc() {
     fts_.spike = reinterpret_cast<double*>(d_ft_buf_ + o_spike);
     fts_.sp_work = reinterpret_cast<double*>(d_ft_buf_ + o_spw);
     fts_.x_work = ft_tier_ >= 2 ? reinterpret_cast<double*>(d_ft_buf_ + o_xw) : nullptr;
-    fts_.chunk_mask = ft_tier_ >= 2 ? reinterpret_cast<unsigned long long*>(d_ft_buf_ + o_cm) : nullptr;
-    fts_.nz_idx = ft_tier_ >= 2 ? reinterpret_cast<int32_t*>(d_ft_buf_ + o_nzi) : nullptr;
-    fts_.nz_val = ft_tier_ >= 2 ? reinterpret_cast<double*>(d_ft_buf_ + o_nzv) : nullptr;
+    fts_.chunk_mask = ft_tier_ >= 1 ? reinterpret_cast<unsigned long long*>(d_ft_buf_ + o_cm) : nullptr;
+    fts_.nz_idx = ft_tier_ >= 1 ? reinterpret_cast<int32_t*>(d_ft_buf_ + o_nzi) : nullptr;
+    fts_.nz_val = ft_tier_ >= 1 ? reinterpret_cast<double*>(d_ft_buf_ + o_nzv) : nullptr;
     fts_.rho_idx = ft_tier_ >= 2 ? reinterpret_cast<int32_t*>(d_ft_buf_ + o_rhoi) : nullptr;
     fts_.nzc = reinterpret_cast<int32_t*>(d_ft_buf_ + o_nzc);
     fts_.bits_save = ft_tier_ >= 2 ? reinterpret_cast<uint32_t*>(d_ft_buf_ + o_bits) : nullptr;

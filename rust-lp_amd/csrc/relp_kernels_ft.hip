@@ -92,7 +92,7 @@ struct FtCtxT {
     typedef typename std::conditional<big, int32_t, unsigned short>::type perm_t;
     typedef typename std::conditional<huge, int32_t, signed char>::type tslot_t;
     // the wavefront that owns pivot k in the bucketed lists (eta pool, spike pool): see ft_compact
-    static __device__ __forceinline__ int bucket_of(int k) { return huge ? (k >> 6) % NW : k % NW; }
+    static __device__ __forceinline__ int bucket_of(int k) { return big ? (k >> 6) % NW : k % NW; }
     unsigned long long* chunk_mask;                    // (layout 2) ceil(m / 64) ballots, scratch of ft_compact
     // (layout 2) x and the spike as sparse vectors: dense arrays in L2 plus "may be non-zero" bitmaps in LDS, a bit per 2^gs
     // entries.  Invariant: bit clear => the entries are 0.0 in memory.  Every store of a value that may be non-zero marks
@@ -119,6 +119,7 @@ __device__ __forceinline__ void ft_bind(Ctx& c, char* lds, const DeviceLU& lu, c
     else { c.x = (double*)(lds + L.x); c.pi = (double*)(lds + L.pi); c.tslot = (signed char*)(lds + L.tslot); }
     c.TC = (double*)(lds + L.tc);
     if constexpr (Ctx::big) {
+        c.chunk_mask = st.chunk_mask;
         c.sp = st.sp_work; c.irp = st.inv_rowperm; c.icp = st.inv_colperm; c.rp = lu.rowperm;
         c.eta_idx = st.eta_idx; c.eta_val = st.eta_val;
     } else {
@@ -680,6 +681,65 @@ __device__ __forceinline__ int ft_compact(Ctx& c, const double* vec, const uint3
         __syncthreads();
         return total;
     }
+    if constexpr (Ctx::big) {
+        // Layout 1 (the slot table and x in LDS, the spike in L2): the same 64-pivot chunks as layout 2, so that the spike is
+        // read in whole cache lines (pivots k = wave + 8 i were every eighth word of 64 lines per load); four chunks requested
+        // before the first is looked at; the first pass leaves every chunk's ballot in `chunk_mask`, the second touches the
+        // chunks that hold anything only.
+        const int n_chunks = (c.m + 63) >> 6;
+        const int mine_chunks = (n_chunks - wave + NW - 1) / NW;       // chunks wave + NW * i, i < mine_chunks
+        unsigned long long* masks = c.chunk_mask;
+        int cnt = 0;
+        for (int i0 = 0; i0 < mine_chunks; i0 += 4) {
+            int ts[4];
+            double vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(((wave + NW * min(i0 + u, mine_chunks - 1)) << 6) + lane, c.m - 1);
+                ts[u] = c.tslot[k]; vv[u] = vec[k];
+            }
+            asm volatile("" : "+v"(ts[0]), "+v"(ts[1]), "+v"(ts[2]), "+v"(ts[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = wave + NW * (i0 + u), k = (ch << 6) + lane;
+                const bool on = i0 + u < mine_chunks && k < c.m && k != skip && ts[u] < 0 && vv[u] != 0.0;
+                const unsigned long long mask = __ballot(on);
+                if (i0 + u < mine_chunks && lane == 0) masks[ch] = mask;
+                cnt += __popcll(mask);
+            }
+        }
+        if (lane == 0) c.red_i[wave] = cnt;
+        __syncthreads();
+        int mine = 0, total = 0;
+        for (int w = 0; w < NW; ++w) { const int v = c.red_i[w]; if (w < wave) mine += v; total += v; }
+        if (total > room) { __syncthreads(); return -1; }
+        if (tid <= NW) {
+            int o = 0;
+            for (int w = 0; w < tid; ++w) o += c.red_i[w];
+            off_out[tid] = off_base + o;
+        }
+        int pos = out_base + mine;
+        for (int i0 = 0; i0 < mine_chunks && cnt > 0; i0 += 64) {      // (a wavefront reads 64 of its own masks at a time)
+            const int i = i0 + lane;
+            const unsigned long long mk = i < mine_chunks ? masks[wave + NW * i] : 0ull;
+            unsigned long long any = __ballot(mk != 0ull);
+            while (any) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)any) - 1);
+                any &= any - 1;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)mk, src), hi = __builtin_amdgcn_readlane((unsigned)(mk >> 32), src);
+                const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+                const int k = ((wave + NW * (i0 + src)) << 6) + lane;
+                if ((mask >> lane) & 1ull) {
+                    const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
+                    out_idx[at] = k;
+                    out_val[at] = vec[k];
+                }
+                pos += __popcll(mask);
+            }
+        }
+        __syncthreads();
+        return total;
+    }
     const int per_wave = (c.m - wave + NW - 1) / NW;           // pivots k = wave + NW * i, i < per_wave
     int cnt = 0;
     for (int i0 = 0; i0 < per_wave; i0 += 64) {
@@ -1154,30 +1214,52 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
 
         // ---- RATIO TEST (tableau/mod.rs:221-247; two passes as relp_device_common.h ratio_body) ------------------------
         double br;
-        if constexpr (kTier >= 2) {
-        // Layout 2: the solve leaves x pivot-indexed and mostly zero.  One coalesced pass over x scatters alpha (dense, for
+        if constexpr (kTier >= 1) {
+        // Layouts 1 and 2: the solve leaves x pivot-indexed and mostly zero.  One coalesced pass over x scatters alpha (dense, for
         // whoever reads it after the launch) and appends the non-zeros as (row, alpha) pairs to a list; the ratio test, the tie
         // band, the leaving row and the update of b then touch the list only (tableau/mod.rs:221-247 walks the stored
         // non-zeros of the column just the same).  Every reduction is order-free (minima), so the list's order does not matter.
         // pb.alpha (dense, for whoever reads it after the launch): zeroed where the previous column was not -- its list is
         // still there -- then the non-zeros of x, found through the bitmap, are scattered and listed
-        if (alpha_nnz < 0) { for (int i = tid; i < m; i += NT) pb.alpha[i] = 0.0; }
-        else for (int e = tid; e < alpha_nnz; e += NT) pb.alpha[st.nz_idx[e]] = 0.0;
-        if (tid == 0) c.red_i[2 * NW] = 0;
-        __syncthreads();
-        hs_for_each(c.bx, c.gs, 0, m, [&](int k) {
-            const double v = c.x[k];
-            if (v != 0.0) {
-                const int i = lu.colperm[k];
-                pb.alpha[i] = v;
-                const int e = atomicAdd(&c.red_i[2 * NW], 1);
-                st.nz_idx[e] = i; st.nz_val[e] = v;
+        if constexpr (kTier >= 2) {
+            if (alpha_nnz < 0) { for (int i = tid; i < m; i += NT) pb.alpha[i] = 0.0; }
+            else for (int e = tid; e < alpha_nnz; e += NT) pb.alpha[st.nz_idx[e]] = 0.0;
+            if (tid == 0) c.red_i[2 * NW] = 0;
+            __syncthreads();
+            hs_for_each(c.bx, c.gs, 0, m, [&](int k) {
+                const double v = c.x[k];
+                if (v != 0.0) {
+                    const int i = lu.colperm[k];
+                    pb.alpha[i] = v;
+                    const int e = atomicAdd(&c.red_i[2 * NW], 1);
+                    st.nz_idx[e] = i; st.nz_val[e] = v;
+                }
+            });
+        } else {
+            // (layout 1: x in LDS, no bitmap -- one pass over x with the permutation coalesced from L2 beside it: alpha written
+            // everywhere, the non-zeros listed.  The three passes this replaces each went x[icp[i]], b[i], basis[i] through L2
+            // for every row.)
+            if (tid == 0) c.red_i[2 * NW] = 0;
+            __syncthreads();
+            for (int k0 = tid; k0 < m; k0 += 4 * NT) {
+                int cp[4];
+                double xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int k = min(k0 + u * NT, m - 1); xv[u] = c.x[k]; cp[u] = lu.colperm[k]; }
+                asm volatile("" : "+v"(cp[0]), "+v"(cp[1]), "+v"(cp[2]), "+v"(cp[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u * NT < m) {
+                        pb.alpha[cp[u]] = xv[u];
+                        if (xv[u] != 0.0) { const int e = atomicAdd(&c.red_i[2 * NW], 1); st.nz_idx[e] = cp[u]; st.nz_val[e] = xv[u]; }
+                    }
+                }
             }
-        });
+        }
         __syncthreads();
         const int nnz = c.red_i[2 * NW];
         alpha_nnz = nnz;
-        if (c.clk.on) { c.clk.nnz[0] += nnz; c.clk.nnz[3] += 1; }
+        if constexpr (kTier >= 2) if (c.clk.on) { c.clk.nnz[0] += nnz; c.clk.nnz[3] += 1; }
         // (the first entry of every thread stays in registers: a column rarely has more than NT non-zeros)
         const bool h0 = tid < nnz;
         const int i0 = h0 ? st.nz_idx[tid] : 0;
