@@ -59,6 +59,7 @@ class Engine {
     relp_status_t lu_set_device_factorisation(bool on);
     relp_status_t lu_factor_residual(double* out);
     relp_status_t lu_basis_columns(std::vector<std::vector<std::pair<int32_t, double>>>& cols);
+    relp_status_t lu_basis_flat(std::vector<int64_t>& ptr, std::vector<int32_t>& idx, std::vector<double>& val);
     relp_status_t lu_phase_cycles(int64_t* out16);
     relp_status_t lu_download_basis();
     relp_status_t lu_factor_downloaded_basis();
@@ -200,6 +201,7 @@ class Engine {
     LUFactors hlu_;
     char* d_lu_buf_ = nullptr; int64_t lu_cap_ = 0;       // packed factors (permutations, rows, entries, levels)
     std::vector<std::vector<std::pair<int32_t, double>>> basis_cols_;      // the basis columns handed to lu_factor
+    std::vector<int64_t> basis_ptr_; std::vector<int32_t> basis_idx_; std::vector<double> basis_val_;   // ... as one flat copy (lu_factor_csc)
     // two helper threads for the host side of a refactorisation (created at first use, joined with the engine)
     struct HostPool {
         struct Slot { std::thread th; std::mutex mu; std::condition_variable cv; std::function<void()> job; bool busy = false, stop = false; };

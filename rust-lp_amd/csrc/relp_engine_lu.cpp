@@ -96,8 +96,43 @@ relp_status_t Engine::lu_basis_columns(std::vector<std::vector<std::pair<int32_t
     return RELP_OK;
 }
 
+// The same columns as one flat copy (column i = entries [ptr[i], ptr[i + 1])): what lu_factor_csc wants -- at 64,000 rows the
+// vector per column was a cache miss per column and pass.
+relp_status_t Engine::lu_basis_flat(std::vector<int64_t>& ptr, std::vector<int32_t>& idx, std::vector<double>& val) {
+    const int32_t* const basis = h_basis_;
+    ptr.assign((size_t)m_ + 1, 0);
+    idx.clear(); val.clear();
+    auto put = [&](int32_t row, double v) { idx.push_back(row); val.push_back(v); };
+    for (int32_t i = 0; i < m_; ++i) {
+        const int32_t j = basis[i];
+        if (j < nr_artificial_) put(column_to_row_[j], 1.0);
+        else if (j >= kWrappedArtificialBase) put(column_to_row_[wrapped_na_ - 1 - (INT32_MAX - j)], 1.0);
+        else {
+            const int32_t p = j - nr_artificial_;
+            if (p < nr_normal_) {
+                for (int64_t e = hc_ptr_[p]; e < hc_ptr_[p + 1]; ++e) put(hc_idx_[e], hc_val_[e]);
+                if (bound_row_h_[p] >= 0) put(bound_row_h_[p], 1.0);
+            } else {
+                const int32_t v = p - nr_normal_;
+                if (v >= nr_virtual_) return fail(RELP_E_STATE, "basis column out of range");
+                if (vrow0_h_[v] >= 0) put(vrow0_h_[v], (double)vsign_h_[v]);
+                if (vrow1_h_[v] >= 0) put(vrow1_h_[v], 1.0);
+            }
+        }
+        ptr[(size_t)i + 1] = (int64_t)idx.size();
+    }
+    return RELP_OK;
+}
+
 // P B Q = L U on the host for the basis in h_basis_ (hlu_ is overwritten)
 relp_status_t Engine::lu_factor_downloaded_basis() {
+    if (!std::getenv("RELP_DUMP_BASIS")) {
+        const relp_status_t fst = lu_basis_flat(basis_ptr_, basis_idx_, basis_val_);
+        if (fst) return fst;
+        std::string msg;
+        if (!lu_factor_csc(m_, basis_ptr_.data(), basis_idx_.data(), basis_val_.data(), &hlu_, &msg)) return fail(RELP_E_SINGULAR, msg);
+        return RELP_OK;
+    }
     std::vector<std::vector<std::pair<int32_t, double>>>& cols = basis_cols_;     // (kept: no 790 allocations per refactorisation)
     const relp_status_t cst = lu_basis_columns(cols);
     if (cst) return cst;

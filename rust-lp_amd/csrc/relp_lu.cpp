@@ -2,6 +2,8 @@
 // schedules for the device triangular solves.  See relp_lu.hpp.
 #include "relp_lu.hpp"
 
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -109,10 +111,23 @@ void lu_levels_from_rows(int32_t m, const std::vector<double>& diag, bool ascend
 
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err) {
+    std::vector<int64_t> ptr((size_t)m + 1, 0);
+    for (int32_t j = 0; j < m; ++j) ptr[(size_t)j + 1] = ptr[j] + (int64_t)columns[j].size();
+    std::vector<int32_t> idx((size_t)ptr[m]);
+    std::vector<double> val((size_t)ptr[m]);
+    for (int32_t j = 0; j < m; ++j) {
+        int64_t o = ptr[j];
+        for (auto& e : columns[j]) { idx[(size_t)o] = e.first; val[(size_t)o] = e.second; ++o; }
+    }
+    return lu_factor_csc(m, ptr.data(), idx.data(), val.data(), out, err);
+}
+
+// The same on a flat copy of the basis (column j = entries [ptr[j], ptr[j + 1]) of idx / val): what the engine hands over at
+// every refactorisation -- 64,000 separately allocated column vectors were a cache miss each, twice per factorisation.
+bool lu_factor_csc(int32_t m, const int64_t* cptr, const int32_t* cidx, const double* cval, LUFactors* out, std::string* err) {
     // active submatrix, row major: entries (column, value) of row i at rc / rv [rows.beg[i], + rows.len[i]); colrows: the rows
     // that (may) hold an entry of a column (stale members are dropped whenever the list is scanned for its maximum)
-    size_t nnz = 0;
-    for (int32_t j = 0; j < m; ++j) nnz += columns[j].size();
+    const size_t nnz = (size_t)cptr[m];
     ListArena<int32_t> rows, colrows;
     std::vector<double> rv;                                            // values parallel to rows.store
     rows.init(m, 4 * nnz + 8 * (size_t)m); colrows.init(m, 4 * nnz + 8 * (size_t)m);
@@ -121,15 +136,21 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     {
         std::vector<int32_t> rcount(m, 0);
         for (int32_t j = 0; j < m; ++j)
-            for (auto& e : columns[j]) if (e.second != 0.0) { ++rcount[e.first]; ++ccount[j]; }
-        for (int32_t i = 0; i < m; ++i) { rows.beg[i] = rows.alloc(rcount[i] + 4); rows.cap[i] = rcount[i] + 4; }
+            for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) if (cval[e] != 0.0) { ++rcount[cidx[e]]; ++ccount[j]; }
+        // (every list gets its room by one prefix sum and one resize: 128,000 separate allocations at 64,000 rows were a third
+        // of a refactorisation that has no bump to eliminate)
+        int64_t at = 0;
+        for (int32_t i = 0; i < m; ++i) { rows.beg[i] = (int32_t)at; rows.cap[i] = rcount[i] + 4; at += rcount[i] + 4; }
+        rows.store.resize((size_t)at);
         rv.resize(rows.store.size());
-        for (int32_t j = 0; j < m; ++j) { colrows.beg[j] = colrows.alloc(ccount[j] + 4); colrows.cap[j] = ccount[j] + 4; }
+        at = 0;
+        for (int32_t j = 0; j < m; ++j) { colrows.beg[j] = (int32_t)at; colrows.cap[j] = ccount[j] + 4; at += ccount[j] + 4; }
+        colrows.store.resize((size_t)at);
         for (int32_t j = 0; j < m; ++j)
-            for (auto& e : columns[j]) {
-                if (e.second == 0.0) continue;
-                const int32_t i = e.first, o = rows.beg[i] + rows.len[i]++;
-                rows.store[o] = j; rv[o] = e.second;
+            for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+                if (cval[e] == 0.0) continue;
+                const int32_t i = cidx[e], o = rows.beg[i] + rows.len[i]++;
+                rows.store[o] = j; rv[o] = cval[e];
                 colrows.store[colrows.beg[j] + colrows.len[j]++] = i;
             }
     }
@@ -166,12 +187,19 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
     for (int32_t j = 0; j < m; ++j) if (ccount[j] == 1) col_single.push_back(j);
     for (int32_t i = 0; i < m; ++i) if (rows.len[i] == 1) row_single.push_back(i);
     // the sparsest active row / column of the bump, ties to the lower index
+    // (built when the first pivot has to be SEARCHED for: while singletons last -- a whole multi-commodity basis of 64,000 rows,
+    // the triangular part of every other -- the two sets of 64 bit-vectors of m bits each are neither filled nor maintained;
+    // the sets then hold exactly what incremental maintenance would have left: the active lines by their current counts)
     CountBuckets row_set, col_set;
-    row_set.init(m); col_set.init(m);
-    for (int32_t i = 0; i < m; ++i) row_set.insert(i, rows.len[i]);
-    for (int32_t j = 0; j < m; ++j) col_set.insert(j, ccount[j]);
+    bool buckets_live = false;
+    auto buckets_build = [&]() {
+        row_set.init(m); col_set.init(m);
+        for (int32_t i = 0; i < m; ++i) if (!row_done[i]) row_set.insert(i, rows.len[i]);
+        for (int32_t j = 0; j < m; ++j) if (step_of_col[j] < 0) col_set.insert(j, ccount[j]);
+        buckets_live = true;
+    };
     auto col_count_changed = [&](int32_t j, int32_t from) {
-        if (step_of_col[j] < 0) col_set.move(j, from, ccount[j]);
+        if (buckets_live && step_of_col[j] < 0) col_set.move(j, from, ccount[j]);
     };
     // largest active |entry| of column j; the scan also drops the stale members of colrows[j] (finished rows,
     // rows that lost the entry, duplicates), so the lists stay as short as the columns are
@@ -220,6 +248,7 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
         // count; the lower (r - 1)(c - 1) wins.
         int32_t ra = -1;
         if (spj < 0) {
+            if (!buckets_live) buckets_build();
             ra = row_set.top(0, [&](int32_t i) { return rows.len[i]; });
             if (ra < 0) { if (err) *err = "singular basis (no active row)"; return false; }
             if (rows.len[ra] == 0) { if (err) *err = "singular basis (empty row during LU)"; return false; }
@@ -275,8 +304,7 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
         out->rowperm[k] = pi; out->colperm[k] = pj;
         step_of_row[pi] = k; step_of_col[pj] = k;
         row_done[pi] = 1;
-        row_set.erase(pi, rows.len[pi]);
-        col_set.erase(pj, ccount[pj]);
+        if (buckets_live) { row_set.erase(pi, rows.len[pi]); col_set.erase(pj, ccount[pj]); }
         udiag[k] = pv;
         ubeg[k] = (int32_t)ucol.size();
         {
@@ -330,7 +358,7 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
                 }
                 nc[o] = nc[u]; nv[o] = nv[u]; ++o;
             }
-            row_set.move(i, n, o);
+            if (buckets_live) row_set.move(i, n, o);
             row_store(i, nc, nv, o);
             if (o == 1) row_single.push_back(i);
         }
@@ -350,10 +378,22 @@ bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, doubl
             ucol_t.push_back(Triplet{l, k, uval[t]});                  // column l of U: rows k < l
         }
     std::vector<double> ones(m, 1.0);
-    rows_from_triplets(m, lrow_t, &out->Lf); finish_schedule(m, ones, true, &out->Lf);
-    rows_from_triplets(m, urow_t, &out->Uf); finish_schedule(m, udiag, false, &out->Uf);
-    rows_from_triplets(m, ucol_t, &out->Ub); finish_schedule(m, udiag, true, &out->Ub);
-    rows_from_triplets(m, lcol_t, &out->Lb); finish_schedule(m, ones, false, &out->Lb);
+    // (the four schedules are independent; beyond a few thousand rows the two of U, the larger ones, go to a second thread)
+    auto forward = [&]() {
+        rows_from_triplets(m, urow_t, &out->Uf); finish_schedule(m, udiag, false, &out->Uf);
+        rows_from_triplets(m, lrow_t, &out->Lf); finish_schedule(m, ones, true, &out->Lf);
+    };
+    auto backward = [&]() {
+        rows_from_triplets(m, ucol_t, &out->Ub); finish_schedule(m, udiag, true, &out->Ub);
+        rows_from_triplets(m, lcol_t, &out->Lb); finish_schedule(m, ones, false, &out->Lb);
+    };
+    if (m >= 8192) {
+        std::thread helper(backward);
+        forward();
+        helper.join();
+    } else {
+        forward(); backward();
+    }
     out->nnz_l = (int64_t)lrow_t.size();
     out->nnz_u = (int64_t)ucol.size() + m;
     return true;

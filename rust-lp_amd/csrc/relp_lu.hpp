@@ -43,6 +43,8 @@ struct LUFactors {
 // Returns false (and a message) when B is numerically singular.
 bool lu_factor(int32_t m, const std::vector<std::vector<std::pair<int32_t, double>>>& columns, LUFactors* out,
                std::string* err);
+// the same from a flat copy of the columns (column j = entries [ptr[j], ptr[j + 1]) of idx / val)
+bool lu_factor_csc(int32_t m, const int64_t* ptr, const int32_t* idx, const double* val, LUFactors* out, std::string* err);
 
 // Levels for a schedule whose rows (ptr / idx / val) are given, e.g. by the device factorisation (relp_lu_factor_core.h):
 // fills diag, level_ptr, level_rows.  ascending: the dependencies of a row have smaller indices.
