@@ -395,7 +395,7 @@ __device__ __forceinline__ void ft_ftran(const DeviceLU& lu, const FtState& st, 
             double sum = 0.0;
             if (s < t) {
                 const int e0 = c.eta_off[s * (NW + 1)], e1 = c.eta_off[s * (NW + 1) + NW];
-                if constexpr (Ctx::huge) {             // (pool and x in L2: four entries requested before the first is used)
+                if constexpr (Ctx::big) {              // (the pool in L2 -- in layout 2 x too: four entries requested before the first is used)
                     for (int e = e0 + l; e < e1; e += 4 * G) {
                         int k[4];
                         double v[4], xv[4];
@@ -1405,6 +1405,21 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
             });
             __syncthreads();
             rho_nnz = c.red_i[2 * NW + 1];
+        } else if constexpr (kTier == 1) {             // (the permutation comes from L2: four rows requested at a time)
+            for (int k0 = tid; k0 < m; k0 += 4 * NT) {
+                int ii[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ii[u] = c.rp[min(k0 + u * NT, m - 1)];
+                asm volatile("" : "+v"(ii[0]), "+v"(ii[1]), "+v"(ii[2]), "+v"(ii[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u * NT < m) {
+                        const double rho = c.x[k0 + u * NT] * rho_scale;
+                        pb.rho[ii[u]] = rho;
+                        c.pi[ii[u]] = fma(-d_q, rho, c.pi[ii[u]]);
+                    }
+                }
+            }
         } else
         for (int k = tid; k < m; k += NT) {
             const int i = c.rp[k];
