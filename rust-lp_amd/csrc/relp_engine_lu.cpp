@@ -801,6 +801,9 @@ FtProblem Engine::ft_problem(int rule) const {
 relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome) {
     relp_status_t st = download_rec();
     if (st) return st;
+    // (layout 2 keeps lists of where alpha and rho are not zero and rewrites those places only; whatever ran since the last call --
+    // step-wise API, phase switch, warm start -- may have written the two vectors: the first pivot rewrites them densely)
+    if (ft_tier_ >= 2) HIP_TRY(hipMemsetAsync(fts_.nzc, 0xFF, 2 * sizeof(int32_t), stream_));
     const long long start = h_rec_->iterations;
     const int rule = phase_ == 1 ? cfg_.phase_one_rule : cfg_.phase_two_rule;
     struct Tick { int64_t& t; ~Tick() { ++t; } };
