@@ -1449,6 +1449,11 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
     if constexpr (kTier >= 2) if (tid == 0) { st.nzc[0] = alpha_nnz; st.nzc[1] = rho_nnz; }
     c.clk.lap(FT_LOAD_STORE);
     c.clk.flush(st.prof, kTier >= 2);
+#ifdef PASS_DIAG
+    if (tid == 0 && outcome != DEV_RUNNING)
+        printf("pass_diag: own-pass clocks %llu / %llu over %llu / %llu passes; barrier clocks %llu / %llu over %llu / %llu; fetch clocks %llu / %llu; other set's passes %llu / %llu\n",
+               pass_diag[0], pass_diag[1], pass_diag[2], pass_diag[3], pass_diag[4], pass_diag[5], pass_diag[6], pass_diag[7], pass_diag[8], pass_diag[9], pass_diag[10], pass_diag[11]);
+#endif
     if (tid == 0) {
         rec->outcome = outcome; rec->q = q; rec->d_q = d_q; rec->r = r; rec->leaving = leaving; rec->alpha_r = alpha_r;
         rec->b_r = b_r; rec->minus_objective = minus_objective; rec->iterations = iterations;

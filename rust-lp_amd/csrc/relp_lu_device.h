@@ -294,6 +294,12 @@ struct EllImage {
 // four at a time
 // (kL2 also: x is a sparse vector, `bx` its "may be non-zero" bitmap in LDS with a bit per 2^gs entries -- relp_kernels_ft.hip,
 // hs_*: only the copies of non-zero right-hand sides are made, the stale ones of an earlier sweep zeroed first)
+#ifdef PASS_DIAG
+// cycle stamps of the pass loop of ell_solve_pp (lane 0 of wavefronts 0 and 4, one per set), diagnostic builds only:
+// [set]: clocks in own passes, [2 + set]: own passes, [4 + set]: clocks at level-end barriers, [6 + set]: barriers,
+// [8 + set]: clocks fetching the next own pass, [10 + set]: clocks in the other set's passes
+__device__ unsigned long long pass_diag[12];
+#endif
 template <int NT, class F>
 __device__ __forceinline__ void ell_for_each_bit(const uint32_t* bits, int gs, int first, int n, F f) {
     const int w0 = (first >> gs) >> 5, w1 = (((n - 1) >> gs) >> 5) + 1;
@@ -584,6 +590,9 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
     double m_diag = rdiag[min(m_iv & kEllIdxMask, mm)];
     int z = hdr[p0].z, zn = hdr[p0 + 1].z;
     for (int p = p0; p < p1; ++p) {
+#ifdef PASS_DIAG
+        const long long pd0 = clock64();
+#endif
         const int znn = hdr[p + 2].z;
         const int info = __builtin_amdgcn_readfirstlane(z);
         const bool mine = ((p - p0) & 1) == set;       // (uniform per wavefront)
@@ -621,7 +630,13 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
             x[lead ? c_idx : dummy] = sum * m_diag;
 #endif
         }
+#ifdef PASS_DIAG
+        const long long pd1 = clock64();
         if (info & 0x100) __syncthreads();
+        const long long pd2 = clock64();
+#else
+        if (info & 0x100) __syncthreads();
+#endif
         if (mine) {                                    // off the critical path: the other set is solving pass p + 1
             hm = hm2;
             hm2 = hdr[p + 4];
@@ -629,6 +644,15 @@ __device__ __forceinline__ int ell_solve_pp(const EllSchedule& s, char* base, do
             m_iv = sidx[sm]; m_val = sval[sm];
             m_diag = rdiag[min(m_iv & kEllIdxMask, mm)];
         }
+#ifdef PASS_DIAG
+        if (lt == 0) {
+            const long long pd3 = clock64();
+            atomicAdd(&pass_diag[(mine ? 0 : 10) + set], (unsigned long long)(pd1 - pd0));
+            if (mine) atomicAdd(&pass_diag[2 + set], 1ull);
+            if (info & 0x100) { atomicAdd(&pass_diag[4 + set], (unsigned long long)(pd2 - pd1)); atomicAdd(&pass_diag[6 + set], 1ull); }
+            if (mine) atomicAdd(&pass_diag[8 + set], (unsigned long long)(pd3 - pd2));
+        }
+#endif
         z = zn; zn = znn;
     }
     return p1 - p0;
