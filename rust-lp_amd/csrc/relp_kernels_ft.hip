@@ -327,14 +327,6 @@ __device__ __forceinline__ double tc_chain(const double* TC, int ldt, int t, int
 // lanes per update slot when all t slots are worked on at once: 64, 32, 16 or 8 (as a shift)
 __device__ __forceinline__ int slot_lanes_shift(int t) { return t <= NT / 64 ? 6 : t <= NT / 32 ? 5 : t <= NT / 16 ? 4 : 3; }
 
-// sum over the 8 lanes of a group (valid in the group's lane 0), register to register
-__device__ __forceinline__ double sum8(double v) {
-    v += dpp_row_shl<0x104>(v);
-    v += dpp_row_shl<0x102>(v);
-    v += dpp_row_shl<0x101>(v);
-    return v;
-}
-
 // `which`: 0 L, 1 U, 2 U', 3 L'.  first_level: levels below it hold zeros only (0 = everything).
 template <class Ctx> __device__ __forceinline__ int block_min_int(Ctx& c, int v);
 

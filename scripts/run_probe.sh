@@ -1,11 +1,7 @@
+# scratch script of the GPU box runs (gpurun -- 'bash scripts/run_probe.sh'); as committed: smoke, then the whole GPU tier
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for sh in 0 1; do
-  RELP_LU_LOOKAHEAD_SHORT=$sh timeout -k 10 200 python scripts/lu_large.py netlib/25FV47.SIF 0 lu 30000 11 > gpurun_out/fv11.log 2>&1 || true
-  echo "25FV47 block 11, short look-ahead $sh"; grep "optimal\|lookahead" gpurun_out/fv11.log | tail -n 2 | cut -c1-300
-done
-for b in 8 11 16; do
-  timeout -k 10 200 python scripts/lu_large.py netlib/25FV47.SIF 0 lu 30000 $b > gpurun_out/fv11.log 2>&1 || true
-  echo "block $b"; grep "optimal" gpurun_out/fv11.log | tail -n 1 | cut -c1-200
-done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 2
+timeout -k 10 1150 python -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/gpu_tier.log 2>&1 || { tail -n 60 gpurun_out/gpu_tier.log; exit 1; }
+tail -n 10 gpurun_out/gpu_tier.log
