@@ -493,7 +493,7 @@ def sparse_large():
     return out
 
 
-def sparse_scale():
+def sparse_scale(with_cpu=True):
     """Where the sparse engine is the engine to take: a multi-commodity flow LP of the KEN / PDS shape
     (synthetic.multicommodity_lp: 12 commodities on 4,000 nodes / 16,000 arcs -> 63,988 rows x 255,988 columns, 3 entries per
     column), far beyond what one CU's LDS holds per row.  The persistent pivot kernel runs in its third layout (x, -pi and the
@@ -536,6 +536,30 @@ def sparse_scale():
     first = out["lu"].pop("first_pivots")
     for label, _, _, _ in legs[1:]:
         out[label]["first_250_pivots_equal_the_lu_engines"] = out[label].pop("first_pivots") == first
+    if with_cpu:
+        # the f64 CPU port (oracle/relp_f64.c: explicit inverse as sparse rows, one core) over the first 5,000 pivots, and the LU
+        # engine once more over the same stretch: same pivots, same objective
+        from oracle import relp_f64
+        ref = relp_f64.OracleF64(md)
+        t0 = time.perf_counter()
+        ref.run(max_iters=5000)
+        cdt = time.perf_counter() - t0
+        t = engine.Tableau(md, engine=engine.ENGINE_LU, trace_capacity=5000)
+        total = 0
+        t1 = time.perf_counter()
+        while total < 5000:
+            done, oc = t.run(5000 - total)
+            total += done
+            if oc not in (engine.RUNNING, engine.PHASE_ONE_DONE) or done == 0:
+                break
+        gdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": len(ref.trace) / cdt, "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "lu_engine_value_over_sample": total / gdt,
+                               "sample": f"first 5000 pivots of the same LP, oracle/relp_f64.c, {cdt:.1f} s",
+                               "objective_after_sample": ref.objective,
+                               "lu_engine_objective_after_sample": t.objective_function_value(),
+                               "lu_engine_takes_the_same_5000_pivots": [list(p) for p in t.trace()] == [list(p) for p in ref.trace]}
+        t.close()
     out["lu_over_fallback"] = round(out["lu"]["value"] / out["lu_product_form_fallback"]["value"], 2)
     out["lu_over_tableau"] = round(out["lu"]["value"] / out["tableau"]["value"], 2)
     return out
@@ -714,7 +738,7 @@ def main():
     if sparse is not None:
         sparse["large"] = sparse_large()
         if not args.no_scale:
-            sparse["scale"] = sparse_scale()
+            sparse["scale"] = sparse_scale(not args.no_cpu_baseline)
     c1 = config_one(not args.no_cpu_baseline) if solo and not args.no_c1 else None
     c5 = config_five() if solo and not args.no_c5 else None
 

@@ -64,6 +64,8 @@ def test_driver_command_emits_one_complete_json_line():
         assert scale[leg]["first_250_pivots_equal_the_lu_engines"] is True, leg
     assert scale["lu"]["rows"] == 63988 and scale["lu"]["pivots"] == 20000 and scale["lu"]["value"] > 1000
     assert scale["lu_over_fallback"] > 5 and scale["lu"]["pivot_kernel_clocks_per_pivot"] > 0
+    assert scale["cpu_baseline"]["lu_engine_takes_the_same_5000_pivots"] is True and scale["cpu_baseline"]["value"] > 0
+    assert abs(scale["cpu_baseline"]["objective_after_sample"] - scale["cpu_baseline"]["lu_engine_objective_after_sample"]) < 1e-6
     stride = out["kernel_event_stride"]
     assert stride % block != 0                                            # (no aliasing with the block)
 
