@@ -1,5 +1,7 @@
+# scratch script of the GPU box runs (gpurun -- 'bash scripts/run_probe.sh'); as committed: smoke, then the whole GPU tier
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_final.json 2> gpurun_out/r03_bench_final.err || { tail -n 30 gpurun_out/r03_bench_final.err; exit 1; }
-python scripts/show_scale.py gpurun_out/r03_bench_final.json
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 2
+timeout -k 10 1150 python -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/gpu_tier.log 2>&1 || { tail -n 60 gpurun_out/gpu_tier.log; exit 1; }
+tail -n 10 gpurun_out/gpu_tier.log
