@@ -119,9 +119,11 @@ typedef struct {
      * another row survives into phase 2 as a free column on that row -- Netlib GREENBEA ends 73,482 below its optimum that
      * way), on the first non-basic column with a non-zero element in that row, whatever that column's reduced cost (the
      * pivot is at zero level either way; phase_one.rs:239-244 only tries columns whose reduced cost is exactly zero), and
-     * a row without such a column is removed as itself (phase_one.rs:252 pushes the artificial's INDEX, which names another
-     * row as soon as `<=` rows lie in front of the artificial's row: the reference then deletes a non-redundant row and
-     * optimises a relaxation -- Netlib 80BAU3B ends at 964,593.50 instead of 987,224.19 that way). */
+     * where there is no such column the artificial's OWN constraint is removed together with the basis position it sits in
+     * (the two positions are exchanged first -- rows of B^-1 / of the tableau, b, the basis array -- so that one index names
+     * both: that pair always leaves a basis of the filtered problem; phase_one.rs:252 pushes the artificial's INDEX, which
+     * names another row as soon as `<=` rows lie in front of the artificial's row: the reference then deletes a
+     * non-redundant row and optimises a relaxation -- Netlib 80BAU3B ends at 964,593.50 instead of 987,224.19 that way). */
     int32_t artificial_removal;
 } relp_config_t;
 
@@ -218,7 +220,8 @@ relp_status_t relp_lu_lookahead_stats(const relp_engine_t *h, int64_t *out4);
  * per step), its layout (0: work vectors, eta file and permutations in one CU's LDS; 1: x, -pi and the slot tables in LDS, the
  * rest in L2; 2: nothing per row in LDS, any m), slots of the dense tail of U (= the longest refactorisation interval), PRICE as
  * a grid launch per pivot (Dantzig's rule over >= 32,768 columns in layout 2; RELP_FT_GRID_PRICE) }.  RELP_FT_BIG = 0 / 1 / 2
- * forces a layout at create; a layout that does not fit falls through to the next one. */
+ * forces that layout at create: when the forced layout does not fit, no other layout is tried and the engine runs the
+ * product-form fallback (out[0] = 0) -- bench.py's `lu_product_form_fallback` leg relies on exactly that. */
 relp_status_t relp_lu_kernel_layout(const relp_engine_t *h, int32_t *out4);
 /* RELP_ENGINE_LU: refactorise ON THE DEVICE (LUDecomposition::invert -> decomposition/mod.rs:27-138 with the Markowitz
  * pivoting of decomposition/pivoting.rs:45-81): singleton rows / columns peeled in parallel rounds, the bump eliminated on
@@ -231,7 +234,9 @@ relp_status_t relp_lu_set_device_factorisation(relp_engine_t *h, int32_t on);
 relp_status_t relp_lu_device_factorisation_stats(const relp_engine_t *h, int64_t *out6);
 /* max |P B Q - L U| over all entries for the factors in use and the current basis (decomposition/mod.rs:301-491 asserts
  * the factors themselves; pivot orders differ, the identity is what they have in common).  Dense arithmetic on the host:
- * m <= 1,024, else *out = -1. */
+ * m <= 1,024, else *out = -1.  The factors describe the basis of the last refactorisation: with Forrest-Tomlin updates
+ * pending the comparison would be against another basis, and *out = -1 as well (call it right after relp_from_basis /
+ * a refactorisation). */
 relp_status_t relp_lu_factor_residual(relp_engine_t *h, double *out);
 
 /* RELP_ENGINE_LU in Forrest-Tomlin mode: shader clocks spent per phase of the pivot inside the persistent kernel since create

@@ -51,6 +51,7 @@ struct oracle_engine {
     /* rank-deficient view (filter/generic_wrapper.rs:51): sorted rows deleted from the provider */
     int32_t nr_filtered; int32_t *filtered;
     int32_t nr_zero_level;                  /* pivots made by remove_artificial_basis_variables */
+    int32_t nr_exchanges;                   /* stuck artificials moved into their own row (artificial_removal 1) */
 
     oracle_config_t cfg;
 
@@ -361,6 +362,7 @@ oracle_engine_t *oracle_create(const oracle_matrix_data_t *md, const oracle_conf
     for (int g = 0; g < 6; g++) { e->col_start[g + 1] = e->col_start[g] + camt[g]; e->row_start[g + 1] = e->row_start[g] + ramt[g]; }
     e->nr_filtered = 0; e->filtered = NULL;
     e->nr_zero_level = 0;
+    e->nr_exchanges = 0;
     sv_init(&e->scratch_col); sv_init(&e->scratch_alpha);
 
     /* Tableau::<_, Partially<_>>::new, partially.rs:125-206 */
@@ -461,13 +463,34 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
             record(n_done, cap, tp, te, tr, tl, 1, q, pivot_row, leaving);
             e->nr_zero_level++;
         } else {
-            /* NB: the reference pushes the artificial's INDEX (phase_one.rs:252); artificial_removal 1 (an extension)
-             * marks the row the artificial is basic in */
-            rows_to_remove[nrem++] = e->cfg.artificial_removal ? pivot_row : a;
+            /* NB: the reference pushes the artificial's INDEX (phase_one.rs:252).  artificial_removal 1 (an extension)
+             * removes the artificial's OWN constraint together with the basis position it sits in: the two positions
+             * are exchanged first (rows of B^-1, b, basis), so that one index names both -- the pair (own row, position)
+             * always leaves a basis of the filtered problem, (position, position) only if B^-1[r][r] != 0 */
+            if (e->cfg.artificial_removal) {
+                int32_t o = e->column_to_row[a];
+                if (o != pivot_row) {
+                    e->nr_exchanges++;
+                    svec tr_ = e->rows[o]; e->rows[o] = e->rows[pivot_row]; e->rows[pivot_row] = tr_;
+                    double tb = e->b[o]; e->b[o] = e->b[pivot_row]; e->b[pivot_row] = tb;
+                    int32_t ti = e->basis_indices[o]; e->basis_indices[o] = e->basis_indices[pivot_row]; e->basis_indices[pivot_row] = ti;
+                }
+                rows_to_remove[nrem++] = o;
+            } else {
+                rows_to_remove[nrem++] = a;
+            }
         }
     }
     sv_free(&alpha);
-    return nrem;
+    /* ascending and distinct: switch_to_phase_two walks the list beside the rows (literal mode pushes ascending indices) */
+    for (int32_t i = 1; i < nrem; i++) {
+        int32_t v = rows_to_remove[i], j = i - 1;
+        while (j >= 0 && rows_to_remove[j] > v) { rows_to_remove[j + 1] = rows_to_remove[j]; j--; }
+        rows_to_remove[j + 1] = v;
+    }
+    int32_t uniq = 0;
+    for (int32_t i = 0; i < nrem; i++) if (uniq == 0 || rows_to_remove[uniq - 1] != rows_to_remove[i]) rows_to_remove[uniq++] = rows_to_remove[i];
+    return uniq;
 }
 
 /* non_artificial.rs:151-220 + carry/mod.rs:484-510, 650-689 */
@@ -567,6 +590,7 @@ int32_t oracle_phase(const oracle_engine_t *e) { return e->phase; }
 int32_t oracle_nr_artificial(const oracle_engine_t *e) { return e->nr_artificial; }
 int32_t oracle_nr_filtered_rows(const oracle_engine_t *e) { return e->nr_filtered; }
 int32_t oracle_nr_zero_level_pivots(const oracle_engine_t *e) { return e->nr_zero_level; }
+int32_t oracle_nr_position_exchanges(const oracle_engine_t *e) { return e->nr_exchanges; }
 void oracle_get_filtered_rows(const oracle_engine_t *e, int32_t *out) { for (int32_t k = 0; k < e->nr_filtered; k++) out[k] = e->filtered[k]; }
 double  oracle_objective(const oracle_engine_t *e) { return -e->minus_objective; }
 void oracle_get_b(const oracle_engine_t *e, double *out) { memcpy(out, e->b, sizeof(double) * (size_t)e->m); }

@@ -56,7 +56,7 @@ def lib():
         L.oracle_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.POINTER(C.c_int64)]
         for name in ("oracle_m", "oracle_n", "oracle_phase", "oracle_nr_artificial", "oracle_nr_filtered_rows",
-                     "oracle_nr_zero_level_pivots"):
+                     "oracle_nr_zero_level_pivots", "oracle_nr_position_exchanges"):
             getattr(L, name).restype = C.c_int32
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_objective.restype = C.c_double
@@ -122,6 +122,7 @@ class OracleF64:
     phase = property(lambda self: lib().oracle_phase(self._h))
     nr_artificial = property(lambda self: lib().oracle_nr_artificial(self._h))
     nr_zero_level_pivots = property(lambda self: lib().oracle_nr_zero_level_pivots(self._h))
+    nr_position_exchanges = property(lambda self: lib().oracle_nr_position_exchanges(self._h))
 
     def filtered_rows(self):
         """Rows removed as redundant at the phase switch."""

@@ -52,9 +52,9 @@ typedef struct {
      *   lowest leaving column (tableau/mod.rs:229-239 has only the latter);
      * artificial_removal 1: a basic artificial is pivoted out in the row it is basic IN (phase_one.rs:236 takes the row it
      *   started in, so one that re-entered elsewhere survives into phase 2 as a free column) on ANY non-basic column with a
-     *   non-zero element in that row (phase_one.rs:239-244 tries only columns with zero reduced cost), and a row without one
-     *   is removed as ITSELF (phase_one.rs:252 pushes the artificial's index, which is another row once `<=` rows lie in
-     *   front). */
+     *   non-zero element in that row (phase_one.rs:239-244 tries only columns with zero reduced cost), and where there is
+     *   none the artificial's OWN constraint is removed together with the basis position it sits in (the two positions are
+     *   exchanged first; phase_one.rs:252 pushes the artificial's index, which is another row once `<=` rows lie in front). */
     int32_t ratio_rule;
     int32_t artificial_removal;
 } oracle_config_t;
@@ -84,6 +84,8 @@ int32_t oracle_nr_artificial(const oracle_engine_t *e);
 int32_t oracle_nr_filtered_rows(const oracle_engine_t *e);
 /* pivots made at zero level to drive basic artificial variables out at the end of phase 1 (phase_one.rs:236-250) */
 int32_t oracle_nr_zero_level_pivots(const oracle_engine_t *e);
+/* artificial_removal 1: stuck artificial variables that sat in a foreign basis position and were moved into their own row */
+int32_t oracle_nr_position_exchanges(const oracle_engine_t *e);
 void oracle_get_filtered_rows(const oracle_engine_t *e, int32_t *out);
 double  oracle_objective(const oracle_engine_t *e);
 void    oracle_get_b(const oracle_engine_t *e, double *out);

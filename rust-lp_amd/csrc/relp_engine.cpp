@@ -111,6 +111,7 @@ relp_status_t Engine::set_stream(hipStream_t s) {
 // artificial start (partially.rs:125-206, carry/mod.rs:381-426)
 // ------------------------------------------------------------------------------------------------
 relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& cfg) {
+    (void)hipGetLastError();                               // (the launch check at the end must only see this create's launches)
     cfg_ = cfg;
     if (md.nr_normal < 0 || md.nr_eq < 0 || md.nr_range < 0 || md.nr_le < 0 || md.nr_ge < 0)
         return fail(RELP_E_ARG, "negative size");
@@ -957,8 +958,13 @@ relp_status_t Engine::remove_artificial_basis_variables(std::vector<int32_t>& ro
             if (!textbook && std::fabs(d[j]) > cfg_.tol_cost) continue;        // phase_one.rs:241: cost.is_zero()
             if (std::fabs(tau[j]) > cfg_.tol_pivot) { q = j; break; }
         }
-        // phase_one.rs:252 pushes the artificial's index; RELP_ARTIFICIAL_TEXTBOOK the row it is basic in (relp_engine.h)
-        if (q < 0) { rows_to_remove.push_back(textbook ? pivot_row : a); continue; }
+        // phase_one.rs:252 pushes the artificial's index; RELP_ARTIFICIAL_TEXTBOOK its own row, and remove_rows moves the
+        // artificial into that position first (relp_engine.h)
+        if (q < 0) {
+            if (textbook) { stuck_artificials_.push_back(a); rows_to_remove.push_back(column_to_row_[a]); }
+            else rows_to_remove.push_back(a);
+            continue;
+        }
         if ((st = generate_column(q, nullptr))) return st;
         if ((st = bring_into_basis(q, pivot_row, d[q], nullptr))) return st;
         basis[pivot_row] = q;
@@ -973,7 +979,14 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
     // the host-side copies below go through the null stream, which does not order with stream_: everything
     // enqueued so far (the flush, a possible re-pricing that uses d_w_) must have finished first
     HIP_TRY(hipStreamSynchronize(stream_));
-    if (!rows_to_remove.empty() && (st = remove_rows(rows_to_remove))) return st;
+    if (!rows_to_remove.empty()) {
+        std::vector<int32_t> rows(rows_to_remove);          // ascending and distinct: remove_rows walks the list beside the rows
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        st = remove_rows(rows);
+        stuck_artificials_.clear();
+        if (st) return st;
+    }
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     const int32_t na = nr_artificial_;
@@ -1033,6 +1046,8 @@ relp_status_t Engine::switch_to_phase_two(const std::vector<int32_t>& rows_to_re
 // delete the given rows (and the same columns of B^-1) everywhere.  Rare, host round trip.
 relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     if (cfg_.shard_count > 1 && !tableau_) return fail(RELP_E_UNSUPPORTED, "row removal in the sharded revised engine");
+    for (size_t k = 0; k < rows.size(); ++k)
+        if (rows[k] < 0 || rows[k] >= m_ || (k > 0 && rows[k] <= rows[k - 1])) return fail(RELP_E_STATE, "rows to remove must be ascending and distinct");
     std::vector<int32_t> map(m_, 0);   // old row -> new row, -1 = removed
     {
         size_t f = 0; int32_t out = 0;
@@ -1047,6 +1062,26 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     // basis of the filtered problem: the literal state is kept from here on, never rebuilt from the columns.
     for (int32_t r : rows) if (r >= nr_eq_ + nr_range_) reinvert_interval_ = 0;
     const int32_t mc_new = mc_ - (int32_t)rows.size();
+    // RELP_ARTIFICIAL_TEXTBOOK: an artificial variable that is stuck in basis position r but started in row o != r takes
+    // its own constraint with it, i.e. the pair (constraint o, position r) goes -- always a basis of the filtered problem,
+    // which (r, r) is only if (B^-1)[r][r] != 0.  Positions are labels: exchanging r and o (rows of B^-1 / of the tableau,
+    // b, the basis array) first lets one index name both.  perm: position i of the new order holds the old position perm[i].
+    std::vector<int32_t> perm(m_), basis_perm;
+    for (int32_t i = 0; i < m_; ++i) perm[i] = i;
+    bool identity_perm = true;
+    if (!stuck_artificials_.empty()) {
+        basis_perm.resize(m_);
+        HIP_TRY(hipStreamSynchronize(stream_));
+        HIP_TRY(hipMemcpy(basis_perm.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+        for (int32_t a : stuck_artificials_) {
+            const int32_t o = column_to_row_[a];
+            const int32_t cur = (int32_t)(std::find(basis_perm.begin(), basis_perm.end(), a) - basis_perm.begin());
+            if (cur >= m_) return fail(RELP_E_STATE, "a stuck artificial variable is not basic");
+            if (cur == o) continue;
+            std::swap(basis_perm[cur], basis_perm[o]); std::swap(perm[cur], perm[o]);
+            identity_perm = false;
+        }
+    }
     // B^-1 (or the tableau), b, basis
     const bool no_inv = tableau_ || lu_;
     std::vector<double> Bh(no_inv ? 1 : (size_t)m_ * ld_b_), b(m_);
@@ -1060,7 +1095,7 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
         for (int32_t c = 0; c < n_owned; ++c) {
             HIP_TRY(hipMemcpy(col.data(), dT0_ + (int64_t)c * ld_t_, sizeof(double) * m_, hipMemcpyDeviceToHost));
             std::fill(coln.begin(), coln.end(), 0.0);
-            for (int32_t i = 0; i < m_; ++i) if (map[i] >= 0) coln[map[i]] = col[i];
+            for (int32_t i = 0; i < m_; ++i) if (map[i] >= 0) coln[map[i]] = col[perm[i]];
             HIP_TRY(hipMemcpy(dT0_ + (int64_t)c * ld_t_, coln.data(), sizeof(double) * ld_t_, hipMemcpyHostToDevice));
         }
         std::vector<int32_t> idn;
@@ -1090,6 +1125,16 @@ relp_status_t Engine::remove_rows(const std::vector<int32_t>& rows) {
     }
     HIP_TRY(hipMemcpy(b.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
+    if (!identity_perm) {                              // the stuck artificial variables move into their own rows (see above)
+        std::vector<double> b0(b), B0;
+        for (int32_t i = 0; i < m_; ++i) b[i] = b0[perm[i]];
+        basis = basis_perm;
+        if (!no_inv) {
+            B0 = Bh;
+            for (int32_t i = 0; i < m_; ++i)
+                if (perm[i] != i) std::copy(B0.begin() + (size_t)perm[i] * ld_b_, B0.begin() + (size_t)(perm[i] + 1) * ld_b_, Bh.begin() + (size_t)i * ld_b_);
+        }
+    }
     const int64_t ld_new = ld_b_;
     std::vector<double> Bn(no_inv ? 1 : (size_t)m_ * ld_new, 0.0), bn(m_, 0.0);
     std::vector<int32_t> basisn(m_, 0);

@@ -350,6 +350,9 @@ class Engine {
     relp_status_t finish_phase_one(int32_t* outcome);
     relp_status_t remove_artificial_basis_variables(std::vector<int32_t>& rows_to_remove);
     relp_status_t switch_to_phase_two(const std::vector<int32_t>& rows_to_remove);
+    // RELP_ARTIFICIAL_TEXTBOOK: artificial variables no zero-level pivot could remove; remove_rows exchanges the basis position
+    // each one sits in with its own row before both go (the pair (own constraint, position) always leaves a basis)
+    std::vector<int32_t> stuck_artificials_;
     relp_status_t remove_rows(const std::vector<int32_t>& rows);
     void free_all();
 };

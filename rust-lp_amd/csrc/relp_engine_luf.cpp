@@ -271,6 +271,11 @@ relp_status_t Engine::lu_factor_residual(double* out) {
     *out = -1.0;
     const int32_t m = m_;
     if (m > 1024 || hlu_.m != m) return RELP_OK;
+    if (ft_) {                                             // updates pending: the factors are those of an earlier basis
+        relp_status_t hs = ft_read_hdr();
+        if (hs) return hs;
+    }
+    if (since_flush_ > 0) return RELP_OK;
     relp_status_t st = lu_host_factors();
     if (st) return st;
     if ((st = lu_download_basis())) return st;

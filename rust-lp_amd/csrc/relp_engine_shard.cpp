@@ -203,7 +203,11 @@ relp_status_t Engine::remove_artificial_basis_variables_sharded(std::vector<int3
         launch_tab_select_candidate_ratio(d_msg_cands_, g, cand_len_, m_, d_alpha_, d_b_, d_basis_, RELP_RULE_FIRST_PROFITABLE,
                                           tolerances(), du, pivot_row, d_rec_, stream_);
         if ((st = download_rec())) return st;
-        if (h_rec_->outcome == DEV_NO_CANDIDATE) { rows_to_remove.push_back(textbook ? pivot_row : a); continue; }
+        if (h_rec_->outcome == DEV_NO_CANDIDATE) {      // (textbook: the artificial's own row; remove_rows moves it there first)
+            if (textbook) { stuck_artificials_.push_back(a); rows_to_remove.push_back(column_to_row_[a]); }
+            else rows_to_remove.push_back(a);
+            continue;
+        }
         if (h_rec_->alpha_r == 0.0) return fail(RELP_E_ZERO_PIVOT, "Pivot value can't be zero.");
         launch_tab_update_all(tv, du, sp, m_, d_alpha_, d_b_, d_basis_, d_in_basis_, d_trace_, trace_cap_, d_rec_, stream_);
         tab_partials_valid_ = false;

@@ -388,9 +388,11 @@ bool lu_factor_csc(int32_t m, const int64_t* cptr, const int32_t* cidx, const do
         rows_from_triplets(m, lcol_t, &out->Lb); finish_schedule(m, ones, false, &out->Lb);
     };
     if (m >= 8192) {
-        std::thread helper(backward);
+        struct Joined {                                    // (joins on every path out: an exception in forward() must not
+            std::thread t;                                 // reach std::terminate through a joinable thread)
+            ~Joined() { if (t.joinable()) t.join(); }
+        } helper{std::thread(backward)};
         forward();
-        helper.join();
     } else {
         forward(); backward();
     }
