@@ -18,7 +18,8 @@ struct Engine::LufState {
     int32_t cap = 0, nb_cap = 0;
     bool dirty = true;
     int32_t key[4] = {-1, -1, -1, -1};                         // (m, artificial columns, phase, wrapped artificials) the tables were built for
-    LufSchedWork SW{}; LufSchedIn sin[4]; LufSchedOut sout[4];   // the schedules (relp_lu_schedule_core.h)
+    LufSchedWork SW[4]; LufSchedIn sin[4]; LufSchedOut sout[4];   // the schedules (relp_lu_schedule_core.h), one work set each
+    int32_t x_cap = 0, pool_cap = 0;
     FtPivotInfo* pinfo = nullptr;
     int64_t img_cap = 0;
     bool resident = false;                                       // hlu_ does not hold the rows of the factors in use (they are on the device)
@@ -53,10 +54,12 @@ relp_status_t Engine::luf_prepare() {
     std::vector<double> rval((size_t)nnz);
     each([&](int32_t i, int32_t p, double v) { const int32_t o = fill[i]++; rcol[o] = p; rval[o] = v; });
     for (int32_t a = 0; a < na; ++a) art_of_row[column_to_row_[a]] = a;
-    // sizes: the bump is eliminated on a dense working copy of at most nb_cap x nb_cap (a larger bump falls back to the host)
+    // sizes: the bump is eliminated on sparse rows in an arena; RELP_LUF_BUMP_CAP bounds its rows (default: any), a bump or a
+    // fill-in beyond the arrays falls back to the host
     const char* cap_env = std::getenv("RELP_LUF_BUMP_CAP");
-    S.nb_cap = std::min<int32_t>(m, cap_env ? std::max(16, std::atoi(cap_env)) : 2048);
-    S.cap = (int32_t)std::min<int64_t>(INT32_MAX / 2, nnz + (int64_t)wrapped_na_ + na + 2 * (int64_t)m + (int64_t)S.nb_cap * S.nb_cap / 2 + 1024);
+    S.nb_cap = std::min<int32_t>(m, cap_env ? std::max(16, std::atoi(cap_env)) : m);
+    const int64_t arena_cap = std::min<int64_t>(INT32_MAX / 4, 3 * (nnz + (int64_t)wrapped_na_ + na + m) + 64 * (int64_t)S.nb_cap + 1024);
+    S.cap = (int32_t)arena_cap;
     const int32_t nt = luf_threads();
     int64_t o = 0;
     auto take = [&](int64_t bytes) { const int64_t at = o; o += round_up(std::max<int64_t>(bytes, 16), 16); return at; };
@@ -66,25 +69,36 @@ relp_status_t Engine::luf_prepare() {
     int64_t o_m[13];
     for (auto& v : o_m) v = take(4 * (int64_t)m);       // wrow_pos rcount ccount claim claim2 list list2 piv brow bcol lrow lcol (+1 spare)
     const int64_t o_part = take(4 * ((int64_t)nt + 2));
-    int64_t o_nb[8];
-    for (auto& v : o_nb) v = take(4 * (int64_t)S.nb_cap);     // brc bcc ract cact bstep_row bstep_col I J
-    const int64_t o_fmul = take(8 * (int64_t)S.nb_cap), o_red = take(8 * 80), o_D = take(8 * (int64_t)S.nb_cap * S.nb_cap), o_sc = take(64);
+    int64_t o_nb[11];
+    for (auto& v : o_nb) v = take(4 * (int64_t)S.nb_cap);     // rbeg rlen rcap ract cact bcc bstep_row bstep_col cpiv prank acc
+    int64_t o_nb8[5];
+    for (auto& v : o_nb8) v = take(8 * (int64_t)S.nb_cap);    // pval cmax rowmark colbest cprio
+    const int64_t o_ecol = take(4 * arena_cap), o_eval = take(8 * arena_cap);
+    const int64_t o_ltr = take(4 * arena_cap), o_lts = take(4 * arena_cap), o_ltv = take(8 * arena_cap), o_ltp = take(4 * ((int64_t)S.nb_cap + 1)),
+                  o_lto = take(4 * arena_cap), o_cnt = take(64);
+    const int64_t o_red = take(8 * 8), o_sc = take(64);
     const int64_t o_status = take(32), o_rowperm = take(4 * (int64_t)m), o_colperm = take(4 * (int64_t)m), o_rstep = take(4 * (int64_t)m),
                   o_cstep = take(4 * (int64_t)m), o_diag = take(8 * (int64_t)m);
     int64_t o_tp[4], o_ti[4], o_tv[4];
     for (int q = 0; q < 4; ++q) { o_tp[q] = take(4 * ((int64_t)m + 1)); o_ti[q] = take(4 * (int64_t)S.cap); o_tv[q] = take(8 * (int64_t)S.cap); }
-    // the schedules: work arrays, one image arena per schedule, lists and descriptors
+    // the schedules: one set of work arrays, one image arena, lists and descriptors per schedule (four workgroups build them side by side)
     const int32_t nlev_cap = m + 1;
-    int64_t o_sm[4];
-    for (auto& v : o_sm) v = take(4 * (int64_t)m);       // lev lg loff list
-    int64_t o_sl[3];
-    for (auto& v : o_sl) v = take(4 * ((int64_t)nlev_cap + 2));
-    const int64_t o_ovf = take(4 * ((int64_t)m + 1)), o_hist = take(64), o_spart = take(4 * ((int64_t)nt + 2)), o_flag = take(16);
-    S.img_cap = 64 + 40 * ((int64_t)S.cap + 2 * (int64_t)m + 64) + 16 * ((int64_t)m + 8);
-    int64_t o_img[4], o_desc[4], o_triv[4], o_reach[4], o_lof[4];
+    S.x_cap = (int32_t)std::min<int64_t>(INT32_MAX / 8, 4 * (int64_t)S.cap / 3 + 2 * (int64_t)m + 64);       // expanded rows of the fused groups
+    S.pool_cap = (int32_t)std::min<int64_t>(INT32_MAX / 8, 2 * (int64_t)S.x_cap);
+    S.img_cap = 64 + 40 * ((int64_t)S.x_cap + 2 * (int64_t)m + 64) + 16 * ((int64_t)m + 8);
+    const int64_t n_words = m / 32 + 3;
+    struct SchedOff { int64_t m4[10], lv[6], bits[2], xs, xc, xv0, xvn, pool, tmp, tmp2, ovf, sc, img, desc, triv, reach, lof, viap, viapos, rhs_src, rhs_pos, tbits; } so[4];
     for (int q = 0; q < 4; ++q) {
-        o_img[q] = take(S.img_cap); o_desc[q] = take(4 * LUF_D_WORDS); o_triv[q] = take(4 * (int64_t)m); o_reach[q] = take(4 * (int64_t)m);
-        o_lof[q] = take(4 * (int64_t)m);
+        SchedOff& f = so[q];
+        for (auto& v : f.m4) v = take(4 * (int64_t)m);      // indeg lev order grp xbeg xlen lg loff rhs_id (+1 spare)
+        for (auto& v : f.lv) v = take(4 * ((int64_t)nlev_cap + 2));
+        for (auto& v : f.bits) v = take(4 * n_words);
+        f.xs = take(4 * (int64_t)S.x_cap); f.xc = take(8 * (int64_t)S.x_cap); f.xv0 = take(4 * (int64_t)S.x_cap); f.xvn = take(4 * (int64_t)S.x_cap);
+        f.pool = take(4 * (int64_t)S.pool_cap);
+        f.tmp = take(4 * ((int64_t)m + 2)); f.tmp2 = take(4 * ((int64_t)m + 2)); f.ovf = take(4 * ((int64_t)m + 1)); f.sc = take(128);
+        f.img = take(S.img_cap); f.desc = take(4 * LUF_D_WORDS); f.triv = take(4 * (int64_t)m); f.reach = take(4 * (int64_t)m); f.lof = take(4 * (int64_t)m);
+        f.viap = take(4 * ((int64_t)m + 1)); f.viapos = take(4 * (int64_t)S.pool_cap); f.rhs_src = take(4 * (int64_t)m); f.rhs_pos = take(4 * (int64_t)m);
+        f.tbits = take(4 * n_words);
     }
     const int64_t o_pinfo = take((int64_t)sizeof(FtPivotInfo) * m);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.d_buf), (size_t)o));
@@ -109,9 +123,14 @@ relp_status_t Engine::luf_prepare() {
     W.wrow_pos = I32(o_m[0]); W.rcount = I32(o_m[1]); W.ccount = I32(o_m[2]); W.claim = I32(o_m[3]); W.claim2 = I32(o_m[4]);
     W.list = I32(o_m[5]); W.list2 = I32(o_m[6]); W.piv = I32(o_m[7]); W.brow = I32(o_m[8]); W.bcol = I32(o_m[9]);
     W.lrow = I32(o_m[10]); W.lcol = I32(o_m[11]); W.part = I32(o_part);
-    W.brc = I32(o_nb[0]); W.bcc = I32(o_nb[1]); W.ract = I32(o_nb[2]); W.cact = I32(o_nb[3]); W.bstep_row = I32(o_nb[4]);
-    W.bstep_col = I32(o_nb[5]); W.I = I32(o_nb[6]); W.J = I32(o_nb[7]);
-    W.fmul = F64(o_fmul); W.red = reinterpret_cast<unsigned long long*>(B + o_red); W.D = F64(o_D); W.nb_cap = S.nb_cap;
+    W.nb_cap = S.nb_cap;
+    W.rbeg = I32(o_nb[0]); W.rlen = I32(o_nb[1]); W.rcap = I32(o_nb[2]); W.ract = I32(o_nb[3]); W.cact = I32(o_nb[4]); W.bcc = I32(o_nb[5]);
+    W.bstep_row = I32(o_nb[6]); W.bstep_col = I32(o_nb[7]); W.cpiv = I32(o_nb[8]); W.prank = I32(o_nb[9]); W.acc = I32(o_nb[10]);
+    auto U64 = [&](int64_t at) { return reinterpret_cast<unsigned long long*>(B + at); };
+    W.pval = F64(o_nb8[0]); W.cmax = U64(o_nb8[1]); W.rowmark = U64(o_nb8[2]); W.colbest = U64(o_nb8[3]); W.cprio = U64(o_nb8[4]);
+    W.ecol = I32(o_ecol); W.eval = F64(o_eval); W.arena_cap = (int32_t)arena_cap;
+    W.lt_row = I32(o_ltr); W.lt_step = I32(o_lts); W.lt_val = F64(o_ltv); W.lt_cap = (int32_t)arena_cap; W.lt_ptr = I32(o_ltp); W.lt_ord = I32(o_lto);
+    W.counters = I32(o_cnt); W.red = U64(o_red);
     W.scalars = I32(o_sc);
     LufOut& O = S.O;
     O.status = I32(o_status); O.rowperm = I32(o_rowperm); O.colperm = I32(o_colperm); O.row_step = I32(o_rstep); O.col_step = I32(o_cstep);
@@ -119,19 +138,27 @@ relp_status_t Engine::luf_prepare() {
     LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
     for (int q = 0; q < 4; ++q) { tri[q]->ptr = I32(o_tp[q]); tri[q]->idx = I32(o_ti[q]); tri[q]->val = F64(o_tv[q]); }
     O.cap = S.cap;
-    S.SW = LufSchedWork{};
-    S.SW.lev = I32(o_sm[0]); S.SW.lg = I32(o_sm[1]); S.SW.loff = I32(o_sm[2]); S.SW.list = I32(o_sm[3]);
-    S.SW.lvl_lanes = I32(o_sl[0]); S.SW.lvl_pass0 = I32(o_sl[1]); S.SW.lvl_lane0 = I32(o_sl[2]);
-    S.SW.ovf_off = I32(o_ovf); S.SW.hist = I32(o_hist); S.SW.part = I32(o_spart); S.SW.flag = I32(o_flag); S.SW.nlev_cap = nlev_cap;
     {
         const bool wide = ft_big_;
         const LufTriangle* tri4[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
-        const int32_t asc[4] = {1, 0, 1, 0};
+        const LufTriangle* trt4[4] = {&O.Lb, &O.Ub, &O.Uf, &O.Lf};     // the transposed pattern of each
+        // (fused schedules read copies of some right-hand sides behind x: ft_rhs_cap_ words of the layout; RELP_FUSE_LANES, read at create)
+        const int32_t fuse = ft_rhs_cap_ > 0 ? lu_fuse_lanes_env_ : 0;
         for (int q = 0; q < 4; ++q) {
+            const SchedOff& f = so[q];
             const bool maskable = q == 1 || q == 2;
-            S.sin[q] = LufSchedIn{m, tri4[q]->ptr, tri4[q]->idx, tri4[q]->val, maskable ? O.diag : nullptr, asc[q], maskable ? 1 : 0,
-                                  wide ? 1 : 0, wide ? 512 : 0x7fffffff};
-            S.sout[q] = LufSchedOut{B + o_img[q], S.img_cap, I32(o_desc[q]), I32(o_triv[q]), I32(o_reach[q]), I32(o_lof[q])};
+            S.sin[q] = LufSchedIn{m, tri4[q]->ptr, tri4[q]->idx, tri4[q]->val, trt4[q]->ptr, trt4[q]->idx, maskable ? O.diag : nullptr, maskable ? 1 : 0,
+                                  wide ? 1 : 0, wide ? 512 : 0x7fffffff, fuse, ft_rhs_cap_, ft_tier_ >= 2 ? 1 : 0};
+            LufSchedWork& w = S.SW[q];
+            w = LufSchedWork{};
+            w.indeg = I32(f.m4[0]); w.lev = I32(f.m4[1]); w.order = I32(f.m4[2]); w.grp = I32(f.m4[3]); w.xbeg = I32(f.m4[4]); w.xlen = I32(f.m4[5]);
+            w.lg = I32(f.m4[6]); w.loff = I32(f.m4[7]); w.rhs_id = I32(f.m4[8]);
+            w.lvl_ptr = I32(f.lv[0]); w.lvl_grp = I32(f.lv[1]); w.grp_lvl0 = I32(f.lv[2]); w.grp_lane0 = I32(f.lv[3]); w.grp_pass0 = I32(f.lv[4]); w.grp_lanes = I32(f.lv[5]);
+            w.bits0 = reinterpret_cast<uint32_t*>(B + f.bits[0]); w.bits1 = reinterpret_cast<uint32_t*>(B + f.bits[1]);
+            w.x_src = I32(f.xs); w.x_coef = F64(f.xc); w.x_v0 = I32(f.xv0); w.x_vn = I32(f.xvn); w.x_cap = S.x_cap; w.pool = I32(f.pool); w.pool_cap = S.pool_cap;
+            w.tmp = I32(f.tmp); w.tmp2 = I32(f.tmp2); w.ovf_off = I32(f.ovf); w.sc = I32(f.sc); w.nlev_cap = nlev_cap;
+            S.sout[q] = LufSchedOut{B + f.img, S.img_cap, I32(f.desc), I32(f.triv), I32(f.reach), I32(f.lof), I32(f.viap), I32(f.viapos), S.pool_cap,
+                                    I32(f.rhs_src), ft_tier_ >= 2 ? I32(f.rhs_pos) : nullptr, ft_tier_ >= 2 ? reinterpret_cast<uint32_t*>(B + f.tbits) : nullptr};
         }
     }
     S.pinfo = reinterpret_cast<FtPivotInfo*>(B + o_pinfo);
@@ -157,7 +184,7 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     const auto t0 = std::chrono::steady_clock::now();
     S.M.csc = csc(); S.M.ct = table();                  // (pointers may have been re-allocated)
     launch_lu_factor(S.M, d_basis_, S.W, S.O, stream_);
-    if (resident) launch_lu_schedules(S.sin, S.sout, S.SW, S.W, S.O.status, S.pinfo, stream_);
+    if (resident) launch_lu_schedules(S.sin, S.SW, S.sout, S.O.status, S.pinfo, stream_);
     int32_t status[8] = {0}, desc[4][LUF_D_WORDS] = {};
     HIP_TRY(hipMemcpyAsync(status, S.O.status, sizeof status, hipMemcpyDeviceToHost, stream_));
     if (resident) for (int q = 0; q < 4; ++q) HIP_TRY(hipMemcpyAsync(desc[q], S.sout[q].desc, sizeof desc[q], hipMemcpyDeviceToHost, stream_));
@@ -196,14 +223,17 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
         e.rdiag = reinterpret_cast<double*>(img + L.rdiag); e.sval = reinterpret_cast<double*>(img + L.sval);
         e.oval = reinterpret_cast<const double*>(img + L.oval); e.rovf = reinterpret_cast<const int32_t*>(img + L.rovf);
         e.sidx = reinterpret_cast<const uint16_t*>(img + L.sidx); e.oidx = reinterpret_cast<const uint16_t*>(img + L.oidx);
-        e.via_ptr = nullptr; e.via_pos = nullptr;
+        const bool maskable = q == 1 || q == 2;
+        e.via_ptr = maskable ? S.sout[q].via_ptr : nullptr; e.via_pos = maskable ? S.sout[q].via_pos : nullptr;
         e.n_passes = d[LUF_D_PASSES]; e.n_levels = d[LUF_D_LEVELS]; e.m = m; e.n_lanes = d[LUF_D_LANES]; e.n_ovf = d[LUF_D_OVF];
-        e.bytes = d[LUF_D_BYTES]; e.rhs_base = 0;
-        e.n_triv = d[LUF_D_TRIV]; e.triv = S.sout[q].triv; e.reach = S.sout[q].reach; e.rhs_src = nullptr; e.n_rhs = ft_big_ ? 0 : -1;
+        e.bytes = d[LUF_D_BYTES]; e.rhs_base = d[LUF_D_USES_RHS] ? m + 1 : 0;
+        e.n_triv = d[LUF_D_TRIV]; e.triv = S.sout[q].triv; e.reach = S.sout[q].reach; e.rhs_src = S.sout[q].rhs_src;
+        e.n_rhs = ft_big_ ? std::max(d[LUF_D_NRHS], 0) : -1;
+        e.rhs_pos = S.sout[q].rhs_pos; e.triv_bits = S.sout[q].triv_bits;
         fts_.stage[q] = e.bytes <= fts_.stage_bytes ? 1 : 0;
         if (fts_.stage[q]) need = std::max<int64_t>(need, e.bytes);
         ds[q]->n_levels = d[LUF_D_LEVELS];
-        hs[q]->level_ptr.assign((size_t)d[LUF_D_LEVELS] + 1, 0);     // (lu_stats reports the level counts)
+        hs[q]->level_ptr.assign((size_t)d[LUF_D_KAHN_LEVELS] + 1, 0);     // (lu_stats reports the level counts)
     }
     fts_.lds_bytes = (int32_t)(base + need);
     return RELP_OK;

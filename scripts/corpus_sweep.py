@@ -1,0 +1,106 @@
+"""Every LP of the reference's Netlib directory the build's front end accepts (tests/golden/corpus/, made by
+scripts/gen_corpus_fixture.py) on the three engines, under `relp_default_config` (the reference's rules literally) and under the
+two f64 safeguards (`ratio_rule = RELP_RATIO_LARGEST_PIVOT`, `artificial_removal = RELP_ARTIFICIAL_TEXTBOOK`).
+
+Per file, engine and configuration: outcome, pivots, objective, `check_basis` residuals, seconds; then per file the agreement of
+the engines among themselves, with the reference's pin where tests/netlib/test.rs holds one, and with HiGHS on the same
+standardised LP (an independent check, NOT the reference: "parity unpinned" for the ~60 files without a pin).
+
+usage (GPU box): python scripts/corpus_sweep.py [--out gpurun_out/r4/corpus_sweep.json] [--max-pivots 400000] [--seconds 60] [NAME ...]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rust_lp_amd  # noqa: E402,F401
+from rust_lp_amd import engine  # noqa: E402
+import corpus  # noqa: E402
+
+ENGINES = (("lu", engine.ENGINE_LU, -1), ("tableau", engine.ENGINE_TABLEAU, -1), ("revised", engine.ENGINE_REVISED, -1))
+CONFIGS = (("default", {}), ("safeguards", dict(ratio_rule=engine.RATIO_LARGEST_PIVOT, artificial_removal=engine.ARTIFICIAL_TEXTBOOK)))
+
+
+def solve(md, fixed, kind, block, cfg, max_pivots, seconds):
+    t0 = time.perf_counter()
+    out = {}
+    try:
+        t = engine.Tableau(md, engine=kind, update_block=block, **cfg)
+    except engine.RelpError as e:
+        return {"outcome": "create_failed", "error": str(e)[:160]}
+    try:
+        oc, total = engine.RUNNING, 0
+        while True:
+            if t.phase == 1:
+                done, oc = t.run(20000)
+                total += done
+                if oc == engine.PHASE_ONE_DONE:
+                    continue
+            else:
+                done, oc = t.run(20000)
+                total += done
+            if oc != engine.RUNNING or total >= max_pivots or time.perf_counter() - t0 > seconds:
+                break
+        out["outcome"] = engine.OUTCOME_NAMES.get(oc, str(oc)) if oc != engine.RUNNING else "limit"
+        out["pivots"] = int(t.iterations())
+        out["rows"] = int(t.nr_rows())
+        if oc == engine.OPTIMAL:
+            out["objective"] = t.objective_function_value() + fixed
+            ident, basic, min_b = t.check_basis()
+            out["check_basis"] = [ident, basic, min_b]
+        if kind == engine.ENGINE_LU:
+            out["layout"] = t.lu_kernel_layout()["layout"]
+    except engine.RelpError as e:
+        out["outcome"] = "error"
+        out["error"] = str(e)[:160]
+    finally:
+        t.close()
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    return out
+
+
+def rel(a, b):
+    return abs(a - b) / max(1.0, abs(a), abs(b))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r4", "corpus_sweep.json"))
+    ap.add_argument("--max-pivots", type=int, default=400000)
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("names", nargs="*")
+    args = ap.parse_args()
+    idx = corpus.index()
+    names = args.names or sorted(n for n, r in idx.items() if "nr_rows" in r)
+    names.sort(key=lambda n: idx[n]["nr_rows"] * idx[n]["nr_columns"])
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    results = {}
+    for name in names:
+        rec = idx[name]
+        md, fixed = corpus.load(name)
+        res = {"m": rec["nr_rows"], "n": rec["nr_columns"], "nnz": rec["nnz"], "highs": rec.get("highs_objective"),
+               "pin": rec.get("reference_pin"), "pin_tol": rec.get("reference_tolerance"), "runs": {}}
+        for cname, cfg in CONFIGS:
+            for ename, kind, block in ENGINES:
+                res["runs"][f"{cname}/{ename}"] = solve(md, fixed, kind, block, cfg, args.max_pivots, args.seconds)
+        # agreement
+        for cname, _ in CONFIGS:
+            objs = {e: res["runs"][f"{cname}/{e}"].get("objective") for e, _, _ in ENGINES}
+            have = [v for v in objs.values() if v is not None]
+            res[f"{cname}_all_optimal"] = len(have) == len(ENGINES)
+            res[f"{cname}_engines_agree"] = bool(have) and len(have) == len(ENGINES) and max(rel(a, have[0]) for a in have) <= 1e-6
+            if res["highs"] is not None and have:
+                res[f"{cname}_vs_highs"] = max(rel(a, res["highs"]) for a in have)
+            if res["pin"] is not None and have:
+                res[f"{cname}_meets_pin"] = all(abs(a - res["pin"]) <= max(res["pin_tol"], 1e-9 * abs(res["pin"])) for a in have)
+        results[name] = res
+        line = " ".join(f"{k}={v.get('outcome')}:{v.get('pivots')}:{v.get('objective', float('nan')):.9g}:{v.get('seconds')}s" for k, v in res["runs"].items())
+        print(f"{name} m={res['m']} n={res['n']} highs={res['highs']} pin={res['pin']} | {line}", flush=True)
+        json.dump(results, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

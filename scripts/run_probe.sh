@@ -1,7 +1,9 @@
-# scratch script of the GPU box runs (gpurun -- 'bash scripts/run_probe.sh'); as committed: smoke, then the whole GPU tier
-set -e
+# scratch script of the GPU box runs (gpurun -- 'bash scripts/run_probe.sh')
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 2
-timeout -k 10 1150 python -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/gpu_tier.log 2>&1 || { tail -n 60 gpurun_out/gpu_tier.log; exit 1; }
-tail -n 10 gpurun_out/gpu_tier.log
+mkdir -p gpurun_out/r4
+timeout -k 10 600 python -m pytest tests/test_gpu_lu_device.py -m gpu -x -q > gpurun_out/r4/lu_device.log 2>&1; echo "pytest exit $?"; tail -n 15 gpurun_out/r4/lu_device.log
+for args in "24 1" "-1 1" "11 1" "11 0"; do timeout -k 10 120 python scripts/r4_luf_profile.py $args 2>&1 | tail -n 1; done
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/r4/prof_luf2 -o luf -- python3 $GRAFT_REPO_ROOT/scripts/r4_luf_profile.py 11 1 > $GRAFT_REPO_ROOT/gpurun_out/r4/prof_luf2.log 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/r4/prof_luf2 -name "*kernel_stats.csv" | head -n 1 | xargs -r head -n 8

@@ -66,21 +66,28 @@ struct Provider {
 };
 
 struct Buffers {
-    std::vector<int32_t> ints; std::vector<double> dbl; std::vector<unsigned long long> red;
+    std::vector<int32_t> ints; std::vector<double> dbl; std::vector<unsigned long long> red, u64;
     LufWork W{}; LufOut O{};
-    void setup(const Provider& P, int32_t nb_cap, int32_t cap) {
+    void setup(const Provider& P, int32_t nb_cap, int32_t cap, int32_t arena_cap = -1) {
         const int32_t m = P.m;
-        auto need = (size_t)(P.nn + P.nv) + P.na + 16 * (size_t)m + 8 * (size_t)nb_cap + 128 + 8 * (size_t)(m + 1) + 4 * (size_t)cap + 64;
-        ints.assign(need, 0); dbl.assign((size_t)nb_cap * nb_cap + nb_cap + m + 4 * (size_t)cap + 16, 0.0); red.assign(80, 0);
+        if (arena_cap < 0) arena_cap = cap;
+        auto need = (size_t)(P.nn + P.nv) + P.na + 16 * (size_t)m + 14 * (size_t)nb_cap + 256 + 8 * (size_t)(m + 1) + 4 * (size_t)cap + 64 + (size_t)arena_cap +
+                    3 * (size_t)cap;
+        ints.assign(need, 0); dbl.assign((size_t)nb_cap + m + 4 * (size_t)cap + 16 + (size_t)arena_cap + (size_t)cap, 0.0); red.assign(8, 0);
+        u64.assign(4 * (size_t)nb_cap + 4, 0);
         int32_t* ip = ints.data(); double* dp = dbl.data();
         auto ti = [&](size_t n) { int32_t* r = ip; ip += n; return r; };
         auto td = [&](size_t n) { double* r = dp; dp += n; return r; };
         W.pos_p = ti(P.nn + P.nv + 1); W.pos_a = ti(P.na + 1); W.wrow_pos = ti(m); W.rcount = ti(m); W.ccount = ti(m);
         W.claim = ti(m); W.claim2 = ti(m); W.list = ti(m); W.list2 = ti(m); W.piv = ti(m); W.part = ti(66);
         W.brow = ti(m); W.bcol = ti(m); W.lrow = ti(m); W.lcol = ti(m);
-        W.brc = ti(nb_cap); W.bcc = ti(nb_cap); W.ract = ti(nb_cap); W.cact = ti(nb_cap); W.bstep_row = ti(nb_cap); W.bstep_col = ti(nb_cap);
-        W.I = ti(nb_cap); W.J = ti(nb_cap); W.fmul = td(nb_cap); W.red = red.data(); W.D = td((size_t)nb_cap * nb_cap); W.nb_cap = nb_cap;
-        W.scalars = ti(16);
+        W.nb_cap = nb_cap;
+        W.rbeg = ti(nb_cap); W.rlen = ti(nb_cap); W.rcap = ti(nb_cap); W.ract = ti(nb_cap); W.cact = ti(nb_cap); W.bcc = ti(nb_cap);
+        W.bstep_row = ti(nb_cap); W.bstep_col = ti(nb_cap); W.cpiv = ti(nb_cap); W.prank = ti(nb_cap); W.acc = ti(nb_cap); W.pval = td(nb_cap);
+        W.cmax = u64.data(); W.rowmark = u64.data() + nb_cap; W.colbest = u64.data() + 2 * (size_t)nb_cap; W.cprio = u64.data() + 3 * (size_t)nb_cap;
+        W.ecol = ti(arena_cap); W.eval = td(arena_cap); W.arena_cap = arena_cap;
+        W.lt_row = ti(cap); W.lt_step = ti(cap); W.lt_val = td(cap); W.lt_cap = cap; W.lt_ptr = ti(nb_cap + 1); W.lt_ord = ti(cap);
+        W.counters = ti(8); W.red = red.data(); W.scalars = ti(16);
         O.status = ti(8); O.rowperm = ti(m); O.colperm = ti(m); O.row_step = ti(m); O.col_step = ti(m); O.diag = td(m);
         LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
         for (auto* t : tri) { t->ptr = ti(m + 1); t->idx = ti(cap); t->val = td(cap); }
@@ -214,8 +221,9 @@ static void plain_solve(const LufTriangle& T, const double* diag, bool ascending
         x[k] = diag ? s / diag[k] : s;
     }
 }
-// executes an image the way ell_solve_pp does: rows without entries first, then pass by pass from group `first`
-static void image_solve(const char* img, const int32_t* desc, int32_t m, bool wide, const int32_t* triv, std::vector<double>& x, int first) {
+// executes an image the way ell_solve_pp does: right-hand-side copies behind x, rows without entries first, then pass by pass from
+// group `first`; rdiag / sval may have been edited by a mask (the caller's copies of the image)
+static void image_solve(const char* img, const int32_t* desc, int32_t m, bool wide, const int32_t* triv, const int32_t* rhs_src, std::vector<double>& xm, int first) {
     const LufImageLayout L = luf_image_layout(m, desc[LUF_D_PASSES], desc[LUF_D_LEVELS], desc[LUF_D_LANES], desc[LUF_D_OVF], wide);
     const EllPass* passes = reinterpret_cast<const EllPass*>(img + L.passes);
     const double* rdiag = reinterpret_cast<const double*>(img + L.rdiag);
@@ -225,6 +233,12 @@ static void image_solve(const char* img, const int32_t* desc, int32_t m, bool wi
     const int shift = wide ? kEllLgWide : kEllLg;
     auto sidx = [&](int64_t at) { return wide ? (int)reinterpret_cast<const uint32_t*>(img + L.sidx)[at] : (int)reinterpret_cast<const uint16_t*>(img + L.sidx)[at]; };
     auto oidx = [&](int64_t at) { return wide ? (int)reinterpret_cast<const uint32_t*>(img + L.oidx)[at] : (int)reinterpret_cast<const uint16_t*>(img + L.oidx)[at]; };
+    std::vector<double> x((size_t)2 * m + 2, 0.0);
+    for (int32_t i = 0; i < m; ++i) x[i] = xm[i];
+    if (desc[LUF_D_USES_RHS]) {
+        if (desc[LUF_D_NRHS] < 0) for (int32_t i = 0; i < m; ++i) x[m + 1 + i] = xm[i];                  // a copy per pivot
+        else for (int32_t i = 0; i < desc[LUF_D_NRHS]; ++i) x[m + 1 + i] = xm[rhs_src[i]];               // the compacted copies
+    }
     for (int32_t i = 0; i < desc[LUF_D_TRIV]; ++i) x[triv[i]] *= rdiag[triv[i]];
     for (int32_t p = 0; p < desc[LUF_D_PASSES]; ++p) {
         const EllPass& ps = passes[p];
@@ -240,40 +254,62 @@ static void image_solve(const char* img, const int32_t* desc, int32_t m, bool wi
         }
         for (auto& st : stores) x[st.first] = st.second;
     }
+    for (int32_t i = 0; i < m; ++i) xm[i] = x[i];
 }
 
+struct SchedBuffers {
+    std::vector<int32_t> wi, oi; std::vector<double> wd; std::vector<uint32_t> wb; std::vector<char> image;
+    LufSchedWork S{}; LufSchedOut SO{};
+    void setup(int32_t m, int32_t nnz) {
+        const int32_t xcap = 4 * nnz + 2 * m + 64, pcap = 6 * nnz + 4 * m + 64;
+        wi.assign(12 * (size_t)m + 6 * ((size_t)m + 3) + 3 * (size_t)xcap + pcap + 256, 0); wd.assign((size_t)xcap + 8, 0.0); wb.assign(2 * ((size_t)m / 32 + 3), 0u);
+        int32_t* ip = wi.data();
+        auto ti = [&](size_t n) { int32_t* r = ip; ip += n; return r; };
+        S.indeg = ti(m); S.lev = ti(m); S.order = ti(m); S.nlev_cap = m + 1;
+        S.lvl_ptr = ti(m + 3); S.lvl_grp = ti(m + 3); S.grp_lvl0 = ti(m + 3); S.grp_lane0 = ti(m + 3); S.grp_pass0 = ti(m + 3); S.grp_lanes = ti(m + 3);
+        S.bits0 = wb.data(); S.bits1 = wb.data() + m / 32 + 3;
+        S.grp = ti(m); S.xbeg = ti(m); S.xlen = ti(m);
+        S.x_src = ti(xcap); S.x_coef = wd.data(); S.x_v0 = ti(xcap); S.x_vn = ti(xcap); S.x_cap = xcap; S.pool = ti(pcap); S.pool_cap = pcap;
+        S.lg = ti(m); S.loff = ti(m); S.tmp = ti(m + 2); S.tmp2 = ti(m + 2); S.ovf_off = ti(m + 1); S.rhs_id = ti(m); S.sc = ti(32);
+        const int64_t cap = 64 + 40 * ((int64_t)xcap + 2 * m + 64) + 16 * ((int64_t)m + 8);
+        image.assign((size_t)cap, 0);
+        oi.assign(6 * (size_t)m + LUF_D_WORDS + 2 + pcap + (size_t)m / 32 + 4, 0);
+        int32_t* op = oi.data();
+        auto to = [&](size_t n) { int32_t* r = op; op += n; return r; };
+        SO.image = image.data(); SO.image_cap = cap; SO.desc = to(LUF_D_WORDS); SO.triv = to(m); SO.reach = to(m); SO.level_of = to(m);
+        SO.via_ptr = to(m + 1); SO.via_pos = to(pcap); SO.via_cap = pcap; SO.rhs_src = to(m); SO.rhs_pos = to(m);
+        SO.triv_bits = reinterpret_cast<uint32_t*>(to(m / 32 + 3));
+    }
+};
+
 static void check_schedules(const char* name, const LufOut& O, const LufWork& W, int32_t m, std::mt19937_64& rng) {
+    (void)W;
     const LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
+    const LufTriangle* trt[4] = {&O.Lb, &O.Ub, &O.Uf, &O.Lf};                // the transposed pattern of each
     const bool asc[4] = {true, false, true, false};
     const char* nm[4] = {"L", "U", "U'", "L'"};
     for (int q = 0; q < 4; ++q)
-        for (int variant = 0; variant < 3; ++variant) {
-            const bool wide = variant > 0, maskable = q == 1 || q == 2;
-            if (!wide && m + 1 >= (1 << kEllLg)) continue;
-            LufSchedIn T{m, tri[q]->ptr, tri[q]->idx, tri[q]->val, maskable ? O.diag : nullptr, asc[q] ? 1 : 0, maskable ? 1 : 0, wide ? 1 : 0,
-                         variant == 2 ? 3 : 0x7fffffff};
-            std::vector<int32_t> wi(8 * (size_t)m + 3 * ((size_t)m + 2) + 256, 0), oi(3 * (size_t)m + LUF_D_WORDS, 0);
-            int32_t* ip = wi.data();
-            auto ti = [&](size_t n) { int32_t* r = ip; ip += n; return r; };
-            LufSchedWork S{};
-            S.lev = ti(m); S.lg = ti(m); S.loff = ti(m); S.list = ti(m); S.nlev_cap = m + 1;
-            S.lvl_lanes = ti(m + 2); S.lvl_pass0 = ti(m + 2); S.lvl_lane0 = ti(m + 2); S.ovf_off = ti(m + 1); S.hist = ti(8); S.part = ti(66); S.flag = ti(4);
-            const int64_t cap = 64 + 40 * ((int64_t)tri[q]->ptr[m] + 2 * m + 64) + 16 * ((int64_t)m + 8);
-            std::vector<char> image((size_t)cap, 0);
-            LufSchedOut SO{image.data(), cap, oi.data(), oi.data() + LUF_D_WORDS, oi.data() + LUF_D_WORDS + m, oi.data() + LUF_D_WORDS + 2 * m};
-            luf_build_schedule(T, S, SO, W);
-            CHECK(SO.desc[LUF_D_STATUS] == LUF_OK, "%s %s: schedule status %d", name, nm[q], SO.desc[LUF_D_STATUS]);
+        for (int variant = 0; variant < 5; ++variant) {
+            // 0: 16-bit slots, unfused; 1: 16-bit, fused (a copy per pivot); 2: wide, unfused; 3: wide, fused, compacted copies, rows
+            // without entries listed; 4: wide, fused with a small lane budget
+            const bool wide = variant >= 2, maskable = q == 1 || q == 2;
+            const int fuse = variant == 1 || variant == 3 ? 256 : variant == 4 ? 64 : 0;
+            if (!wide && 2 * m + 2 >= (1 << kEllLg)) continue;
+            LufSchedIn T{m, tri[q]->ptr, tri[q]->idx, tri[q]->val, trt[q]->ptr, trt[q]->idx, maskable ? O.diag : nullptr, maskable ? 1 : 0, wide ? 1 : 0,
+                         variant == 3 ? 3 : 0x7fffffff, fuse, m, 1};
+            SchedBuffers SB;
+            SB.setup(m, tri[q]->ptr[m]);
+            luf_build_schedule(T, SB.S, SB.SO);
+            const LufSchedOut& SO = SB.SO;
+            CHECK(SO.desc[LUF_D_STATUS] == LUF_OK, "%s %s variant %d: schedule status %d", name, nm[q], variant, SO.desc[LUF_D_STATUS]);
             if (SO.desc[LUF_D_STATUS] != LUF_OK) continue;
             std::vector<double> b(m), want, got;
             for (auto& v : b) v = (rng() % 3 == 0) ? (double)((int)(rng() % 13) - 6) : 0.0;
             want = b; got = b;
             plain_solve(*tri[q], T.diag, asc[q], m, want);
-            image_solve(image.data(), SO.desc, m, wide, SO.triv, got, 0);
+            image_solve(SB.image.data(), SO.desc, m, wide, SO.triv, SO.rhs_src, got, 0);
             CHECK(max_rel(got, want) <= 1e-9, "%s %s variant %d: image solve differs by %.3e", name, nm[q], variant, max_rel(got, want));
-            // levels are levels: every entry of a row lives in an earlier level
-            bool ok = true;
-            for (int32_t k = 0; k < m && ok; ++k) for (int32_t e = tri[q]->ptr[k]; e < tri[q]->ptr[k + 1]; ++e) if (SO.level_of[tri[q]->idx[e]] >= SO.level_of[k]) ok = false;
-            CHECK(ok, "%s %s: an entry in the same or a later level", name, nm[q]);
+            CHECK(SO.desc[LUF_D_LEVELS] <= SO.desc[LUF_D_KAHN_LEVELS], "%s %s variant %d: more groups than levels", name, nm[q], variant);
             // hyper-sparse start from the reach array
             std::vector<double> bs(m, 0.0);
             for (int t = 0; t < 3; ++t) bs[rng() % m] = (double)((int)(rng() % 9) + 1);
@@ -281,8 +317,52 @@ static void check_schedules(const char* name, const LufOut& O, const LufWork& W,
             for (int32_t i = 0; i < m; ++i) if (bs[i] != 0.0) g0 = std::min(g0, SO.reach[i]);
             want = bs; got = bs;
             plain_solve(*tri[q], T.diag, asc[q], m, want);
-            image_solve(image.data(), SO.desc, m, wide, SO.triv, got, g0);
+            image_solve(SB.image.data(), SO.desc, m, wide, SO.triv, SO.rhs_src, got, g0);
             CHECK(max_rel(got, want) <= 1e-9, "%s %s variant %d: sweep from group %d differs by %.3e", name, nm[q], variant, g0, max_rel(got, want));
+            // level_of (start_after of fuse_levels): a right-hand side that is zero on p and on everything solved no later than p lets
+            // the sweep start at group level_of[p] + 1
+            {
+                std::vector<int> lev(m, 0);
+                for (int32_t qq = 0; qq < m; ++qq) {
+                    const int32_t k = asc[q] ? qq : m - 1 - qq;
+                    int lv = 0;
+                    for (int32_t e = tri[q]->ptr[k]; e < tri[q]->ptr[k + 1]; ++e) lv = std::max(lv, lev[tri[q]->idx[e]] + 1);
+                    lev[k] = lv;
+                }
+                const int32_t p = (int32_t)(rng() % m);
+                std::vector<double> bz = b;
+                for (int32_t k = 0; k < m; ++k) if (lev[k] <= lev[p]) bz[k] = 0.0;
+                want = bz; got = bz;
+                plain_solve(*tri[q], T.diag, asc[q], m, want);
+                image_solve(SB.image.data(), SO.desc, m, wide, SO.triv, SO.rhs_src, got, SO.level_of[p] + 1);
+                CHECK(max_rel(got, want) <= 1e-9, "%s %s variant %d: sweep behind pivot %d (group %d) differs by %.3e", name, nm[q], variant, p, SO.level_of[p] + 1,
+                      max_rel(got, want));
+            }
+            if (!maskable || m < 2) continue;
+            // mask a few pivots the way ft_update does: 1 / diagonal := 0, the listed slots := 0, x[p] := 0 on entry
+            const LufImageLayout L = luf_image_layout(m, SO.desc[LUF_D_PASSES], SO.desc[LUF_D_LEVELS], SO.desc[LUF_D_LANES], SO.desc[LUF_D_OVF], wide);
+            double* rdiag = reinterpret_cast<double*>(SB.image.data() + L.rdiag);
+            double* sval = reinterpret_cast<double*>(SB.image.data() + L.sval);
+            std::vector<char> masked(m, 0);
+            for (int t = 0; t < std::min(m, 6); ++t) {
+                const int p = (int)(rng() % m);
+                if (masked[p]) continue;
+                masked[p] = 1;
+                rdiag[p] = 0.0;
+                for (int v = SO.via_ptr[p]; v < SO.via_ptr[p + 1]; ++v) sval[SO.via_pos[v]] = 0.0;
+                std::vector<double> bm = b;
+                for (int i = 0; i < m; ++i) if (masked[i]) bm[i] = 0.0;
+                want = bm; got = bm;
+                // the plain solve with the pivots masked: x[p] = 0
+                for (int32_t qq = 0; qq < m; ++qq) {
+                    const int32_t k = asc[q] ? qq : m - 1 - qq;
+                    double s2 = want[k];
+                    for (int32_t e = tri[q]->ptr[k]; e < tri[q]->ptr[k + 1]; ++e) s2 -= tri[q]->val[e] * want[tri[q]->idx[e]];
+                    want[k] = masked[k] ? 0.0 : s2 / T.diag[k];
+                }
+                image_solve(SB.image.data(), SO.desc, m, wide, SO.triv, SO.rhs_src, got, 0);
+                CHECK(max_rel(got, want) <= 1e-9, "%s %s variant %d: image solve with %d masked pivots differs by %.3e", name, nm[q], variant, t + 1, max_rel(got, want));
+            }
         }
 }
 
@@ -303,7 +383,67 @@ static void check_square(const char* name, int m, const Cols& cols, std::mt19937
     check(name, P, basis, rng, singular);
 }
 
-int main() {
+// optional: `test_lu_device_model BASIS.txt` (a RELP_DUMP_BASIS text dump) -- bump, rounds and fill of the device algorithm beside
+// the host factorisation's, for DESIGN.md
+static int probe(const char* path) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) return 2;
+    int m;
+    if (std::fscanf(f, "%d", &m) != 1) return 2;
+    Cols cols(m);
+    size_t nnz = 0;
+    for (auto& c : cols) {
+        int n; if (std::fscanf(f, "%d", &n) != 1) return 2;
+        c.resize(n);
+        for (auto& e : c) if (std::fscanf(f, "%d %lf", &e.first, &e.second) != 2) return 2;
+        std::sort(c.begin(), c.end());
+        nnz += c.size();
+    }
+    std::fclose(f);
+    const Provider P = square(m, cols);
+    std::vector<int32_t> basis(m);
+    for (int c = 0; c < m; ++c) basis[c] = c;
+    Buffers B;
+    B.setup(P, m, (int32_t)(8 * nnz + 16 * (size_t)m));
+    luf_factor(P.view(), basis.data(), B.W, B.O);
+    LUFactors hf; std::string err;
+    const bool ok = lu_factor(m, cols, &hf, &err);
+    std::printf("m %d, nnz(B) %zu: device status %d, bump %d, peeled %d, rounds %d, nnz(L) %d, nnz(U) %d (off-diagonal)  |  host %s: nnz(L) %lld, nnz(U) %lld\n",
+                m, nnz, B.O.status[0], B.O.status[1], B.O.status[2], B.W.counters[2], B.O.status[3], B.O.status[4], ok ? "ok" : err.c_str(),
+                (long long)hf.nnz_l, (long long)hf.nnz_u - m);
+    auto levels = [&](const LufTriangle& T, bool asc) {
+        std::vector<int> lev(m, 0); int nl = 0;
+        for (int q = 0; q < m; ++q) { const int k = asc ? q : m - 1 - q; int l = 0; for (int e = T.ptr[k]; e < T.ptr[k + 1]; ++e) l = std::max(l, lev[T.idx[e]] + 1); lev[k] = l; nl = std::max(nl, l + 1); }
+        return nl;
+    };
+    std::printf("levels device: L %d, U %d, U' %d, L' %d  |  host: L %zu, U %zu, U' %zu, L' %zu\n", levels(B.O.Lf, true), levels(B.O.Uf, false),
+                levels(B.O.Ub, true), levels(B.O.Lb, false), hf.Lf.level_ptr.size() - 1, hf.Uf.level_ptr.size() - 1, hf.Ub.level_ptr.size() - 1, hf.Lb.level_ptr.size() - 1);
+    // passes per sweep: the device's factors through the device's fusion, the host's through fuse_levels / ell_pack
+    const LufTriangle* tri[4] = {&B.O.Lf, &B.O.Uf, &B.O.Ub, &B.O.Lb};
+    const LufTriangle* trt[4] = {&B.O.Lb, &B.O.Ub, &B.O.Uf, &B.O.Lf};
+    const TriangularSchedule* hs[4] = {&hf.Lf, &hf.Uf, &hf.Ub, &hf.Lb};
+    const char* nm[4] = {"L", "U", "U'", "L'"};
+    int dev_total = 0, host_total = 0;
+    for (int q = 0; q < 4; ++q) {
+        const bool maskable = q == 1 || q == 2;
+        LufSchedIn T{m, tri[q]->ptr, tri[q]->idx, tri[q]->val, trt[q]->ptr, trt[q]->idx, maskable ? B.O.diag : nullptr, maskable ? 1 : 0, 0, 0x7fffffff, 256, m, 0};
+        SchedBuffers SB;
+        SB.setup(m, tri[q]->ptr[m]);
+        luf_build_schedule(T, SB.S, SB.SO);
+        FusedSchedule fs; EllPacked e;
+        fuse_levels(*hs[q], maskable, maskable, 256, &fs);
+        ell_pack(fs, maskable, &e);
+        std::printf("%s: device %d levels -> %d groups, %d passes, %d lanes, image %d bytes, via %d (status %d)  |  host %zu levels -> %zu groups, %zu passes, %zu lanes\n",
+                    nm[q], SB.SO.desc[LUF_D_KAHN_LEVELS], SB.SO.desc[LUF_D_LEVELS], SB.SO.desc[LUF_D_PASSES], SB.SO.desc[LUF_D_LANES], SB.SO.desc[LUF_D_BYTES],
+                    SB.SO.desc[LUF_D_VIA], SB.SO.desc[LUF_D_STATUS], hs[q]->level_ptr.size() - 1, fs.s.level_ptr.size() - 1, e.passes.size(), e.lanes());
+        dev_total += SB.SO.desc[LUF_D_PASSES]; host_total += (int)e.passes.size();
+    }
+    std::printf("passes of the four sweeps: device %d, host %d\n", dev_total, host_total);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) return probe(argv[1]);
     std::mt19937_64 rng(20250611);
     // the reference's factorisation cases (decomposition/mod.rs:301-491), column by column
     check_square("identity 2", 2, {{{0, 1.0}}, {{1, 1.0}}}, rng);
