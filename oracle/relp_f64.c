@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 typedef struct { int64_t idx; double val; } tup;          /* Rust (usize, f64) */
 typedef struct { tup *d; int64_t n, cap; } svec;
@@ -190,9 +191,11 @@ static void generate_column(oracle_engine_t *e, int32_t j, svec *alpha) {
 static int32_t select_primal_pivot_row(const oracle_engine_t *e, const svec *alpha) {
     const oracle_config_t *c = &e->cfg;
     double min_ratio = INFINITY; int any = 0;
+    double tol_pivot = c->tol_pivot;
+    if (getenv("ORACLE_PIVOT_REL")) { double mx = 0.0; for (int64_t k = 0; k < alpha->n; k++) mx = fmax(mx, fabs(alpha->d[k].val)); tol_pivot *= mx; }
     for (int64_t k = 0; k < alpha->n; k++) {
         double x = alpha->d[k].val;
-        if (x > c->tol_pivot) {
+        if (x > tol_pivot) {
             double bi = e->b[alpha->d[k].idx];
             if (bi <= c->tol_zero) bi = 0.0;      /* also clamps a b_i that rounding pushed below 0 */
             double ratio = bi / x;
@@ -205,7 +208,7 @@ static int32_t select_primal_pivot_row(const oracle_engine_t *e, const svec *alp
     uint32_t best_size = 0;     /* ratio_rule 1 (an f64 extension, not the reference's rule): largest pivot first */
     for (int64_t k = 0; k < alpha->n; k++) {
         double x = alpha->d[k].val;
-        if (x > c->tol_pivot) {
+        if (x > tol_pivot) {
             int32_t row = (int32_t)alpha->d[k].idx;
             double bi = e->b[row];
             if (bi <= c->tol_zero) bi = 0.0;      /* also clamps a b_i that rounding pushed below 0 */
@@ -575,9 +578,11 @@ int oracle_run(oracle_engine_t *e, int64_t max_iters, int through_phases,
         }
         generate_column(e, q, alpha);
         int32_t r = select_primal_pivot_row(e, alpha);
-        if (r < 0) { status = e->phase == 2 ? ORACLE_UNBOUNDED : ORACLE_ERROR; break; }
+        if (r < 0) {
+            if (getenv("ORACLE_DEBUG")) { double mx = -1e300; for (int64_t k = 0; k < alpha->n; k++) mx = fmax(mx, alpha->d[k].val); fprintf(stderr, "[oracle] no row: q %d d %.17g alpha nnz %lld max %.17g\n", q, dq, (long long)alpha->n, mx); }
+            status = e->phase == 2 ? ORACLE_UNBOUNDED : ORACLE_ERROR; break; }
         int32_t leaving = change_basis(e, r, q, alpha, dq);
-        if (leaving < 0) { status = ORACLE_ERROR; break; }
+        if (leaving < 0) { if (getenv("ORACLE_DEBUG")) fprintf(stderr, "[oracle] zero pivot: q %d r %d\n", q, r); status = ORACLE_ERROR; break; }
         record(&n_done, cap, tp, te, tr, tl, e->phase, q, r, leaving);
     }
     if (n_done_out) *n_done_out = n_done;

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -58,7 +59,9 @@ relp_status_t Engine::luf_prepare() {
     // fill-in beyond the arrays falls back to the host
     const char* cap_env = std::getenv("RELP_LUF_BUMP_CAP");
     S.nb_cap = std::min<int32_t>(m, cap_env ? std::max(16, std::atoi(cap_env)) : m);
-    const int64_t arena_cap = std::min<int64_t>(INT32_MAX / 4, 3 * (nnz + (int64_t)wrapped_na_ + na + m) + 64 * (int64_t)S.nb_cap + 1024);
+    // (a small dense bump may fill in completely)
+    const int64_t arena_cap = std::min<int64_t>(INT32_MAX / 4, 3 * (nnz + (int64_t)wrapped_na_ + na + m) + 64 * (int64_t)S.nb_cap + 1024 +
+                                                                  4 * std::min<int64_t>((int64_t)S.nb_cap * S.nb_cap, int64_t(1) << 21));
     S.cap = (int32_t)arena_cap;
     const int32_t nt = luf_threads();
     int64_t o = 0;
@@ -75,7 +78,7 @@ relp_status_t Engine::luf_prepare() {
     for (auto& v : o_nb8) v = take(8 * (int64_t)S.nb_cap);    // pval cmax rowmark colbest cprio
     const int64_t o_ecol = take(4 * arena_cap), o_eval = take(8 * arena_cap);
     const int64_t o_ltr = take(4 * arena_cap), o_lts = take(4 * arena_cap), o_ltv = take(8 * arena_cap), o_ltp = take(4 * ((int64_t)S.nb_cap + 1)),
-                  o_lto = take(4 * arena_cap), o_cnt = take(64);
+                  o_lto = take(4 * arena_cap), o_cnt = take(512);
     const int64_t o_red = take(8 * 8), o_sc = take(64);
     const int64_t o_status = take(32), o_rowperm = take(4 * (int64_t)m), o_colperm = take(4 * (int64_t)m), o_rstep = take(4 * (int64_t)m),
                   o_cstep = take(4 * (int64_t)m), o_diag = take(8 * (int64_t)m);
@@ -191,6 +194,25 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     HIP_TRY(hipStreamSynchronize(stream_));
     luf_kernel_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     ++luf_runs_;
+    if (std::getenv("RELP_DEBUG") && luf_runs_ % 200 == 0) {          // phase clocks of the factorisation kernel (relp_lu_factor_core.h: LUF_LAP)
+        int32_t cnt[128] = {0};
+        HIP_TRY(hipMemcpy(cnt, S.W.counters, sizeof cnt, hipMemcpyDeviceToHost));
+        const unsigned long long* ph = reinterpret_cast<const unsigned long long*>(cnt + 8);
+        static const char* nm[11] = {"maps+counts", "peel", "bump setup", "r:column max", "r:proposals", "r:independence+accept", "r:elimination", "r:leave",
+                                     "multipliers by row", "row views", "column views"};
+        std::fprintf(stderr, "[relp] device factorisation, %lld runs, %.0f us each (host clock, schedules included), last: %d rounds; clocks per run:", (long long)luf_runs_,
+                     luf_kernel_us_ / luf_runs_, cnt[2]);
+        for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)ph[i] / luf_runs_);
+        std::fprintf(stderr, "\n");
+        static const char* sn[4] = {"L", "U", "U'", "L'"};
+        for (int q = 0; q < 4 && resident; ++q) {
+            int32_t sc[32] = {0};
+            HIP_TRY(hipMemcpy(sc, S.SW[q].sc, sizeof sc, hipMemcpyDeviceToHost));
+            const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(sc + 8);
+            std::fprintf(stderr, "[relp]   schedule %s clocks per run: levels %.0f, fusion %.0f, classify + offsets %.0f, image %.0f, via %.0f\n", sn[q],
+                         (double)sp[0] / luf_runs_, (double)sp[1] / luf_runs_, (double)sp[2] / luf_runs_, (double)sp[3] / luf_runs_, (double)sp[4] / luf_runs_);
+        }
+    }
     luf_last_bump_ = status[1]; luf_last_peeled_ = status[2];
     if (device_status) *device_status = status[0];
     if (status[0] == LUF_SINGULAR) return fail(RELP_E_SINGULAR, "singular basis (device factorisation)");

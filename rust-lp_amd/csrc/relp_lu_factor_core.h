@@ -87,12 +87,15 @@ struct LufWork {
 #define LUF_NT ((int)blockDim.x)
 #define LUF_TID ((int)threadIdx.x)
 #define PAR_FOR(i, n) for (int i = LUF_TID; i < (n); i += LUF_NT)
-// (a barrier between agent-scope fences: words written by atomics -- executed in L2 -- are read by plain loads in later phases,
-// which must not hit a line the CU's L1 cached before the atomic; with the working set in LDS the fences cost nothing that matters)
-#define PAR_END __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#define LUF_SINGLE if (LUF_TID == 0)
 // Global atomics execute in L2 and leave the CU's L1 alone: a word that is ever touched by an atomic is read and written
-// through L2 as well (agent-scope atomic load / store), never by a plain access that could hit a stale L1 line.
+// through L2 as well (luf_ld / luf_st below), never by a plain access that could hit a stale L1 line.  RELP_LUF_FENCES wraps
+// every barrier in agent-scope fences instead (L1 invalidated at every phase: a debugging aid, several times slower).
+#if defined(RELP_LUF_FENCES)
+#define PAR_END __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+#define PAR_END __syncthreads();
+#endif
+#define LUF_SINGLE if (LUF_TID == 0)
 LUF_FN void luf_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
 LUF_FN int32_t luf_fetch_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
 LUF_FN int32_t luf_cas(int32_t* p, int32_t expect, int32_t v) { return atomicCAS(p, expect, v); }
@@ -126,6 +129,17 @@ LUF_FN unsigned long long luf_ld64(const unsigned long long* p) { return *p; }
 LUF_FN void luf_st64(unsigned long long* p, unsigned long long v) { *p = v; }
 #endif
 
+// phase clocks (thread 0, device only): counters[8 + 2 i], [9 + 2 i] = low / high word of the clocks of phase i
+#if defined(RELP_LUF_DEVICE)
+#define LUF_LAP_AT(base, i) do { if (LUF_TID == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); const long long d_ = now_ - lap_; lap_ = now_; \
+    unsigned long long* p_ = reinterpret_cast<unsigned long long*>(base) + (i); *p_ += (unsigned long long)d_; } } while (0)
+#define LUF_LAP(i) LUF_LAP_AT(W.counters + 8, i)
+#define LUF_LAP_BEGIN long long lap_ = (long long)__builtin_readcyclecounter();
+#else
+#define LUF_LAP(i) do {} while (0)
+#define LUF_LAP_AT(base, i) do {} while (0)
+#define LUF_LAP_BEGIN
+#endif
 LUF_FN unsigned long long luf_bits(double v) {      // |v| as an integer that orders like the value
     union { double d; unsigned long long u; } x;
     x.d = v < 0 ? -v : v;
@@ -225,6 +239,7 @@ LUF_FN void luf_fail(const LufOut& O, int32_t why) { LUF_SINGLE { O.status[0] = 
 LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O) {
     const int32_t m = M.m;
     constexpr double kThreshold = 0.1;
+    LUF_LAP_BEGIN
     // ---- maps: who is basic where ----------------------------------------------------------------------------------------
     PAR_FOR(p, M.n_provider) W.pos_p[p] = -1; PAR_END
     PAR_FOR(a, M.na) W.pos_a[a] = -1; PAR_END
@@ -242,6 +257,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
     PAR_FOR(c, m) { int32_t n = 0; luf_col_entries(M, basis[c], [&](int32_t, double) { ++n; }); luf_st(&W.ccount[c], n); } PAR_END
     PAR_FOR(i, m) { int32_t n = 0; luf_row_entries(M, W, i, [&](int32_t, double) { ++n; }); luf_st(&W.rcount[i], n); } PAR_END
 
+    LUF_LAP(0);
     // ---- singletons, round by round ----------------------------------------------------------------------------------------
     int32_t k = 0;
     for (;;) {
@@ -308,6 +324,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         if (made == 0) break;
     }
     const int32_t k_peel = k;
+    LUF_LAP(1);
 
     // ---- the bump: sparse rows in an arena -------------------------------------------------------------------------------------
     const int32_t nbr = luf_select(m, [&](int32_t i) { return O.row_step[i] < 0; }, W.brow);
@@ -340,6 +357,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
             });
         } PAR_END
     }
+    LUF_LAP(2);
     int32_t done = 0;
     while (done < nb) {
         // (1) per column: the largest active entry (threshold test), and the marks of this round
@@ -352,6 +370,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
             for (int32_t e = b; e < b + n; ++e) luf_max64(&W.cmax[W.ecol[e]], luf_bits(W.eval[e]));
         } PAR_END
         if (luf_ld(&W.scalars[0])) { luf_fail(O, LUF_SINGULAR); return; }
+        LUF_LAP(3);
         // (2) every row proposes its entry of lowest Markowitz count (r - 1)(c - 1) among those that pass the threshold
         //     (pivoting.rs:45-81 takes the minimum over all entries; ties: the lower column, then the lower row)
         PAR_FOR(t, nb) {
@@ -372,6 +391,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         } PAR_END
         const unsigned long long lead = luf_ld64(&W.red[0]);
         if (lead == ~0ull) { luf_fail(O, LUF_SINGULAR); return; }                  // (every non-empty column has an entry that passes)
+        LUF_LAP(4);
         // (3) independence: EVERY proposal takes part (measured on a mid-solve basis of 25FV47, bump 401: 36 rounds and 4,136
         //     entries of fill-in, against 181 rounds / 4,162 entries when only the proposals of the round's minimum count may
         //     stand -- the priorities already favour the low counts -- and 4,190 entries of the host's lu_factor);
@@ -404,6 +424,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
             const int32_t i = W.brow[t], c = W.bcol[pc], k = k_peel + done + a;
             O.row_step[i] = k; O.col_step[c] = k; O.rowperm[k] = i; O.colperm[k] = c; O.diag[k] = pv;
         } PAR_END
+        LUF_LAP(5);
         // (4) elimination: every other active row is rewritten by one thread, the pivots that reach it in ascending rank
         PAR_FOR(t, nb) {
             if (!W.ract[t]) continue;
@@ -445,6 +466,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
                 W.rlen[t] = n;
             }
         } PAR_END
+        LUF_LAP(6);
         // (5) the pivot rows leave: their columns lose an active entry; the round's column marks are taken back
         PAR_FOR(a, n_acc) {
             const int32_t t = W.acc[a], pc = W.cpiv[t], b = W.rbeg[t], n = W.rlen[t];
@@ -454,6 +476,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         LUF_SINGLE { ++W.counters[2]; } PAR_END
         if (luf_ld(&W.scalars[0]) || luf_ld(&W.counters[1]) > W.lt_cap) { luf_fail(O, LUF_NO_ROOM); return; }
         done += n_acc;
+        LUF_LAP(7);
     }
     const int32_t n_lt = nb > 0 ? luf_ld(&W.counters[1]) : 0;
     // the multipliers by row (counting sort; the order inside a row is settled when the rows of L are sorted below)
@@ -466,6 +489,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         PAR_FOR(q, n_lt) { const int32_t t = W.lt_row[q]; W.lt_ord[W.lt_ptr[t] + luf_fetch_add(&W.bcc[t], 1)] = q; } PAR_END
     }
 
+    LUF_LAP(8);
     // ---- L and U in pivot coordinates, row-wise and column-wise; every row / column is written by ONE thread and sorted by ------
     // ---- index, so the order of its entries does not depend on the execution (two passes: count, then fill behind a running sum)
     auto sort_range = [&](int32_t* idx, double* val, int32_t b, int32_t e) {       // insertion sort: rows are short
@@ -512,6 +536,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
             if (O.status[0] != LUF_OK) return;
         }
     }
+    LUF_LAP(9);
     // the column views are the transposes: count by index, offsets, scatter behind an atomic cursor, sort every column
     for (int q = 0; q < 2; ++q) {
         const LufTriangle& R = q ? O.Uf : O.Lf;
@@ -530,6 +555,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         } PAR_END
         PAR_FOR(l, m) sort_range(C.idx, C.val, C.ptr[l], C.ptr[l + 1]); PAR_END
     }
+    LUF_LAP(10);
 }
 
 }  // namespace relp

@@ -96,10 +96,10 @@ LUF_FN int32_t luf_select_bits(const uint32_t* words, int32_t n_words, int32_t* 
     const int32_t nt = LUF_NT, chunk = (n_words + nt - 1) / nt;
     const int32_t t = LUF_TID, lo = t * chunk < n_words ? t * chunk : n_words, hi = lo + chunk < n_words ? lo + chunk : n_words;
     int32_t cnt = 0;
-    for (int32_t w = lo; w < hi; ++w) cnt += luf_popc(words[w]);
+    for (int32_t w = lo; w < hi; ++w) cnt += luf_popc((uint32_t)luf_ld(reinterpret_cast<const int32_t*>(words) + w));      // (set by atomics: through L2)
     int32_t total = 0;
     int32_t at = luf_block_exscan(cnt, &total);
-    for (int32_t w = lo; w < hi; ++w) { uint32_t v = words[w]; while (v) { out[at++] = (w << 5) + __ffs((int)v) - 1; v &= v - 1; } }
+    for (int32_t w = lo; w < hi; ++w) { uint32_t v = (uint32_t)luf_ld(reinterpret_cast<const int32_t*>(words) + w); while (v) { out[at++] = (w << 5) + __ffs((int)v) - 1; v &= v - 1; } }
     PAR_END
     return total;
 #else
@@ -121,6 +121,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
     const int32_t m = T.m;
     const bool maskable = T.keep_trivial != 0, wide = T.wide != 0;
     const int32_t rhs_base = m + 1;
+    LUF_LAP_BEGIN
     LUF_SINGLE { for (int q = 0; q < LUF_D_WORDS; ++q) O.desc[q] = 0; } PAR_END
     auto n_of = [&](int32_t k) { return T.ptr[k + 1] - T.ptr[k]; };
     auto diag_of = [&](int32_t k) { return T.diag ? T.diag[k] : 1.0; };
@@ -151,6 +152,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
         }
     }
     LUF_SINGLE { S.lvl_ptr[nlev] = m; O.desc[LUF_D_KAHN_LEVELS] = nlev; } PAR_END
+    LUF_LAP_AT(S.sc + 8, 0);
     // ---- groups of levels (relp_lu.hpp: fuse_levels) ---------------------------------------------------------------------------
     // Rows that join an open group are rewritten: an entry that reads a row j of the same group is replaced by j's
     // equation -- (rhs copy of j, v / d_j) and -v / d_j times j's own (expanded) entries -- so that the rows of a group
@@ -176,7 +178,9 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
                         else for (int32_t u = S.xbeg[j]; u < S.xbeg[j] + S.xlen[j]; ++u) pub += S.x_vn[u] + 1;
                     }
                 }
-                if (ub > 448) luf_st(&S.sc[1], 1);
+                // (an upper bound before duplicates are combined; the combining below searches the row: 128^2 steps at worst --
+                // a row of L was seen to spend 6.5 M clocks here at 448)
+                if (ub > 128) luf_st(&S.sc[1], 1);
             }
             S.tmp[q + 1] = ub; S.tmp2[q + 1] = maskable ? pub : 0;
         } PAR_END
@@ -241,6 +245,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
         LUF_SINGLE { S.lvl_grp[l] = g; } PAR_END
     }
     const int32_t ngroups = g + 1;
+    LUF_LAP_AT(S.sc + 8, 1);
     LUF_SINGLE { S.grp_lvl0[ngroups] = nlev; } PAR_END
     // ---- what each row is: left out, listed, or a slot row of 2^lg lanes -----------------------------------------------------
     const int32_t n_trivial = T.keep_trivial ? luf_select(m, [&](int32_t k) { return n_of(k) == 0; }, S.tmp) : 0;
@@ -285,6 +290,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
         S.grp_pass0[ngroups] = pass0; S.grp_lane0[ngroups] = lane0;
     } PAR_END
     const int32_t n_passes = S.grp_pass0[ngroups], n_lanes = S.grp_lane0[ngroups];
+    LUF_LAP_AT(S.sc + 8, 2);
     // ---- right-hand-side copies: compacted for the wide layouts (ell_pack: rhs_src) -----------------------------------------------
     int32_t n_rhs = 0, uses_rhs = 0;
     if (x_top > 0) {
@@ -363,6 +369,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
             luf_min32(&O.reach[src >= rhs_base ? src - rhs_base : src], q);
         }
     } PAR_END
+    LUF_LAP_AT(S.sc + 8, 3);
     // ---- per pivot: the slots whose substitution path runs through it (what a Forrest-Tomlin update zeroes) -------------------------
     int32_t n_via = 0;
     if (maskable) {
@@ -385,6 +392,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
         PAR_FOR(i, n_triv_listed) luf_or32(&O.triv_bits[O.triv[i] >> 5], 1u << (O.triv[i] & 31)); PAR_END
     }
     LUF_SINGLE { O.desc[LUF_D_VIA] = n_via; } PAR_END
+    LUF_LAP_AT(S.sc + 8, 4);
 }
 
 #if !defined(RELP_LUF_DEVICE)

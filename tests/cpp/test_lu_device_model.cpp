@@ -71,7 +71,7 @@ struct Buffers {
     void setup(const Provider& P, int32_t nb_cap, int32_t cap, int32_t arena_cap = -1) {
         const int32_t m = P.m;
         if (arena_cap < 0) arena_cap = cap;
-        auto need = (size_t)(P.nn + P.nv) + P.na + 16 * (size_t)m + 14 * (size_t)nb_cap + 256 + 8 * (size_t)(m + 1) + 4 * (size_t)cap + 64 + (size_t)arena_cap +
+        auto need = (size_t)(P.nn + P.nv) + P.na + 16 * (size_t)m + 14 * (size_t)nb_cap + 512 + 8 * (size_t)(m + 1) + 4 * (size_t)cap + 64 + (size_t)arena_cap +
                     3 * (size_t)cap;
         ints.assign(need, 0); dbl.assign((size_t)nb_cap + m + 4 * (size_t)cap + 16 + (size_t)arena_cap + (size_t)cap, 0.0); red.assign(8, 0);
         u64.assign(4 * (size_t)nb_cap + 4, 0);
@@ -87,7 +87,7 @@ struct Buffers {
         W.cmax = u64.data(); W.rowmark = u64.data() + nb_cap; W.colbest = u64.data() + 2 * (size_t)nb_cap; W.cprio = u64.data() + 3 * (size_t)nb_cap;
         W.ecol = ti(arena_cap); W.eval = td(arena_cap); W.arena_cap = arena_cap;
         W.lt_row = ti(cap); W.lt_step = ti(cap); W.lt_val = td(cap); W.lt_cap = cap; W.lt_ptr = ti(nb_cap + 1); W.lt_ord = ti(cap);
-        W.counters = ti(8); W.red = red.data(); W.scalars = ti(16);
+        W.counters = ti(128); W.red = red.data(); W.scalars = ti(16);
         O.status = ti(8); O.rowperm = ti(m); O.colperm = ti(m); O.row_step = ti(m); O.col_step = ti(m); O.diag = td(m);
         LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
         for (auto* t : tri) { t->ptr = ti(m + 1); t->idx = ti(cap); t->val = td(cap); }
