@@ -40,6 +40,8 @@ static const double *sv_get(const svec *v, int64_t idx) {
     return (lo < v->n && v->d[lo].idx == idx) ? &v->d[lo].val : NULL;
 }
 
+#include "relp_f64_lu.h"
+
 struct oracle_engine {
     /* ---- MatrixData (matrix_provider/matrix_data.rs:54-90) ---- */
     int32_t nr_normal, nr_eq, nr_range, nr_le, nr_ge;
@@ -66,7 +68,11 @@ struct oracle_engine {
     double minus_objective;
     double *minus_pi, *b;
     int32_t *basis_indices;
-    svec *rows;                      /* BasisInverseRows (basis_inverse_rows.rs:20) */
+    svec *rows;                      /* BasisInverseRows (basis_inverse_rows.rs:20); NULL with the LU back-end */
+    lu_t *lu;                        /* LUDecomposition (lower_upper/mod.rs:35-57), cfg.basis_inverse = 1 */
+    svec spike;                      /* ColumnAndSpike::spike of the last generate_column (lower_upper/mod.rs:376-391) */
+    int64_t lu_refactorisations; int lu_failed;
+    int32_t wrapped_na;              /* artificial columns of phase 1 (a survivor keeps the wrapped index INT32_MAX - (na - 1 - a)) */
 
     /* ---- Tableau (tableau/mod.rs:24-38): basis membership set ---- */
     uint8_t *in_basis; int32_t n_flags;
@@ -181,6 +187,7 @@ static void generate_column(oracle_engine_t *e, int32_t j, svec *alpha) {
     svec *col = &e->scratch_col;
     kind_original_column(e, j, col);
     sv_clear(alpha);
+    if (e->lu) { lu_generate_column(e->lu, col, alpha, &e->spike); return; }     /* lower_upper/mod.rs:157-190 */
     for (int32_t i = 0; i < e->m; i++) {
         double v = sparse_inner(&e->rows[i], col);
         if (v != 0.0) sv_push(alpha, i, v);
@@ -258,6 +265,20 @@ static int32_t change_basis(oracle_engine_t *e, int32_t r, int32_t q, const svec
     for (int64_t k = 0; k < alpha->n; k++) {
         int64_t i = alpha->d[k].idx;
         if (i != r) e->b[i] -= alpha->d[k].val * br;
+    }
+    if (e->lu) {
+        /* LUDecomposition::change_basis (lower_upper/mod.rs:92-155), then row r of the NEW inverse by BTRAN (:204-222) */
+        if (!lu_change_basis(e->lu, r, &e->spike)) e->lu_failed = 1;
+        svec rho; sv_init(&rho);
+        lu_basis_inverse_row(e->lu, r, &rho);
+        for (int64_t k = 0; k < rho.n; k++) e->minus_pi[rho.d[k].idx] -= relative_cost_q * rho.d[k].val;
+        sv_free(&rho);
+        e->minus_objective -= relative_cost_q * e->b[r];
+        int32_t leaving_lu = e->basis_indices[r];
+        e->basis_indices[r] = q;
+        if (leaving_lu < e->n_flags) e->in_basis[leaving_lu] = 0;
+        e->in_basis[q] = 1;
+        return leaving_lu;
     }
     /* BasisInverseRows::change_basis, basis_inverse_rows.rs:131-142, 42-83 */
     svec *prow = &e->rows[r];
@@ -409,8 +430,13 @@ oracle_engine_t *oracle_create(const oracle_matrix_data_t *md, const oracle_conf
     for (int32_t k = 0; k < na; k++) { objective += e->b[e->column_to_row[k]]; e->minus_pi[e->column_to_row[k]] = -1.0; }
     e->minus_objective = -objective;
     e->initial_phase1_objective = objective;
-    e->rows = (svec *)malloc(sizeof(svec) * (size_t)m);
-    for (int32_t r = 0; r < m; r++) { sv_init(&e->rows[r]); sv_push(&e->rows[r], r, 1.0); }
+    sv_init(&e->spike);
+    if (e->cfg.basis_inverse == 1) {
+        e->lu = lu_identity(m);                                /* lower_upper/mod.rs:66-74 */
+    } else {
+        e->rows = (svec *)malloc(sizeof(svec) * (size_t)m);
+        for (int32_t r = 0; r < m; r++) { sv_init(&e->rows[r]); sv_push(&e->rows[r], r, 1.0); }
+    }
     e->n_flags = na + md_nr_columns(e);
     e->in_basis = (uint8_t *)calloc((size_t)e->n_flags, 1);
     for (int32_t r = 0; r < m; r++) e->in_basis[e->basis_indices[r]] = 1;
@@ -420,7 +446,8 @@ oracle_engine_t *oracle_create(const oracle_matrix_data_t *md, const oracle_conf
 
 void oracle_destroy(oracle_engine_t *e) {
     if (!e) return;
-    for (int32_t r = 0; r < e->m; r++) sv_free(&e->rows[r]);
+    if (e->rows) for (int32_t r = 0; r < e->m; r++) sv_free(&e->rows[r]);
+    lu_free(e->lu); sv_free(&e->spike);
     free(e->rows); free(e->in_basis); free(e->minus_pi); free(e->b); free(e->basis_indices);
     free(e->column_to_row); free(e->var_to_bound); free(e->bound_to_var);
     free(e->col_ptr); free(e->row_idx); free(e->values); free(e->b0); free(e->ranges); free(e->cost); free(e->upper);
@@ -439,6 +466,7 @@ static void record(int64_t *n_done, int64_t cap, int32_t *tp, int32_t *te, int32
     (*n_done)++;
 }
 
+static int lu_refactor(oracle_engine_t *e);
 /* phase_one.rs:223-260.  Returns number of redundant "rows" written to rows_to_remove. */
 static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *rows_to_remove,
                                                  int64_t *n_done, int64_t cap, int32_t *tp, int32_t *te,
@@ -457,12 +485,20 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
             double d = relative_cost(e, j);
             if (!e->cfg.artificial_removal && fabs(d) > e->cfg.tol_cost) continue;   /* cost.is_zero() */
             kind_original_column(e, j, &e->scratch_col);
-            double el = sparse_inner(&e->rows[pivot_row], &e->scratch_col); /* generate_element */
+            double el;
+            if (e->lu) {                                        /* lower_upper/mod.rs:192-197: a whole FTRAN */
+                lu_generate_column(e->lu, &e->scratch_col, &alpha, &e->spike);
+                const double *pv = sv_get(&alpha, pivot_row);
+                el = pv ? *pv : 0.0;
+            } else {
+                el = sparse_inner(&e->rows[pivot_row], &e->scratch_col); /* generate_element */
+            }
             if (fabs(el) > e->cfg.tol_pivot) { found = 1; q = j; cost = d; }
         }
         if (found) {
             generate_column(e, q, &alpha);
             int32_t leaving = change_basis(e, pivot_row, q, &alpha, cost);
+            if (e->lu && leaving >= 0 && e->lu->n_updates > (e->cfg.refactor_after > 0 ? e->cfg.refactor_after : 10)) lu_refactor(e);
             record(n_done, cap, tp, te, tr, tl, 1, q, pivot_row, leaving);
             e->nr_zero_level++;
         } else {
@@ -474,7 +510,7 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
                 int32_t o = e->column_to_row[a];
                 if (o != pivot_row) {
                     e->nr_exchanges++;
-                    svec tr_ = e->rows[o]; e->rows[o] = e->rows[pivot_row]; e->rows[pivot_row] = tr_;
+                    if (e->rows) { svec tr_ = e->rows[o]; e->rows[o] = e->rows[pivot_row]; e->rows[pivot_row] = tr_; }     /* (LU: re-inverted below) */
                     double tb = e->b[o]; e->b[o] = e->b[pivot_row]; e->b[pivot_row] = tb;
                     int32_t ti = e->basis_indices[o]; e->basis_indices[o] = e->basis_indices[pivot_row]; e->basis_indices[pivot_row] = ti;
                 }
@@ -496,6 +532,52 @@ static int32_t remove_artificial_basis_variables(oracle_engine_t *e, int32_t *ro
     return uniq;
 }
 
+/* BI::invert(basis columns) for the LU back-end (carry/mod.rs:602-614, 512-547): returns 0 when a basis column cannot be
+ * generated (a wrapped artificial index: the reference's release build would index out of range there) or B is singular */
+static int lu_refactor(oracle_engine_t *e) {
+    int32_t m = e->m, n = kind_nr_columns(e);
+    svec *cols = (svec *)calloc((size_t)m, sizeof(svec));
+    int ok = 1;
+    for (int32_t i = 0; i < m && ok; i++) {
+        if (e->basis_indices[i] >= n) {
+            /* an artificial variable that survived phase 1 with a wrapped index (switch_to_phase_two): the reference's release
+             * build would index its provider out of range here; the column is still the unit column of the artificial's row,
+             * which is what the GPU engines factorise (relp_engine_lu.cpp: lu_basis_columns) */
+            int64_t a = (int64_t)e->wrapped_na - 1 - ((int64_t)INT32_MAX - e->basis_indices[i]);
+            if (e->phase != 2 || a < 0 || a >= e->wrapped_na) { ok = 0; break; }
+            sv_clear(&e->scratch_col); sv_push(&e->scratch_col, e->column_to_row[a], 1.0);
+            filter_column(e, &e->scratch_col);
+            if (e->scratch_col.n != 1) { ok = 0; break; }
+            lsv_copy(&cols[i], &e->scratch_col);
+            continue;
+        }
+        kind_original_column(e, e->basis_indices[i], &e->scratch_col);
+        lsv_copy(&cols[i], &e->scratch_col);
+    }
+    lu_t *f = ok ? lu_invert_thr(m, cols, e->cfg.lu_threshold) : NULL;
+    for (int32_t i = 0; i < m; i++) sv_free(&cols[i]);
+    free(cols);
+    if (!f) { e->lu_failed = 1; return 0; }
+    lu_free(e->lu);
+    e->lu = f;
+    e->lu_refactorisations++;
+    return 1;
+}
+/* the rows of B^-1 through the LU back-end the way create_minus_pi_from_artificial builds them (carry/mod.rs:226-236): one unit
+ * FTRAN per column j, entries (i, v) appended to row i, i.e. every row sorted by j */
+static svec *lu_inverse_rows(oracle_engine_t *e) {
+    int32_t m = e->m;
+    svec *rows = (svec *)calloc((size_t)m, sizeof(svec));
+    svec unit, column, spike; sv_init(&unit); sv_init(&column); sv_init(&spike);
+    for (int32_t j = 0; j < m; j++) {
+        sv_clear(&unit); sv_push(&unit, j, 1.0);
+        lu_generate_column(e->lu, &unit, &column, &spike);
+        for (int64_t k = 0; k < column.n; k++) sv_push(&rows[column.d[k].idx], j, column.d[k].val);
+    }
+    sv_free(&unit); sv_free(&column); sv_free(&spike);
+    return rows;
+}
+
 /* non_artificial.rs:151-220 + carry/mod.rs:484-510, 650-689 */
 static void switch_to_phase_two(oracle_engine_t *e, const int32_t *rows_to_remove, int32_t nrem) {
     int32_t na = e->nr_artificial;
@@ -506,11 +588,12 @@ static void switch_to_phase_two(oracle_engine_t *e, const int32_t *rows_to_remov
         e->filtered = (int32_t *)dup_mem(rows_to_remove, sizeof(int32_t) * (size_t)nrem);
         int32_t out = 0, f = 0;
         for (int32_t r = 0; r < m_old; r++) {
-            if (f < nrem && rows_to_remove[f] == r) { f++; sv_free(&e->rows[r]); continue; }
-            e->rows[out] = e->rows[r]; e->b[out] = e->b[r]; e->basis_indices[out] = e->basis_indices[r]; out++;
+            if (f < nrem && rows_to_remove[f] == r) { f++; if (e->rows) sv_free(&e->rows[r]); continue; }
+            if (e->rows) e->rows[out] = e->rows[r];
+            e->b[out] = e->b[r]; e->basis_indices[out] = e->basis_indices[r]; out++;
         }
         e->m = out;
-        for (int32_t r = 0; r < e->m; r++) {                /* remove_sparse_indices on every row */
+        for (int32_t r = 0; e->rows && r < e->m; r++) {     /* remove_sparse_indices on every row */
             svec *row = &e->rows[r]; int64_t o = 0; int32_t skipped = 0;
             for (int64_t k = 0; k < row->n; k++) {
                 int64_t i = row->d[k].idx;
@@ -532,6 +615,7 @@ static void switch_to_phase_two(oracle_engine_t *e, const int32_t *rows_to_remov
         else e->basis_indices[r] -= na;
     }
     e->phase = 2;
+    e->wrapped_na = na;
     e->nr_artificial = 0;
     int32_t n2 = md_nr_columns(e);
     memset(e->in_basis, 0, (size_t)e->n_flags);
@@ -540,12 +624,20 @@ static void switch_to_phase_two(oracle_engine_t *e, const int32_t *rows_to_remov
     /* create_minus_pi_from_artificial, carry/mod.rs:214-248.  The reference builds every column of
      * B^-1 by a unit FTRAN and re-assembles rows; entry (i,j) of that is exactly rows[i][j], and the
      * accumulation order (i ascending, then j ascending) is kept. */
+    svec *inv_rows = e->rows;
+    if (e->lu) {
+        /* the generic from_artificial_remove_rows (carry/mod.rs:512-547) re-inverts from the filtered columns; without removed
+         * rows the factors are kept as they are (from_artificial, :484-510) */
+        if (nrem > 0 && !lu_refactor(e)) return;
+        inv_rows = lu_inverse_rows(e);
+    }
     for (int32_t j = 0; j < e->m; j++) e->minus_pi[j] = 0.0;
     for (int32_t i = 0; i < e->m; i++) {
         if (e->basis_indices[i] >= e->nr_normal) continue;      /* cost None (slacks, wrapped artificials) */
         double c = md_cost_value(e, e->basis_indices[i]);
-        for (int64_t k = 0; k < e->rows[i].n; k++) e->minus_pi[e->rows[i].d[k].idx] += e->rows[i].d[k].val * c;
+        for (int64_t k = 0; k < inv_rows[i].n; k++) e->minus_pi[inv_rows[i].d[k].idx] += inv_rows[i].d[k].val * c;
     }
+    if (e->lu) { for (int32_t i = 0; i < e->m; i++) sv_free(&inv_rows[i]); free(inv_rows); }
     for (int32_t j = 0; j < e->m; j++) e->minus_pi[j] = -e->minus_pi[j];
     /* create_minus_obj_from_artificial, carry/mod.rs:258-271 */
     double objective = 0.0;
@@ -582,6 +674,9 @@ int oracle_run(oracle_engine_t *e, int64_t max_iters, int through_phases,
             if (getenv("ORACLE_DEBUG")) { double mx = -1e300; for (int64_t k = 0; k < alpha->n; k++) mx = fmax(mx, alpha->d[k].val); fprintf(stderr, "[oracle] no row: q %d d %.17g alpha nnz %lld max %.17g\n", q, dq, (long long)alpha->n, mx); }
             status = e->phase == 2 ? ORACLE_UNBOUNDED : ORACLE_ERROR; break; }
         int32_t leaving = change_basis(e, r, q, alpha, dq);
+        /* after_basis_change, carry/mod.rs:602-614: should_refactor() = updates.len() > 10 (lower_upper/mod.rs:199-202) */
+        if (e->lu && leaving >= 0 && e->lu->n_updates > (e->cfg.refactor_after > 0 ? e->cfg.refactor_after : 10)) lu_refactor(e);
+        if (e->lu_failed) { status = ORACLE_ERROR; break; }
         if (leaving < 0) { if (getenv("ORACLE_DEBUG")) fprintf(stderr, "[oracle] zero pivot: q %d r %d\n", q, r); status = ORACLE_ERROR; break; }
         record(&n_done, cap, tp, te, tr, tl, e->phase, q, r, leaving);
     }
@@ -603,9 +698,87 @@ void oracle_get_minus_pi(const oracle_engine_t *e, double *out) { memcpy(out, e-
 void oracle_get_basis(const oracle_engine_t *e, int32_t *out) { memcpy(out, e->basis_indices, sizeof(int32_t) * (size_t)e->m); }
 void oracle_get_basis_inverse(const oracle_engine_t *e, double *out) {
     memset(out, 0, sizeof(double) * (size_t)e->m * (size_t)e->m);
+    if (e->lu) {
+        svec *rows = lu_inverse_rows((oracle_engine_t *)e);
+        for (int32_t i = 0; i < e->m; i++) { for (int64_t k = 0; k < rows[i].n; k++) out[(size_t)i * e->m + rows[i].d[k].idx] = rows[i].d[k].val; sv_free(&rows[i]); }
+        free(rows);
+        return;
+    }
     for (int32_t i = 0; i < e->m; i++)
         for (int64_t k = 0; k < e->rows[i].n; k++) out[(size_t)i * e->m + e->rows[i].d[k].idx] = e->rows[i].d[k].val;
 }
 int64_t oracle_basis_inverse_nnz(const oracle_engine_t *e) {
-    int64_t t = 0; for (int32_t i = 0; i < e->m; i++) t += e->rows[i].n; return t;
+    int64_t t = 0;
+    if (e->lu) { for (int32_t j = 0; j < e->m; j++) t += e->lu->lower[j].n + e->lu->upper[j].n; return t; }
+    for (int32_t i = 0; i < e->m; i++) t += e->rows[i].n;
+    return t;
+}
+void oracle_lu_stats(const oracle_engine_t *e, int64_t *out4) {
+    out4[0] = e->lu_refactorisations; out4[1] = e->lu ? e->lu->n_updates : 0; out4[2] = 0; out4[3] = 0;
+    if (e->lu) for (int32_t j = 0; j < e->m; j++) { out4[2] += e->lu->lower[j].n; out4[3] += e->lu->upper[j].n; }
+}
+
+/* ---- the LU back-end by itself (tests: the reference's known answers of lower_upper/mod.rs:488-867, decomposition/mod.rs:301-491) ---- */
+struct oracle_lu { lu_t *f; svec column, spike; };
+static void olu_columns(int32_t m, const int64_t *ptr, const int32_t *idx, const double *val, svec *cols) {
+    for (int32_t j = 0; j < m; j++) { sv_init(&cols[j]); for (int64_t k = ptr[j]; k < ptr[j + 1]; k++) sv_push(&cols[j], idx[k], val[k]); }
+}
+/* `LUDecomposition { lower_triangular, upper_triangular, .. }` literally, P = Q = I: L column-major without the unit diagonal,
+ * U column-major with the diagonal among the entries of each column (stored last: the largest row index) */
+oracle_lu_t *oracle_lu_from_triangles(int32_t m, const int64_t *lptr, const int32_t *lidx, const double *lval,
+                                      const int64_t *uptr, const int32_t *uidx, const double *uval) {
+    oracle_lu_t *h = (oracle_lu_t *)calloc(1, sizeof(*h));
+    h->f = lu_alloc(m);
+    for (int32_t i = 0; i < m; i++) { h->f->rp_fwd[i] = i; h->f->cp_fwd[i] = i; h->f->cp_bwd[i] = i; }
+    olu_columns(m, lptr, lidx, lval, h->f->lower);
+    olu_columns(m, uptr, uidx, uval, h->f->upper);
+    for (int32_t j = 0; j < m; j++) { qsort(h->f->lower[j].d, (size_t)h->f->lower[j].n, sizeof(tup), lsv_cmp); qsort(h->f->upper[j].d, (size_t)h->f->upper[j].n, sizeof(tup), lsv_cmp); }
+    sv_init(&h->column); sv_init(&h->spike);
+    return h;
+}
+/* LUDecomposition::invert(columns) (lower_upper/mod.rs:76-90); NULL when singular */
+oracle_lu_t *oracle_lu_invert(int32_t m, const int64_t *cptr, const int32_t *cidx, const double *cval) {
+    svec *cols = (svec *)calloc((size_t)m, sizeof(svec));
+    olu_columns(m, cptr, cidx, cval, cols);
+    lu_t *f = lu_invert(m, cols);
+    for (int32_t j = 0; j < m; j++) sv_free(&cols[j]);
+    free(cols);
+    if (!f) return NULL;
+    oracle_lu_t *h = (oracle_lu_t *)calloc(1, sizeof(*h));
+    h->f = f; sv_init(&h->column); sv_init(&h->spike);
+    return h;
+}
+void oracle_lu_destroy(oracle_lu_t *h) { if (!h) return; lu_free(h->f); sv_free(&h->column); sv_free(&h->spike); free(h); }
+/* generate_column (FTRAN): dense result by basis position; the spike is kept for the next oracle_lu_change_basis */
+void oracle_lu_generate_column(oracle_lu_t *h, int32_t n, const int32_t *idx, const double *val, double *out_m) {
+    svec col; sv_init(&col);
+    for (int32_t k = 0; k < n; k++) sv_push(&col, idx[k], val[k]);
+    lu_generate_column(h->f, &col, &h->column, &h->spike);
+    memset(out_m, 0, sizeof(double) * (size_t)h->f->m);
+    for (int64_t k = 0; k < h->column.n; k++) out_m[h->column.d[k].idx] = h->column.d[k].val;
+    sv_free(&col);
+}
+int oracle_lu_change_basis(oracle_lu_t *h, int32_t pivot_row_index) { return lu_change_basis(h->f, pivot_row_index, &h->spike); }
+void oracle_lu_basis_inverse_row(oracle_lu_t *h, int32_t row, double *out_m) {
+    svec r; sv_init(&r);
+    lu_basis_inverse_row(h->f, row, &r);
+    memset(out_m, 0, sizeof(double) * (size_t)h->f->m);
+    for (int64_t k = 0; k < r.n; k++) out_m[r.d[k].idx] = r.d[k].val;
+    sv_free(&r);
+}
+int32_t oracle_lu_nr_updates(const oracle_lu_t *h) { return h->f->n_updates; }
+/* update k: the eta's pivot (= the RotateToBack index) and its values as a dense vector of m */
+void oracle_lu_get_update(const oracle_lu_t *h, int32_t k, int32_t *pivot, double *values_m) {
+    *pivot = h->f->etas[k].pivot;
+    memset(values_m, 0, sizeof(double) * (size_t)h->f->m);
+    for (int64_t t = 0; t < h->f->etas[k].values.n; t++) values_m[h->f->etas[k].values.d[t].idx] = h->f->etas[k].values.d[t].val;
+}
+/* which = 0: lower, 1: upper; dense m x m, row-major (entry [i][j] = column j, row i); permutations by forward index */
+void oracle_lu_get_factor(const oracle_lu_t *h, int which, double *out_mm, int32_t *row_forward, int32_t *column_forward) {
+    const int32_t m = h->f->m;
+    memset(out_mm, 0, sizeof(double) * (size_t)m * (size_t)m);
+    const svec *cols = which ? h->f->upper : h->f->lower;
+    for (int32_t j = 0; j < m; j++) for (int64_t k = 0; k < cols[j].n; k++) out_mm[(size_t)cols[j].d[k].idx * m + j] = cols[j].d[k].val;
+    if (row_forward) memcpy(row_forward, h->f->rp_fwd, sizeof(int32_t) * (size_t)m);
+    if (column_forward) memcpy(column_forward, h->f->cp_fwd, sizeof(int32_t) * (size_t)m);
 }

@@ -31,7 +31,8 @@ class _Config(C.Structure):
     _fields_ = [("tol_cost", C.c_double), ("tol_pivot", C.c_double), ("tol_zero", C.c_double),
                 ("tol_tie", C.c_double), ("tol_feas", C.c_double),
                 ("phase_one_rule", C.c_int32), ("phase_two_rule", C.c_int32),
-                ("ratio_rule", C.c_int32), ("artificial_removal", C.c_int32)]
+                ("ratio_rule", C.c_int32), ("artificial_removal", C.c_int32),
+                ("basis_inverse", C.c_int32), ("refactor_after", C.c_int32), ("lu_threshold", C.c_double)]
 
 
 def build(force: bool = False) -> str:
@@ -66,6 +67,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_basis_inverse_nnz.restype = C.c_int64
         L.oracle_basis_inverse_nnz.argtypes = [C.c_void_p]
+        L.oracle_lu_stats.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -77,7 +79,10 @@ class OracleF64:
     """One f64 CPU solve state (`Tableau<Carry<f64, BasisInverseRows<f64>>, _>`)."""
 
     def __init__(self, problem, phase_one_rule=RULE_FIRST_PROFITABLE_WITH_MEMORY,
-                 phase_two_rule=RULE_STEEPEST_DESCENT, ratio_rule=0, artificial_removal=0, **tolerances):
+                 phase_two_rule=RULE_STEEPEST_DESCENT, ratio_rule=0, artificial_removal=0, basis_inverse=0, refactor_after=10,
+                 lu_threshold=0.0, **tolerances):
+        """basis_inverse: 0 = `BasisInverseRows`, 1 = `LUDecomposition` with its update file (what src/bin/main.rs:52 runs),
+        re-inverted from the basis columns when more than `refactor_after` updates are pending (lower_upper/mod.rs:199-202: 10)."""
         tol = dict(DEFAULT_TOLERANCES)
         tol.update(tolerances)
         self._keep = [np.ascontiguousarray(problem.col_ptr, dtype=np.int64),
@@ -90,7 +95,7 @@ class OracleF64:
         md = _MatrixData(problem.nr_normal, problem.nr_eq, problem.nr_range, problem.nr_le, problem.nr_ge,
                          *[a.ctypes.data for a in self._keep])
         cfg = _Config(tol["tol_cost"], tol["tol_pivot"], tol["tol_zero"], tol["tol_tie"], tol["tol_feas"],
-                      phase_one_rule, phase_two_rule, ratio_rule, artificial_removal)
+                      phase_one_rule, phase_two_rule, ratio_rule, artificial_removal, basis_inverse, refactor_after, lu_threshold)
         self._h = lib().oracle_create(C.byref(md), C.byref(cfg))
         self.trace = []          # (phase, entering, row, leaving)
 
@@ -133,6 +138,11 @@ class OracleF64:
     objective = property(lambda self: lib().oracle_objective(self._h))
     basis_inverse_nnz = property(lambda self: lib().oracle_basis_inverse_nnz(self._h))
 
+    def lu_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().oracle_lu_stats(self._h, out.ctypes.data)
+        return dict(zip(("refactorisations", "updates_pending", "nnz_l", "nnz_u"), (int(v) for v in out)))
+
     def _vec(self, fn, dtype, n):
         out = np.zeros(n, dtype=dtype)
         getattr(lib(), fn)(self._h, out.ctypes.data)
@@ -150,3 +160,100 @@ class OracleF64:
     def basis_inverse(self):
         m = self.m
         return self._vec("oracle_get_basis_inverse", np.float64, m * m).reshape(m, m)
+
+
+class LUF64:
+    """`LUDecomposition` of the C oracle by itself (oracle/relp_f64_lu.h), for the reference's own LU known answers."""
+
+    def __init__(self, handle, m):
+        self._h, self.m = handle, m
+
+    @staticmethod
+    def _csc(cols, m):
+        cols = list(cols) + [[] for _ in range(m - len(cols))]
+        ptr = np.zeros(m + 1, dtype=np.int64)
+        for j, c in enumerate(cols):
+            ptr[j + 1] = ptr[j] + len(c)
+        idx = np.ascontiguousarray([i for c in cols for i, _ in c] or [0], dtype=np.int32)
+        val = np.ascontiguousarray([float(v) for c in cols for _, v in c] or [0.0], dtype=np.float64)
+        return ptr, idx, val
+
+    @classmethod
+    def _setup(cls):
+        L = lib()
+        if not getattr(L, "_lu_ready", False):
+            L.oracle_lu_from_triangles.restype = C.c_void_p
+            L.oracle_lu_from_triangles.argtypes = [C.c_int32] + [C.c_void_p] * 6
+            L.oracle_lu_invert.restype = C.c_void_p
+            L.oracle_lu_invert.argtypes = [C.c_int32] + [C.c_void_p] * 3
+            L.oracle_lu_destroy.argtypes = [C.c_void_p]
+            L.oracle_lu_generate_column.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.oracle_lu_change_basis.restype = C.c_int
+            L.oracle_lu_change_basis.argtypes = [C.c_void_p, C.c_int32]
+            L.oracle_lu_basis_inverse_row.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+            L.oracle_lu_nr_updates.restype = C.c_int32
+            L.oracle_lu_nr_updates.argtypes = [C.c_void_p]
+            L.oracle_lu_get_update.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+            L.oracle_lu_get_factor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            L._lu_ready = True
+        return L
+
+    @classmethod
+    def from_triangles(cls, m, lower_columns, upper_columns):
+        L = cls._setup()
+        lp, li, lv = cls._csc(lower_columns, m)
+        up, ui, uv = cls._csc(upper_columns, m)
+        return cls(L.oracle_lu_from_triangles(m, lp.ctypes.data, li.ctypes.data, lv.ctypes.data, up.ctypes.data, ui.ctypes.data, uv.ctypes.data), m)
+
+    @classmethod
+    def identity(cls, m):
+        return cls.from_triangles(m, [[] for _ in range(m)], [[(i, 1.0)] for i in range(m)])
+
+    @classmethod
+    def invert(cls, columns):
+        L = cls._setup()
+        m = len(columns)
+        p, i, v = cls._csc(columns, m)
+        h = L.oracle_lu_invert(m, p.ctypes.data, i.ctypes.data, v.ctypes.data)
+        return cls(h, m) if h else None
+
+    def close(self):
+        if self._h:
+            lib().oracle_lu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def generate_column(self, column):
+        idx = np.ascontiguousarray([i for i, _ in column] or [0], dtype=np.int32)
+        val = np.ascontiguousarray([float(v) for _, v in column] or [0.0], dtype=np.float64)
+        out = np.zeros(self.m)
+        lib().oracle_lu_generate_column(self._h, len(column), idx.ctypes.data, val.ctypes.data, out.ctypes.data)
+        return out
+
+    def change_basis(self, pivot_row_index):
+        return bool(lib().oracle_lu_change_basis(self._h, pivot_row_index))
+
+    def basis_inverse_row(self, row):
+        out = np.zeros(self.m)
+        lib().oracle_lu_basis_inverse_row(self._h, row, out.ctypes.data)
+        return out
+
+    def updates(self):
+        out = []
+        for k in range(lib().oracle_lu_nr_updates(self._h)):
+            pivot, vals = C.c_int32(), np.zeros(self.m)
+            lib().oracle_lu_get_update(self._h, k, C.byref(pivot), vals.ctypes.data)
+            out.append((pivot.value, vals))
+        return out
+
+    def factor(self, which):
+        """(dense m x m factor, row permutation forward, column permutation forward); which = "lower" / "upper"."""
+        a = np.zeros((self.m, self.m))
+        rf, cf = np.zeros(self.m, dtype=np.int32), np.zeros(self.m, dtype=np.int32)
+        lib().oracle_lu_get_factor(self._h, 1 if which == "upper" else 0, a.ctypes.data, rf.ctypes.data, cf.ctypes.data)
+        return a, rf, cf

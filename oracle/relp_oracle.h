@@ -57,6 +57,15 @@ typedef struct {
      *   exchanged first; phase_one.rs:252 pushes the artificial's index, which is another row once `<=` rows lie in front). */
     int32_t ratio_rule;
     int32_t artificial_removal;
+    /* basis_inverse 0: `BasisInverseRows` (carry/basis_inverse_rows.rs: explicit inverse as sparse rows, never refactorised);
+     * 1: `LUDecomposition` (carry/lower_upper: P B Q = L U with Markowitz pivoting, Forrest-Tomlin-style update file),
+     * what src/bin/main.rs:52 runs.  refactor_after: the basis is re-inverted from its columns when MORE than this many updates
+     * are pending (lower_upper/mod.rs:199-202 has 10); <= 0 means 10. */
+    int32_t basis_inverse;
+    int32_t refactor_after;
+    /* LU back-end, f64 only: a Markowitz pivot must be at least this fraction of its column's largest active entry (0 = the
+     * reference's search over every entry, pivoting.rs:45-81) */
+    double lu_threshold;
 } oracle_config_t;
 
 enum { ORACLE_RULE_FIRST_PROFITABLE = 0, ORACLE_RULE_FIRST_PROFITABLE_WITH_MEMORY = 1, ORACLE_RULE_STEEPEST_DESCENT = 2 };
@@ -94,6 +103,21 @@ void    oracle_get_basis(const oracle_engine_t *e, int32_t *out);
 /* dense row-major copy of B^-1 (m*m) */
 void    oracle_get_basis_inverse(const oracle_engine_t *e, double *out);
 int64_t oracle_basis_inverse_nnz(const oracle_engine_t *e);
+/* LU back-end: { refactorisations so far, updates pending, entries of L, entries of U (with the diagonal) } */
+void    oracle_lu_stats(const oracle_engine_t *e, int64_t *out4);
+
+/* ---- the LU back-end by itself, for the reference's own known answers (lower_upper/mod.rs:488-867) ---- */
+typedef struct oracle_lu oracle_lu_t;
+oracle_lu_t *oracle_lu_from_triangles(int32_t m, const int64_t *lptr, const int32_t *lidx, const double *lval,
+                                      const int64_t *uptr, const int32_t *uidx, const double *uval);
+oracle_lu_t *oracle_lu_invert(int32_t m, const int64_t *cptr, const int32_t *cidx, const double *cval);
+void oracle_lu_destroy(oracle_lu_t *h);
+void oracle_lu_generate_column(oracle_lu_t *h, int32_t n, const int32_t *idx, const double *val, double *out_m);
+int  oracle_lu_change_basis(oracle_lu_t *h, int32_t pivot_row_index);      /* with the spike of the last generate_column */
+void oracle_lu_basis_inverse_row(oracle_lu_t *h, int32_t row, double *out_m);
+int32_t oracle_lu_nr_updates(const oracle_lu_t *h);
+void oracle_lu_get_update(const oracle_lu_t *h, int32_t k, int32_t *pivot, double *values_m);
+void oracle_lu_get_factor(const oracle_lu_t *h, int which, double *out_mm, int32_t *row_forward, int32_t *column_forward);
 
 #ifdef __cplusplus
 }
