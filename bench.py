@@ -202,12 +202,15 @@ def assemble(args_ns, world, primary_kind, primary, secondary=None, c2=None, c4=
         roofline["revised_engine"]["pivot"] = secondary["pivot_roofline"]
     out = {
         "metric": "simplex iterations/sec", "value": primary["value"], "unit": "iterations/s", "n_gpus": world,
-        "steps": primary["steps"], "warmup": args_ns.warmup, "ms_per_step": primary["ms_per_step"],
+        "steps": primary["steps"], "steps_requested": args_ns.steps, "warmup": args_ns.warmup, "ms_per_step": primary["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args_ns.workload}: synthetic dense LP {m}x{n} f64 (+{m} slack columns), SteepestDescent, "
                                + ("dense tableau with blocked f64-MFMA updates" if primary_kind == "tableau"
                                   else "explicit dense basis inverse"),
                    "m": m, "n": n, "seed": seed, "engine": primary_kind, "update_block": primary["update_block"],
+                   "steps_note": "--steps is honoured as AT LEAST: a timed window is a whole number of update blocks (max(steps, 4 blocks) "
+                                 "rounded up to the block), because a window that ends inside a block would leave the block's one "
+                                 "O(m n) flush out of the time; `steps` is what was timed, `steps_requested` what was asked for",
                    "parallelism": "single GPU" if world == 1 else
                    (f"stored tableau columns sharded x{world}, one all-gather per pivot" if primary_kind == "tableau"
                     else f"columns of A and rows of B^-1 sharded x{world}")},
@@ -247,10 +250,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(m, n, seed, warmup, budget_s=CPU_BUDGET_S, max_pivots=2000):
+def cpu_baseline(m, n, seed, warmup, budget_s=None, max_pivots=2000):
     """The C (f64) restatement of the reference path (oracle/relp_f64.c, kind "port"), one core, timed on the same
     LP from iteration `warmup` on until ~budget_s of CPU time (independent of --steps)."""
     from rust_lp_amd import MatrixData, synthetic
+    budget_s = CPU_BUDGET_S if budget_s is None else budget_s
     from oracle import relp_f64
     lp = synthetic.dense_lp(m, n, seed)
     md = MatrixData.from_dense_le(lp["A"], lp["b"], lp["c"]).ensure_csc()
@@ -605,6 +609,58 @@ def sparse_scale(with_cpu=True):
     return out
 
 
+def sparse_replicas(counts=(1, 8, 32, 64), fixture="netlib/25FV47.SIF", fixed=True, device=None):
+    """"LU / eta engine -- replicas only".  R independent LU handles on ONE GPU, each with its own stream, its own
+    persistent pivot workgroup (one CU) and its own refactorisations, each solving the same LP to optimality from its own host
+    thread (the C calls release the GIL); every replica must walk the solo run's pivot sequence.  Aggregate iterations/s =
+    all pivots / wall time of the slowest replica.  This is what an N-GPU run of the sparse path consists of (N x R replicas,
+    no collective), and what the 255 CUs the pivot kernel leaves idle are for; it is NOT the headline metric (one LP, one
+    solve) and is labelled so."""
+    import threading
+    from rust_lp_amd import engine
+    gf, md = _load_fixture(fixture, fixed)
+    out = {"workload": f"{fixture} on R independent LU engines of one GPU (own stream, own persistent kernel, own refactorisations)",
+           "unit": "iterations/s (aggregate over the replicas)", "replicas": {}}
+    solo_trace = None
+    for R in counts:
+        kw = dict(engine=engine.ENGINE_LU, trace_capacity=1 << 15)
+        if device is not None:
+            kw["device"] = device
+        ts = [engine.Tableau(md, **kw) for _ in range(R)]
+        res = [None] * R
+        go = threading.Barrier(R + 1)
+
+        def work(i):
+            go.wait()
+            t0 = time.perf_counter()
+            oc = ts[i].solve_relaxation()
+            res[i] = (oc, time.perf_counter() - t0)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(R)]
+        for x in th:
+            x.start()
+        go.wait()
+        t0 = time.perf_counter()
+        for x in th:
+            x.join()
+        wall = time.perf_counter() - t0
+        pivots = [t.iterations() for t in ts]
+        traces = [t.trace() for t in ts]
+        if solo_trace is None:
+            solo_trace = traces[0]
+        objective = ts[0].objective_function_value() + float(gf.fixed_cost)
+        for t in ts:
+            t.close()
+        out["replicas"][str(R)] = {"value": sum(pivots) / wall, "seconds": wall, "pivots_per_replica": pivots[0],
+                                   "all_optimal": all(r[0] == engine.OPTIMAL for r in res),
+                                   "every_replica_walks_the_solo_pivots": all(tr == solo_trace for tr in traces),
+                                   "slowest_over_fastest_replica": max(r[1] for r in res) / max(min(r[1] for r in res), 1e-9),
+                                   "objective": objective}
+    one = out["replicas"].get("1", {}).get("value")
+    if one:
+        out["scaling_over_one_replica"] = {k: round(v["value"] / one, 2) for k, v in out["replicas"].items()}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU as a fresh child process (nothing in
@@ -627,8 +683,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dense10k", choices=sorted(WORKLOADS))
-    ap.add_argument("--engine", default="default", choices=["default", "revised", "tableau"],
-                    help="default = tableau as the measured engine (+ the revised engine's numbers at N = 1)")
+    ap.add_argument("--engine", default="default", choices=["default", "revised", "tableau", "lu"],
+                    help="default = tableau as the measured engine (+ the revised engine's numbers at N = 1); lu = the sparse path as "
+                         "independent replicas (SURVEY.md 8e: replicas only), --replicas per GPU, no collective in the data path")
+    ap.add_argument("--replicas", type=int, default=8, help="--engine lu: LU engines per GPU")
+    ap.add_argument("--no-replicas", action="store_true", help="skip the sparse_engine.replicas section (1 / 8 / 32 / 64 LU engines on one GPU)")
     ap.add_argument("--update-block", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-path (LU engine, Netlib 25FV47) section")
@@ -637,6 +696,10 @@ def main():
     ap.add_argument("--no-c1", action="store_true", help="skip the configs[0] (adlittle, exact CPU path beside the f64 engines) section")
     ap.add_argument("--no-scale", action="store_true", help="skip the 63,988-row multi-commodity section (LU engine, third kernel layout)")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] (MIPLIB relaxations, degenerate pivot counts) section")
+    ap.add_argument("--quick", action="store_true",
+                    help="the line's schema in a fraction of the time (tests/test_bench_gpu.py): no c4 / c5 / sparse.large / "
+                         "sparse.scale / sparse.replicas, CPU samples of 3 s; the headline, roofline, cpu_baseline, c1, c2 and the 25FV47 "
+                         "section are measured as always")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=64,
                     help="bracket the kernels of every n-th pivot with HIP events (1 = every pivot)")
@@ -646,6 +709,10 @@ def main():
                     help="run the multi-GPU loop (torch.distributed collectives) even at N = 1 (rehearsal)")
     args = ap.parse_args()
 
+    if args.quick:
+        global CPU_BUDGET_S
+        CPU_BUDGET_S = 3.0
+        args.no_c4 = args.no_c5 = args.no_scale = args.no_replicas = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -683,6 +750,35 @@ def main():
 
     K, W = max(args.steps, 1), max(args.warmup, 0)
     lib = engine.load_library()
+    if args.engine == "lu":
+        # the sparse path on N GPUs: replicas only -- every rank solves Netlib 25FV47 on `--replicas` independent LU
+        # engines, no data-path collective; barrier + synchronize on both sides, MAX over ranks, value = all pivots / that time
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rep = sparse_replicas(counts=(args.replicas,), device=local_rank)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r = rep["replicas"][str(args.replicas)]
+        pivots = torch.tensor([float(r["pivots_per_replica"] * args.replicas)], dtype=torch.float64, device=dev if not rehearse else "cpu")
+        secs = torch.tensor([r["seconds"]], dtype=torch.float64, device=dev if not rehearse else "cpu")
+        if sharded:
+            dist.barrier()
+            dist.all_reduce(pivots, op=dist.ReduceOp.SUM)
+            dist.all_reduce(secs, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            line = {"metric": "simplex iterations/sec (sparse path: independent LU-engine replicas, SURVEY.md 8e)", "value": pivots.item() / secs.item(),
+                    "unit": "iterations/s", "n_gpus": world, "steps": int(r["pivots_per_replica"]), "warmup": 0,
+                    "ms_per_step": 1e3 * secs.item() / max(r["pivots_per_replica"], 1), "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "f64", "data": "Netlib 25FV47 (tests/golden/mps), whole two-phase solves",
+                    "config": {"workload": "sparse_replicas", "replicas_per_gpu": args.replicas, "engine": "lu", "parallelism": f"replicas x{world}",
+                               "note": "not BASELINE's headline metric (one LP per engine); --steps is the pivot count of a whole solve"},
+                    "replicas": r, "seconds_including_create": dt}
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if sharded:
+            dist.destroy_process_group()
+        return
     events = not args.no_kernel_events
     primary_kind = "tableau" if args.engine in ("default", "tableau") else "revised"
     loop_kind = {}
@@ -776,9 +872,12 @@ def main():
                                                       + ("single GPU" if world == 1 else f"stored columns sharded x{world}"))
     sparse = sparse_path(events, not args.no_cpu_baseline) if solo and not args.no_sparse else None
     if sparse is not None:
-        sparse["large"] = sparse_large()
+        if not args.quick:
+            sparse["large"] = sparse_large()
         if not args.no_scale:
             sparse["scale"] = sparse_scale(not args.no_cpu_baseline)
+        if not args.no_replicas:
+            sparse["replicas"] = sparse_replicas()
     c1 = config_one(not args.no_cpu_baseline) if solo and not args.no_c1 else None
     c5 = config_five() if solo and not args.no_c5 else None
 

@@ -125,6 +125,19 @@ typedef struct {
      * names another row as soon as `<=` rows lie in front of the artificial's row: the reference then deletes a
      * non-redundant row and optimises a relaxation -- Netlib 80BAU3B ends at 964,593.50 instead of 987,224.19 that way). */
     int32_t artificial_removal;
+    /* RELP_PIVOT_RESCUE (1): a pivot loop that ends without a pivot row is looked at before it is believed.  The reference
+     * takes every alpha_i > 0 (tableau/mod.rs:227); f64 needs `tol_pivot`, and an ABSOLUTE one is wrong both ways on unscaled
+     * data: Netlib SIERRA (entries up to 1e5) has legitimate columns whose largest entry is 1e-5 -- all of it below the
+     * tolerance, phase 1 "unbounded" after 620 pivots on every engine -- while SCSD6 prices a column whose reduced cost
+     * (-2.2e-7) and positive entries (2.2e-7 beside entries of -5) are both artefacts of its six-digit data.  With the
+     * rescue the engine reads alpha back: positive entries of at least tol_pivot * max|alpha| are pivoted on (one step with the
+     * tolerance lowered to that), otherwise the column is barred from pricing until the basis has changed, and an outcome
+     * reached with barred columns is confirmed once more without them.  Rare events, handled on the host. */
+    int32_t pivot_rescue;
+    /* 1: the explicit inverse / the tableau is rebuilt from the basis columns at an interval the engine adapts itself -- halved
+     * (down to 32 pivots) when a rebuild moves b by more than 1e-7 relative, doubled (up to 4,096) when by less than 1e-10 --
+     * instead of the hand-set relp_set_reinversion_interval (the LU engine refactorises every update_block pivots anyway). */
+    int32_t auto_reinversion;
 } relp_config_t;
 
 typedef enum { RELP_RATIO_REFERENCE = 0, RELP_RATIO_LARGEST_PIVOT = 1 } relp_ratio_rule_t;
@@ -142,10 +155,24 @@ typedef enum {
      * phases, artificial removal and redundant-row removal included (the revised engine shards only LPs with a full
      * slack basis). */
     RELP_ENGINE_TABLEAU = 1,
-    RELP_ENGINE_LU = 2        /* sparse LU of the basis + pending updates (Carry<_, LUDecomposition<_>>) */
+    RELP_ENGINE_LU = 2,       /* sparse LU of the basis + pending updates (Carry<_, LUDecomposition<_>>) */
+    /* resolved at create (relp_engine_kind tells which): the dense tableau while it fits comfortably -- 8 m n <= 64 GB and
+     * m <= 50,000 rows, where it is the fastest engine on every file of the reference -- the LU engine beyond,
+     * where its O(nnz) memory and the persistent kernel's third layout win (5.3b) */
+    RELP_ENGINE_AUTO = 3
 } relp_engine_kind_t;
 
+/* relp_default_config: the reference's rules literally (every safeguard 0, engine RELP_ENGINE_REVISED).
+ * relp_robust_config: what an f64 caller who wants the optimum rather than the reference's pivot sequence should take --
+ * ratio_rule = RELP_RATIO_LARGEST_PIVOT, artificial_removal = RELP_ARTIFICIAL_TEXTBOOK, pivot_rescue, auto_reinversion,
+ * engine = RELP_ENGINE_AUTO; no per-file knobs (tests/test_gpu_big_pins.py, tests/test_gpu_corpus.py). */
 void relp_default_config(relp_config_t *cfg);
+void relp_robust_config(relp_config_t *cfg);
+/* the engine in use (RELP_ENGINE_AUTO resolved) */
+int32_t relp_engine_kind(const relp_engine_t *h);
+/* RELP_PIVOT_RESCUE / auto_reinversion at work: out[4] = { pivots made with a lowered tolerance, columns barred, outcomes
+ * confirmed without barred columns, the re-inversion interval in effect } */
+relp_status_t relp_robust_stats(const relp_engine_t *h, int64_t *out4);
 const char *relp_last_error(const relp_engine_t *h);
 const char *relp_version(void);
 

@@ -25,6 +25,17 @@ void relp_default_config(relp_config_t* cfg) {
     cfg->engine = RELP_ENGINE_REVISED;
 }
 
+void relp_robust_config(relp_config_t* cfg) {
+    relp_default_config(cfg);
+    cfg->ratio_rule = RELP_RATIO_LARGEST_PIVOT;
+    cfg->artificial_removal = RELP_ARTIFICIAL_TEXTBOOK;
+    cfg->pivot_rescue = 1;
+    cfg->auto_reinversion = 1;
+    cfg->engine = RELP_ENGINE_AUTO;
+}
+int32_t relp_engine_kind(const relp_engine_t* h) { return h ? H(h).engine_kind() : -1; }
+relp_status_t relp_robust_stats(const relp_engine_t* h, int64_t* out4) { return (h && out4) ? H(h).robust_stats(out4) : RELP_E_ARG; }
+
 const char* relp_last_error(const relp_engine_t* h) { return h ? H(h).last_error() : "null handle"; }
 const char* relp_version(void) { return "relp-mi355x 0.2 (gfx950; engines: explicit inverse, dense tableau, sparse LU + Forrest-Tomlin)"; }
 

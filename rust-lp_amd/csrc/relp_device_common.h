@@ -200,13 +200,33 @@ __device__ __forceinline__ void tie_reduce(tie_key_t& key, int& row, tie_key_t* 
 // written and the block bookkeeping of the deferred update (row r of W saved, slot of W chosen) is done.
 template <int BS>
 __device__ __forceinline__ void ratio_commit(tie_key_t best_key, int best_row, const double* alpha, const double* b,
-                                             const DeferredUpdate& du, int p, PivotRecord* rec, bool wide = false) {
+                                             const DeferredUpdate& du, int p, PivotRecord* rec, bool wide = false, int guard_m = 0,
+                                             double guard_rel = 0.0) {
     __shared__ tie_key_t s_cl[BS / 64];
     __shared__ int s_cr[BS / 64];
     // (everything the epilogue reads from memory -- alpha_r, b_r, row r of W, the slot of row r -- goes out in ONE round trip)
     tie_reduce<BS>(best_key, best_row, s_cl, s_cr, wide);
     const int best_leave = tie_key_leaving(best_key);
     const int r = best_row;
+    if (guard_m > 0) {
+        // Tolerances::pivot_guard: the chosen element against the largest |entry| of the column (one pass of the workgroup
+        // over alpha; nothing has been written yet)
+        __shared__ double s_gm[BS / 64];
+        double mx = 0.0;
+        for (int i = threadIdx.x; i < guard_m; i += BS) mx = fmax(mx, fabs(alpha[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_gm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        double amax = s_gm[0];
+#pragma unroll
+        for (int w = 1; w < BS / 64; ++w) amax = fmax(amax, s_gm[w]);
+        if (alpha[r] < guard_rel * amax) {
+            if (threadIdx.x == 0) rec->outcome = DEV_NO_ROW;
+            return;
+        }
+    }
     const bool deferred = du.kmax > 0;
     double a_r = 0.0, b_r = 0.0;
     int jt = 0;
@@ -311,7 +331,7 @@ __device__ __forceinline__ void ratio_body(const double* alpha, const double* b,
             }
         }
     }
-    ratio_commit<BS>(best_key, best_row, alpha, b, du, p, rec, tol.ratio_rule != 0);
+    ratio_commit<BS>(best_key, best_row, alpha, b, du, p, rec, tol.ratio_rule != 0, tol.pivot_guard ? m : 0, tol.guard_rel);
 }
 
 // Ratio test of a workgroup of BS threads from the minimum ratio of every block of `rpb` rows (`rmin`, nblk
@@ -379,7 +399,7 @@ __device__ __forceinline__ void ratio_blocks_body(const double* __restrict__ alp
             if (key < best_key) { best_key = key; best_row = i; }
         }
     }
-    ratio_commit<BS>(best_key, best_row, alpha, b, du, p, rec, tol.ratio_rule != 0);
+    ratio_commit<BS>(best_key, best_row, alpha, b, du, p, rec, tol.ratio_rule != 0, tol.pivot_guard ? m : 0, tol.guard_rel);
 }
 
 // The same choice without the bookkeeping: every thread of the workgroup returns with (row, leaving column), row = -1 when

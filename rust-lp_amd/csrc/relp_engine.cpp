@@ -59,7 +59,7 @@ ColumnTable Engine::table() const {
     return ct;
 }
 
-Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie, cfg_.ratio_rule, 0}; }
+Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie, cfg_.ratio_rule, pivot_guard_on_ ? 1 : 0, guard_rel_}; }
 
 TableauView Engine::tview() const {
     TableauView tv;
@@ -133,6 +133,12 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         if (std::isfinite(upper_h_[j])) { bound_row_h_[j] = mc_ + (int32_t)bound_to_var.size(); bound_to_var.push_back(j); }
     nr_bounds_ = (int32_t)bound_to_var.size();
     m_ = mc_ + nr_bounds_ + nr_range_;
+    if (cfg_.engine == RELP_ENGINE_AUTO) {
+        // INTEGRATION.md "which engine for which LP": the dense tableau while it fits comfortably, the LU engine beyond
+        const double n_all = (double)nr_normal_ + nr_range_ + nr_le_ + nr_ge_ + nr_bounds_ + nr_range_ + m_;       // (+ m: identity / artificial block)
+        const bool fits = 8.0 * (double)m_ * n_all <= 64e9 && m_ <= 50000;
+        cfg_.engine = (cfg_.shard_count > 1 || fits) ? RELP_ENGINE_TABLEAU : RELP_ENGINE_LU;
+    }
     if (m_ < 1) return fail(RELP_E_ARG, "empty problem");
     const int32_t row_start[7] = {0, nr_eq_, nr_eq_ + nr_range_, nr_eq_ + nr_range_ + nr_le_, mc_, mc_ + nr_bounds_, m_};
     // virtual columns in provider order: range slack | <= slack | >= slack | bound slack | range-bound slack
@@ -334,6 +340,7 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         {   // two launches per pivot instead of three in the single-GPU loop (RELP_FUSED_UPDATE=0: k_ratio_blocks + k_tab_update_all)
             const char* e = std::getenv("RELP_FUSED_UPDATE");
             fused_update_ = !(e && std::atoi(e) == 0);      // (also the native sharded loop, relp_shard_run)
+            if (cfg_.pivot_rescue && cfg_.shard_count == 1) fused_update_ = false;       // (the pivot guard lives in the shared ratio epilogue)
             if (fused_update_) {
                 HIP_TRY(dev_alloc(&d_b_alt_, ld_b_));
                 HIP_TRY(dev_alloc(&d_basis_alt_, m_));
@@ -406,6 +413,8 @@ relp_status_t Engine::create(const relp_matrix_data_t& md, const relp_config_t& 
         if (md.format == RELP_FORMAT_CSC && md.col_ptr && nr_normal_ > 0 && mc_ > 0)
             sparse_input = (double)md.col_ptr[nr_normal_] <= 0.10 * (double)nr_normal_ * (double)mc_;
         reinvert_interval_ = (!lu_ && cfg_.shard_count == 1 && m_ <= 4096 && sparse_input) ? 1000 : 0;
+        // relp_config_t.auto_reinversion: any LP, starting at 256 pivots; every rebuild measures what it corrected and adapts
+        if (cfg_.auto_reinversion && !lu_ && cfg_.shard_count == 1) reinvert_interval_ = 256;
     }
     std::memset(h_rec_, 0, sizeof(PivotRecord));
     h_rec_->outcome = DEV_RUNNING;
@@ -839,7 +848,115 @@ relp_status_t Engine::bring_into_basis(int32_t column, int32_t row, double cost,
 // ------------------------------------------------------------------------------------------------
 // Loops (phase_one.rs:125-170, phase_two.rs:22-51)
 // ------------------------------------------------------------------------------------------------
+static constexpr int32_t kHeldNoCandidate = 100;          // run_loop: no candidate left while columns are barred (pivot_rescue)
+
+relp_status_t Engine::robust_stats(int64_t* out4) const {
+    out4[0] = rescue_small_pivots_; out4[1] = rescue_barred_; out4[2] = rescue_confirmations_; out4[3] = reinvert_interval_;
+    return RELP_OK;
+}
+
+relp_status_t Engine::rescue_unbar_all() {
+    if (barred_.empty()) return RELP_OK;
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const uint8_t zero = 0;
+    for (int32_t j : barred_) HIP_TRY(hipMemcpy(d_in_basis_ + j, &zero, 1, hipMemcpyHostToDevice));
+    barred_.clear();
+    return RELP_OK;
+}
+
+// phase_one::primal / phase_two::primal with relp_config_t.pivot_rescue: the loop itself is run_loop(); an exit without a pivot
+// row (phase_one.rs:143 panics there, phase_two.rs:44 returns Unbounded) is believed only when the entering column really has no
+// entry worth pivoting on.
 relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
+    if (!cfg_.pivot_rescue || cfg_.shard_count > 1) return run_loop(max_iters, done, outcome);
+    if (const char* e = std::getenv("RELP_PIVOT_GUARD")) guard_rel_ = std::atof(e);          // (measurement aid: the guard's relative threshold)
+    struct GuardScope { bool& g; GuardScope(bool& x) : g(x) { g = true; } ~GuardScope() { g = false; } } guard_scope(pivot_guard_on_);
+    int64_t total = 0;
+    int32_t oc = RELP_RUNNING;
+    relp_status_t st;
+    bool confirming = false;                  // the outcome is being re-checked with every column priced again
+    for (int guard = 0;; ++guard) {
+        int64_t d = 0;
+        hold_phase_end_ = !barred_.empty();
+        st = run_loop(std::max<int64_t>(max_iters - total, 0), &d, &oc);
+        hold_phase_end_ = false;
+        if (st) return st;
+        total += d;
+        if (d > 0) confirming = false;
+        const bool no_row = oc == RELP_NO_ROW_PHASE_ONE || oc == RELP_UNBOUNDED;
+        if (no_row && guard < 100000) {
+            if (d > 0 && (st = rescue_unbar_all())) return st;             // the basis has changed: the bars are out of date
+            const int32_t q = h_rec_->q;
+            const double d_q = h_rec_->d_q;
+            std::vector<double> alpha(m_);
+            HIP_TRY(hipStreamSynchronize(stream_));
+            HIP_TRY(hipMemcpy(alpha.data(), d_alpha_, sizeof(double) * m_, hipMemcpyDeviceToHost));
+            double amax = 0.0, apos = 0.0;
+            for (double v : alpha) { amax = std::max(amax, std::fabs(v)); apos = std::max(apos, v); }
+            if (apos > 0.0 && apos >= guard_rel_ * amax && apos > cfg_.tol_zero) {
+                // a column with entries worth pivoting on relative to its own size (all of it small, or the loop's choice was
+                // small beside larger entries): ONE pivot by the full-scan ratio test with the tolerance relative to the column
+                const double keep = cfg_.tol_pivot;
+                cfg_.tol_pivot = std::min(keep, std::max(guard_rel_ * amax, 1e-300) * (1.0 - 1e-12));
+                pivot_guard_on_ = false;
+                int32_t found = 0, r = -1;
+                st = generate_column(q, nullptr);
+                if (!st) st = select_primal_pivot_row(&found, &r);
+                if (!st && found) st = bring_into_basis(q, r, d_q, nullptr);
+                cfg_.tol_pivot = keep;
+                pivot_guard_on_ = true;
+                if (st) return st;
+                if (found) {
+                    ++rescue_small_pivots_; ++total;
+                    if ((st = download_rec())) return st;
+                    h_rec_->outcome = DEV_RUNNING;                          // (the update kernels have counted and traced the pivot)
+                    if ((st = upload_rec())) return st;
+                    if (total >= max_iters) { oc = RELP_RUNNING; break; }
+                    continue;
+                }
+            }
+            if (apos <= 0.0 && barred_.empty() && !confirming) break;      // nothing positive at all: the outcome stands
+            if (apos > 0.0 || !barred_.empty()) {
+                if (apos <= 0.0) break;                                    // a genuinely unbounded column beside barred ones
+                // positive entries that are noise beside the column's size (or below every tolerance): not a column to enter now
+                const uint8_t two = 2;
+                HIP_TRY(hipMemcpy(d_in_basis_ + q, &two, 1, hipMemcpyHostToDevice));
+                barred_.push_back(q);
+                ++rescue_barred_;
+                if ((st = download_rec())) return st;
+                h_rec_->outcome = DEV_RUNNING;
+                if ((st = upload_rec())) return st;
+                continue;
+            }
+            break;
+        }
+        if (oc == kHeldNoCandidate) {
+            // no candidate left, but some columns were barred: price them again and see whether the outcome survives
+            if (!confirming) {
+                if ((st = rescue_unbar_all())) return st;
+                confirming = true;
+                ++rescue_confirmations_;
+                if ((st = download_rec())) return st;
+                h_rec_->outcome = DEV_RUNNING;
+                if ((st = upload_rec())) return st;
+                continue;
+            }
+            // barred again without a pivot in between: they stay out, the phase ends
+            if ((st = download_rec())) return st;
+            h_rec_->outcome = DEV_NO_CANDIDATE;
+            if (phase_ == 2) oc = RELP_OPTIMAL;
+            else if ((st = finish_phase_one(&oc))) return st;
+            barred_.clear();                                               // (the phase switch rebuilt the flags)
+            break;
+        }
+        break;
+    }
+    if (done) *done = total;
+    if (outcome) *outcome = oc;
+    return RELP_OK;
+}
+
+relp_status_t Engine::run_loop(int64_t max_iters, int64_t* done, int32_t* outcome) {
     if (ft_) return run_ft(max_iters, done, outcome);
     relp_status_t st = download_rec();
     if (st) return st;
@@ -880,7 +997,8 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
     if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
     int32_t oc = RELP_RUNNING;
     if (h_rec_->outcome == DEV_NO_CANDIDATE) {
-        if (phase_ == 2) oc = RELP_OPTIMAL;
+        if (hold_phase_end_) oc = kHeldNoCandidate;
+        else if (phase_ == 2) oc = RELP_OPTIMAL;
         else if ((st = finish_phase_one(&oc))) return st;
     } else if (h_rec_->outcome == DEV_NO_ROW) {
         oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;
@@ -1237,6 +1355,8 @@ relp_status_t Engine::retabulate() {
     retab_done_ = false;
     enqueue_flush();
     HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<double> b_before;
+    if (cfg_.auto_reinversion) { b_before.resize(m_); HIP_TRY(hipMemcpy(b_before.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost)); }
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     std::vector<std::vector<std::pair<int32_t, double>>> cols;
@@ -1277,6 +1397,7 @@ relp_status_t Engine::retabulate() {
     h_rec_->minus_objective = -objective;
     ++reinversions_;
     retab_done_ = true;
+    if (cfg_.auto_reinversion) auto_reinversion_adapt(b_before, b);
     return upload_rec();
 }
 
@@ -1287,6 +1408,8 @@ relp_status_t Engine::reinvert() {
     since_reinvert_ = 0;
     enqueue_flush();
     HIP_TRY(hipStreamSynchronize(stream_));
+    std::vector<double> b_before;
+    if (cfg_.auto_reinversion) { b_before.resize(m_); HIP_TRY(hipMemcpy(b_before.data(), d_b_, sizeof(double) * m_, hipMemcpyDeviceToHost)); }
     std::vector<int32_t> basis(m_);
     HIP_TRY(hipMemcpy(basis.data(), d_basis_, sizeof(int32_t) * m_, hipMemcpyDeviceToHost));
     std::vector<std::vector<std::pair<int32_t, double>>> cols;
@@ -1319,7 +1442,19 @@ relp_status_t Engine::reinvert() {
     for (int32_t i = 0; i < m_; ++i) objective += w[i] * b[i];
     h_rec_->minus_objective = -objective;
     ++reinversions_;
+    if (cfg_.auto_reinversion) auto_reinversion_adapt(b_before, b);
     return upload_rec();
+}
+
+// relp_config_t.auto_reinversion: a rebuild that moved b by more than 1e-7 (relative to its largest entry) came too late -- the
+// interval is halved, down to 32 pivots; one that moved it by less than 1e-10 could have waited -- doubled, up to 4,096
+void Engine::auto_reinversion_adapt(const std::vector<double>& before, const std::vector<double>& after) {
+    double diff = 0.0, scale = 1.0;
+    for (size_t i = 0; i < after.size() && i < before.size(); ++i) { diff = std::max(diff, std::fabs(after[i] - before[i])); scale = std::max(scale, std::fabs(after[i])); }
+    last_reinvert_drift_ = diff / scale;
+    if (last_reinvert_drift_ > 1e-7) reinvert_interval_ = std::max<int64_t>(32, reinvert_interval_ / 2);
+    else if (last_reinvert_drift_ < 1e-10) reinvert_interval_ = std::min<int64_t>(4096, reinvert_interval_ * 2);
+    if (std::getenv("RELP_DEBUG")) std::fprintf(stderr, "[relp] rebuild %lld: b moved by %.2e (relative), interval now %lld\n", (long long)reinversions_, last_reinvert_drift_, (long long)reinvert_interval_);
 }
 
 relp_status_t Engine::from_basis(const int32_t* basis_columns) {

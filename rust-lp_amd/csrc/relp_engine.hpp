@@ -46,6 +46,8 @@ class Engine {
 
     // loops
     relp_status_t run(int64_t max_iters, int64_t* done, int32_t* outcome);
+    int32_t engine_kind() const { return cfg_.engine; }
+    relp_status_t robust_stats(int64_t* out4) const;
     relp_status_t solve_relaxation(int64_t max_iters, int32_t* outcome);
     relp_status_t from_basis(const int32_t* basis_columns);
     relp_status_t set_reinversion_interval(int64_t pivots);
@@ -353,6 +355,16 @@ class Engine {
     // RELP_ARTIFICIAL_TEXTBOOK: artificial variables no zero-level pivot could remove; remove_rows exchanges the basis position
     // each one sits in with its own row before both go (the pair (own constraint, position) always leaves a basis)
     std::vector<int32_t> stuck_artificials_;
+    // relp_config_t.pivot_rescue (relp_engine.h): the loop of run_loop() behind a look at every exit without a pivot row
+    relp_status_t run_loop(int64_t max_iters, int64_t* done, int32_t* outcome);
+    relp_status_t rescue_unbar_all();
+    void auto_reinversion_adapt(const std::vector<double>& before, const std::vector<double>& after);
+    std::vector<int32_t> barred_;                  // columns barred from pricing (in_basis flag 2) until the basis changes
+    double guard_rel_ = 1e-7;                      // a pivot element must be at least this fraction of the column's largest |entry|
+    bool pivot_guard_on_ = false;                  // Tolerances::pivot_guard of the launches (on inside the rescued loop only)
+    bool hold_phase_end_ = false;                  // run_loop returns kHeldNoCandidate instead of ending the phase
+    int64_t rescue_small_pivots_ = 0, rescue_barred_ = 0, rescue_confirmations_ = 0;
+    double last_reinvert_drift_ = -1.0;            // relp_config_t.auto_reinversion: what the last rebuild moved b by (relative)
     relp_status_t remove_rows(const std::vector<int32_t>& rows);
     void free_all();
 };

@@ -843,7 +843,8 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     if (hipGetLastError() != hipSuccess) return fail(RELP_E_HIP, "kernel launch failed");
     int32_t oc = RELP_RUNNING;
     if (h_rec_->outcome == DEV_NO_CANDIDATE) {
-        if (phase_ == 2) oc = RELP_OPTIMAL;
+        if (hold_phase_end_) oc = 100;                     // (kHeldNoCandidate, relp_engine.cpp: columns are barred by the pivot rescue)
+        else if (phase_ == 2) oc = RELP_OPTIMAL;
         else if ((st = finish_phase_one(&oc))) return st;
     } else if (h_rec_->outcome == DEV_NO_ROW) {
         oc = phase_ == 2 ? RELP_UNBOUNDED : RELP_NO_ROW_PHASE_ONE;

@@ -70,7 +70,10 @@ struct ColumnTable {
     const double*  cost;          // structural p -> phase-2 cost             (nr_normal)
 };
 
-struct Tolerances { double cost, pivot, zero, tie; int32_t ratio_rule, pad_; };   // ratio_rule: relp_ratio_rule_t
+// ratio_rule: relp_ratio_rule_t.  pivot_guard (relp_config_t.pivot_rescue): a pivot row whose element is below `pivot` times the
+// largest |entry| of the entering column ends the loop as "no row" -- the host looks at the column and pivots with a tolerance
+// relative to it or bars the column (Engine::run) -- instead of being pivoted on
+struct Tolerances { double cost, pivot, zero, tie; int32_t ratio_rule, pivot_guard; double guard_rel; };
 
 // PRICE -> entering-column choice without a second pass over d: every PRICE workgroup leaves the
 // best (key, j) of its own columns here (key as in k_select_column), k_select_partials reduces them.

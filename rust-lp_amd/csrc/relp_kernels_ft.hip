@@ -1285,6 +1285,12 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         __syncthreads();
         alpha_r = c.red_d[NW];
         b_r = c.red_d[NW + 1];
+        if (pb.tol.pivot_guard) {                      // (Tolerances::pivot_guard: too small beside the column's largest entry)
+            double mx = h0 ? fabs(a0) : 0.0;
+            for (int e = tid + NT; e < nnz; e += NT) mx = fmax(mx, fabs(st.nz_val[e]));
+            const double amax = -block_min_double(c, -mx);
+            if (alpha_r < pb.tol.guard_rel * amax) { outcome = DEV_NO_ROW; break; }
+        }
         c.clk.lap(FT_RATIO);
         br = b_r / alpha_r;
         if (h0) pb.b[i0] = i0 == r ? br : fma(-a0, br, b0);
@@ -1345,6 +1351,12 @@ __global__ __launch_bounds__(NT) void k_ft_run(DeviceLU lu, FtState st, FtProble
         __syncthreads();
         alpha_r = c.red_d[NW];
         b_r = c.red_d[NW + 1];
+        if (pb.tol.pivot_guard) {                      // (Tolerances::pivot_guard: too small beside the column's largest entry)
+            double mx = fmax(h0 ? fabs(a0) : 0.0, h1 ? fabs(a1) : 0.0);
+            for (int i = tid + 2 * NT; i < m; i += NT) mx = fmax(mx, fabs(c.x[c.icp[i]]));
+            const double amax = -block_min_double(c, -mx);
+            if (alpha_r < pb.tol.guard_rel * amax) { outcome = DEV_NO_ROW; break; }
+        }
         c.clk.lap(FT_RATIO);
 
         // ---- b (carry/mod.rs:283-313) while alpha is still in x -----------------------------------------------------

@@ -35,7 +35,7 @@ OUTCOME_NAMES = {RUNNING: "running", OPTIMAL: "optimal", UNBOUNDED: "unbounded",
  K_UPDATE_W, K_FLUSH, K_FT_RUN) = range(11)
 KERNEL_NAMES = ["price", "select_column", "build_column", "ftran", "ratio", "update_vectors", "update_inverse",
                 "apply_w", "update_w", "flush", "ft_run"]
-ENGINE_REVISED, ENGINE_TABLEAU, ENGINE_LU = 0, 1, 2   # relp_engine_kind_t
+ENGINE_REVISED, ENGINE_TABLEAU, ENGINE_LU, ENGINE_AUTO = 0, 1, 2, 3   # relp_engine_kind_t
 RATIO_REFERENCE, RATIO_LARGEST_PIVOT = 0, 1           # relp_ratio_rule_t (f64 safeguard; 0 = tableau/mod.rs:229-239)
 ARTIFICIAL_REFERENCE, ARTIFICIAL_TEXTBOOK = 0, 1      # relp_artificial_removal_t (0 = phase_one.rs:223-260 literally)
 # relp_status_t
@@ -64,12 +64,16 @@ class Config(C.Structure):
                 ("poll_interval", C.c_int32), ("trace_capacity", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
                 ("update_block", C.c_int32), ("engine", C.c_int32),
-                ("ratio_rule", C.c_int32), ("artificial_removal", C.c_int32)]
+                ("ratio_rule", C.c_int32), ("artificial_removal", C.c_int32),
+                ("pivot_rescue", C.c_int32), ("auto_reinversion", C.c_int32)]
 
 
 # every symbol include/relp_engine.h declares (tests/test_abi.py checks the export list against the header)
 _SIGNATURES = {
     "relp_default_config": (None, [C.POINTER(Config)]),
+    "relp_robust_config": (None, [C.POINTER(Config)]),
+    "relp_engine_kind": (C.c_int32, [C.c_void_p]),
+    "relp_robust_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "relp_last_error": (C.c_char_p, [C.c_void_p]),
     "relp_version": (C.c_char_p, []),
     "relp_engine_create": (C.c_int, [C.POINTER(_MatrixData), C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -169,6 +173,18 @@ def load_library():
 def default_config(**overrides) -> Config:
     cfg = Config()
     load_library().relp_default_config(C.byref(cfg))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def robust_config(**overrides) -> Config:
+    """relp_robust_config: the f64 safeguards (largest-pivot ratio rule, textbook artificial removal, pivot rescue, adaptive
+    re-inversion) and RELP_ENGINE_AUTO -- no per-file knobs."""
+    cfg = Config()
+    load_library().relp_robust_config(C.byref(cfg))
     for k, v in overrides.items():
         if not hasattr(cfg, k):
             raise TypeError(f"unknown config field {k}")
@@ -357,6 +373,15 @@ class Tableau:
 
     def update_block(self) -> int:
         return self._lib.relp_update_block(self._h)
+
+    def engine_kind(self) -> int:
+        """The engine in use (RELP_ENGINE_AUTO resolved at create)."""
+        return int(self._lib.relp_engine_kind(self._h))
+
+    def robust_stats(self) -> dict:
+        out = (C.c_int64 * 4)()
+        self._ck(self._lib.relp_robust_stats(self._h, out))
+        return dict(zip(("small_pivots", "columns_barred", "confirmations", "reinversion_interval"), (int(v) for v in out)))
 
     def lu_stats(self) -> dict:
         """Factor statistics of the LU engine (relp_lu_stats)."""

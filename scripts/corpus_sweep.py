@@ -1,6 +1,6 @@
 """Every LP of the reference's Netlib directory the build's front end accepts (tests/golden/corpus/, made by
 scripts/gen_corpus_fixture.py) on the three engines, under `relp_default_config` (the reference's rules literally) and under the
-two f64 safeguards (`ratio_rule = RELP_RATIO_LARGEST_PIVOT`, `artificial_removal = RELP_ARTIFICIAL_TEXTBOOK`).
+f64 safeguards of `relp_robust_config` (largest-pivot ratio rule, textbook artificial removal, pivot rescue, adaptive re-inversion).
 
 Per file, engine and configuration: outcome, pivots, objective, `check_basis` residuals, seconds; then per file the agreement of
 the engines among themselves, with the reference's pin where tests/netlib/test.rs holds one, and with HiGHS on the same
@@ -21,7 +21,8 @@ from rust_lp_amd import engine  # noqa: E402
 import corpus  # noqa: E402
 
 ENGINES = (("lu", engine.ENGINE_LU, -1), ("tableau", engine.ENGINE_TABLEAU, -1), ("revised", engine.ENGINE_REVISED, -1))
-CONFIGS = (("default", {}), ("safeguards", dict(ratio_rule=engine.RATIO_LARGEST_PIVOT, artificial_removal=engine.ARTIFICIAL_TEXTBOOK)))
+CONFIGS = (("default", {}), ("robust", dict(ratio_rule=engine.RATIO_LARGEST_PIVOT, artificial_removal=engine.ARTIFICIAL_TEXTBOOK,
+                                           pivot_rescue=1, auto_reinversion=1)))       # relp_robust_config with the engine of the leg
 
 
 def solve(md, fixed, kind, block, cfg, max_pivots, seconds):
@@ -53,6 +54,8 @@ def solve(md, fixed, kind, block, cfg, max_pivots, seconds):
             out["check_basis"] = [ident, basic, min_b]
         if kind == engine.ENGINE_LU:
             out["layout"] = t.lu_kernel_layout()["layout"]
+        if cfg.get("pivot_rescue"):
+            out["robust_stats"] = t.robust_stats()
     except engine.RelpError as e:
         out["outcome"] = "error"
         out["error"] = str(e)[:160]
@@ -100,6 +103,28 @@ def main():
         line = " ".join(f"{k}={v.get('outcome')}:{v.get('pivots')}:{v.get('objective', float('nan')):.9g}:{v.get('seconds')}s" for k, v in res["runs"].items())
         print(f"{name} m={res['m']} n={res['n']} highs={res['highs']} pin={res['pin']} | {line}", flush=True)
         json.dump(results, open(args.out, "w"), indent=1)
+    markdown(results, os.path.splitext(args.out)[0] + ".md")
+
+
+def markdown(results, path):
+    """The table of DESIGN.md 6.3 / profiles/r04_corpus_sweep.md."""
+    rows = ["| file | m x n | HiGHS (same LP) | reference pin | default: lu / tableau / revised | robust: lu / tableau / revised |", "|---|---|---|---|---|---|"]
+
+    def cell(res, cfg):
+        out = []
+        for e in ("lu", "tableau", "revised"):
+            r = res["runs"][f"{cfg}/{e}"]
+            if r.get("outcome") == "optimal":
+                ok = res["highs"] is not None and rel(r["objective"], res["highs"]) <= 1e-6
+                out.append(f"{'ok' if ok else 'OPT?'} {r['pivots']}")
+            else:
+                out.append(f"{r.get('outcome')} {r.get('pivots', '')}".strip())
+        return " / ".join(out)
+    for name in sorted(results):
+        res = results[name]
+        rows.append(f"| {name} | {res['m']} x {res['n']} | {res['highs']:.10g} | {res['pin'] if res['pin'] is not None else ''} | {cell(res, 'default')} | {cell(res, 'robust')} |")
+    with open(path, "w") as f:
+        f.write("\n".join(rows) + "\n")
 
 
 if __name__ == "__main__":

@@ -138,3 +138,18 @@ def test_event_stride_never_aliases_with_the_update_block(stride, block):
     if block > 1:
         assert got % block != 0 and math.gcd(got, block) == 1
         assert {(k * got) % block for k in range(block)} == set(range(block))
+
+
+def test_recorded_bench_line_of_the_round_is_complete():
+    """The driver's exact command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`) run on an MI355X and recorded as
+    profiles/r04_bench.json: every section the GPU tier's `--quick` form leaves out (c4, c5, sparse.large, sparse.scale,
+    sparse.replicas) is checked here against the same assertions (tests/test_bench_gpu.py)."""
+    path = os.path.join(ROOT, "profiles", "r04_bench.json")
+    if not os.path.exists(path):
+        pytest.skip("no recorded line yet")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_bench_gpu
+    with open(path) as f:
+        out = json.load(f)
+    test_bench_gpu.check_headline(out, quick=False)
+    test_bench_gpu.check_full_sections(out)
