@@ -151,6 +151,8 @@ struct Options {
     Options& trace_capacity(int32_t n) { cfg.trace_capacity = n; return *this; }
     Options& device(int32_t d) { cfg.device = d; return *this; }
     Options& shard(int32_t rank, int32_t count) { cfg.shard_rank = rank; cfg.shard_count = count; return *this; }
+    // relp_robust_config: every f64 safeguard and RELP_ENGINE_AUTO instead of the reference's literal rules (no per-file knobs)
+    static Options robust() { Options o; relp_robust_config(&o.cfg); return o; }
 };
 
 // tableau/mod.rs:24-38.  Starts like `Tableau::<_, Partially<_>>::new(&matrix_data)` (artificial variables on

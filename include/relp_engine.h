@@ -135,7 +135,7 @@ typedef struct {
      * reached with barred columns is confirmed once more without them.  Rare events, handled on the host. */
     int32_t pivot_rescue;
     /* 1: the explicit inverse / the tableau is rebuilt from the basis columns at an interval the engine adapts itself -- halved
-     * (down to 32 pivots) when a rebuild moves b by more than 1e-7 relative, doubled (up to 4,096) when by less than 1e-10 --
+     * (down to 32 pivots) when a rebuild moves b by more than 1e-7 relative, doubled (up to 1,024) when by less than 1e-10 --
      * instead of the hand-set relp_set_reinversion_interval (the LU engine refactorises every update_block pivots anyway). */
     int32_t auto_reinversion;
 } relp_config_t;

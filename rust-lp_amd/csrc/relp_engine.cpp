@@ -59,7 +59,7 @@ ColumnTable Engine::table() const {
     return ct;
 }
 
-Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie, cfg_.ratio_rule, pivot_guard_on_ ? 1 : 0, guard_rel_}; }
+Tolerances Engine::tolerances() const { return Tolerances{cfg_.tol_cost, cfg_.tol_pivot, cfg_.tol_zero, cfg_.tol_tie, cfg_.ratio_rule, (pivot_guard_on_ && guard_rel_ > 0.0) ? 1 : 0, guard_rel_}; }
 
 TableauView Engine::tview() const {
     TableauView tv;
@@ -893,11 +893,12 @@ relp_status_t Engine::run(int64_t max_iters, int64_t* done, int32_t* outcome) {
             HIP_TRY(hipMemcpy(alpha.data(), d_alpha_, sizeof(double) * m_, hipMemcpyDeviceToHost));
             double amax = 0.0, apos = 0.0;
             for (double v : alpha) { amax = std::max(amax, std::fabs(v)); apos = std::max(apos, v); }
-            if (apos > 0.0 && apos >= guard_rel_ * amax && apos > cfg_.tol_zero) {
+            const double rel = guard_rel_ > 0.0 ? guard_rel_ : cfg_.tol_pivot;       // the rescue's tolerance is relative to the column
+            if (apos > 0.0 && apos >= rel * amax && apos > cfg_.tol_zero) {
                 // a column with entries worth pivoting on relative to its own size (all of it small, or the loop's choice was
                 // small beside larger entries): ONE pivot by the full-scan ratio test with the tolerance relative to the column
                 const double keep = cfg_.tol_pivot;
-                cfg_.tol_pivot = std::min(keep, std::max(guard_rel_ * amax, 1e-300) * (1.0 - 1e-12));
+                cfg_.tol_pivot = std::min(keep, std::max(rel * amax, 1e-300) * (1.0 - 1e-12));
                 pivot_guard_on_ = false;
                 int32_t found = 0, r = -1;
                 st = generate_column(q, nullptr);
@@ -1447,13 +1448,14 @@ relp_status_t Engine::reinvert() {
 }
 
 // relp_config_t.auto_reinversion: a rebuild that moved b by more than 1e-7 (relative to its largest entry) came too late -- the
-// interval is halved, down to 32 pivots; one that moved it by less than 1e-10 could have waited -- doubled, up to 4,096
+// interval is halved, down to 32 pivots; one that moved it by less than 1e-10 could have waited -- doubled, up to 1,024 (a small
+// drift of b does not vouch for the inverse: GREENBEA's tableau is lost at 4,096)
 void Engine::auto_reinversion_adapt(const std::vector<double>& before, const std::vector<double>& after) {
     double diff = 0.0, scale = 1.0;
     for (size_t i = 0; i < after.size() && i < before.size(); ++i) { diff = std::max(diff, std::fabs(after[i] - before[i])); scale = std::max(scale, std::fabs(after[i])); }
     last_reinvert_drift_ = diff / scale;
     if (last_reinvert_drift_ > 1e-7) reinvert_interval_ = std::max<int64_t>(32, reinvert_interval_ / 2);
-    else if (last_reinvert_drift_ < 1e-10) reinvert_interval_ = std::min<int64_t>(4096, reinvert_interval_ * 2);
+    else if (last_reinvert_drift_ < 1e-10) reinvert_interval_ = std::min<int64_t>(1024, reinvert_interval_ * 2);
     if (std::getenv("RELP_DEBUG")) std::fprintf(stderr, "[relp] rebuild %lld: b moved by %.2e (relative), interval now %lld\n", (long long)reinversions_, last_reinvert_drift_, (long long)reinvert_interval_);
 }
 

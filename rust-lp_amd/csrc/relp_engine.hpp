@@ -360,7 +360,10 @@ class Engine {
     relp_status_t rescue_unbar_all();
     void auto_reinversion_adapt(const std::vector<double>& before, const std::vector<double>& after);
     std::vector<int32_t> barred_;                  // columns barred from pricing (in_basis flag 2) until the basis changes
-    double guard_rel_ = 1e-7;                      // a pivot element must be at least this fraction of the column's largest |entry|
+    // RELP_PIVOT_GUARD: a pivot element below this fraction of the column's largest |entry| ends the loop for a rescue.  0 = off,
+    // the default: measured on 16 files of the corpus (profiles/r04_guard_sweep.md), 1e-5 / 1e-7 / 1e-9 fire on most pivots of the
+    // ill-conditioned files and the ratio test without the small rows overshoots them -- wrong `infeasible` outcomes on four files
+    double guard_rel_ = 0.0;
     bool pivot_guard_on_ = false;                  // Tolerances::pivot_guard of the launches (on inside the rescued loop only)
     bool hold_phase_end_ = false;                  // run_loop returns kHeldNoCandidate instead of ending the phase
     int64_t rescue_small_pivots_ = 0, rescue_barred_ = 0, rescue_confirmations_ = 0;

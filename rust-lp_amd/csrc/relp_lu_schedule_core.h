@@ -116,6 +116,9 @@ LUF_FN void luf_or32(uint32_t* p, uint32_t v) {
 #endif
 }
 
+#if defined(LUF_COUNT)
+static long long g_luf_count[4] = {0, 0, 0, 0};
+#endif
 // One schedule.  `W` of the factorisation supplies nothing any more (kept out of the signature); everything is in S.
 LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const LufSchedOut& O) {
     const int32_t m = T.m;
@@ -162,6 +165,9 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
     for (int32_t l = 0; l < nlev; ++l) {
         const int32_t r0 = S.lvl_ptr[l], nr = S.lvl_ptr[l + 1] - r0;
         LUF_SINGLE { luf_st(&S.sc[0], 0); luf_st(&S.sc[1], 0); luf_st(&S.sc[2], 0); } PAR_END
+#if defined(LUF_COUNT)
+        g_luf_count[1] += 1; g_luf_count[2] += nr;
+#endif
         bool ok = try_fuse && g >= 0;
         // lanes the level takes as it is; upper bounds of the expanded rows
         PAR_FOR(q, nr) {
@@ -199,6 +205,9 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
                 int32_t n = 0, pp = p_top + S.tmp2[q];
                 auto term = [&](int32_t src, double coef, int32_t v0, int32_t vn) {
                     if (!maskable) {                                 // one entry per index, summed in the order met
+#if defined(LUF_COUNT)
+                        g_luf_count[0] += n;
+#endif
                         for (int32_t a = xb; a < xb + n; ++a) if (S.x_src[a] == src) { S.x_coef[a] += coef; return; }
                     }
                     S.x_src[xb + n] = src; S.x_coef[xb + n] = coef;

@@ -429,7 +429,13 @@ static int probe(const char* path) {
         LufSchedIn T{m, tri[q]->ptr, tri[q]->idx, tri[q]->val, trt[q]->ptr, trt[q]->idx, maskable ? B.O.diag : nullptr, maskable ? 1 : 0, 0, 0x7fffffff, 256, m, 0};
         SchedBuffers SB;
         SB.setup(m, tri[q]->ptr[m]);
+#if defined(LUF_COUNT)
+        g_luf_count[0] = g_luf_count[1] = g_luf_count[2] = 0;
+#endif
         luf_build_schedule(T, SB.S, SB.SO);
+#if defined(LUF_COUNT)
+        std::printf("   %s: term-search steps %lld, levels %lld, rows visited %lld\n", nm[q], g_luf_count[0], g_luf_count[1], g_luf_count[2]);
+#endif
         FusedSchedule fs; EllPacked e;
         fuse_levels(*hs[q], maskable, maskable, 256, &fs);
         ell_pack(fs, maskable, &e);

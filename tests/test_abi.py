@@ -35,9 +35,9 @@ def test_default_config_matches_reference_defaults():
 
 
 def test_struct_layouts_match_header():
-    # relp_matrix_data_t: 7 int32 (+pad) then pointers; relp_config_t: 3 int32 (+pad), 5 doubles, 8 int32
+    # relp_matrix_data_t: 7 int32 (+pad) then pointers; relp_config_t: 3 int32 (+pad), 5 doubles, 10 int32
     assert ctypes.sizeof(engine._MatrixData) == 32 + 8 * 9
-    assert ctypes.sizeof(engine.Config) == 16 + 40 + 16 + 8 + 8
+    assert ctypes.sizeof(engine.Config) == 16 + 40 + 16 + 8 + 8 + 8
 
 
 def test_null_handles_are_rejected_not_crashing():
