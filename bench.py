@@ -609,7 +609,7 @@ def sparse_scale(with_cpu=True):
     return out
 
 
-def sparse_replicas(counts=(1, 8, 32, 64), fixture="netlib/25FV47.SIF", fixed=True, device=None):
+def sparse_replicas(counts=(1, 8, 32, 64), fixture="netlib/25FV47.SIF", fixed=True, device=None, device_factorisation=False):
     """"LU / eta engine -- replicas only".  R independent LU handles on ONE GPU, each with its own stream, its own
     persistent pivot workgroup (one CU) and its own refactorisations, each solving the same LP to optimality from its own host
     thread (the C calls release the GIL); every replica must walk the solo run's pivot sequence.  Aggregate iterations/s =
@@ -619,7 +619,8 @@ def sparse_replicas(counts=(1, 8, 32, 64), fixture="netlib/25FV47.SIF", fixed=Tr
     import threading
     from rust_lp_amd import engine
     gf, md = _load_fixture(fixture, fixed)
-    out = {"workload": f"{fixture} on R independent LU engines of one GPU (own stream, own persistent kernel, own refactorisations)",
+    out = {"workload": f"{fixture} on R independent LU engines of one GPU (own stream, own persistent kernel, own refactorisations"
+                       + (" ON THE DEVICE)" if device_factorisation else " on host threads)"),
            "unit": "iterations/s (aggregate over the replicas)", "replicas": {}}
     solo_trace = None
     for R in counts:
@@ -627,6 +628,9 @@ def sparse_replicas(counts=(1, 8, 32, 64), fixture="netlib/25FV47.SIF", fixed=Tr
         if device is not None:
             kw["device"] = device
         ts = [engine.Tableau(md, **kw) for _ in range(R)]
+        if device_factorisation:                      # no host thread per refactorisation: k_lu_factor + k_lu_schedules on the replica's stream
+            for t in ts:
+                t.lu_set_device_factorisation(True)
         res = [None] * R
         go = threading.Barrier(R + 1)
 

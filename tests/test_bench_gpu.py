@@ -126,6 +126,17 @@ def test_multi_rank_command_rehearsed_with_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
 
 
+def test_sparse_replicas_over_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2 --engine lu`: what an N-GPU run of the sparse path consists of (replicas only) -- one
+    process per GPU, every rank its own LU engines, no data-path collective, barrier + max-over-ranks timing, value = all pivots /
+    that time.  Rehearsed with both ranks on this box's one GPU (gloo carries the two scalar reductions)."""
+    env = dict(os.environ, RELP_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--engine", "lu", "--replicas", "2"]
+    out = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600))
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "replicas x2"
+    assert out["replicas"]["every_replica_walks_the_solo_pivots"] is True and out["value"] > 10000
+
+
 def test_sharded_loop_over_rccl_with_one_rank():
     """`--force-sharded` at N = 1: the native multi-GPU loop (relp_shard_run) with RCCL itself -- ncclCommInitRank from the id
     torch.distributed broadcasts, ncclAllGather between the kernels on the engine's stream -- on a communicator of one rank."""

@@ -4,7 +4,7 @@ pivoting of `decomposition/pivoting.rs:45-81`; its 14 unit cases are `decomposit
 factors are asserted and seven cases of the row update `subtract_multiple_of_row_from_other_row` (`:141-205`).
 
 The factors of a device factorisation cannot equal the reference's literally (another pivot order: singletons are peeled in
-parallel rounds), so what is checked is what every valid factorisation shares: P B Q = L U to 1e-12 (relp_lu_factor_residual),
+parallel rounds, the bump is eliminated in rounds of mutually independent Markowitz pivots [r4]), so what is checked is what every valid factorisation shares: P B Q = L U to 1e-12 (relp_lu_factor_residual),
 every column (FTRAN of unit vectors) and every row (BTRAN) of the inverse against numpy, and the reference's known answers of
 `wikipedia_example2`.  The same code runs on the host, serially, in tests/cpp/test_lu_device_model.cpp (CPU tier)."""
 import numpy as np
@@ -89,7 +89,7 @@ def test_row_update_cases_as_elimination_steps_on_the_device(name):
     t.close()
 
 
-@pytest.mark.parametrize("m,density,seed", [(6, 0.5, 1), (40, 0.08, 2), (150, 0.03, 3), (300, 0.015, 4), (300, 0.2, 5), (700, 0.006, 6)])
+@pytest.mark.parametrize("m,density,seed", [(6, 0.5, 1), (40, 0.08, 4), (150, 0.03, 3), (300, 0.015, 4), (300, 0.2, 5), (700, 0.006, 6)])      # ((40, 0.08, 2) was singular: cond 4e16)
 def test_random_sparse_bases_device_factors_equal_the_host_factors_in_every_solve(m, density, seed):
     """LP-like bases (a permuted diagonal + random entries, a few dense columns): FTRAN / BTRAN through the device factors
     equal those through relp_lu.cpp's lu_factor (the engine with the device factorisation switched off) to 1e-9, both equal
@@ -135,10 +135,10 @@ def test_whole_solves_with_every_refactorisation_on_the_device(path, fixed, obje
     from lp_files import load
     gf, ex, md, emd = load(path, fixed=fixed)
     big = "25FV47" in path
-    # (25FV47 at an interval of 24: with unfused schedules -- the device builds them level by level -- and the full 48-update
-    # file, the literal ratio rule takes a noise pivot after ~6,700 pivots on this file, with the HOST's factors packed unfused
-    # just the same; that is the f64 fragility of DESIGN.md section 6, not the factorisation: the next test pins it down)
-    t = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=24 if big else 11, trace_capacity=1 << 15)
+    # [r4] 25FV47 at the DEFAULT interval (48 updates) under relp_default_config: round 3's device path blew up there after ~6,700
+    # pivots (unfused schedules rounding differently, the literal ratio rule then accepting a noise pivot) and ran at 24 instead; with
+    # the schedules fused on the device and factors as sparse as the host's it solves (fourth criterion)
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=-1 if big else 11, trace_capacity=1 << 15)
     t.lu_set_device_factorisation(True)
     assert t.solve_relaxation() == engine.OPTIMAL
     got = t.objective_function_value() + float(gf.fixed_cost)
