@@ -186,12 +186,17 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
     const bool resident = ft_ && !luf_download_;
     const auto t0 = std::chrono::steady_clock::now();
     S.M.csc = csc(); S.M.ct = table();                  // (pointers may have been re-allocated)
-    launch_lu_factor(S.M, d_basis_, S.W, S.O, stream_);
-    if (resident) launch_lu_schedules(S.sin, S.SW, S.sout, S.O.status, S.pinfo, stream_);
     int32_t status[8] = {0}, desc[4][LUF_D_WORDS] = {};
-    HIP_TRY(hipMemcpyAsync(status, S.O.status, sizeof status, hipMemcpyDeviceToHost, stream_));
-    if (resident) for (int q = 0; q < 4; ++q) HIP_TRY(hipMemcpyAsync(desc[q], S.sout[q].desc, sizeof desc[q], hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    // (the bump's working set in LDS when it fits, RELP_LUF_LDS=0 keeps it in L2; an arena that overflows in LDS: once more from L2)
+    static const bool lds_env = !(std::getenv("RELP_LUF_LDS") && std::atoi(std::getenv("RELP_LUF_LDS")) == 0);
+    for (int attempt = lds_env ? 0 : 1; attempt < 2; ++attempt) {
+        launch_lu_factor(S.M, d_basis_, S.W, S.O, stream_, attempt == 0);
+        if (resident) launch_lu_schedules(S.sin, S.SW, S.sout, S.O.status, S.pinfo, stream_);
+        HIP_TRY(hipMemcpyAsync(status, S.O.status, sizeof status, hipMemcpyDeviceToHost, stream_));
+        if (resident) for (int q = 0; q < 4; ++q) HIP_TRY(hipMemcpyAsync(desc[q], S.sout[q].desc, sizeof desc[q], hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (!(attempt == 0 && status[0] == LUF_NO_ROOM)) break;
+    }
     luf_kernel_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     ++luf_runs_;
     if (std::getenv("RELP_DEBUG") && luf_runs_ % 200 == 0) {          // phase clocks of the factorisation kernel (relp_lu_factor_core.h: LUF_LAP)
@@ -200,8 +205,8 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
         const unsigned long long* ph = reinterpret_cast<const unsigned long long*>(cnt + 8);
         static const char* nm[11] = {"maps+counts", "peel", "bump setup", "r:column max", "r:proposals", "r:independence+accept", "r:elimination", "r:leave",
                                      "multipliers by row", "row views", "column views"};
-        std::fprintf(stderr, "[relp] device factorisation, %lld runs, %.0f us each (host clock, schedules included), last: %d rounds; clocks per run:", (long long)luf_runs_,
-                     luf_kernel_us_ / luf_runs_, cnt[2]);
+        std::fprintf(stderr, "[relp] device factorisation, %lld runs (%d with the bump in LDS), %.0f us each (host clock, schedules included), last: %d rounds; clocks per run:",
+                     (long long)luf_runs_, cnt[3], luf_kernel_us_ / luf_runs_, cnt[2]);
         for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)ph[i] / luf_runs_);
         std::fprintf(stderr, "\n");
         static const char* sn[4] = {"L", "U", "U'", "L'"};

@@ -18,8 +18,42 @@ namespace relp {
 namespace {
 constexpr int kLufThreads = 512;
 
-__global__ __launch_bounds__(kLufThreads) void k_lu_factor(LufMatrix M, const int32_t* basis, LufWork W, LufOut O) {
-    luf_factor(M, basis, W, O);
+// The bump's working set in LDS when it fits (lds_nb rows / columns, lds_arena entries: a dependent LDS round trip is ~64 clocks,
+// one to L2 ~700, and every phase of a round is a chain of them): the peel runs on the global arrays, then the bump and the views
+// on a LufWork whose bump arrays, arena and hot counters point into LDS.  A bump beyond lds_nb rows takes the global arrays; an
+// arena that overflows in LDS ends LUF_NO_ROOM and the host launches the kernel again with lds_nb = 0.
+__global__ __launch_bounds__(kLufThreads) void k_lu_factor(LufMatrix M, const int32_t* basis, LufWork W, LufOut O, int32_t lds_nb, int32_t lds_arena) {
+    extern __shared__ __align__(16) char luf_smem[];
+    const int32_t k_peel = luf_peel(M, basis, W, O);
+    if (k_peel < 0) return;
+    const int32_t nb = M.m - k_peel;
+    if (lds_nb > 0 && nb > 0 && nb <= lds_nb) {
+        LufWork L = W;
+        char* p = luf_smem;
+        auto i32 = [&](int64_t n) { int32_t* r = reinterpret_cast<int32_t*>(p); p += (4 * n + 15) / 16 * 16; return r; };
+        auto f64 = [&](int64_t n) { double* r = reinterpret_cast<double*>(p); p += 8 * n; return r; };
+        auto u64 = [&](int64_t n) { unsigned long long* r = reinterpret_cast<unsigned long long*>(p); p += 8 * n; return r; };
+        L.pval = f64(lds_nb); L.cmax = u64(lds_nb); L.rowmark = u64(lds_nb); L.colbest = u64(lds_nb); L.cprio = u64(lds_nb);
+        L.eval = f64(lds_arena); L.red = u64(8);
+        L.rbeg = i32(lds_nb); L.rlen = i32(lds_nb); L.rcap = i32(lds_nb); L.ract = i32(lds_nb); L.cact = i32(lds_nb); L.bcc = i32(lds_nb);
+        L.bstep_row = i32(lds_nb); L.bstep_col = i32(lds_nb); L.cpiv = i32(lds_nb); L.prank = i32(lds_nb); L.acc = i32(lds_nb);
+        L.ecol = i32(lds_arena); L.scalars = i32(16); L.counters = i32(128);
+        L.nb_cap = lds_nb; L.arena_cap = lds_arena;
+        for (int i = threadIdx.x; i < 128; i += blockDim.x) L.counters[i] = 0;
+        __syncthreads();
+        luf_bump(M, basis, L, O, k_peel);
+        __syncthreads();
+        // rounds and phase clocks back to where the host reads them
+        if (threadIdx.x == 0) {
+            W.counters[2] = L.counters[2];
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(W.counters + 8);
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(L.counters + 8);
+            for (int i = 2; i < 12; ++i) dst[i] += src[i];
+            W.counters[3] += 1;                            // factorisations whose bump ran in LDS
+        }
+    } else {
+        luf_bump(M, basis, W, O, k_peel);
+    }
 }
 }  // namespace
 
@@ -60,8 +94,17 @@ void launch_lu_schedules(const LufSchedIn in[4], const LufSchedWork work[4], con
     hipLaunchKernelGGL(k_lu_pinfo, dim3((m + 255) / 256), dim3(256), 0, s, m, in[1].ptr, out[1].via_ptr, out[2].via_ptr, out[2].level_of, status, pinfo);
 }
 
-void launch_lu_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, hipStream_t s) {
-    hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(kLufThreads), 0, s, M, basis, W, O);
+// LDS for a bump of lds_nb rows with an arena of lds_arena entries (launch_lu_factor's dynamic shared memory)
+static size_t luf_lds_bytes(int32_t lds_nb, int32_t lds_arena) {
+    auto up = [](size_t b) { return (b + 15) / 16 * 16; };
+    return 5 * 8 * (size_t)lds_nb + 8 * (size_t)lds_arena + 64 + 11 * up(4 * (size_t)lds_nb) + up(4 * (size_t)lds_arena) + up(64) + up(512) + 64;
+}
+void launch_lu_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, hipStream_t s, bool lds) {
+    // (what one CU's 160 KB hold beside the kernel's static 100 bytes: 512 bump rows, 9,216 arena entries = 155 KB)
+    const int32_t lds_nb = lds ? 512 : 0, lds_arena = lds ? 9216 : 0;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lu_factor), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
+    hipLaunchKernelGGL(k_lu_factor, dim3(1), dim3(kLufThreads), lds ? luf_lds_bytes(lds_nb, lds_arena) : 0, s, M, basis, W, O, lds_nb, lds_arena);
 }
 int32_t luf_threads() { return kLufThreads; }
 

@@ -236,7 +236,8 @@ LUF_FN void luf_fail(const LufOut& O, int32_t why) { LUF_SINGLE { O.status[0] = 
 // ---------------------------------------------------------------------------------------------------------------------
 // The factorisation.  `basis`: m column ids (engine numbering).
 // ---------------------------------------------------------------------------------------------------------------------
-LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O) {
+// Part 1: maps, counts, singletons.  Returns the number of peeled pivots, or -1 when the basis is singular (status set).
+LUF_FN int32_t luf_peel(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O) {
     const int32_t m = M.m;
     constexpr double kThreshold = 0.1;
     LUF_LAP_BEGIN
@@ -276,7 +277,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
                 }
             } PAR_END
             PAR_FOR(t, n1) { if (W.piv[t] < 0) O.status[0] = LUF_SINGULAR; } PAR_END
-            if (O.status[0] != LUF_OK) return;
+            if (O.status[0] != LUF_OK) return -1;
             PAR_FOR(t, n1) {
                 const int32_t c = W.list[t], i = W.piv[t];
                 O.row_step[i] = k + t; O.col_step[c] = k + t; O.rowperm[k + t] = i; O.colperm[k + t] = c;
@@ -307,7 +308,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
                     const int32_t t = W.list2[u], i = W.list[t], c = W.piv[t];
                     if (luf_cas(&W.claim2[c], -1, i) != -1) O.status[0] = LUF_SINGULAR;             // two rows on one column
                 } PAR_END
-                if (O.status[0] != LUF_OK) return;
+                if (O.status[0] != LUF_OK) return -1;
                 PAR_FOR(u, n2a) {
                     const int32_t t = W.list2[u], i = W.list[t], c = W.piv[t];
                     double val = 0.0;
@@ -323,9 +324,17 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         }
         if (made == 0) break;
     }
-    const int32_t k_peel = k;
     LUF_LAP(1);
+    return k;
+}
 
+// Part 2: the bump and the four views.  `W` may carry the bump's arrays (rbeg .. cprio, ecol / eval, counters, red, scalars) in
+// LDS while everything else stays in global memory (relp_kernels_luf.hip: k_lu_factor).
+LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, const int32_t k_peel) {
+    const int32_t m = M.m;
+    constexpr double kThreshold = 0.1;
+    LUF_LAP_BEGIN
+    (void)basis;
     // ---- the bump: sparse rows in an arena -------------------------------------------------------------------------------------
     const int32_t nbr = luf_select(m, [&](int32_t i) { return O.row_step[i] < 0; }, W.brow);
     const int32_t nbc = luf_select(m, [&](int32_t c) { return O.col_step[c] < 0; }, W.bcol);
@@ -338,11 +347,12 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
             W.lrow[W.brow[t]] = t; W.lcol[W.bcol[t]] = t; W.ract[t] = 1; W.cact[t] = 1; luf_st(&W.bcc[t], 0);
             W.bstep_row[t] = -1; W.bstep_col[t] = -1; W.prank[t] = -1;
         } PAR_END
-        // room per row: what it holds + half as much again (+ 4); a row that outgrows it moves to the end of the arena
+        // room per row: what it holds + a quarter (+ 2); a row that outgrows it moves to the end of the arena with half as much again
+        // (the arena of the LDS variant is 9,216 entries: tight rooms, cheap moves)
         PAR_FOR(t, nb) {
             int32_t n = 0;
             luf_row_entries(M, W, W.brow[t], [&](int32_t c, double v) { if (W.lcol[c] >= 0 && v != 0.0) ++n; });
-            W.rlen[t] = n; W.rcap[t] = n + n / 2 + 4; W.lt_ptr[t + 1] = n + n / 2 + 4;
+            W.rlen[t] = n; W.rcap[t] = n + n / 4 + 2; W.lt_ptr[t + 1] = n + n / 4 + 2;
         } PAR_END
         const int32_t room = luf_offsets_from_counts(W.lt_ptr, nb);
         if (room > W.arena_cap) { luf_fail(O, LUF_NO_ROOM); return; }
@@ -454,7 +464,7 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
                         }
                     } else {                                               // fill
                         if (n == W.rcap[t]) {
-                            const int32_t want = 2 * n + 4, nbeg = luf_fetch_add(&W.counters[0], want);
+                            const int32_t want = n + n / 2 + 4, nbeg = luf_fetch_add(&W.counters[0], want);
                             if (nbeg + want > W.arena_cap) { luf_st(&W.scalars[0], 2); continue; }      // (reported behind the round)
                             for (int32_t e = 0; e < n; ++e) { W.ecol[nbeg + e] = W.ecol[b + e]; W.eval[nbeg + e] = W.eval[b + e]; }
                             b = nbeg; W.rbeg[t] = nbeg; W.rcap[t] = want;
@@ -475,6 +485,10 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
         PAR_FOR(a, n_acc) { W.prank[W.cpiv[W.acc[a]]] = -1; } PAR_END
         LUF_SINGLE { ++W.counters[2]; } PAR_END
         if (luf_ld(&W.scalars[0]) || luf_ld(&W.counters[1]) > W.lt_cap) { luf_fail(O, LUF_NO_ROOM); return; }
+#if defined(LUF_ROUND_TRACE)
+        { int32_t act = 0, mx = 0; long long tot = 0; for (int32_t t = 0; t < nb; ++t) if (W.ract[t]) { ++act; tot += W.rlen[t]; if (W.rlen[t] > mx) mx = W.rlen[t]; }
+          std::printf("round %d: accepted %d, active rows left %d, entries %lld, longest row %d\n", W.counters[2], n_acc, act, tot, mx); }
+#endif
         done += n_acc;
         LUF_LAP(7);
     }
@@ -558,12 +572,18 @@ LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& 
     LUF_LAP(10);
 }
 
+LUF_FN void luf_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O) {
+    const int32_t k_peel = luf_peel(M, basis, W, O);
+    if (k_peel < 0) return;
+    luf_bump(M, basis, W, O, k_peel);
+}
+
 }  // namespace relp
 
 #if !defined(RELP_LUF_DEVICE)
 namespace relp {
 // relp_kernels_luf.hip: the same algorithm as one workgroup of luf_threads() threads on stream s
-void launch_lu_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, hipStream_t s);
+void launch_lu_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, hipStream_t s, bool lds = true);
 int32_t luf_threads();
 }  // namespace relp
 #endif
