@@ -80,6 +80,11 @@ relp_status_t Engine::luf_prepare() {
     const int64_t o_ltr = take(4 * arena_cap), o_lts = take(4 * arena_cap), o_ltv = take(8 * arena_cap), o_ltp = take(4 * ((int64_t)S.nb_cap + 1)),
                   o_lto = take(4 * arena_cap), o_cnt = take(512);
     const int64_t o_red = take(8 * 8), o_sc = take(64);
+    const char* dense_env = std::getenv("RELP_LUF_DENSE");                   // rows of the dense finish (<= 64; 0 = off)
+    const int32_t dense_cap = dense_env ? std::max(0, std::min(64, std::atoi(dense_env))) : 64;
+    const int64_t o_dense = take(8 * (int64_t)64 * 64), o_dint = take(4 * 6 * 64);
+    const int64_t o_utr = take(4 * arena_cap), o_utc = take(4 * arena_cap), o_utv = take(8 * arena_cap), o_vw = take(4 * ((int64_t)m + 2)),
+                  o_vtmp = take(4 * arena_cap);
     const int64_t o_status = take(32), o_rowperm = take(4 * (int64_t)m), o_colperm = take(4 * (int64_t)m), o_rstep = take(4 * (int64_t)m),
                   o_cstep = take(4 * (int64_t)m), o_diag = take(8 * (int64_t)m);
     int64_t o_tp[4], o_ti[4], o_tv[4];
@@ -135,6 +140,8 @@ relp_status_t Engine::luf_prepare() {
     W.lt_row = I32(o_ltr); W.lt_step = I32(o_lts); W.lt_val = F64(o_ltv); W.lt_cap = (int32_t)arena_cap; W.lt_ptr = I32(o_ltp); W.lt_ord = I32(o_lto);
     W.counters = I32(o_cnt); W.red = U64(o_red);
     W.scalars = I32(o_sc);
+    W.dense = F64(o_dense); W.dint = I32(o_dint); W.dense_cap = dense_cap;
+    W.ut_row = I32(o_utr); W.ut_col = I32(o_utc); W.ut_val = F64(o_utv); W.vw = I32(o_vw); W.vtmp = I32(o_vtmp); W.vtmp_lds = nullptr; W.vtmp_lds_cap = 0;
     LufOut& O = S.O;
     O.status = I32(o_status); O.rowperm = I32(o_rowperm); O.colperm = I32(o_colperm); O.row_step = I32(o_rstep); O.col_step = I32(o_cstep);
     O.diag = F64(o_diag);
@@ -203,8 +210,8 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
         int32_t cnt[128] = {0};
         HIP_TRY(hipMemcpy(cnt, S.W.counters, sizeof cnt, hipMemcpyDeviceToHost));
         const unsigned long long* ph = reinterpret_cast<const unsigned long long*>(cnt + 8);
-        static const char* nm[11] = {"maps+counts", "peel", "bump setup", "r:column max", "r:proposals", "r:independence+accept", "r:elimination", "r:leave",
-                                     "multipliers by row", "row views", "column views"};
+        static const char* nm[11] = {"maps+counts", "peel", "bump setup", "r:column max", "r:proposals", "r:independence+accept", "r:elimination", "r:leave + dense finish",
+                                     "triplets", "row views", "column views"};
         std::fprintf(stderr, "[relp] device factorisation, %lld runs (%d with the bump in LDS), %.0f us each (host clock, schedules included), last: %d rounds; clocks per run:",
                      (long long)luf_runs_, cnt[3], luf_kernel_us_ / luf_runs_, cnt[2]);
         for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)ph[i] / luf_runs_);

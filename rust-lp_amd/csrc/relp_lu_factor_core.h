@@ -76,10 +76,16 @@ struct LufWork {
     unsigned long long* cprio;                                       // nb, by row: Markowitz count << 32 | row (~0: nothing to propose)
     int32_t* ecol; double* eval; int32_t arena_cap;                  // the arena of the rows
     int32_t* lt_row; int32_t* lt_step; double* lt_val; int32_t lt_cap;     // multipliers (local row, step, value), in no particular order
-    int32_t* lt_ptr; int32_t* lt_ord;                                // nb + 1 / lt_cap: the multipliers bucketed by row (built behind the elimination)
+    int32_t* lt_ptr; int32_t* lt_ord;                                // nb + 1 / lt_cap: room sizes of the bump's rows (setup) / spare
+    int32_t* ut_row; int32_t* ut_col; double* ut_val;                // lt_cap each: the triplets of U (those of L join the multipliers)
+    int32_t* vw;                                                     // m + 2: counts / cursors of a view
+    int32_t* vtmp; int32_t* vtmp_lds; int32_t vtmp_lds_cap;          // lt_cap: the buckets of a view; the same in LDS for up to vtmp_lds_cap entries
     int32_t* counters;                                               // [0] arena top, [1] multipliers, [2] rounds of the bump
     unsigned long long* red;                                         // 8 words of reductions
     int32_t* scalars;                                                // 16 ints of uniform state
+    // the dense finish: once <= dense_cap (<= 64) rows are active they go into a dense block (the tail of a bump is a small
+    // dense corner that yields one pivot per round); 0 = off
+    double* dense; int32_t* dint; int32_t dense_cap;                 // dense_cap^2 doubles; 6 * dense_cap ints
 };
 
 #if defined(RELP_LUF_DEVICE)
@@ -87,6 +93,8 @@ struct LufWork {
 #define LUF_NT ((int)blockDim.x)
 #define LUF_TID ((int)threadIdx.x)
 #define PAR_FOR(i, n) for (int i = LUF_TID; i < (n); i += LUF_NT)
+// (i, j) over ni x nj with nj <= 64: a wave per row, a lane per column
+#define PAR_FOR2(i, j, ni, nj) for (int i = LUF_TID >> 6; i < (ni); i += LUF_NT >> 6) for (int j = LUF_TID & 63; j < (nj); j += 64)
 // Global atomics execute in L2 and leave the CU's L1 alone: a word that is ever touched by an atomic is read and written
 // through L2 as well (luf_ld / luf_st below), never by a plain access that could hit a stale L1 line.  RELP_LUF_FENCES wraps
 // every barrier in agent-scope fences instead (L1 invalidated at every phase: a debugging aid, several times slower).
@@ -113,6 +121,7 @@ LUF_FN void luf_st64(unsigned long long* p, unsigned long long v) { __hip_atomic
 #define LUF_NT 64
 #define LUF_TID 0
 #define PAR_FOR(i, n) for (int i = 0; i < (n); ++i)
+#define PAR_FOR2(i, j, ni, nj) for (int i = 0; i < (ni); ++i) for (int j = 0; j < (nj); ++j)
 #define PAR_END
 #define LUF_SINGLE
 LUF_FN void luf_add(int32_t* p, int32_t v) { *p += v; }
@@ -231,6 +240,34 @@ LUF_FN int32_t luf_offsets_from_counts(int32_t* a, int32_t n) {
 #endif
 }
 
+// minimum over the workgroup of one value per thread, into *dst (preset to ~0 behind a barrier): a shuffle tree per wave, then one
+// atomic per wave
+LUF_FN void luf_block_min64(unsigned long long v, unsigned long long* dst) {
+#if defined(RELP_LUF_DEVICE)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int lo = __shfl_xor((unsigned int)v, off, 64), hi = __shfl_xor((unsigned int)(v >> 32), off, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        if (o < v) v = o;
+    }
+    if ((LUF_TID & 63) == 0 && v != ~0ull) atomicMin(dst, v);
+#else
+    if (v < *dst) *dst = v;
+#endif
+}
+
+// inside PAR_FOR2(i, j, ..): the number of columns j of row i with `nz`, into *dst (zero before the loop).  On the device the lanes
+// of the wave that holds row i count by ballot (64 lanes adding to ONE LDS word serialise: 13,000 clocks per step of the dense
+// finish, measured).
+LUF_FN void luf_row_tally(int32_t* dst, bool nz) {
+#if defined(RELP_LUF_DEVICE)
+    const unsigned long long in = __ballot(1), b = __ballot(nz);
+    if ((LUF_TID & 63) == __ffsll(in) - 1) luf_st(dst, (int32_t)__popcll(b));
+#else
+    if (nz) ++*dst;
+#endif
+}
+
 LUF_FN void luf_fail(const LufOut& O, int32_t why) { LUF_SINGLE { O.status[0] = why; } PAR_END }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -328,6 +365,99 @@ LUF_FN int32_t luf_peel(const LufMatrix& M, const int32_t* basis, const LufWork&
     return k;
 }
 
+// The dense finish of the bump.  What is left after a few rounds is a small corner that fills in completely and yields one pivot
+// per round (25FV47 mid-solve, bump 401: 64 rows after 11 rounds, then 25 rounds for them): with <= dense_cap rows active the
+// block goes into a dense array and is eliminated step by step, every step the entry of lowest Markowitz count under the same
+// threshold test (ties: the lower column, then the lower row), a wave per row.  Afterwards the multipliers join the list and
+// every row's part of U goes back into the arena, so the views below read one format.
+LUF_FN int32_t luf_dense_finish(const LufWork& W, const LufOut& O, const int32_t k_peel, const int32_t nb, const int32_t done) {
+    constexpr double kThreshold = 0.1;
+    const int32_t cap = W.dense_cap;
+    int32_t* drow = W.dint; int32_t* dcol = W.dint + cap; int32_t* drc = W.dint + 2 * cap; int32_t* dcc = W.dint + 3 * cap;
+    int32_t* dsr = W.dint + 4 * cap; int32_t* dsc = W.dint + 5 * cap;      // step of a dense row / column, -1 while active
+    const int32_t na = luf_select(nb, [&](int32_t t) { return W.ract[t] != 0; }, drow);
+    const int32_t nc = luf_select(nb, [&](int32_t u) { return W.cact[u] != 0; }, dcol);
+    if (na != nc) return LUF_SINGULAR;
+    double* D = W.dense;
+    PAR_FOR(j, na) { W.prank[dcol[j]] = j; dsr[j] = -1; dsc[j] = -1; luf_st(&drc[j], 0); luf_st(&dcc[j], 0); luf_st64(&W.cmax[j], 0ull); }
+    PAR_FOR(e, na * na) D[e] = 0.0;
+    LUF_SINGLE { luf_st64(&W.red[0], ~0ull); luf_st64(&W.red[1], ~0ull); luf_st(&W.scalars[0], 0); } PAR_END
+    PAR_FOR(i, na) {
+        const int32_t t = drow[i], b = W.rbeg[t], n = W.rlen[t];
+        for (int32_t e = b; e < b + n; ++e) D[i * na + W.prank[W.ecol[e]]] = W.eval[e];
+    } PAR_END
+    PAR_FOR2(i, j, na, na) {
+        const double v = D[i * na + j];
+        luf_row_tally(&drc[i], v != 0.0);
+        if (v != 0.0) { luf_add(&dcc[j], 1); luf_max64(&W.cmax[j], luf_bits(v)); }
+    } PAR_END
+    for (int32_t s = 0; s < na; ++s) {
+        unsigned long long best = ~0ull;
+        PAR_FOR2(i, j, na, na) {
+            if (dsr[i] >= 0 || dsc[j] >= 0) continue;
+            const double v = D[i * na + j];
+            if (v == 0.0) continue;
+            if (luf_bits(v) < luf_bits(kThreshold * luf_from_bits(luf_ld64(&W.cmax[j])))) continue;
+            const unsigned long long cost = (unsigned long long)(uint32_t)(luf_ld(&drc[i]) - 1) * (unsigned long long)(uint32_t)(luf_ld(&dcc[j]) - 1);
+            const unsigned long long key = (cost << 32) | ((unsigned long long)(uint32_t)j << 16) | (uint32_t)i;
+            if (key < best) best = key;
+        }
+        luf_block_min64(best, &W.red[s & 1]);
+        PAR_END
+        const unsigned long long key = luf_ld64(&W.red[s & 1]);
+        if (key == ~0ull) return LUF_SINGULAR;
+        const int32_t pi = (int32_t)(key & 0xffffu), pj = (int32_t)((key >> 16) & 0xffffu);
+        const double pv = D[pi * na + pj];
+        LUF_SINGLE {
+            luf_st64(&W.red[(s + 1) & 1], ~0ull);
+            dsr[pi] = done + s; dsc[pj] = done + s;
+            const int32_t t = drow[pi], u = dcol[pj];
+            W.ract[t] = 0; W.cact[u] = 0; W.bstep_row[t] = done + s; W.bstep_col[u] = done + s; W.cpiv[t] = u;
+            const int32_t i = W.brow[t], c = W.bcol[u], k = k_peel + done + s;
+            O.row_step[i] = k; O.col_step[c] = k; O.rowperm[k] = i; O.colperm[k] = c; O.diag[k] = pv;
+        }
+        PAR_FOR(j, na) { luf_st(&drc[j], 0); luf_st(&dcc[j], 0); luf_st64(&W.cmax[j], 0ull); }
+        PAR_FOR(i, na) {                                                       // the multipliers stay where the column was
+            if (i == pi || dsr[i] >= 0) continue;
+            const double v = D[i * na + pj];
+            if (v != 0.0) D[i * na + pj] = v / pv;
+        } PAR_END
+        PAR_FOR2(i, j, na, na) {                                               // rank-1 update; the counts of the next step
+            if (dsr[i] >= 0 || dsc[j] >= 0) continue;
+            double v = D[i * na + j];
+            const double f = D[i * na + pj];
+            if (f != 0.0) { const double pw = D[pi * na + j]; if (pw != 0.0) { v -= f * pw; D[i * na + j] = v; } }
+            luf_row_tally(&drc[i], v != 0.0);
+            if (v != 0.0) { luf_add(&dcc[j], 1); luf_max64(&W.cmax[j], luf_bits(v)); }
+        } PAR_END
+    }
+    PAR_FOR2(i, j, na, na) {
+        if (dsc[j] >= dsr[i]) continue;
+        const double v = D[i * na + j];
+        if (v == 0.0) continue;
+        const int32_t at = luf_fetch_add(&W.counters[1], 1);
+        if (at < W.lt_cap) { W.lt_row[at] = drow[i]; W.lt_step[at] = dsc[j]; W.lt_val[at] = v; }
+    }
+    PAR_FOR(i, na) {
+        const int32_t t = drow[i];
+        int32_t n = 0;
+        for (int32_t j = 0; j < na; ++j) if (dsc[j] >= dsr[i] && D[i * na + j] != 0.0) ++n;
+        int32_t b = W.rbeg[t];
+        if (n > W.rcap[t]) {
+            b = luf_fetch_add(&W.counters[0], n);
+            if (b + n > W.arena_cap) { luf_st(&W.scalars[0], 2); continue; }
+            W.rbeg[t] = b; W.rcap[t] = n;
+        }
+        n = 0;
+        for (int32_t j = 0; j < na; ++j) if (dsc[j] >= dsr[i] && D[i * na + j] != 0.0) { W.ecol[b + n] = dcol[j]; W.eval[b + n] = D[i * na + j]; ++n; }
+        W.rlen[t] = n;
+    }
+    PAR_FOR(j, na) W.prank[dcol[j]] = -1;
+    LUF_SINGLE { ++W.counters[2]; W.counters[4] += na; } PAR_END
+    if (luf_ld(&W.scalars[0]) || luf_ld(&W.counters[1]) > W.lt_cap) return LUF_NO_ROOM;
+    return LUF_OK;
+}
+
 // Part 2: the bump and the four views.  `W` may carry the bump's arrays (rbeg .. cprio, ecol / eval, counters, red, scalars) in
 // LDS while everything else stays in global memory (relp_kernels_luf.hip: k_lu_factor).
 LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, const int32_t k_peel) {
@@ -370,6 +500,12 @@ LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W,
     LUF_LAP(2);
     int32_t done = 0;
     while (done < nb) {
+        if (W.dense_cap > 0 && nb - done <= W.dense_cap) {
+            const int32_t rc = luf_dense_finish(W, O, k_peel, nb, done);
+            if (rc != LUF_OK) { luf_fail(O, rc); return; }
+            LUF_LAP(7);
+            break;
+        }
         // (1) per column: the largest active entry (threshold test), and the marks of this round
         PAR_FOR(u, nb) { if (W.cact[u]) { luf_st64(&W.cmax[u], 0ull); luf_st64(&W.rowmark[u], ~0ull); luf_st64(&W.colbest[u], ~0ull); } }
         LUF_SINGLE { luf_st64(&W.red[0], ~0ull); luf_st(&W.scalars[0], 0); } PAR_END
@@ -435,9 +571,9 @@ LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W,
             O.row_step[i] = k; O.col_step[c] = k; O.rowperm[k] = i; O.colperm[k] = c; O.diag[k] = pv;
         } PAR_END
         LUF_LAP(5);
-        // (4) elimination: every other active row is rewritten by one thread, the pivots that reach it in ascending rank
-        PAR_FOR(t, nb) {
-            if (!W.ract[t]) continue;
+        // (4) elimination: every other active row is rewritten by ONE wave (device) / one thread (host model), the pivots that reach
+        //     it in ascending rank, so the arithmetic does not depend on the execution
+        auto eliminate_serial = [&](int32_t t) {
             for (;;) {
                 int32_t b = W.rbeg[t], n = W.rlen[t], hit = -1, rank = 0x7fffffff;
                 for (int32_t e = b; e < b + n; ++e) { const int32_t r = W.prank[W.ecol[e]]; if (r >= 0 && r < rank) { rank = r; hit = e; } }
@@ -475,7 +611,91 @@ LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W,
                 }
                 W.rlen[t] = n;
             }
+        };
+#if defined(RELP_LUF_DEVICE)
+        // A wave per row: the row sits in registers (one entry per lane, rows of <= 64 entries), a pivot row is read one entry per
+        // lane and walked by broadcast: `ballot(col == w)` finds the entry to update or says fill-in.  One thread per row (the
+        // serial form above) cost 2.5 M clocks per factorisation of a 25FV47 basis: its worst row does hits x |pivot row| x |row|
+        // dependent LDS reads while 500 threads wait at the barrier.
+        {
+            const int lane = LUF_TID & 63, wave = LUF_TID >> 6, nw = LUF_NT >> 6;
+            for (int32_t t = wave; t < nb; t += nw) {
+                if (!W.ract[t]) continue;
+                int32_t b = W.rbeg[t], n = W.rlen[t];
+                int32_t col = lane < n && n <= 64 ? W.ecol[b + lane] : -1;
+                double val = lane < n && n <= 64 ? W.eval[b + lane] : 0.0;
+                int32_t rk = col >= 0 ? W.prank[col] : -1;
+                unsigned long long hits = __ballot(rk >= 0);
+                if (n <= 64 && !hits) continue;
+                // what the row can grow to: beyond 64 entries it takes the serial form
+                int32_t grow = rk >= 0 ? W.rlen[W.acc[rk]] - 1 : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) grow += __shfl_xor(grow, off, 64);
+                if (n > 64 || n + grow > 64) { if (lane == 0) eliminate_serial(t); continue; }
+                while (hits) {
+                    int32_t r = rk >= 0 ? rk : 0x7fffffff;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { const int32_t o = __shfl_xor(r, off, 64); r = o < r ? o : r; }
+                    const int hl = __ffsll((unsigned long long)__ballot(rk == r)) - 1;
+                    const double f = __shfl(val, hl, 64) / W.pval[r];
+                    const int32_t pc = __shfl(col, hl, 64);
+                    if (lane == 0) {
+                        const int32_t at = luf_fetch_add(&W.counters[1], 1);
+                        if (at < W.lt_cap) { W.lt_row[at] = t; W.lt_step[at] = done + r; W.lt_val[at] = f; }
+                    }
+                    {   // the entry of the pivot column leaves the row: the last entry takes its place
+                        const int32_t lc = __shfl(col, n - 1, 64), lr = __shfl(rk, n - 1, 64); const double lv = __shfl(val, n - 1, 64);
+                        if (lane == hl) { col = lc; val = lv; rk = lr; }
+                        if (lane == n - 1) { col = -1; val = 0.0; rk = -1; }
+                        --n;
+                    }
+                    const int32_t pr = W.acc[r], pb = W.rbeg[pr], pn = W.rlen[pr];
+                    for (int32_t q0 = 0; q0 < pn; q0 += 64) {
+                        const int32_t myw = q0 + lane < pn ? W.ecol[pb + q0 + lane] : -1;
+                        const double mypw = q0 + lane < pn ? W.eval[pb + q0 + lane] : 0.0;
+                        const int32_t cnt = pn - q0 < 64 ? pn - q0 : 64;
+                        for (int32_t q = 0; q < cnt; ++q) {
+                            const int32_t w = __shfl(myw, q, 64);
+                            if (w == pc) continue;
+                            const double pw = __shfl(mypw, q, 64);
+                            const unsigned long long mt = __ballot(col == w);
+                            if (mt) {
+                                const int ml = __ffsll(mt) - 1;
+                                const double nv = val - f * pw;
+                                if (__shfl(nv == 0.0 ? 1 : 0, ml, 64)) {                   // exact cancellation (decomposition/mod.rs:178)
+                                    const int32_t lc = __shfl(col, n - 1, 64), lr = __shfl(rk, n - 1, 64); const double lv = __shfl(val, n - 1, 64);
+                                    if (lane == ml) { col = lc; val = lv; rk = lr; }
+                                    if (lane == n - 1) { col = -1; val = 0.0; rk = -1; }
+                                    --n;
+                                    if (lane == 0) luf_add(&W.bcc[w], -1);
+                                } else if (lane == ml) {
+                                    val = nv;
+                                }
+                            } else {                                                       // fill (never in a column that pivots this round)
+                                if (lane == n) { col = w; val = -f * pw; rk = -1; }
+                                ++n;
+                                if (lane == 0) luf_add(&W.bcc[w], 1);
+                            }
+                        }
+                    }
+                    hits = __ballot(rk >= 0);
+                }
+                if (n > W.rcap[t]) {
+                    const int32_t want = n + n / 2 + 4;
+                    int32_t nbeg = 0;
+                    if (lane == 0) nbeg = luf_fetch_add(&W.counters[0], want);
+                    nbeg = __shfl(nbeg, 0, 64);
+                    if (nbeg + want > W.arena_cap) { if (lane == 0) luf_st(&W.scalars[0], 2); continue; }     // (reported behind the round)
+                    b = nbeg;
+                    if (lane == 0) { W.rbeg[t] = nbeg; W.rcap[t] = want; }
+                }
+                if (lane < n) { W.ecol[b + lane] = col; W.eval[b + lane] = val; }
+                if (lane == 0) W.rlen[t] = n;
+            }
         } PAR_END
+#else
+        PAR_FOR(t, nb) { if (W.ract[t]) eliminate_serial(t); } PAR_END
+#endif
         LUF_LAP(6);
         // (5) the pivot rows leave: their columns lose an active entry; the round's column marks are taken back
         PAR_FOR(a, n_acc) {
@@ -492,83 +712,69 @@ LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W,
         done += n_acc;
         LUF_LAP(7);
     }
-    const int32_t n_lt = nb > 0 ? luf_ld(&W.counters[1]) : 0;
-    // the multipliers by row (counting sort; the order inside a row is settled when the rows of L are sorted below)
-    if (nb > 0) {
-        PAR_FOR(t, nb + 1) luf_st(&W.lt_ptr[t], 0); PAR_END
-        PAR_FOR(q, n_lt) luf_add(&W.lt_ptr[W.lt_row[q] + 1], 1); PAR_END
-        PAR_FOR(t, nb + 1) { const int32_t v = luf_ld(&W.lt_ptr[t]); W.lt_ptr[t] = v; } PAR_END      // (plain copies for the scan)
-        (void)luf_offsets_from_counts(W.lt_ptr, nb);
-        PAR_FOR(t, nb) luf_st(&W.bcc[t], 0); PAR_END                                                  // (reused: fill cursor per row)
-        PAR_FOR(q, n_lt) { const int32_t t = W.lt_row[q]; W.lt_ord[W.lt_ptr[t] + luf_fetch_add(&W.bcc[t], 1)] = q; } PAR_END
+    // ---- L and U in pivot coordinates: first as triplets (row step, column step, value), then the four views -----------------------
+    // The multipliers of the bump already are triplets of L (local row, local step): into pivot coordinates where they lie.  Every
+    // other entry comes from a basis column (outside bump x bump: never modified) or from a bump row as it was when it became the
+    // pivot row, appended behind an atomic cursor -- the order of the triplets does not matter, a view places every entry by its
+    // coordinates alone.  [r4: one thread per row walking luf_row_entries twice and insertion-sorting its rows in global memory
+    // cost 1.9 M clocks of the 3.9 M of a factorisation of 25FV47.]
+    const int32_t n_lt = luf_ld(&W.counters[1]);
+    LUF_SINGLE { luf_st(&W.counters[5], 0); } PAR_END
+    PAR_FOR(q, n_lt) { W.lt_row[q] = k_peel + W.bstep_row[W.lt_row[q]]; W.lt_step[q] += k_peel; }
+    PAR_FOR(c, m) {
+        const int32_t kc = O.col_step[c];
+        const bool cb = W.lcol[c] >= 0;
+        luf_col_entries(M, basis[c], [&](int32_t r, double v) {
+            if (cb && W.lrow[r] >= 0) return;                              // bump x bump: from the arena
+            const int32_t kk = O.row_step[r];
+            if (kc > kk) {
+                const int32_t at = luf_fetch_add(&W.counters[5], 1);
+                if (at < W.lt_cap) { W.ut_row[at] = kk; W.ut_col[at] = kc; W.ut_val[at] = v; }
+            } else if (kc < kk) {
+                const int32_t at = luf_fetch_add(&W.counters[1], 1);
+                if (at < W.lt_cap) { W.lt_row[at] = kk; W.lt_step[at] = kc; W.lt_val[at] = v / O.diag[kc]; }
+            }
+        });
     }
-
+    PAR_FOR(t, nb) {
+        const int32_t pc = W.cpiv[t], kk = k_peel + W.bstep_row[t];
+        for (int32_t e = W.rbeg[t]; e < W.rbeg[t] + W.rlen[t]; ++e) {
+            if (W.ecol[e] == pc) continue;
+            const int32_t at = luf_fetch_add(&W.counters[5], 1);
+            if (at < W.lt_cap) { W.ut_row[at] = kk; W.ut_col[at] = k_peel + W.bstep_col[W.ecol[e]]; W.ut_val[at] = W.eval[e]; }
+        }
+    } PAR_END
+    const int32_t n_l = luf_ld(&W.counters[1]), n_u = luf_ld(&W.counters[5]);
+    LUF_SINGLE {
+        if (n_l > W.lt_cap || n_u > W.lt_cap || n_l > O.cap || n_u > O.cap) O.status[0] = LUF_NO_ROOM;
+        O.status[3] = n_l; O.status[4] = n_u;
+    } PAR_END
+    if (n_l > W.lt_cap || n_u > W.lt_cap || n_l > O.cap || n_u > O.cap) return;
     LUF_LAP(8);
-    // ---- L and U in pivot coordinates, row-wise and column-wise; every row / column is written by ONE thread and sorted by ------
-    // ---- index, so the order of its entries does not depend on the execution (two passes: count, then fill behind a running sum)
-    auto sort_range = [&](int32_t* idx, double* val, int32_t b, int32_t e) {       // insertion sort: rows are short
-        for (int32_t i = b + 1; i < e; ++i) {
-            const int32_t ci = idx[i]; const double cv = val[i];
-            int32_t j = i - 1;
-            while (j >= b && idx[j] > ci) { idx[j + 1] = idx[j]; val[j + 1] = val[j]; --j; }
-            idx[j + 1] = ci; val[j + 1] = cv;
-        }
+    // A view: the triplets bucketed by `bk`, every bucket ascending in `od` -- count, offsets, the `od` of every bucket side by side
+    // (any order), then each entry goes to offset + (the number of entries of its bucket with a smaller `od`): coordinates are
+    // unique, so the result does not depend on the execution.  (From here on the arena is free: `vw` / `vtmp` may lie in its LDS.)
+    auto view = [&](int32_t n, const int32_t* bk, const int32_t* od, const double* val, const LufTriangle& R) {
+        int32_t* cnt = W.vw;
+        int32_t* tmp = n <= W.vtmp_lds_cap ? W.vtmp_lds : W.vtmp;
+        PAR_FOR(k, m + 1) luf_st(&cnt[k], 0); PAR_END
+        PAR_FOR(e, n) luf_add(&cnt[bk[e] + 1], 1); PAR_END
+        PAR_FOR(k, m + 1) { R.ptr[k] = luf_ld(&cnt[k]); } PAR_END
+        (void)luf_offsets_from_counts(R.ptr, m);
+        PAR_FOR(k, m + 1) luf_st(&cnt[k], 0); PAR_END
+        PAR_FOR(e, n) { const int32_t b = bk[e]; tmp[R.ptr[b] + luf_fetch_add(&cnt[b], 1)] = od[e]; } PAR_END
+        PAR_FOR(e, n) {
+            const int32_t b = bk[e], mine = od[e], lo = R.ptr[b], hi = R.ptr[b + 1];
+            int32_t rank = 0;
+            for (int32_t a = lo; a < hi; ++a) rank += tmp[a] < mine ? 1 : 0;
+            R.idx[lo + rank] = mine; R.val[lo + rank] = val[e];
+        } PAR_END
     };
-    for (int pass = 0; pass < 2; ++pass) {
-        PAR_FOR(kk, m) {
-            const int32_t i = O.rowperm[kk], t = W.lrow[i];
-            int32_t nl = 0, nu = 0;
-            const int32_t bl = pass ? O.Lf.ptr[kk] : 0, bu = pass ? O.Uf.ptr[kk] : 0;
-            luf_row_entries(M, W, i, [&](int32_t c, double v) {
-                const int32_t kc = O.col_step[c];
-                if (t >= 0 && W.lcol[c] >= 0) return;                      // bump x bump: from the arena below
-                if (kc > kk) { if (pass) { O.Uf.idx[bu + nu] = kc; O.Uf.val[bu + nu] = v; } ++nu; }
-                else if (kc < kk) { if (pass) { O.Lf.idx[bl + nl] = kc; O.Lf.val[bl + nl] = v / O.diag[kc]; } ++nl; }
-            });
-            if (t >= 0) {
-                const int32_t pc = W.cpiv[t];
-                for (int32_t e = W.rbeg[t]; e < W.rbeg[t] + W.rlen[t]; ++e) {          // the row as it was when it became the pivot row
-                    if (W.ecol[e] == pc) continue;
-                    if (pass) { O.Uf.idx[bu + nu] = k_peel + W.bstep_col[W.ecol[e]]; O.Uf.val[bu + nu] = W.eval[e]; }
-                    ++nu;
-                }
-                for (int32_t q = W.lt_ptr[t]; q < W.lt_ptr[t + 1]; ++q) {
-                    if (pass) { const int32_t o = W.lt_ord[q]; O.Lf.idx[bl + nl] = k_peel + W.lt_step[o]; O.Lf.val[bl + nl] = W.lt_val[o]; }
-                    ++nl;
-                }
-            }
-            if (!pass) { O.Lf.ptr[kk + 1] = nl; O.Uf.ptr[kk + 1] = nu; }
-            else { sort_range(O.Lf.idx, O.Lf.val, bl, bl + nl); sort_range(O.Uf.idx, O.Uf.val, bu, bu + nu); }
-        } PAR_END
-        if (!pass) {
-            int32_t tot[2];
-            tot[0] = luf_offsets_from_counts(O.Lf.ptr, m); tot[1] = luf_offsets_from_counts(O.Uf.ptr, m);
-            LUF_SINGLE {
-                for (int q = 0; q < 2; ++q) if (tot[q] > O.cap) O.status[0] = LUF_NO_ROOM;
-                O.status[3] = tot[0]; O.status[4] = tot[1];
-            } PAR_END
-            if (O.status[0] != LUF_OK) return;
-        }
-    }
+    view(n_l, W.lt_row, W.lt_step, W.lt_val, O.Lf);
+    view(n_u, W.ut_row, W.ut_col, W.ut_val, O.Uf);
     LUF_LAP(9);
-    // the column views are the transposes: count by index, offsets, scatter behind an atomic cursor, sort every column
-    for (int q = 0; q < 2; ++q) {
-        const LufTriangle& R = q ? O.Uf : O.Lf;
-        const LufTriangle& C = q ? O.Ub : O.Lb;
-        const int32_t n = R.ptr[m];
-        PAR_FOR(k, m + 1) luf_st(&C.ptr[k], 0); PAR_END
-        PAR_FOR(e, n) luf_add(&C.ptr[R.idx[e] + 1], 1); PAR_END
-        PAR_FOR(k, m + 1) { const int32_t v = luf_ld(&C.ptr[k]); C.ptr[k] = v; } PAR_END
-        (void)luf_offsets_from_counts(C.ptr, m);
-        PAR_FOR(k, m) luf_st(&W.claim[k], 0); PAR_END                      // (reused: fill cursor per column)
-        PAR_FOR(kk, m) {
-            for (int32_t e = R.ptr[kk]; e < R.ptr[kk + 1]; ++e) {
-                const int32_t l = R.idx[e], o = C.ptr[l] + luf_fetch_add(&W.claim[l], 1);
-                C.idx[o] = kk; C.val[o] = R.val[e];
-            }
-        } PAR_END
-        PAR_FOR(l, m) sort_range(C.idx, C.val, C.ptr[l], C.ptr[l + 1]); PAR_END
-    }
+    view(n_l, W.lt_step, W.lt_row, W.lt_val, O.Lb);
+    view(n_u, W.ut_col, W.ut_row, W.ut_val, O.Ub);
     LUF_LAP(10);
 }
 

@@ -199,6 +199,50 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
             if ((int64_t)x_top + tot_x > S.x_cap || (int64_t)p_top + tot_p > S.pool_cap) ok = false;
         }
         if (ok) {
+#if defined(RELP_LUF_DEVICE)
+            if (!maskable) {
+                // A wave per row, the expanded row in registers (one term per lane: a row beyond 63 terms ends the group anyway): a
+                // term is combined with the one of the same index by `ballot(src == s)`, the rows it substitutes are read one entry
+                // per lane and walked by broadcast.  The sums run in the order of the serial form below.  (One thread per row
+                // searched its row in global memory for every term: 25,000 dependent steps and 4.8 M clocks on one row of L.)
+                const int lane = LUF_TID & 63, wave = LUF_TID >> 6, nw = LUF_NT >> 6;
+                for (int32_t q = wave; q < nr; q += nw) {
+                    const int32_t k = S.order[r0 + q];
+                    const int32_t xb = x_top + S.tmp[q];
+                    int32_t src = -1, n = 0;
+                    double coef = 0.0;
+                    auto term = [&](int32_t s_, double c_) {
+                        const unsigned long long mt = __ballot(src == s_);
+                        if (mt) { if (lane == __ffsll(mt) - 1) coef += c_; }
+                        else { if (lane == n) { src = s_; coef = c_; } ++n; }
+                    };
+                    for (int32_t e = T.ptr[k]; e < T.ptr[k + 1]; ++e) {
+                        const int32_t j = T.idx[e];
+                        const double v = T.val[e];
+                        if (S.grp[j] != g) { term(j, v); continue; }
+                        const double f = v / diag_of(j);
+                        term(rhs_base + j, f);
+                        const bool raw = S.xbeg[j] < 0;
+                        const int32_t sb = raw ? T.ptr[j] : S.xbeg[j], sn = raw ? T.ptr[j + 1] - T.ptr[j] : S.xlen[j];
+                        for (int32_t u0 = 0; u0 < sn; u0 += 64) {
+                            const bool in = u0 + lane < sn;
+                            const int32_t my_s = in ? (raw ? T.idx[sb + u0 + lane] : S.x_src[sb + u0 + lane]) : -1;
+                            const double my_c = in ? (raw ? T.val[sb + u0 + lane] : S.x_coef[sb + u0 + lane]) : 0.0;
+                            const int32_t cnt = sn - u0 < 64 ? sn - u0 : 64;
+                            for (int32_t u = 0; u < cnt; ++u) term(__shfl(my_s, u, 64), -f * __shfl(my_c, u, 64));
+                        }
+                    }
+                    if (lane < n && lane < 64) { S.x_src[xb + lane] = src; S.x_coef[xb + lane] = coef; }
+                    if (lane == 0) {
+                        if (n > 63) luf_st(&S.sc[1], 1);
+                        S.loff[k] = xb; S.lg[k] = n;
+                        if (packed(k)) luf_add(&S.sc[2], luf_lanes_of(n));
+                    }
+                }
+                __syncthreads();
+            } else
+#endif
+            {
             PAR_FOR(q, nr) {
                 const int32_t k = S.order[r0 + q];
                 const int32_t xb = x_top + S.tmp[q];
@@ -240,6 +284,7 @@ LUF_FN void luf_build_schedule(const LufSchedIn& T, const LufSchedWork& S, const
                 S.loff[k] = xb; S.lg[k] = n;                              // (kept aside until the level is accepted)
                 if (packed(k)) luf_add(&S.sc[2], luf_lanes_of(n));
             } PAR_END
+            }
             add = luf_ld(&S.sc[2]);
             if (luf_ld(&S.sc[1]) || lanes + add > T.fuse_lanes) ok = false;
         }

@@ -67,7 +67,9 @@ struct Provider {
 
 struct Buffers {
     std::vector<int32_t> ints; std::vector<double> dbl; std::vector<unsigned long long> red, u64;
+    std::vector<double> dense, utv; std::vector<int32_t> dint, uti;
     LufWork W{}; LufOut O{};
+    static int& dense_cap() { static int c = 64; return c; }       // (the tests run with the dense finish on and off)
     void setup(const Provider& P, int32_t nb_cap, int32_t cap, int32_t arena_cap = -1) {
         const int32_t m = P.m;
         if (arena_cap < 0) arena_cap = cap;
@@ -88,6 +90,12 @@ struct Buffers {
         W.ecol = ti(arena_cap); W.eval = td(arena_cap); W.arena_cap = arena_cap;
         W.lt_row = ti(cap); W.lt_step = ti(cap); W.lt_val = td(cap); W.lt_cap = cap; W.lt_ptr = ti(nb_cap + 1); W.lt_ord = ti(cap);
         W.counters = ti(128); W.red = red.data(); W.scalars = ti(16);
+        const int dc = dense_cap();
+        dense.assign((size_t)dc * dc + 1, 0.0); dint.assign(6 * (size_t)dc + 1, 0);
+        W.dense = dense.data(); W.dint = dint.data(); W.dense_cap = dc;
+        utv.assign((size_t)cap + 1, 0.0); uti.assign(3 * (size_t)cap + m + 4, 0);
+        W.ut_row = uti.data(); W.ut_col = uti.data() + cap; W.ut_val = utv.data(); W.vtmp = uti.data() + 2 * (size_t)cap; W.vw = uti.data() + 3 * (size_t)cap;
+        W.vtmp_lds = nullptr; W.vtmp_lds_cap = 0;
         O.status = ti(8); O.rowperm = ti(m); O.colperm = ti(m); O.row_step = ti(m); O.col_step = ti(m); O.diag = td(m);
         LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
         for (auto* t : tri) { t->ptr = ti(m + 1); t->idx = ti(cap); t->val = td(cap); }
@@ -408,8 +416,8 @@ static int probe(const char* path) {
     luf_factor(P.view(), basis.data(), B.W, B.O);
     LUFactors hf; std::string err;
     const bool ok = lu_factor(m, cols, &hf, &err);
-    std::printf("m %d, nnz(B) %zu: device status %d, bump %d, peeled %d, rounds %d, nnz(L) %d, nnz(U) %d (off-diagonal)  |  host %s: nnz(L) %lld, nnz(U) %lld\n",
-                m, nnz, B.O.status[0], B.O.status[1], B.O.status[2], B.W.counters[2], B.O.status[3], B.O.status[4], ok ? "ok" : err.c_str(),
+    std::printf("m %d, nnz(B) %zu: device status %d, bump %d, peeled %d, rounds %d (dense finish on %d rows, arena top %d), nnz(L) %d, nnz(U) %d (off-diagonal)  |  host %s: nnz(L) %lld, nnz(U) %lld\n",
+                m, nnz, B.O.status[0], B.O.status[1], B.O.status[2], B.W.counters[2], B.W.counters[4], B.W.counters[0], B.O.status[3], B.O.status[4], ok ? "ok" : err.c_str(),
                 (long long)hf.nnz_l, (long long)hf.nnz_u - m);
     auto levels = [&](const LufTriangle& T, bool asc) {
         std::vector<int> lev(m, 0); int nl = 0;
@@ -448,8 +456,7 @@ static int probe(const char* path) {
     return 0;
 }
 
-int main(int argc, char** argv) {
-    if (argc > 1) return probe(argv[1]);
+static void all_checks() {
     std::mt19937_64 rng(20250611);
     // the reference's factorisation cases (decomposition/mod.rs:301-491), column by column
     check_square("identity 2", 2, {{{0, 1.0}}, {{1, 1.0}}}, rng);
@@ -529,6 +536,12 @@ int main(int argc, char** argv) {
         std::snprintf(nm, sizeof nm, "provider %d (m = %d, %d structural, %d artificial)", trial, P.m, P.nn, P.na);
         check(nm, P, basis, rng);
     }
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2) Buffers::dense_cap() = std::atoi(argv[2]);
+    if (argc > 1) return probe(argv[1]);
+    for (int dc : {64, 0, 7}) { Buffers::dense_cap() = dc; all_checks(); }     // the dense finish at the kernel's size, off, tiny
     std::printf("test_lu_device_model: %d checks, %d failed\n", g_checks, g_failed);
     return g_failed ? 1 : 0;
 }
