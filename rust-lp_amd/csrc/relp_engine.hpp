@@ -271,7 +271,7 @@ class Engine {
     struct LufState;
     LufState* luf_ = nullptr;
     bool luf_enabled_ = false;
-    int64_t luf_runs_ = 0, luf_fallbacks_ = 0; double luf_kernel_us_ = 0.0; int32_t luf_last_bump_ = 0, luf_last_peeled_ = 0;
+    int64_t luf_runs_ = 0, luf_fallbacks_ = 0, luf_lds_retries_ = 0; double luf_kernel_us_ = 0.0; int32_t luf_last_bump_ = 0, luf_last_peeled_ = 0;
     relp_status_t luf_prepare();
     relp_status_t lu_factor_on_device(int32_t* device_status);
     relp_status_t luf_download_factors();

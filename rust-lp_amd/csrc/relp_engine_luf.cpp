@@ -75,14 +75,14 @@ relp_status_t Engine::luf_prepare() {
     int64_t o_nb[11];
     for (auto& v : o_nb) v = take(4 * (int64_t)S.nb_cap);     // rbeg rlen rcap ract cact bcc bstep_row bstep_col cpiv prank acc
     int64_t o_nb8[5];
-    for (auto& v : o_nb8) v = take(8 * (int64_t)S.nb_cap);    // pval cmax rowmark colbest cprio
+    for (auto& v : o_nb8) v = take(8 * (int64_t)std::max(S.nb_cap, 512));     // (>= 512: the dense finish keeps 8 x 64 partials there)    // pval cmax rowmark colbest cprio
     const int64_t o_ecol = take(4 * arena_cap), o_eval = take(8 * arena_cap);
     const int64_t o_ltr = take(4 * arena_cap), o_lts = take(4 * arena_cap), o_ltv = take(8 * arena_cap), o_ltp = take(4 * ((int64_t)S.nb_cap + 1)),
                   o_lto = take(4 * arena_cap), o_cnt = take(512);
     const int64_t o_red = take(8 * 8), o_sc = take(64);
     const char* dense_env = std::getenv("RELP_LUF_DENSE");                   // rows of the dense finish (<= 64; 0 = off)
     const int32_t dense_cap = dense_env ? std::max(0, std::min(64, std::atoi(dense_env))) : 64;
-    const int64_t o_dense = take(8 * (int64_t)64 * 64), o_dint = take(4 * 6 * 64);
+    const int64_t o_dense = take(8 * (int64_t)64 * 64), o_dint = take(4 * 8 * 64);
     const int64_t o_utr = take(4 * arena_cap), o_utc = take(4 * arena_cap), o_utv = take(8 * arena_cap), o_vw = take(4 * ((int64_t)m + 2)),
                   o_vtmp = take(4 * arena_cap);
     const int64_t o_status = take(32), o_rowperm = take(4 * (int64_t)m), o_colperm = take(4 * (int64_t)m), o_rstep = take(4 * (int64_t)m),
@@ -141,7 +141,7 @@ relp_status_t Engine::luf_prepare() {
     W.counters = I32(o_cnt); W.red = U64(o_red);
     W.scalars = I32(o_sc);
     W.dense = F64(o_dense); W.dint = I32(o_dint); W.dense_cap = dense_cap;
-    W.ut_row = I32(o_utr); W.ut_col = I32(o_utc); W.ut_val = F64(o_utv); W.vw = I32(o_vw); W.vtmp = I32(o_vtmp); W.vtmp_lds = nullptr; W.vtmp_lds_cap = 0;
+    W.ut_row = I32(o_utr); W.ut_col = I32(o_utc); W.ut_val = F64(o_utv); W.vw = I32(o_vw); W.vtmp = I32(o_vtmp); W.vtmp_cap = (int32_t)arena_cap;
     LufOut& O = S.O;
     O.status = I32(o_status); O.rowperm = I32(o_rowperm); O.colperm = I32(o_colperm); O.row_step = I32(o_rstep); O.col_step = I32(o_cstep);
     O.diag = F64(o_diag);
@@ -203,6 +203,7 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
         if (resident) for (int q = 0; q < 4; ++q) HIP_TRY(hipMemcpyAsync(desc[q], S.sout[q].desc, sizeof desc[q], hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         if (!(attempt == 0 && status[0] == LUF_NO_ROOM)) break;
+        ++luf_lds_retries_;
     }
     luf_kernel_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     ++luf_runs_;
@@ -212,10 +213,12 @@ relp_status_t Engine::lu_factor_on_device(int32_t* device_status) {
         const unsigned long long* ph = reinterpret_cast<const unsigned long long*>(cnt + 8);
         static const char* nm[11] = {"maps+counts", "peel", "bump setup", "r:column max", "r:proposals", "r:independence+accept", "r:elimination", "r:leave + dense finish",
                                      "triplets", "row views", "column views"};
-        std::fprintf(stderr, "[relp] device factorisation, %lld runs (%d with the bump in LDS), %.0f us each (host clock, schedules included), last: %d rounds; clocks per run:",
-                     (long long)luf_runs_, cnt[3], luf_kernel_us_ / luf_runs_, cnt[2]);
+        std::fprintf(stderr, "[relp] device factorisation, %lld runs (%d with the bump in LDS, %lld of them again in global memory, dense finish on %.1f rows), %.0f us each (host clock, schedules included), last: %d rounds; clocks per run:",
+                     (long long)luf_runs_, cnt[3], (long long)luf_lds_retries_, cnt[3] ? (double)cnt[4] / cnt[3] : 0.0, luf_kernel_us_ / luf_runs_, cnt[2]);
         for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)ph[i] / luf_runs_);
         std::fprintf(stderr, "\n");
+        if (ph[12 + 5]) std::fprintf(stderr, "[relp]   wave 0 of the elimination: rows %llu, hits %llu, pivot entries %llu; clocks: idle/loop %llu, row setup %llu, hit prologue %llu, entries %llu, write-back %llu\n",
+                                     ph[17], ph[18], ph[19], ph[12], ph[13], ph[14], ph[15], ph[16]);
         static const char* sn[4] = {"L", "U", "U'", "L'"};
         for (int q = 0; q < 4 && resident; ++q) {
             int32_t sc[32] = {0};

@@ -38,10 +38,13 @@ __global__ __launch_bounds__(kLufThreads) void k_lu_factor(LufMatrix M, const in
         L.rbeg = i32(lds_nb); L.rlen = i32(lds_nb); L.rcap = i32(lds_nb); L.ract = i32(lds_nb); L.cact = i32(lds_nb); L.bcc = i32(lds_nb);
         L.bstep_row = i32(lds_nb); L.bstep_col = i32(lds_nb); L.cpiv = i32(lds_nb); L.prank = i32(lds_nb); L.acc = i32(lds_nb);
         L.ecol = i32(lds_arena); L.scalars = i32(16); L.counters = i32(128);
-        if (W.dense_cap > 0) { L.dense = f64((int64_t)W.dense_cap * W.dense_cap); L.dint = i32(6 * (int64_t)W.dense_cap); }
+        // (unconditional, like everything carved here: a pointer that is LDS on one path and global on the other is a generic
+        // pointer, and every access through it a FLAT instruction)
+        L.dense = f64((int64_t)W.dense_cap * W.dense_cap); L.dint = i32(8 * (int64_t)W.dense_cap + 4);
         L.nb_cap = lds_nb; L.arena_cap = lds_arena;
         // (the views run when the arena is no longer read: their counts and buckets in its values' LDS)
-        if ((int64_t)M.m + 2 <= lds_arena) { L.vw = reinterpret_cast<int32_t*>(L.eval); L.vtmp_lds = L.vw + ((M.m + 2 + 3) / 4) * 4; L.vtmp_lds_cap = 2 * lds_arena - ((M.m + 2 + 3) / 4) * 4; }
+        // (launch_lu_factor takes this variant only when m + 2 counters fit beside the buckets)
+        L.vw = reinterpret_cast<int32_t*>(L.eval); L.vtmp = L.vw + ((M.m + 2 + 3) / 4) * 4; L.vtmp_cap = 2 * lds_arena - ((M.m + 2 + 3) / 4) * 4;
         for (int i = threadIdx.x; i < 128; i += blockDim.x) L.counters[i] = 0;
         __syncthreads();
         luf_bump(M, basis, L, O, k_peel);
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(kLufThreads) void k_lu_factor(LufMatrix M, const in
             W.counters[2] = L.counters[2]; W.counters[4] += L.counters[4];
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(W.counters + 8);
             const unsigned long long* src = reinterpret_cast<const unsigned long long*>(L.counters + 8);
-            for (int i = 2; i < 12; ++i) dst[i] += src[i];
+            for (int i = 2; i < 24; ++i) dst[i] += src[i];
             W.counters[3] += 1;                            // factorisations whose bump ran in LDS
         }
     } else {
@@ -101,11 +104,12 @@ void launch_lu_schedules(const LufSchedIn in[4], const LufSchedWork work[4], con
 static size_t luf_lds_bytes(int32_t lds_nb, int32_t lds_arena, int32_t dense_cap) {
     auto up = [](size_t b) { return (b + 15) / 16 * 16; };
     return 5 * 8 * (size_t)lds_nb + 8 * (size_t)lds_arena + 64 + 11 * up(4 * (size_t)lds_nb) + up(4 * (size_t)lds_arena) + up(64) + up(512) + 64 +
-           8 * (size_t)dense_cap * dense_cap + up(4 * 6 * (size_t)dense_cap);
+           8 * (size_t)dense_cap * dense_cap + up(4 * (8 * (size_t)dense_cap + 4));
 }
 void launch_lu_factor(const LufMatrix& M, const int32_t* basis, const LufWork& W, const LufOut& O, hipStream_t s, bool lds) {
     // (what one CU's 160 KB hold beside the kernel's static 100 bytes: 512 bump rows, the 64 x 64 block of the dense finish and
     // what is left as arena: 7,040 entries with the block, 9,216 without)
+    if (M.m + 2 > 7040) lds = false;                   // (the views' counters sit in the arena's LDS)
     const int32_t lds_nb = lds ? 512 : 0, lds_arena = lds ? (W.dense_cap > 32 ? 7040 : W.dense_cap > 0 ? 8448 : 9216) : 0;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lu_factor), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }

@@ -79,13 +79,13 @@ struct LufWork {
     int32_t* lt_ptr; int32_t* lt_ord;                                // nb + 1 / lt_cap: room sizes of the bump's rows (setup) / spare
     int32_t* ut_row; int32_t* ut_col; double* ut_val;                // lt_cap each: the triplets of U (those of L join the multipliers)
     int32_t* vw;                                                     // m + 2: counts / cursors of a view
-    int32_t* vtmp; int32_t* vtmp_lds; int32_t vtmp_lds_cap;          // lt_cap: the buckets of a view; the same in LDS for up to vtmp_lds_cap entries
+    int32_t* vtmp; int32_t vtmp_cap;                                 // the buckets of a view (a factor with more entries: LUF_NO_ROOM)
     int32_t* counters;                                               // [0] arena top, [1] multipliers, [2] rounds of the bump
     unsigned long long* red;                                         // 8 words of reductions
     int32_t* scalars;                                                // 16 ints of uniform state
     // the dense finish: once <= dense_cap (<= 64) rows are active they go into a dense block (the tail of a bump is a small
     // dense corner that yields one pivot per round); 0 = off
-    double* dense; int32_t* dint; int32_t dense_cap;                 // dense_cap^2 doubles; 6 * dense_cap ints
+    double* dense; int32_t* dint; int32_t dense_cap;                 // dense_cap^2 doubles; 8 * dense_cap ints
 };
 
 #if defined(RELP_LUF_DEVICE)
@@ -375,6 +375,7 @@ LUF_FN int32_t luf_dense_finish(const LufWork& W, const LufOut& O, const int32_t
     const int32_t cap = W.dense_cap;
     int32_t* drow = W.dint; int32_t* dcol = W.dint + cap; int32_t* drc = W.dint + 2 * cap; int32_t* dcc = W.dint + 3 * cap;
     int32_t* dsr = W.dint + 4 * cap; int32_t* dsc = W.dint + 5 * cap;      // step of a dense row / column, -1 while active
+    int32_t* dpi = W.dint + 6 * cap; int32_t* dpj = W.dint + 7 * cap;      // dense row / column of a step
     const int32_t na = luf_select(nb, [&](int32_t t) { return W.ract[t] != 0; }, drow);
     const int32_t nc = luf_select(nb, [&](int32_t u) { return W.cact[u] != 0; }, dcol);
     if (na != nc) return LUF_SINGULAR;
@@ -386,6 +387,84 @@ LUF_FN int32_t luf_dense_finish(const LufWork& W, const LufOut& O, const int32_t
         const int32_t t = drow[i], b = W.rbeg[t], n = W.rlen[t];
         for (int32_t e = b; e < b + n; ++e) D[i * na + W.prank[W.ecol[e]]] = W.eval[e];
     } PAR_END
+#if defined(RELP_LUF_DEVICE)
+    // The block in REGISTERS: wave w holds rows w, w + 8, .., lane j column j.  A step is three barriers: the waves' partial column
+    // counts / maxima through LDS, the best entry (a shuffle tree per wave, one atomic per wave), the pivot row through LDS; the
+    // multipliers are read across the wave's lanes.  (The loop on the LDS copy below took 14,000 clocks per step: every one of
+    // its eight rows per wave a chain of six dependent LDS reads.)
+    if ((LUF_NT >> 6) == 8 && W.nb_cap >= 512) {
+        const int lane = LUF_TID & 63, wave = LUF_TID >> 6;
+        constexpr int R = 8;
+        int32_t* pc_i = reinterpret_cast<int32_t*>(W.rowmark);             // [8][64] partial counts
+        double* pm_d = reinterpret_cast<double*>(W.cmax);                   // [8][64] partial maxima
+        double* prow = reinterpret_cast<double*>(W.colbest);                // [64] the pivot row
+        double v[R];
+        uint32_t rmask = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int i = wave + 8 * k;
+            v[k] = (i < na && lane < na) ? D[i * na + lane] : 0.0;
+            if (i < na) rmask |= 1u << k;
+        }
+        bool cact = lane < na;
+        __syncthreads();                                                   // (cmax was zeroed above: now the partial maxima live there)
+        for (int32_t s = 0; s < na; ++s) {
+            int32_t pcnt = 0; double pmax = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) if ((rmask >> k) & 1u) { const double a = luf_abs(v[k]); pcnt += v[k] != 0.0 ? 1 : 0; pmax = a > pmax ? a : pmax; }
+            pc_i[wave * 64 + lane] = pcnt; pm_d[wave * 64 + lane] = pmax;
+            __syncthreads();
+            int32_t cc = 0; double cmx = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < 8; ++w2) { cc += pc_i[w2 * 64 + lane]; const double a = pm_d[w2 * 64 + lane]; cmx = a > cmx ? a : cmx; }
+            const double thr = kThreshold * cmx;
+            uint32_t best = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < R; ++k) if ((rmask >> k) & 1u) {
+                const bool nz = cact && v[k] != 0.0;
+                const int32_t rc = (int32_t)__popcll(__ballot(nz));
+                if (nz && !(luf_abs(v[k]) < thr)) {
+                    const uint32_t key = ((uint32_t)((rc - 1) * (cc - 1)) << 12) | ((uint32_t)lane << 6) | (uint32_t)(wave + 8 * k);
+                    best = key < best ? key : best;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int32_t)best, off, 64); best = o < best ? o : best; }
+            if (lane == 0 && best != 0xffffffffu) atomicMin(&W.red[s & 1], (unsigned long long)best);
+            __syncthreads();
+            const unsigned long long key64 = W.red[s & 1];
+            if (key64 == ~0ull) return LUF_SINGULAR;
+            const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)key64);
+            const int pi = (int)(key & 63u), pj = (int)((key >> 6) & 63u), wp = pi & 7, kp = pi >> 3;
+            if (wave == wp) {
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) if (k == kp) x = v[k];
+                prow[lane] = x;
+                rmask &= ~(1u << kp);
+            }
+            if (LUF_TID == 0) { W.red[(s + 1) & 1] = ~0ull; dsr[pi] = done + s; dsc[pj] = done + s; dpi[s] = pi; dpj[s] = pj; }
+            __syncthreads();
+            const double pw = prow[lane], pv = prow[pj];
+            if (lane == pj) cact = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) if ((rmask >> k) & 1u) {
+                union { double d; int32_t w[2]; } u; u.d = v[k];
+                u.w[0] = __builtin_amdgcn_readlane(u.w[0], pj); u.w[1] = __builtin_amdgcn_readlane(u.w[1], pj);
+                if (u.d != 0.0) {
+                    const double f = u.d / pv;
+                    if (lane == pj) v[k] = f;                                  // the multipliers stay where the column was
+                    else if (cact && pw != 0.0) v[k] -= f * pw;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < R; ++k) { const int i = wave + 8 * k; if (i < na && lane < na) D[i * na + lane] = v[k]; }
+        __syncthreads();
+    } else
+#endif
+    {
     PAR_FOR2(i, j, na, na) {
         const double v = D[i * na + j];
         luf_row_tally(&drc[i], v != 0.0);
@@ -399,23 +478,16 @@ LUF_FN int32_t luf_dense_finish(const LufWork& W, const LufOut& O, const int32_t
             if (v == 0.0) continue;
             if (luf_bits(v) < luf_bits(kThreshold * luf_from_bits(luf_ld64(&W.cmax[j])))) continue;
             const unsigned long long cost = (unsigned long long)(uint32_t)(luf_ld(&drc[i]) - 1) * (unsigned long long)(uint32_t)(luf_ld(&dcc[j]) - 1);
-            const unsigned long long key = (cost << 32) | ((unsigned long long)(uint32_t)j << 16) | (uint32_t)i;
+            const unsigned long long key = (cost << 12) | ((unsigned long long)(uint32_t)j << 6) | (uint32_t)i;
             if (key < best) best = key;
         }
         luf_block_min64(best, &W.red[s & 1]);
         PAR_END
         const unsigned long long key = luf_ld64(&W.red[s & 1]);
         if (key == ~0ull) return LUF_SINGULAR;
-        const int32_t pi = (int32_t)(key & 0xffffu), pj = (int32_t)((key >> 16) & 0xffffu);
+        const int32_t pi = (int32_t)(key & 63u), pj = (int32_t)((key >> 6) & 63u);
         const double pv = D[pi * na + pj];
-        LUF_SINGLE {
-            luf_st64(&W.red[(s + 1) & 1], ~0ull);
-            dsr[pi] = done + s; dsc[pj] = done + s;
-            const int32_t t = drow[pi], u = dcol[pj];
-            W.ract[t] = 0; W.cact[u] = 0; W.bstep_row[t] = done + s; W.bstep_col[u] = done + s; W.cpiv[t] = u;
-            const int32_t i = W.brow[t], c = W.bcol[u], k = k_peel + done + s;
-            O.row_step[i] = k; O.col_step[c] = k; O.rowperm[k] = i; O.colperm[k] = c; O.diag[k] = pv;
-        }
+        LUF_SINGLE { luf_st64(&W.red[(s + 1) & 1], ~0ull); dsr[pi] = done + s; dsc[pj] = done + s; dpi[s] = pi; dpj[s] = pj; }
         PAR_FOR(j, na) { luf_st(&drc[j], 0); luf_st(&dcc[j], 0); luf_st64(&W.cmax[j], 0ull); }
         PAR_FOR(i, na) {                                                       // the multipliers stay where the column was
             if (i == pi || dsr[i] >= 0) continue;
@@ -430,6 +502,14 @@ LUF_FN int32_t luf_dense_finish(const LufWork& W, const LufOut& O, const int32_t
             luf_row_tally(&drc[i], v != 0.0);
             if (v != 0.0) { luf_add(&dcc[j], 1); luf_max64(&W.cmax[j], luf_bits(v)); }
         } PAR_END
+    }
+    }
+    // the steps on record; the multipliers join the list, every row's part of U goes back into the arena
+    PAR_FOR(s, na) {
+        const int32_t pi = dpi[s], pj = dpj[s], t = drow[pi], u = dcol[pj];
+        W.ract[t] = 0; W.cact[u] = 0; W.bstep_row[t] = done + s; W.bstep_col[u] = done + s; W.cpiv[t] = u;
+        const int32_t i = W.brow[t], c = W.bcol[u], k = k_peel + done + s;
+        O.row_step[i] = k; O.col_step[c] = k; O.rowperm[k] = i; O.colperm[k] = c; O.diag[k] = D[pi * na + pj];
     }
     PAR_FOR2(i, j, na, na) {
         if (dsc[j] >= dsr[i]) continue;
@@ -619,81 +699,119 @@ LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W,
         // dependent LDS reads while 500 threads wait at the barrier.
         {
             const int lane = LUF_TID & 63, wave = LUF_TID >> 6, nw = LUF_NT >> 6;
-            for (int32_t t = wave; t < nb; t += nw) {
-                if (!W.ract[t]) continue;
-                int32_t b = W.rbeg[t], n = W.rlen[t];
-                int32_t col = lane < n && n <= 64 ? W.ecol[b + lane] : -1;
-                double val = lane < n && n <= 64 ? W.eval[b + lane] : 0.0;
-                int32_t rk = col >= 0 ? W.prank[col] : -1;
-                unsigned long long hits = __ballot(rk >= 0);
-                if (n <= 64 && !hits) continue;
-                // what the row can grow to: beyond 64 entries it takes the serial form
-                int32_t grow = rk >= 0 ? W.rlen[W.acc[rk]] - 1 : 0;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) grow += __shfl_xor(grow, off, 64);
-                if (n > 64 || n + grow > 64) { if (lane == 0) eliminate_serial(t); continue; }
-                while (hits) {
-                    int32_t r = rk >= 0 ? rk : 0x7fffffff;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { const int32_t o = __shfl_xor(r, off, 64); r = o < r ? o : r; }
-                    const int hl = __ffsll((unsigned long long)__ballot(rk == r)) - 1;
-                    const double f = __shfl(val, hl, 64) / W.pval[r];
-                    const int32_t pc = __shfl(col, hl, 64);
-                    if (lane == 0) {
-                        const int32_t at = luf_fetch_add(&W.counters[1], 1);
-                        if (at < W.lt_cap) { W.lt_row[at] = t; W.lt_step[at] = done + r; W.lt_val[at] = f; }
-                    }
-                    {   // the entry of the pivot column leaves the row: the last entry takes its place
-                        const int32_t lc = __shfl(col, n - 1, 64), lr = __shfl(rk, n - 1, 64); const double lv = __shfl(val, n - 1, 64);
-                        if (lane == hl) { col = lc; val = lv; rk = lr; }
-                        if (lane == n - 1) { col = -1; val = 0.0; rk = -1; }
-                        --n;
-                    }
-                    const int32_t pr = W.acc[r], pb = W.rbeg[pr], pn = W.rlen[pr];
-                    for (int32_t q0 = 0; q0 < pn; q0 += 64) {
-                        const int32_t myw = q0 + lane < pn ? W.ecol[pb + q0 + lane] : -1;
-                        const double mypw = q0 + lane < pn ? W.eval[pb + q0 + lane] : 0.0;
-                        const int32_t cnt = pn - q0 < 64 ? pn - q0 : 64;
-                        for (int32_t q = 0; q < cnt; ++q) {
-                            const int32_t w = __shfl(myw, q, 64);
-                            if (w == pc) continue;
-                            const double pw = __shfl(mypw, q, 64);
-                            const unsigned long long mt = __ballot(col == w);
-                            if (mt) {
-                                const int ml = __ffsll(mt) - 1;
-                                const double nv = val - f * pw;
-                                if (__shfl(nv == 0.0 ? 1 : 0, ml, 64)) {                   // exact cancellation (decomposition/mod.rs:178)
-                                    const int32_t lc = __shfl(col, n - 1, 64), lr = __shfl(rk, n - 1, 64); const double lv = __shfl(val, n - 1, 64);
-                                    if (lane == ml) { col = lc; val = lv; rk = lr; }
-                                    if (lane == n - 1) { col = -1; val = 0.0; rk = -1; }
-                                    --n;
-                                    if (lane == 0) luf_add(&W.bcc[w], -1);
-                                } else if (lane == ml) {
-                                    val = nv;
+            // (values of a lane the whole wave agrees on: v_readlane, not a trip through the LDS crossbar)
+            auto rl = [](int32_t x, int l) { return __builtin_amdgcn_readlane(x, l); };
+            auto rld = [](double x, int l) {
+                union { double d; int32_t w[2]; } u; u.d = x;
+                u.w[0] = __builtin_amdgcn_readlane(u.w[0], l); u.w[1] = __builtin_amdgcn_readlane(u.w[1], l);
+                return u.d;
+            };
+            // the rows with an entry in one of this round's pivot columns, listed (a thread per row looks), then dealt to the waves
+            // one by one: the rows that keep being hit sit together, a wave that owned a block of rows did most of the round alone
+            int32_t* const hitlist = reinterpret_cast<int32_t*>(W.cprio);                      // (the priorities are spent)
+            int32_t* const hitgrow = hitlist + W.nb_cap;
+            PAR_FOR(tl, nb) {
+                int32_t my_grow = 0; bool hit = false;                                       // entries the pivot rows can add
+                if (W.ract[tl]) {
+                    const int32_t my_b = W.rbeg[tl], my_n = W.rlen[tl];
+                    for (int32_t e = my_b; e < my_b + my_n; ++e) { const int32_t r = W.prank[W.ecol[e]]; if (r >= 0) { hit = true; my_grow += W.rlen[W.acc[r]] - 1; } }
+                }
+                hitgrow[tl] = hit ? my_grow : -1;
+            } PAR_END
+            const int32_t nhit = luf_select(nb, [&](int32_t t) { return hitgrow[t] >= 0; }, hitlist);
+            {
+#if defined(LUF_WAVE_CLOCKS)
+                unsigned long long* const wc = reinterpret_cast<unsigned long long*>(W.counters + 8) + 12;
+                long long wt = (long long)__builtin_readcyclecounter();
+#define LUF_WLAP(i) do { const long long now_ = (long long)__builtin_readcyclecounter(); if (wave == 0 && lane == 0) wc[i] += (unsigned long long)(now_ - wt); wt = now_; } while (0)
+#define LUF_WCNT(i) do { if (wave == 0 && lane == 0) wc[i] += 1; } while (0)
+#else
+#define LUF_WLAP(i) do {} while (0)
+#define LUF_WCNT(i) do {} while (0)
+#endif
+                for (int32_t h = wave; h < nhit; h += nw) {
+                    LUF_WLAP(0);
+                    const int32_t t = hitlist[h];
+                    int32_t b = W.rbeg[t], n = W.rlen[t];
+                    const int32_t grow = hitgrow[t];
+                    if (n + grow > 64) { if (lane == 0) eliminate_serial(t); continue; }          // (what the row can grow to)
+                    int32_t col = lane < n ? W.ecol[b + lane] : -1;
+                    double val = lane < n ? W.eval[b + lane] : 0.0;
+                    int32_t rk = col >= 0 ? W.prank[col] : -1;
+                    unsigned long long hits = __ballot(rk >= 0);
+                    LUF_WLAP(1); LUF_WCNT(5);
+                    while (hits) {
+                        int32_t r = 0x7fffffff; int hl = 0;                                     // the lowest rank among the hits
+                        for (unsigned long long h = hits; h; h &= h - 1) { const int l = __ffsll(h) - 1; const int32_t x = rl(rk, l); if (x < r) { r = x; hl = l; } }
+                        const double f = rld(val, hl) / W.pval[r];
+                        const int32_t pc = rl(col, hl);
+                        if (lane == 0) {
+                            const int32_t at = luf_fetch_add(&W.counters[1], 1);
+                            if (at < W.lt_cap) { W.lt_row[at] = t; W.lt_step[at] = done + r; W.lt_val[at] = f; }
+                        }
+                        {   // the entry of the pivot column leaves the row: the last entry takes its place
+                            const int32_t lc = rl(col, n - 1), lr = rl(rk, n - 1); const double lv = rld(val, n - 1);
+                            if (lane == hl) { col = lc; val = lv; rk = lr; }
+                            if (lane == n - 1) { col = -1; val = 0.0; rk = -1; }
+                            --n;
+                        }
+                        const int32_t pr = W.acc[r], pb = W.rbeg[pr], pn = W.rlen[pr];
+                        for (int32_t q0 = 0; q0 < pn; q0 += 64) {
+                            const int32_t myw = q0 + lane < pn ? W.ecol[pb + q0 + lane] : -1;
+                            const double mypw = q0 + lane < pn ? W.eval[pb + q0 + lane] : 0.0;
+                            const int32_t cnt = pn - q0 < 64 ? pn - q0 : 64;
+                            LUF_WLAP(2); LUF_WCNT(6);
+                            for (int32_t q = 0; q < cnt; ++q) {
+                                LUF_WCNT(7);
+                                const int32_t w = rl(myw, q);
+                                if (w == pc) continue;
+                                const double pw = rld(mypw, q);
+                                const unsigned long long mt = __ballot(col == w);
+                                if (mt) {
+                                    const int ml = __ffsll(mt) - 1;
+                                    const double nv = val - f * pw;
+                                    if (rld(nv, ml) == 0.0) {                                  // exact cancellation (decomposition/mod.rs:178)
+                                        const int32_t lc = rl(col, n - 1), lr = rl(rk, n - 1); const double lv = rld(val, n - 1);
+                                        if (lane == ml) { col = lc; val = lv; rk = lr; }
+                                        if (lane == n - 1) { col = -1; val = 0.0; rk = -1; }
+                                        --n;
+                                        if (lane == 0) luf_add(&W.bcc[w], -1);
+                                    } else if (lane == ml) {
+                                        val = nv;
+                                    }
+                                } else {                                                       // fill (never in a column that pivots this round)
+                                    if (lane == n) { col = w; val = -f * pw; rk = -1; }
+                                    ++n;
+                                    if (lane == 0) luf_add(&W.bcc[w], 1);
                                 }
-                            } else {                                                       // fill (never in a column that pivots this round)
-                                if (lane == n) { col = w; val = -f * pw; rk = -1; }
-                                ++n;
-                                if (lane == 0) luf_add(&W.bcc[w], 1);
                             }
                         }
+                        hits = __ballot(rk >= 0);
+                        LUF_WLAP(3);
                     }
-                    hits = __ballot(rk >= 0);
+                    if (n > W.rcap[t]) {
+                        const int32_t want = n + n / 2 + 4;
+                        int32_t nbeg = 0;
+                        if (lane == 0) nbeg = luf_fetch_add(&W.counters[0], want);
+                        nbeg = __builtin_amdgcn_readfirstlane(nbeg);
+                        if (nbeg + want > W.arena_cap) { if (lane == 0) luf_st(&W.scalars[0], 2); continue; }     // (reported behind the round)
+                        b = nbeg;
+                        if (lane == 0) { W.rbeg[t] = nbeg; W.rcap[t] = want; }
+                    }
+                    if (lane < n) { W.ecol[b + lane] = col; W.eval[b + lane] = val; }
+                    if (lane == 0) W.rlen[t] = n;
+                    LUF_WLAP(4);
                 }
-                if (n > W.rcap[t]) {
-                    const int32_t want = n + n / 2 + 4;
-                    int32_t nbeg = 0;
-                    if (lane == 0) nbeg = luf_fetch_add(&W.counters[0], want);
-                    nbeg = __shfl(nbeg, 0, 64);
-                    if (nbeg + want > W.arena_cap) { if (lane == 0) luf_st(&W.scalars[0], 2); continue; }     // (reported behind the round)
-                    b = nbeg;
-                    if (lane == 0) { W.rbeg[t] = nbeg; W.rcap[t] = want; }
-                }
-                if (lane < n) { W.ecol[b + lane] = col; W.eval[b + lane] = val; }
-                if (lane == 0) W.rlen[t] = n;
             }
         } PAR_END
 #else
+#if defined(LUF_ROUND_TRACE)
+        { int rows = 0, hits = 0, over = 0, work = 0, maxwork = 0;
+          for (int32_t t = 0; t < nb; ++t) { if (!W.ract[t]) continue; int h = 0, grow = 0;
+              for (int32_t e = W.rbeg[t]; e < W.rbeg[t] + W.rlen[t]; ++e) { const int32_t r = W.prank[W.ecol[e]]; if (r >= 0) { ++h; grow += W.rlen[W.acc[r]] - 1; } }
+              if (h) { ++rows; hits += h; work += grow; if (grow > maxwork) maxwork = grow; if (W.rlen[t] + grow > 64) ++over; } }
+          std::printf("   elimination: %d rows hit, %d hits, %d pivot entries walked (most on one row %d), %d rows beyond the 64-entry bound\n", rows, hits, work, maxwork, over); }
+#endif
         PAR_FOR(t, nb) { if (W.ract[t]) eliminate_serial(t); } PAR_END
 #endif
         LUF_LAP(6);
@@ -746,17 +864,17 @@ LUF_FN void luf_bump(const LufMatrix& M, const int32_t* basis, const LufWork& W,
     } PAR_END
     const int32_t n_l = luf_ld(&W.counters[1]), n_u = luf_ld(&W.counters[5]);
     LUF_SINGLE {
-        if (n_l > W.lt_cap || n_u > W.lt_cap || n_l > O.cap || n_u > O.cap) O.status[0] = LUF_NO_ROOM;
+        if (n_l > W.lt_cap || n_u > W.lt_cap || n_l > O.cap || n_u > O.cap || n_l > W.vtmp_cap || n_u > W.vtmp_cap) O.status[0] = LUF_NO_ROOM;
         O.status[3] = n_l; O.status[4] = n_u;
     } PAR_END
-    if (n_l > W.lt_cap || n_u > W.lt_cap || n_l > O.cap || n_u > O.cap) return;
+    if (n_l > W.lt_cap || n_u > W.lt_cap || n_l > O.cap || n_u > O.cap || n_l > W.vtmp_cap || n_u > W.vtmp_cap) return;
     LUF_LAP(8);
     // A view: the triplets bucketed by `bk`, every bucket ascending in `od` -- count, offsets, the `od` of every bucket side by side
     // (any order), then each entry goes to offset + (the number of entries of its bucket with a smaller `od`): coordinates are
     // unique, so the result does not depend on the execution.  (From here on the arena is free: `vw` / `vtmp` may lie in its LDS.)
     auto view = [&](int32_t n, const int32_t* bk, const int32_t* od, const double* val, const LufTriangle& R) {
         int32_t* cnt = W.vw;
-        int32_t* tmp = n <= W.vtmp_lds_cap ? W.vtmp_lds : W.vtmp;
+        int32_t* tmp = W.vtmp;
         PAR_FOR(k, m + 1) luf_st(&cnt[k], 0); PAR_END
         PAR_FOR(e, n) luf_add(&cnt[bk[e] + 1], 1); PAR_END
         PAR_FOR(k, m + 1) { R.ptr[k] = luf_ld(&cnt[k]); } PAR_END

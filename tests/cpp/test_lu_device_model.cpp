@@ -91,11 +91,11 @@ struct Buffers {
         W.lt_row = ti(cap); W.lt_step = ti(cap); W.lt_val = td(cap); W.lt_cap = cap; W.lt_ptr = ti(nb_cap + 1); W.lt_ord = ti(cap);
         W.counters = ti(128); W.red = red.data(); W.scalars = ti(16);
         const int dc = dense_cap();
-        dense.assign((size_t)dc * dc + 1, 0.0); dint.assign(6 * (size_t)dc + 1, 0);
+        dense.assign((size_t)dc * dc + 1, 0.0); dint.assign(8 * (size_t)dc + 1, 0);
         W.dense = dense.data(); W.dint = dint.data(); W.dense_cap = dc;
         utv.assign((size_t)cap + 1, 0.0); uti.assign(3 * (size_t)cap + m + 4, 0);
         W.ut_row = uti.data(); W.ut_col = uti.data() + cap; W.ut_val = utv.data(); W.vtmp = uti.data() + 2 * (size_t)cap; W.vw = uti.data() + 3 * (size_t)cap;
-        W.vtmp_lds = nullptr; W.vtmp_lds_cap = 0;
+        W.vtmp_cap = cap;
         O.status = ti(8); O.rowperm = ti(m); O.colperm = ti(m); O.row_step = ti(m); O.col_step = ti(m); O.diag = td(m);
         LufTriangle* tri[4] = {&O.Lf, &O.Uf, &O.Ub, &O.Lb};
         for (auto* t : tri) { t->ptr = ti(m + 1); t->idx = ti(cap); t->val = td(cap); }
