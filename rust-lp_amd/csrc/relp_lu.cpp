@@ -186,6 +186,9 @@ bool lu_factor_csc(int32_t m, const int64_t* cptr, const int32_t* cidx, const do
     col_single.reserve(4 * (size_t)m); row_single.reserve(4 * (size_t)m);
     for (int32_t j = 0; j < m; ++j) if (ccount[j] == 1) col_single.push_back(j);
     for (int32_t i = 0; i < m; ++i) if (rows.len[i] == 1) row_single.push_back(i);
+    static const bool peel_stacks = std::getenv("RELP_LU_PEEL_STACKS") && std::atoi(std::getenv("RELP_LU_PEEL_STACKS")) != 0;
+    int64_t col_head = 0, col_end = (int64_t)col_single.size(), row_head = 0, row_end = 0;
+    bool peel_cols = true;
     // the sparsest active row / column of the bump, ties to the lower index
     // (built when the first pivot has to be SEARCHED for: while singletons last -- a whole multi-commodity basis of 64,000 rows,
     // the triangular part of every other -- the two sets of 64 bit-vectors of m bits each are neither filled nor maintained;
@@ -226,21 +229,39 @@ bool lu_factor_csc(int32_t m, const int64_t* cptr, const int32_t* cidx, const do
 
     for (int32_t k = 0; k < m; ++k) {
         int32_t spi = -1, spj = -1; double spv = 0.0;
-        while (!col_single.empty() && spj < 0) {
-            const int32_t j = col_single.back(); col_single.pop_back();
-            if (step_of_col[j] >= 0 || ccount[j] != 1) continue;
-            for (int32_t t = 0; t < colrows.len[j]; ++t) {
-                const int32_t i = colrows.store[colrows.beg[j] + t];
-                if (row_done[i]) continue;
-                const int32_t at = find_in_row(i, j);
-                if (at >= 0 && rv[at] != 0.0) { spi = i; spj = j; spv = rv[at]; break; }
+        // Singletons are taken in ROUNDS, column singletons and row singletons in turn (queues, a round = what was queued when it
+        // began): a basis that is all singletons -- the multi-commodity bases of 64,000 rows -- is triangular either way, but taken
+        // as column singletons only (what the stacks of rounds 1-3 did) it is ONE triangle, U, 115 levels deep; eaten from both
+        // ends it is an L and a U of 32 levels each, and the sweeps of a pivot walk 64 levels instead of 115 (measured: 183,000
+        // clocks per pivot against 223,000).  RELP_LU_PEEL_STACKS=1 restores the old order (measurements).
+        auto next_col_singleton = [&]() {
+            while (col_head < col_end && spj < 0) {
+                const int32_t j = col_single[col_head++];
+                if (step_of_col[j] >= 0 || ccount[j] != 1) continue;
+                for (int32_t t = 0; t < colrows.len[j]; ++t) {
+                    const int32_t i = colrows.store[colrows.beg[j] + t];
+                    if (row_done[i]) continue;
+                    const int32_t at = find_in_row(i, j);
+                    if (at >= 0 && rv[at] != 0.0) { spi = i; spj = j; spv = rv[at]; break; }
+                }
             }
-        }
-        while (!row_single.empty() && spj < 0) {
-            const int32_t i = row_single.back(); row_single.pop_back();
-            if (row_done[i] || rows.len[i] != 1) continue;
-            const int32_t j = rows.store[rows.beg[i]]; const double v = rv[rows.beg[i]];
-            if (v != 0.0 && std::fabs(v) >= 0.1 * col_max_of(j)) { spi = i; spj = j; spv = v; }
+        };
+        auto next_row_singleton = [&]() {
+            while (row_head < row_end && spj < 0) {
+                const int32_t i = row_single[row_head++];
+                if (row_done[i] || rows.len[i] != 1) continue;
+                const int32_t j = rows.store[rows.beg[i]]; const double v = rv[rows.beg[i]];
+                if (v != 0.0 && std::fabs(v) >= 0.1 * col_max_of(j)) { spi = i; spj = j; spv = v; }
+            }
+        };
+        if (peel_stacks) {                                  // columns while there are any, then rows, newest first
+            while (!col_single.empty() && spj < 0) { col_head = (int64_t)col_single.size() - 1; col_end = col_head + 1; next_col_singleton(); col_single.pop_back(); }
+            while (!row_single.empty() && spj < 0) { row_head = (int64_t)row_single.size() - 1; row_end = row_head + 1; next_row_singleton(); row_single.pop_back(); }
+        } else {
+            for (int turn = 0; turn < 3 && spj < 0; ++turn) {
+                if (peel_cols) { next_col_singleton(); if (spj < 0) { peel_cols = false; row_end = (int64_t)row_single.size(); } }
+                else { next_row_singleton(); if (spj < 0) { peel_cols = true; col_end = (int64_t)col_single.size(); } }
+            }
         }
         // Markowitz search restricted to the sparsest active row and the sparsest active column
         // (pivoting.rs:45-81 searches every remaining entry): candidate A = the entry of the sparsest row
