@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r4", "corpus_sweep.json"))
     ap.add_argument("--max-pivots", type=int, default=400000)
     ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--verified", action="store_true", help="engine.solve_verified per file instead of the engine x configuration grid")
     ap.add_argument("names", nargs="*")
     args = ap.parse_args()
     idx = corpus.index()
@@ -81,6 +82,8 @@ def main():
     names.sort(key=lambda n: idx[n]["nr_rows"] * idx[n]["nr_columns"])
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     results = {}
+    if args.verified:
+        return verified(names, idx, args)
     for name in names:
         rec = idx[name]
         md, fixed = corpus.load(name)
@@ -104,6 +107,34 @@ def main():
         print(f"{name} m={res['m']} n={res['n']} highs={res['highs']} pin={res['pin']} | {line}", flush=True)
         json.dump(results, open(args.out, "w"), indent=1)
     markdown(results, os.path.splitext(args.out)[0] + ".md")
+
+
+def verified(names, idx, args):
+    """engine.solve_verified on every file: outcome, the leg that was accepted, agreement with HiGHS."""
+    out, rows = {}, ["| file | m x n | outcome | accepted leg | legs tried | objective | HiGHS (same LP) |", "|---|---|---|---|---|---|---|"]
+    for name in names:
+        rec = idx[name]
+        md, fixed = corpus.load(name)
+        t0 = time.perf_counter()
+        oc, t, report = engine.solve_verified(md, seconds_per_leg=args.seconds)
+        obj = t.objective_function_value() + fixed if (t is not None and oc == engine.OPTIMAL) else None
+        if t is not None:
+            t.close()
+        ok = obj is not None and rec.get("highs_objective") is not None and rel(obj, rec["highs_objective"]) <= 1e-6
+        last = report["legs"][-1]
+        out[name] = {"outcome": engine.OUTCOME_NAMES.get(oc, str(oc)), "verified": report["verified"], "objective": obj, "agrees_with_highs": ok,
+                     "legs": report["legs"], "seconds": round(time.perf_counter() - t0, 2)}
+        rows.append(f"| {name} | {rec['nr_rows']} x {rec['nr_columns']} | {out[name]['outcome']}{'' if report['verified'] else ' (unverified)'} | "
+                    f"{last['config'] + ' / ' + last['engine'] if report['verified'] else ''} | {len(report['legs'])} | {'' if obj is None else f'{obj:.10g}'} | {rec.get('highs_objective'):.10g} |")
+        print(name, out[name]["outcome"], report["verified"], ok, len(report["legs"]), out[name]["seconds"], flush=True)
+        json.dump(out, open(args.out, "w"), indent=1)
+    n_ok = sum(1 for v in out.values() if v["agrees_with_highs"] and v["verified"])
+    n_wrong = sum(1 for v in out.values() if v["verified"] and v["outcome"] == "optimal" and not v["agrees_with_highs"])
+    rows.append("")
+    rows.append(f"{n_ok} of {len(out)} files: a verified optimum that agrees with HiGHS; {n_wrong} verified optima that do not.")
+    with open(os.path.splitext(args.out)[0] + ".md", "w") as f:
+        f.write("\n".join(rows) + "\n")
+    print(rows[-1])
 
 
 def markdown(results, path):
