@@ -342,4 +342,46 @@ inline OptimizationResult solve_relaxation(const MatrixData& data, const Options
     return t.solve_relaxation();
 }
 
+// Beyond the reference: one answer, checked, out of several attempts (rust-lp_amd/engine.py: solve_verified is the same
+// procedure).  Legs of (configuration, engine) -- the safeguards of relp_robust_config on LU, revised, tableau, then the literal
+// rules on the three -- each with a pivot budget; `FiniteOptimum` stands only with relp_check_basis residuals inside
+// (1e-5, 1e-3, b >= -1e-6), `Infeasible` / `Unbounded` only when a second engine says the same.  Returns the result and
+// whether it verified (`legs_tried` optional); an unverified result is the last leg's, and may be none at all.
+struct VerifiedResult { std::optional<OptimizationResult> result; bool verified = false; int legs_tried = 0; };
+inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_leg = -1) {
+    VerifiedResult out;
+    int infeasible_on = 0, unbounded_on = 0;
+    for (int leg = 0; leg < 6; ++leg) {
+        Options o = leg < 3 ? Options::robust() : Options();
+        o.inverse_maintenance((InverseMaintenance)(leg % 3 == 0 ? RELP_ENGINE_LU : leg % 3 == 1 ? RELP_ENGINE_REVISED : RELP_ENGINE_TABLEAU));
+        ++out.legs_tried;
+        try {
+            Tableau t(data, o);
+            const int64_t budget = pivots_per_leg >= 0 ? pivots_per_leg : 30 * ((int64_t)t.nr_rows() + t.nr_columns());
+            int64_t total = 0, done = 0;
+            relp_outcome_t oc = RELP_RUNNING;
+            while (total < budget) {
+                oc = t.run(std::min<int64_t>(20000, budget - total), &done);
+                total += done;
+                if (oc != RELP_RUNNING && oc != RELP_PHASE_ONE_DONE) break;
+            }
+            if (oc == RELP_OPTIMAL) {
+                double ident = 0, basic = 0, min_b = 0;
+                if (relp_check_basis(t.handle(), &ident, &basic, &min_b) == RELP_OK && ident <= 1e-5 && basic <= 1e-3 && min_b >= -1e-6) {
+                    out.result = OptimizationResult{OptimizationResult::FiniteOptimum, t.current_bfs()};
+                    out.verified = true;
+                    return out;
+                }
+            } else if (oc == RELP_INFEASIBLE || oc == RELP_UNBOUNDED) {
+                int& seen = oc == RELP_INFEASIBLE ? infeasible_on : unbounded_on;
+                out.result = OptimizationResult{oc == RELP_INFEASIBLE ? OptimizationResult::Infeasible : OptimizationResult::Unbounded, {}};
+                if (++seen >= 2) { out.verified = true; return out; }
+            }
+        } catch (const Error&) {
+            // (a leg that fails -- no row in phase 1, a singular basis -- is a leg without an answer)
+        }
+    }
+    return out;
+}
+
 }  // namespace relp_host

@@ -252,6 +252,11 @@ int main() {
             CHECK(t.shard_run() == RELP_OPTIMAL);
             CHECK(near(t.current_bfs(), SparseVector{{1, 0.5}, {3, 2.5}, {4, 1.5}}));
         }
+        {   // solve_verified: the first leg (safeguards, LU) answers and the answer passes relp_check_basis
+            const VerifiedResult v = solve_verified(problem_2());
+            CHECK(v.verified && v.legs_tried == 1 && v.result.has_value());
+            CHECK(v.result->kind == OptimizationResult::FiniteOptimum && near(v.result->solution, SparseVector{{1, 0.5}, {3, 2.5}, {4, 1.5}}));
+        }
     } catch (const std::exception& e) {
         std::printf("unexpected exception: %s\n", e.what());
         return 2;
