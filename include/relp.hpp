@@ -109,6 +109,32 @@ class MatrixData {
     // normal + range/<=/>= slacks + bound slacks (:37-52)
     int32_t nr_columns() const { return nr_normal_ + nr_range_ + nr_le_ + nr_ge_ + nr_variable_bounds(); }
 
+    // Beyond the reference (which solves the data as read): geometric scaling, rows then columns by 1 / sqrt(min |a| max |a|) of the
+    // line, `sweeps` times, every factor rounded to a power of two -- A' = R A S, b' = R b, ranges' = R ranges, c' = S c, upper
+    // bounds' = ub / s; x = S x' and the objective value is unchanged.  What the PILOT family needs (rust-lp_amd/matrix_data.py:
+    // scaled, the same procedure; profiles/r04_corpus_verified.md).
+    struct Scaled;
+    Scaled scaled(int sweeps = 4) const;
+    // a basic feasible solution of scaled().data in the units of *this (columns as in matrix_data.rs:403-409)
+    SparseVector unscale(const SparseVector& bfs, const std::vector<double>& r, const std::vector<double>& s) const {
+        std::vector<int32_t> bounded;
+        for (int32_t j = 0; j < nr_normal_; ++j) if (std::isfinite(upper_[j])) bounded.push_back(j);
+        const int32_t o_range = nr_normal_, o_le = o_range + nr_range_, o_ge = o_le + nr_le_, o_bound = o_ge + nr_ge_, o_rb = o_bound + (int32_t)bounded.size();
+        SparseVector out;
+        for (const auto& e : bfs) {
+            const int32_t c = e.first;
+            double v = e.second;
+            if (c < o_range) v *= s[c];
+            else if (c < o_le) v /= r[nr_eq_ + (c - o_range)];
+            else if (c < o_ge) v /= r[nr_eq_ + nr_range_ + (c - o_le)];
+            else if (c < o_bound) v /= r[nr_eq_ + nr_range_ + nr_le_ + (c - o_ge)];
+            else if (c < o_rb) v *= s[bounded[c - o_bound]];
+            else v /= r[nr_eq_ + (c - o_rb)];
+            out.emplace_back(c, v);
+        }
+        return out;
+    }
+
     relp_matrix_data_t view() const {
         relp_matrix_data_t v{};
         v.nr_normal = nr_normal_; v.nr_eq = nr_eq_; v.nr_range = nr_range_; v.nr_le = nr_le_; v.nr_ge = nr_ge_;
@@ -137,6 +163,38 @@ class MatrixData {
     std::vector<int32_t> row_idx_;
     std::vector<double> values_, b_, ranges_, cost_, upper_;
 };
+
+struct MatrixData::Scaled { MatrixData data; std::vector<double> row_scale, column_scale; };
+inline MatrixData::Scaled MatrixData::scaled(int sweeps) const {
+    const int32_t m = nr_constraints(), n = nr_normal_;
+    std::vector<double> r(m, 1.0), s(n, 1.0);
+    auto pass = [&](bool by_row) {
+        const int32_t count = by_row ? m : n;
+        std::vector<double> lo(count, std::numeric_limits<double>::infinity()), hi(count, 0.0);
+        for (int32_t j = 0; j < n; ++j)
+            for (int64_t e = col_ptr_[j]; e < col_ptr_[j + 1]; ++e) {
+                const double v = std::fabs(values_[e]) * r[row_idx_[e]] * s[j];
+                if (v == 0.0) continue;
+                const int32_t l = by_row ? row_idx_[e] : j;
+                lo[l] = std::min(lo[l], v); hi[l] = std::max(hi[l], v);
+            }
+        std::vector<double>& f = by_row ? r : s;
+        for (int32_t l = 0; l < count; ++l) if (hi[l] > 0.0) f[l] /= std::sqrt(lo[l] * hi[l]);
+    };
+    for (int k = 0; k < sweeps; ++k) { pass(true); pass(false); }
+    for (double& v : r) v = std::exp2(std::nearbyint(std::log2(v)));
+    for (double& v : s) v = std::exp2(std::nearbyint(std::log2(v)));
+    Scaled out{*this, r, s};
+    MatrixData& d = out.data;
+    for (int32_t j = 0; j < n; ++j) {
+        for (int64_t e = col_ptr_[j]; e < col_ptr_[j + 1]; ++e) d.values_[e] = values_[e] * r[row_idx_[e]] * s[j];
+        d.cost_[j] = cost_[j] * s[j];
+        d.upper_[j] = upper_[j] / s[j];
+    }
+    for (int32_t i = 0; i < m; ++i) d.b_[i] = b_[i] * r[i];
+    for (int32_t k = 0; k < nr_range_; ++k) d.ranges_[k] = ranges_[k] * r[nr_eq_ + k];
+    return out;
+}
 
 // relp_config_t with the reference's defaults (FirstProfitableWithMemory in phase 1, phase_one.rs:55,97;
 // SteepestDescent in phase 2, two_phase/mod.rs:44)
@@ -343,20 +401,26 @@ inline OptimizationResult solve_relaxation(const MatrixData& data, const Options
 }
 
 // Beyond the reference: one answer, checked, out of several attempts (rust-lp_amd/engine.py: solve_verified is the same
-// procedure).  Legs of (configuration, engine) -- the safeguards of relp_robust_config on LU, revised, tableau, then the literal
-// rules on the three -- each with a pivot budget; `FiniteOptimum` stands only with relp_check_basis residuals inside
-// (1e-5, 1e-3, b >= -1e-6), `Infeasible` / `Unbounded` only when a second engine says the same.  Returns the result and
-// whether it verified (`legs_tried` optional); an unverified result is the last leg's, and may be none at all.
-struct VerifiedResult { std::optional<OptimizationResult> result; bool verified = false; int legs_tried = 0; };
+// procedure).  Legs of (data as read | scaled, configuration, engine) in a fixed order, each with a pivot budget; `FiniteOptimum`
+// stands only with relp_check_basis residuals inside (1e-5, 1e-3, b >= -1e-6) -- its solution is in the units of the data, whichever
+// leg found it --, `Infeasible` / `Unbounded` only when every leg has run, none reached a verified optimum and two engines said so
+// on the data as read.  An unverified result is the last leg's, and may be none at all.
+struct VerifiedResult { std::optional<OptimizationResult> result; bool verified = false; bool scaled = false; int legs_tried = 0; };
 inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_leg = -1) {
+    struct Leg { bool scaled, robust; int32_t engine; };
+    static const Leg legs[9] = {{false, true, RELP_ENGINE_LU}, {true, true, RELP_ENGINE_LU}, {true, true, RELP_ENGINE_REVISED},
+                                {false, true, RELP_ENGINE_REVISED}, {false, true, RELP_ENGINE_TABLEAU}, {true, true, RELP_ENGINE_TABLEAU},
+                                {false, false, RELP_ENGINE_LU}, {false, false, RELP_ENGINE_REVISED}, {false, false, RELP_ENGINE_TABLEAU}};
     VerifiedResult out;
-    int infeasible_on = 0, unbounded_on = 0;
-    for (int leg = 0; leg < 6; ++leg) {
-        Options o = leg < 3 ? Options::robust() : Options();
-        o.inverse_maintenance((InverseMaintenance)(leg % 3 == 0 ? RELP_ENGINE_LU : leg % 3 == 1 ? RELP_ENGINE_REVISED : RELP_ENGINE_TABLEAU));
+    std::optional<MatrixData::Scaled> sc;
+    uint32_t infeasible_on = 0, unbounded_on = 0;      // bit per engine, data as read
+    for (const Leg& leg : legs) {
+        Options o = leg.robust ? Options::robust() : Options();
+        o.inverse_maintenance((InverseMaintenance)leg.engine);
         ++out.legs_tried;
+        if (leg.scaled && !sc) sc = data.scaled();
         try {
-            Tableau t(data, o);
+            Tableau t(leg.scaled ? sc->data : data, o);
             const int64_t budget = pivots_per_leg >= 0 ? pivots_per_leg : 30 * ((int64_t)t.nr_rows() + t.nr_columns());
             int64_t total = 0, done = 0;
             relp_outcome_t oc = RELP_RUNNING;
@@ -368,19 +432,23 @@ inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_
             if (oc == RELP_OPTIMAL) {
                 double ident = 0, basic = 0, min_b = 0;
                 if (relp_check_basis(t.handle(), &ident, &basic, &min_b) == RELP_OK && ident <= 1e-5 && basic <= 1e-3 && min_b >= -1e-6) {
-                    out.result = OptimizationResult{OptimizationResult::FiniteOptimum, t.current_bfs()};
-                    out.verified = true;
+                    SparseVector x = t.current_bfs();
+                    if (leg.scaled) x = data.unscale(x, sc->row_scale, sc->column_scale);
+                    out.result = OptimizationResult{OptimizationResult::FiniteOptimum, std::move(x)};
+                    out.verified = true; out.scaled = leg.scaled;
                     return out;
                 }
             } else if (oc == RELP_INFEASIBLE || oc == RELP_UNBOUNDED) {
-                int& seen = oc == RELP_INFEASIBLE ? infeasible_on : unbounded_on;
                 out.result = OptimizationResult{oc == RELP_INFEASIBLE ? OptimizationResult::Infeasible : OptimizationResult::Unbounded, {}};
-                if (++seen >= 2) { out.verified = true; return out; }
+                if (!leg.scaled) (oc == RELP_INFEASIBLE ? infeasible_on : unbounded_on) |= 1u << leg.engine;
             }
         } catch (const Error&) {
             // (a leg that fails -- no row in phase 1, a singular basis -- is a leg without an answer)
         }
     }
+    auto two = [](uint32_t bits) { return (bits & (bits - 1)) != 0; };
+    if (two(infeasible_on)) { out.result = OptimizationResult{OptimizationResult::Infeasible, {}}; out.verified = true; }
+    else if (two(unbounded_on)) { out.result = OptimizationResult{OptimizationResult::Unbounded, {}}; out.verified = true; }
     return out;
 }
 

@@ -593,34 +593,41 @@ def solve_relaxation(provider: MatrixData, **config_overrides):
 
 
 # ---- beyond the reference: one answer, checked, out of several attempts -------------------------------------------------------
-# The reference has ONE configuration and no check of what it returns; in f64 its literal rules miss optima the safeguards of
-# relp_robust_config reach, and the other way round (profiles/r04_corpus_sweep.md: 70 of the reference's 83 Netlib LPs clean under the
-# robust configuration on all engines, 73 on at least one, 75 when the literal rules get their turn too).  `solve_verified` is that
-# union as a procedure: legs of (configuration, engine) in a fixed order, each with a pivot and a time budget, and an outcome stands
-# only when it verifies -- `optimal` by the residuals of relp_check_basis (B^-1 B = I, basis columns are unit columns, b >= 0: the
-# wrong optima of the sweep all sit on a basis with b_i < 0 by 0.07 or more), `infeasible` / `unbounded` by a second leg on another
-# engine that says the same.
+# The reference has ONE configuration, solves the data as read and does not check what it returns; in f64 its literal rules miss optima
+# the safeguards of relp_robust_config reach, and the other way round, and the PILOT family needs scaling while six other files of its
+# Netlib directory are LOST by scaling (absolute tolerances on scaled rows).  `solve_verified` is the union as a procedure: legs of
+# (data as read | scaled by MatrixData.scaled, configuration, engine) in a fixed order, each with a pivot and a time budget, and an
+# outcome stands only when it verifies -- `optimal` by the residuals of relp_check_basis (B^-1 B = I, basis columns are unit columns,
+# b >= 0: the wrong optima of the sweeps all sit on a basis with some b_i <= -0.07), `infeasible` / `unbounded` only when every leg
+# has run, none reached a verified optimum, and two engines said so on the data AS READ (on scaled data two engines agreed on a wrong
+# `infeasible` for WOODW).
 VERIFY_IDENTITY, VERIFY_BASIC, VERIFY_MIN_B = 1e-5, 1e-3, -1e-6
-VERIFIED_LEGS = (("robust", ENGINE_LU), ("robust", ENGINE_REVISED), ("robust", ENGINE_TABLEAU),
-                 ("default", ENGINE_LU), ("default", ENGINE_REVISED), ("default", ENGINE_TABLEAU))
+VERIFIED_LEGS = (("read", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_REVISED),
+                 ("read", "robust", ENGINE_REVISED), ("read", "robust", ENGINE_TABLEAU), ("scaled", "robust", ENGINE_TABLEAU),
+                 ("read", "default", ENGINE_LU), ("read", "default", ENGINE_REVISED), ("read", "default", ENGINE_TABLEAU))
 _ENGINE_NAMES = {ENGINE_REVISED: "revised", ENGINE_TABLEAU: "tableau", ENGINE_LU: "lu"}
 
 
 def solve_verified(provider: MatrixData, pivots_per_leg: Optional[int] = None, seconds_per_leg: float = 60.0, legs=VERIFIED_LEGS):
     """Returns (outcome, tableau or None, report).  `report["verified"]` says whether the outcome passed its check; `report["legs"]`
-    lists what every leg did.  The tableau of the leg that was accepted is returned open (close it); the others are closed."""
+    lists what every leg did.  The tableau of the leg that was accepted is returned open (close it); the others are closed.  When
+    the accepted leg ran on scaled data (`report["scaled"]`) the objective value is still the provider's; a solution is brought
+    back by `provider.unscale_bfs(t.current_bfs(), report["row_scale"], report["column_scale"])`."""
     import time
     budget = pivots_per_leg if pivots_per_leg is not None else 30 * (int(provider.nr_rows) + int(provider.nr_columns))
-    report = {"legs": [], "verified": False}
-    terminal = {}                                       # infeasible / unbounded -> engines that said so
-    last = (RUNNING, None)
-    for cfg_name, kind in legs:
-        leg = {"config": cfg_name, "engine": _ENGINE_NAMES[kind]}
+    report = {"legs": [], "verified": False, "scaled": False}
+    scaled = None
+    said = {}                                           # infeasible / unbounded -> engines that said so on the data as read
+    last = RUNNING
+    for data, cfg_name, kind in legs:
+        leg = {"data": data, "config": cfg_name, "engine": _ENGINE_NAMES[kind]}
         report["legs"].append(leg)
         t0 = time.perf_counter()
+        if data == "scaled" and scaled is None:
+            scaled = provider.scaled()
         cfg = robust_config(engine=kind) if cfg_name == "robust" else default_config(engine=kind)
         try:
-            t = Tableau(provider, config=cfg)
+            t = Tableau(scaled[0] if data == "scaled" else provider, config=cfg)
         except RelpError as e:
             leg["outcome"] = "create_failed: " + str(e)[:120]
             continue
@@ -633,20 +640,23 @@ def solve_verified(provider: MatrixData, pivots_per_leg: Optional[int] = None, s
                     break
             leg["pivots"] = total
             leg["outcome"] = OUTCOME_NAMES.get(oc, str(oc)) if oc not in (RUNNING, PHASE_ONE_DONE) else "limit"
+            last = oc
             if oc == OPTIMAL:
                 ident, basic, min_b = t.check_basis()
                 leg["check_basis"] = [ident, basic, min_b]
                 if ident <= VERIFY_IDENTITY and basic <= VERIFY_BASIC and min_b >= VERIFY_MIN_B:
                     report["verified"] = True
-                    report["seconds"] = round(time.perf_counter() - t0, 3)
+                    report["scaled"] = data == "scaled"
+                    if data == "scaled":
+                        report["row_scale"], report["column_scale"] = scaled[1], scaled[2]
                     return OPTIMAL, t, report
-            elif oc in (INFEASIBLE, UNBOUNDED):
-                terminal.setdefault(oc, set()).add(kind)
-                if len(terminal[oc]) >= 2:
-                    report["verified"] = True
-                    return oc, t, report
-            last = (oc, None)
+            elif oc in (INFEASIBLE, UNBOUNDED) and data == "read":
+                said.setdefault(oc, set()).add(kind)
         except RelpError as e:
             leg["outcome"] = "error: " + str(e)[:120]
         t.close()
-    return last[0], None, report
+    for oc, engines in said.items():
+        if len(engines) >= 2:
+            report["verified"] = True
+            return oc, None, report
+    return last, None, report

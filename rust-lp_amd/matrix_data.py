@@ -72,6 +72,68 @@ class MatrixData:
             self.dense = a
         return self
 
+    # ---- beyond the reference: scaling in front of the engines (the reference solves the data as read) ---------------------------
+    def scaled(self, sweeps: int = 4):
+        """Geometric scaling: rows, then columns, by 1 / sqrt(min |a| * max |a|) of the line, `sweeps` times, every factor rounded to
+        a power of two (so scaling and unscaling are exact in f64).  Returns (scaled MatrixData, row factors r, column factors s) with
+        A' = R A S, b' = R b, ranges' = R ranges, c' = S c, upper bounds' = ub / s: x = S x', the objective value is unchanged.
+        On the reference's Netlib directory this is what the PILOT family needs (|a| from 1e-5 to 6e6 -> 1e-2 to 8e1): PEROLD,
+        PILOT-JA and PILOTNOV, unsolved by every engine and configuration on the data as read, solve on the first or second leg of
+        engine.solve_verified (profiles/r04_corpus_verified.md)."""
+        md = self.ensure_csc()
+        m, n = md.nr_constraints, md.nr_normal
+        cols = np.repeat(np.arange(n), np.diff(np.asarray(md.col_ptr)))
+        rows = np.asarray(md.row_idx, dtype=np.int64)
+        a = np.abs(np.asarray(md.values, dtype=np.float64))
+        nz = a > 0
+        r, s = np.ones(m), np.ones(n)
+        for _ in range(sweeps):
+            for line, count, other_is_col in ((rows, m, True), (cols, n, False)):
+                v = a * r[rows] * s[cols]
+                lo, hi = np.full(count, np.inf), np.zeros(count)
+                np.minimum.at(lo, line[nz], v[nz])
+                np.maximum.at(hi, line[nz], v[nz])
+                ok = hi > 0
+                f = np.ones(count)
+                f[ok] = 1.0 / np.sqrt(lo[ok] * hi[ok])
+                if other_is_col:
+                    r *= f
+                else:
+                    s *= f
+        r = 2.0 ** np.round(np.log2(r))
+        s = 2.0 ** np.round(np.log2(s))
+        ranges = np.asarray(md.ranges, dtype=np.float64) * r[md.nr_eq:md.nr_eq + md.nr_range] if md.nr_range else np.zeros(0)
+        out = MatrixData(md.nr_normal, md.nr_eq, md.nr_range, md.nr_le, md.nr_ge, np.asarray(md.b, dtype=np.float64) * r,
+                         np.asarray(md.cost, dtype=np.float64) * s, np.asarray(md.upper_bound, dtype=np.float64) / s, ranges,
+                         np.asarray(md.col_ptr), np.asarray(md.row_idx), np.asarray(md.values, dtype=np.float64) * r[rows] * s[cols])
+        return out, r, s
+
+    def unscale_bfs(self, bfs, r: np.ndarray, s: np.ndarray):
+        """A basic feasible solution [(column, value)] of `self.scaled()` in the units of `self`: structural columns and the slacks
+        of their bounds times s, the slacks of a row (range, <=, >=, range bound) divided by the row's r (columns as in
+        matrix_data.rs:403-409: normal | range slacks | <= slacks | >= slacks | bound slacks | range-bound slacks)."""
+        bounded = np.nonzero(np.isfinite(np.asarray(self.upper_bound)))[0]
+        o_range = self.nr_normal
+        o_le = o_range + self.nr_range
+        o_ge = o_le + self.nr_le
+        o_bound = o_ge + self.nr_ge
+        o_rb = o_bound + len(bounded)
+        out = []
+        for c, v in bfs:
+            if c < o_range:
+                out.append((c, v * s[c]))
+            elif c < o_le:
+                out.append((c, v / r[self.nr_eq + (c - o_range)]))
+            elif c < o_ge:
+                out.append((c, v / r[self.nr_eq + self.nr_range + (c - o_le)]))
+            elif c < o_bound:
+                out.append((c, v / r[self.nr_eq + self.nr_range + self.nr_le + (c - o_ge)]))
+            elif c < o_rb:
+                out.append((c, v * s[bounded[c - o_bound]]))
+            else:
+                out.append((c, v / r[self.nr_eq + (c - o_rb)]))
+        return out
+
     @classmethod
     def from_dense_le(cls, A: np.ndarray, b: np.ndarray, c: np.ndarray) -> "MatrixData":
         """``min c'x, A x <= b, x >= 0`` (all rows `<=`, no bounds): the synthetic dense configs."""

@@ -125,7 +125,7 @@ def verified(names, idx, args):
         out[name] = {"outcome": engine.OUTCOME_NAMES.get(oc, str(oc)), "verified": report["verified"], "objective": obj, "agrees_with_highs": ok,
                      "legs": report["legs"], "seconds": round(time.perf_counter() - t0, 2)}
         rows.append(f"| {name} | {rec['nr_rows']} x {rec['nr_columns']} | {out[name]['outcome']}{'' if report['verified'] else ' (unverified)'} | "
-                    f"{last['config'] + ' / ' + last['engine'] if report['verified'] else ''} | {len(report['legs'])} | {'' if obj is None else f'{obj:.10g}'} | {rec.get('highs_objective'):.10g} |")
+                    f"{last['data'] + ' / ' + last['config'] + ' / ' + last['engine'] if report['verified'] else ''} | {len(report['legs'])} | {'' if obj is None else f'{obj:.10g}'} | {rec.get('highs_objective'):.10g} |")
         print(name, out[name]["outcome"], report["verified"], ok, len(report["legs"]), out[name]["seconds"], flush=True)
         json.dump(out, open(args.out, "w"), indent=1)
     n_ok = sum(1 for v in out.values() if v["agrees_with_highs"] and v["verified"])

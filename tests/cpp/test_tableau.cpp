@@ -256,6 +256,14 @@ int main() {
             const VerifiedResult v = solve_verified(problem_2());
             CHECK(v.verified && v.legs_tried == 1 && v.result.has_value());
             CHECK(v.result->kind == OptimizationResult::FiniteOptimum && near(v.result->solution, SparseVector{{1, 0.5}, {3, 2.5}, {4, 1.5}}));
+            // the same LP scaled: factors are powers of two, the solution comes back in the units of the data
+            const MatrixData::Scaled sc = problem_2().scaled();
+            for (double f : sc.row_scale) CHECK(std::exp2(std::nearbyint(std::log2(f))) == f);
+            for (double f : sc.column_scale) CHECK(std::exp2(std::nearbyint(std::log2(f))) == f);
+            Tableau ts(sc.data, Options::robust());
+            const OptimizationResult rs = ts.solve_relaxation();
+            CHECK(rs.kind == OptimizationResult::FiniteOptimum);
+            CHECK(near(problem_2().unscale(rs.solution, sc.row_scale, sc.column_scale), SparseVector{{1, 0.5}, {3, 2.5}, {4, 1.5}}));
         }
     } catch (const std::exception& e) {
         std::printf("unexpected exception: %s\n", e.what());
