@@ -440,7 +440,11 @@ inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_
                 }
             } else if (oc == RELP_INFEASIBLE || oc == RELP_UNBOUNDED) {
                 out.result = OptimizationResult{oc == RELP_INFEASIBLE ? OptimizationResult::Infeasible : OptimizationResult::Unbounded, {}};
-                if (!leg.scaled) (oc == RELP_INFEASIBLE ? infeasible_on : unbounded_on) |= 1u << leg.engine;
+                // (a claim counts only from a state that is still a basis: an exploded tableau also ends `infeasible`)
+                double ident = 0, basic = 0, min_b = 0;
+                if (!leg.scaled && relp_check_basis(t.handle(), &ident, &basic, &min_b) == RELP_OK && ident <= 1e-5 && basic <= 1e-3 &&
+                    std::isfinite(t.objective_function_value()))
+                    (oc == RELP_INFEASIBLE ? infeasible_on : unbounded_on) |= 1u << leg.engine;
             }
         } catch (const Error&) {
             // (a leg that fails -- no row in phase 1, a singular basis -- is a leg without an answer)

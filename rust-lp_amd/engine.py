@@ -599,8 +599,8 @@ def solve_relaxation(provider: MatrixData, **config_overrides):
 # (data as read | scaled by MatrixData.scaled, configuration, engine) in a fixed order, each with a pivot and a time budget, and an
 # outcome stands only when it verifies -- `optimal` by the residuals of relp_check_basis (B^-1 B = I, basis columns are unit columns,
 # b >= 0: the wrong optima of the sweeps all sit on a basis with some b_i <= -0.07), `infeasible` / `unbounded` only when every leg
-# has run, none reached a verified optimum, and two engines said so on the data AS READ (on scaled data two engines agreed on a wrong
-# `infeasible` for WOODW).
+# has run, none reached a verified optimum, and two engines said so on the data AS READ from a state that passes the first two checks
+# (on scaled data two engines agreed on a wrong `infeasible` for WOODW; PILOT87 ends `infeasible` on an exploded tableau).
 VERIFY_IDENTITY, VERIFY_BASIC, VERIFY_MIN_B = 1e-5, 1e-3, -1e-6
 VERIFIED_LEGS = (("read", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_REVISED),
                  ("read", "robust", ENGINE_REVISED), ("read", "robust", ENGINE_TABLEAU), ("scaled", "robust", ENGINE_TABLEAU),
@@ -651,7 +651,12 @@ def solve_verified(provider: MatrixData, pivots_per_leg: Optional[int] = None, s
                         report["row_scale"], report["column_scale"] = scaled[1], scaled[2]
                     return OPTIMAL, t, report
             elif oc in (INFEASIBLE, UNBOUNDED) and data == "read":
-                said.setdefault(oc, set()).add(kind)
+                # (a claim counts only from a state that is still a basis: PILOT87 on the tableau engine ends `infeasible` with
+                # a phase-1 objective of 1e302 and then inf)
+                ident, basic, min_b = t.check_basis()
+                leg["check_basis"] = [ident, basic, min_b]
+                if ident <= VERIFY_IDENTITY and basic <= VERIFY_BASIC and np.isfinite(t.objective_function_value()):
+                    said.setdefault(oc, set()).add(kind)
         except RelpError as e:
             leg["outcome"] = "error: " + str(e)[:120]
         t.close()
