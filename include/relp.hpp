@@ -407,15 +407,18 @@ inline OptimizationResult solve_relaxation(const MatrixData& data, const Options
 // on the data as read.  An unverified result is the last leg's, and may be none at all.
 struct VerifiedResult { std::optional<OptimizationResult> result; bool verified = false; bool scaled = false; int legs_tried = 0; };
 inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_leg = -1) {
-    struct Leg { bool scaled, robust; int32_t engine; };
-    static const Leg legs[9] = {{false, true, RELP_ENGINE_LU}, {true, true, RELP_ENGINE_LU}, {true, true, RELP_ENGINE_REVISED},
-                                {false, true, RELP_ENGINE_REVISED}, {false, true, RELP_ENGINE_TABLEAU}, {true, true, RELP_ENGINE_TABLEAU},
-                                {false, false, RELP_ENGINE_LU}, {false, false, RELP_ENGINE_REVISED}, {false, false, RELP_ENGINE_TABLEAU}};
+    // (robust = 2: the safeguards with PivotRule::SteepestDescent in phase 1 as well -- what ends the cycling of TUFF, DEGEN3, CYCLE)
+    struct Leg { bool scaled; int robust; int32_t engine; };
+    static const Leg legs[12] = {{false, 1, RELP_ENGINE_LU}, {true, 1, RELP_ENGINE_LU}, {true, 2, RELP_ENGINE_LU}, {true, 2, RELP_ENGINE_TABLEAU},
+                                 {false, 2, RELP_ENGINE_LU}, {true, 1, RELP_ENGINE_REVISED}, {false, 1, RELP_ENGINE_REVISED},
+                                 {false, 1, RELP_ENGINE_TABLEAU}, {true, 1, RELP_ENGINE_TABLEAU},
+                                 {false, 0, RELP_ENGINE_LU}, {false, 0, RELP_ENGINE_REVISED}, {false, 0, RELP_ENGINE_TABLEAU}};
     VerifiedResult out;
     std::optional<MatrixData::Scaled> sc;
     uint32_t infeasible_on = 0, unbounded_on = 0;      // bit per engine, data as read
     for (const Leg& leg : legs) {
         Options o = leg.robust ? Options::robust() : Options();
+        if (leg.robust == 2) o.pivot_rule(PivotRule::SteepestDescent);
         o.inverse_maintenance((InverseMaintenance)leg.engine);
         ++out.legs_tried;
         if (leg.scaled && !sc) sc = data.scaled();

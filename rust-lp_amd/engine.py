@@ -602,7 +602,11 @@ def solve_relaxation(provider: MatrixData, **config_overrides):
 # has run, none reached a verified optimum, and two engines said so on the data AS READ from a state that passes the first two checks
 # (on scaled data two engines agreed on a wrong `infeasible` for WOODW; PILOT87 ends `infeasible` on an exploded tableau).
 VERIFY_IDENTITY, VERIFY_BASIC, VERIFY_MIN_B = 1e-5, 1e-3, -1e-6
-VERIFIED_LEGS = (("read", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_REVISED),
+# ("robust-dantzig": the safeguards with PivotRule::SteepestDescent -- the largest coefficient -- in phase 1 as well, where the
+# reference takes FirstProfitableWithMemory: TUFF, DEGEN3, CYCLE cycle for 600,000 pivots under the reference's phase-1 rule, under
+# Bland's too, and end after 1,708 / 11,775 / 49,326 pivots with this one; PILOT87 reaches Netlib's 301.71072827 with it.)
+VERIFIED_LEGS = (("read", "robust", ENGINE_LU), ("scaled", "robust", ENGINE_LU), ("scaled", "robust-dantzig", ENGINE_LU),
+                 ("scaled", "robust-dantzig", ENGINE_TABLEAU), ("read", "robust-dantzig", ENGINE_LU), ("scaled", "robust", ENGINE_REVISED),
                  ("read", "robust", ENGINE_REVISED), ("read", "robust", ENGINE_TABLEAU), ("scaled", "robust", ENGINE_TABLEAU),
                  ("read", "default", ENGINE_LU), ("read", "default", ENGINE_REVISED), ("read", "default", ENGINE_TABLEAU))
 _ENGINE_NAMES = {ENGINE_REVISED: "revised", ENGINE_TABLEAU: "tableau", ENGINE_LU: "lu"}
@@ -625,7 +629,12 @@ def solve_verified(provider: MatrixData, pivots_per_leg: Optional[int] = None, s
         t0 = time.perf_counter()
         if data == "scaled" and scaled is None:
             scaled = provider.scaled()
-        cfg = robust_config(engine=kind) if cfg_name == "robust" else default_config(engine=kind)
+        if cfg_name == "robust":
+            cfg = robust_config(engine=kind)
+        elif cfg_name == "robust-dantzig":
+            cfg = robust_config(engine=kind, phase_one_rule=STEEPEST_DESCENT, phase_two_rule=STEEPEST_DESCENT)
+        else:
+            cfg = default_config(engine=kind)
         try:
             t = Tableau(scaled[0] if data == "scaled" else provider, config=cfg)
         except RelpError as e:

@@ -1,6 +1,5 @@
 """`engine.solve_verified` (beyond the reference: legs of (configuration, engine), an outcome stands only when it verifies) on files
-of the reference's Netlib directory that need DIFFERENT legs -- profiles/r04_corpus_sweep.md: BNL1 only under the literal rules, MAROS
-not on the first leg, GREENBEA under the safeguards on the LU engine -- and on one that the first leg solves.
+of the reference's Netlib directory that need DIFFERENT legs -- profiles/r04_corpus_sweep.md: BNL1 and MAROS not on the first leg, GREENBEA under the safeguards on the LU engine -- and on one that the first leg solves.
 Expected optima: HiGHS on the same standardised LP (tests/golden/corpus/index.json; NOT the reference: parity unpinned) and the
 reference's pin where it holds one (GREENBEA, tests/netlib/test.rs)."""
 import pytest
@@ -14,7 +13,7 @@ AS_READ = tuple(leg for leg in engine.VERIFIED_LEGS if leg[0] == "read")
 
 
 @pytest.mark.parametrize("name, leg", [("AFIRO", ("robust", "lu")), ("GREENBEA", ("robust", "lu")), ("MAROS", None),
-                                       ("BNL1", ("default", "lu"))])
+                                       ("BNL1", None)])
 def test_solve_verified_reaches_the_optimum_and_says_which_leg_did(name, leg):
     md, fixed = corpus.load(name)
     rec = corpus.index()[name]
@@ -71,6 +70,22 @@ def test_scaled_legs_solve_what_no_leg_solves_on_the_data_as_read(name):
             if j < md.nr_normal:
                 x[j] = v
         assert abs(float(np.dot(np.asarray(md.cost), x)) + fixed - want) <= 1e-6 * max(1.0, abs(want))
+    finally:
+        if t is not None:
+            t.close()
+
+
+@pytest.mark.parametrize("name", ["TUFF", "DEGEN3", "CYCLE"])
+def test_the_largest_coefficient_rule_in_phase_one_ends_the_cycling(name):
+    """TUFF, DEGEN3, CYCLE: 300,000+ pivots without an end under the reference's phase-1 rule (FirstProfitableWithMemory) on every
+    engine and configuration, and under Bland's rule (profiles/r04_stall_probe.md); the `robust-dantzig` legs -- the safeguards with
+    PivotRule::SteepestDescent in phase 1 as well -- end in a verified optimum equal to HiGHS's."""
+    md, fixed = corpus.load(name)
+    want = corpus.index()[name]["highs_objective"]
+    oc, t, report = engine.solve_verified(md, legs=tuple(leg for leg in engine.VERIFIED_LEGS if leg[1] == "robust-dantzig"))
+    try:
+        assert oc == engine.OPTIMAL and report["verified"], report
+        assert abs(t.objective_function_value() + fixed - want) <= 1e-6 * max(1.0, abs(want))
     finally:
         if t is not None:
             t.close()
