@@ -408,11 +408,13 @@ inline OptimizationResult solve_relaxation(const MatrixData& data, const Options
 struct VerifiedResult { std::optional<OptimizationResult> result; bool verified = false; bool scaled = false; int legs_tried = 0; };
 inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_leg = -1) {
     // (robust = 2: the safeguards with PivotRule::SteepestDescent in phase 1 as well -- what ends the cycling of TUFF, DEGEN3, CYCLE)
-    struct Leg { bool scaled; int robust; int32_t engine; };
-    static const Leg legs[12] = {{false, 1, RELP_ENGINE_LU}, {true, 1, RELP_ENGINE_LU}, {true, 2, RELP_ENGINE_LU}, {true, 2, RELP_ENGINE_TABLEAU},
+    // (times: a long leg with that many times the pivot budget -- DFL001 takes 1,990,000 pivots on the last one)
+    struct Leg { bool scaled; int robust; int32_t engine; int times = 1; };
+    static const Leg legs[13] = {{false, 1, RELP_ENGINE_LU}, {true, 1, RELP_ENGINE_LU}, {true, 2, RELP_ENGINE_LU}, {true, 2, RELP_ENGINE_TABLEAU},
                                  {false, 2, RELP_ENGINE_LU}, {true, 1, RELP_ENGINE_REVISED}, {false, 1, RELP_ENGINE_REVISED},
                                  {false, 1, RELP_ENGINE_TABLEAU}, {true, 1, RELP_ENGINE_TABLEAU},
-                                 {false, 0, RELP_ENGINE_LU}, {false, 0, RELP_ENGINE_REVISED}, {false, 0, RELP_ENGINE_TABLEAU}};
+                                 {false, 0, RELP_ENGINE_LU}, {false, 0, RELP_ENGINE_REVISED}, {false, 0, RELP_ENGINE_TABLEAU},
+                                 {false, 2, RELP_ENGINE_TABLEAU, 12}};
     VerifiedResult out;
     std::optional<MatrixData::Scaled> sc;
     uint32_t infeasible_on = 0, unbounded_on = 0;      // bit per engine, data as read
@@ -424,7 +426,7 @@ inline VerifiedResult solve_verified(const MatrixData& data, int64_t pivots_per_
         if (leg.scaled && !sc) sc = data.scaled();
         try {
             Tableau t(leg.scaled ? sc->data : data, o);
-            const int64_t budget = pivots_per_leg >= 0 ? pivots_per_leg : 30 * ((int64_t)t.nr_rows() + t.nr_columns());
+            const int64_t budget = leg.times * (pivots_per_leg >= 0 ? pivots_per_leg : 30 * ((int64_t)t.nr_rows() + t.nr_columns()));
             int64_t total = 0, done = 0;
             relp_outcome_t oc = RELP_RUNNING;
             while (total < budget) {

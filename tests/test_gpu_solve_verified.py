@@ -101,6 +101,6 @@ def test_infeasible_stands_only_when_two_engines_say_so_on_the_data_as_read():
                     upper_bound=np.full(2, np.inf), col_ptr=np.array([0, 2, 4], dtype=np.int64), row_idx=np.array([0, 1, 0, 1], dtype=np.int32),
                     values=np.ones(4))
     oc, t, report = engine.solve_verified(md)
-    assert t is None and oc == engine.INFEASIBLE and report["verified"] and len(report["legs"]) == len(engine.VERIFIED_LEGS), report
+    assert t is None and oc == engine.INFEASIBLE and report["verified"] and len(report["legs"]) == len(engine.VERIFIED_LEGS) == 13, report
     oc, t, report = engine.solve_verified(md, legs=tuple(leg for leg in engine.VERIFIED_LEGS if leg[0] == "scaled"))
     assert t is None and oc == engine.INFEASIBLE and not report["verified"], report
