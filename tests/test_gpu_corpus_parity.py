@@ -1,4 +1,4 @@
-"""The LU engine beside the f64 oracle of the reference's OWN back-end (`LUDecomposition` + eta file at the reference's cadence,
+"""The engines beside the f64 oracles of their own back-ends on the reference's Netlib directory.  First the LU engine beside the f64 oracle of the reference's OWN back-end (`LUDecomposition` + eta file at the reference's cadence,
 oracle/relp_f64_lu.h) on the small files of the reference's Netlib directory (tests/golden/corpus; rows <= 420): the whole pivot
 sequence, the objective and the number of rows, under `relp_default_config` -- the reference's rules literally.  The reference holds
 no pins for most of these files ("parity unpinned" with respect to the reference itself); what is pinned is the build's device
@@ -75,5 +75,26 @@ def test_lu_engine_and_lu_oracle_on_the_mid_size_netlib_files(name):
         else:
             assert tr == ref.trace, f"{name}: common prefix {same} of {len(ref.trace)} pivots"
             assert abs(t.objective_function_value() - ref.objective) <= 1e-9 * max(1.0, abs(ref.objective))
+    finally:
+        t.close()
+
+
+@pytest.mark.parametrize("kind", [engine.ENGINE_REVISED, engine.ENGINE_TABLEAU], ids=["revised", "tableau"])
+@pytest.mark.parametrize("name", NAMES)
+def test_explicit_inverse_and_tableau_engines_walk_the_rows_oracles_pivots(name, kind):
+    """The same small files on the explicit-inverse engine (`Carry<_, BasisInverseRows<_>>`) and on the dense tableau, beside the f64
+    oracle of THAT back-end (oracle/relp_f64.c): whole pivot sequences under `relp_default_config`."""
+    md, fixed = corpus.load(name)
+    want = corpus.index()[name]["highs_objective"]
+    ref = relp_f64.OracleF64(md.ensure_csc())
+    assert ref.run() == "optimal"
+    assert abs(ref.objective + fixed - want) <= 1e-6 * max(1.0, abs(want))
+    t = engine.Tableau(md, engine=kind, trace_capacity=1 << 15)
+    try:
+        assert t.solve_relaxation() == engine.OPTIMAL
+        tr = t.trace()
+        same = next((k for k, (a, b) in enumerate(zip(tr, ref.trace)) if a != b), min(len(tr), len(ref.trace)))
+        assert tr == ref.trace, f"{name}: common prefix {same} of {len(ref.trace)} pivots"
+        assert abs(t.objective_function_value() - ref.objective) <= 1e-9 * max(1.0, abs(ref.objective))
     finally:
         t.close()
