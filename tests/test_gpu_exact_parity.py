@@ -1,5 +1,5 @@
 """The f64 GPU engines beside the EXACT-rational oracle (oracle/relp_exact.py: the reference's own arithmetic, `RationalBig`
-restated with `fractions.Fraction`) on the Netlib files of the reference's test suite that the exact oracle solves in seconds: the
+restated with `fractions.Fraction`) on the Netlib, burkardt and cook files of the reference's test suite that the exact oracle solves in seconds: the
 whole pivot sequence of both phases and the optimum.  The reference computes in exact rationals, so this -- not agreement with an f64
 restatement -- is "the same pivots as the reference": every tie is decided by the reference's rule on exact numbers, and the f64
 engines have to land on the same side of every comparison."""
@@ -10,8 +10,10 @@ from rust_lp_amd import engine
 
 pytestmark = pytest.mark.gpu
 
-FILES = ["AFIRO", "SC50B", "SC50A", "KB2", "BLEND", "SC105", "STOCFOR1", "SHARE2B", "VTP-BASE", "RECIPELP", "SCAGR7", "BORE3D", "ADLITTLE",
-         "SC205", "LOTFI", "SHARE1B", "BOEING2"]
+FILES = ["netlib/AFIRO.SIF", "netlib/SC50B.SIF", "netlib/SC50A.SIF", "netlib/KB2.SIF", "netlib/BLEND.SIF", "netlib/SC105.SIF",
+         "netlib/STOCFOR1.SIF", "netlib/SHARE2B.SIF", "netlib/VTP-BASE.SIF", "netlib/RECIPELP.SIF", "netlib/SCAGR7.SIF", "netlib/BORE3D.SIF",
+         "netlib/ADLITTLE.SIF", "netlib/SC205.SIF", "netlib/LOTFI.SIF", "netlib/SHARE1B.SIF", "netlib/BOEING2.SIF",
+         "burkardt/afiro.mps", "burkardt/testprob.mps", "burkardt/maros.mps", "burkardt/adlittle.mps", "cook/small_example.mps"]
 ENGINES = [("revised", engine.ENGINE_REVISED, 0), ("tableau", engine.ENGINE_TABLEAU, -1), ("lu", engine.ENGINE_LU, 11)]
 _exact = {}
 
@@ -19,7 +21,7 @@ _exact = {}
 def exact_trace(name):
     if name not in _exact:
         from lp_files import exact_solve, load
-        gf, ex, md, emd = load(f"netlib/{name}.SIF", fixed=True)
+        gf, ex, md, emd = load(name, fixed=name.endswith(".SIF"))
         tr = []
         status, obj, sol = exact_solve(gf, emd, trace=tr.append)
         assert status == "optimal"
