@@ -340,6 +340,17 @@ def sparse_path(events, with_cpu):
     res11["refactorisations"] = t.lu_stats()["refactorisations"]
     t.close()
     out["reference_cadence_update_block_11"] = res11
+    # the same cadence with the pipelined look-ahead (RELP_LU_PIPELINE_SHORT, relp_engine_lu.cpp: run_ft): the kernel pivots on into a
+    # tail twice as long while the host factorises; the factors lag one interval behind, the device does not wait for a factorisation
+    os.environ["RELP_LU_PIPELINE_SHORT"] = "1"
+    try:
+        t, res11p = solve(engine.ENGINE_LU, update_block=11)
+        st = t.lu_stats()
+        res11p["refactorisations"] = st["refactorisations"]; res11p["lookahead_installs"] = st["lookahead_installs"]
+        t.close()
+    finally:
+        del os.environ["RELP_LU_PIPELINE_SHORT"]
+    out["reference_cadence_update_block_11_pipelined"] = res11p
     # the same LP on the explicit-inverse engine (m = 790: B^-1 is 5 MB) and on the dense tableau engine
     t, res = solve(engine.ENGINE_REVISED, update_block=0)
     res["reinversions"] = t.reinversions()

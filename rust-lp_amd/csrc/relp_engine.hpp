@@ -247,6 +247,7 @@ class Engine {
     int64_t lu_lookahead_installs_ = 0, lu_replayed_changes_ = 0;     // look-ahead refactorisations installed, journal entries replayed
     int32_t lu_lookahead_env_ = 8, lu_fuse_lanes_env_ = 256;          // RELP_LU_LOOKAHEAD, RELP_FUSE_LANES (read at create)
     bool lu_lookahead_set_ = false;                      // RELP_LU_LOOKAHEAD given (else layout 2 takes 16)
+    int32_t lu_pipeline_cap_ = 0;                        // RELP_LU_PIPELINE_SHORT: the update file's cap while the host factorises (run_ft)
     double refactor_us_[3] = {0.0, 0.0, 0.0};            // host time: basis + columns, factorisation, schedules + upload
     // revised engine: B^-1 is re-inverted from the basis columns every `reinvert_interval_` pivots (0 = never)
     int64_t reinvert_interval_ = 0, since_reinvert_ = 0, reinversions_ = 0;

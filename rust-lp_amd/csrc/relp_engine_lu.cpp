@@ -202,6 +202,7 @@ relp_status_t Engine::lu_refactor_lookahead(int rule, int64_t budget, bool have_
     if (st) return st;
     FtState go = fts_;
     go.max_updates = std::max(go.max_updates, std::min(cfg_.update_block < 0 ? ft_tcap_ : cfg_.update_block, ft_tcap_));
+    if (lu_pipeline_cap_ > 0) go.max_updates = std::min(lu_pipeline_cap_, ft_tcap_);       // (run_ft: RELP_LU_PIPELINE_SHORT)
     prof_tick_ = 0;
     prof_begin(RELP_K_FT_RUN);
     ft_enqueue_pivots(go, rule, budget);
@@ -513,6 +514,8 @@ relp_status_t Engine::ft_plan_and_alloc() {
     // Default interval 48: with a refactorisation at ~0.7 ms and ~1,100 clocks per pending update and pivot, the optimum is
     // flat between 40 and 64, and 48 x 49 doubles leave 14 KB more for the images than 64 x 65.
     int32_t want = cfg_.update_block < 0 ? 48 : std::max(1, std::min(cfg_.update_block, kFtMaxSlots));
+    // (RELP_LU_PIPELINE_SHORT, run_ft: a short interval pivots on into a tail twice as long while the host factorises)
+    if (std::getenv("RELP_LU_PIPELINE_SHORT") && std::atoi(std::getenv("RELP_LU_PIPELINE_SHORT")) != 0 && want < 24) want = 2 * want;
     // Two layouts (relp_kernels_ft.hip: ft_layout).  "All in LDS": x with m right-hand-side copies, spike, -pi, permutations,
     // eta pool -- 63 bytes per row.  "big": x, -pi and the slot tables only (17 bytes per row + 8 per right-hand-side copy the
     // fused schedules may use: as many as fit, a schedule that needs more is packed level by level), the rest read from L2;
@@ -812,12 +815,21 @@ relp_status_t Engine::run_ft(int64_t max_iters, int64_t* done, int32_t* outcome)
     const int32_t la_env = luf_enabled_ ? 0 : (ft_tier_ >= 2 && !lu_lookahead_set_) ? 16 : lu_lookahead_env_;     // (RELP_LU_LOOKAHEAD, read at create; the device
                                                                      // factorisation is synchronous on the engine's stream)
     const int32_t la = (fts_.max_updates >= 24 && la_env > 0) ? std::min(la_env, fts_.max_updates / 3) : 0;
+    // Short intervals (the reference's cadence of 11: too short for the look-ahead above, which needs its updates inside the interval):
+    // RELP_LU_PIPELINE_SHORT=1 lets the kernel return at the interval, pivot on into the REST of the dense tail (up to twice the
+    // interval) while the host factorises, and replays those pivots onto the new factors -- the factors lag one interval behind, the
+    // pivots are the same, the device never waits for a whole factorisation.  Opt-in: a measurement (bench: reference cadence).
+    const char* pipeline_s = std::getenv("RELP_LU_PIPELINE_SHORT");
+    const bool pipeline_env = pipeline_s && std::atoi(pipeline_s) != 0;
+    const bool pipeline_short = pipeline_env && la == 0 && !luf_enabled_ && la_env > 0 && fts_.max_updates < 24 && 2 * fts_.max_updates <= ft_tcap_;
     bool have_basis = false;                               // h_basis_ holds the basis as the last launch left it
     while (h_rec_->outcome == DEV_RUNNING && h_rec_->iterations - start < max_iters) {
         if (ft_need_refactor_) {
-            const bool ahead = la > 0 && h_ft_hdr_[2] == 1 && h_ft_hdr_[0] == fts_.max_updates - la;
+            const bool ahead = (la > 0 && h_ft_hdr_[2] == 1 && h_ft_hdr_[0] == fts_.max_updates - la) ||
+                               (pipeline_short && h_ft_hdr_[2] == 1 && h_ft_hdr_[0] >= fts_.max_updates && h_ft_hdr_[0] < 2 * fts_.max_updates);
             prof_tick_ = 0;                                // refactorisations are always bracketed (like the flush)
             if (ahead) {
+                lu_pipeline_cap_ = pipeline_short ? 2 * fts_.max_updates : 0;
                 if ((st = lu_refactor_lookahead(rule, max_iters - (h_rec_->iterations - start), have_basis))) return st;
                 have_basis = false;                        // (the relaunched kernel has changed the basis since)
                 if (ft_need_refactor_ || h_rec_->outcome != DEV_RUNNING) continue;      // (re-examined at the loop head)

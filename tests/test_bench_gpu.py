@@ -32,6 +32,8 @@ def check_headline(out, quick):
     assert sp["outcome"] == "optimal" and abs(sp["objective"] - 5.5018459e+03) < 1e-4 and sp["tolerances"] == "relp_default_config"
     assert sp["kernel_launches_per_pivot"] <= 2.0 / 11 and sp["pivot_kernel_phase_share"]["u_solve"] > 0      # persistent pivot kernel
     assert sp["reference_cadence_update_block_11"]["outcome"] == "optimal"
+    pp = sp["reference_cadence_update_block_11_pipelined"]              # (RELP_LU_PIPELINE_SHORT: the host factorises behind the kernel's back)
+    assert pp["outcome"] == "optimal" and abs(pp["objective"] - 5.5018459e+03) < 1e-4 and pp["lookahead_installs"] >= pp["refactorisations"] - 4
     for other in ("explicit_inverse_engine", "tableau_engine"):
         assert sp[other]["outcome"] == "optimal" and abs(sp[other]["objective"] - 5.5018459e+03) < 1e-4
     # [r4] the sparse path's CPU baseline is the reference's own back-end for it (LUDecomposition + eta file, oracle/relp_f64_lu.h),

@@ -51,3 +51,22 @@ def test_25fv47_lu_engine_and_lu_oracle_at_the_reference_cadence():
     print(f"25FV47 at update_block 11: the LU engine walks the LU oracle's pivots for the first {same} of 4000")
     assert same >= 1000
     t.close()
+
+
+def test_25fv47_at_the_reference_cadence_with_the_pipelined_look_ahead(monkeypatch):
+    """RELP_LU_PIPELINE_SHORT=1 (opt-in): at an interval too short for the look-ahead inside it (the reference's 11) the kernel
+    returns at the interval, pivots on into a dense tail twice as long while the host factorises, and the pivots made meanwhile are
+    replayed onto the new factors.  Same optimum, every refactorisation but the first two installed behind the kernel's back."""
+    from lp_files import load
+    monkeypatch.setenv("RELP_LU_PIPELINE_SHORT", "1")
+    gf, ex, md, emd = load("netlib/25FV47.SIF", fixed=True)
+    t = engine.Tableau(md, engine=engine.ENGINE_LU, update_block=11)
+    try:
+        assert t.solve_relaxation() == engine.OPTIMAL
+        assert abs(t.objective_function_value() + float(gf.fixed_cost) - 5501.8458883) <= 1e-6
+        st = t.lu_stats()
+        assert st["lookahead_installs"] >= st["refactorisations"] - 4 and st["replayed_changes"] >= 10 * st["lookahead_installs"]
+        ident, basic, min_b = t.check_basis()
+        assert ident <= 1e-7 and min_b >= -1e-7
+    finally:
+        t.close()
